@@ -1,0 +1,42 @@
+import pathlib
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name: str) -> dict:
+    with np.load(GOLDEN / f"{name}.npz") as z:
+        out = {}
+        for k in z.files:
+            a = z[k]
+            if a.dtype.kind in "fiub":
+                out[k] = torch.from_numpy(a.copy()) if a.ndim > 0 else a.item()
+            else:
+                out[k] = a
+        return out
+
+
+@pytest.fixture
+def golden():
+    return load_golden

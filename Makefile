@@ -1,0 +1,21 @@
+# Builds the HIP hot path (libsaev_amd.so) for gfx950.  hipcc cross-compiles without a GPU.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := saev_amd/csrc
+SRCS  := $(CSRC)/ctx.hip $(CSRC)/gemm_encode.hip $(CSRC)/select.hip $(CSRC)/sparse.hip $(CSRC)/tail.hip
+OBJS  := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-value -Iinclude
+
+all: saev_amd/libsaev_amd.so
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/common.h include/saev_amd.h
+	@mkdir -p build
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+saev_amd/libsaev_amd.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+clean:
+	rm -rf build saev_amd/libsaev_amd.so
+
+.PHONY: all clean

@@ -1,0 +1,162 @@
+/*
+ * saev_amd.h — C ABI of libsaev_amd.so: the MI355X (gfx950) TopK-SAE train-step path.
+ *
+ * This is the drop-in boundary for the hot path of OSU-NLP-Group/saev.  The reference has no FFI of
+ * its own (it is pure PyTorch); each entry point below names the reference code it replaces
+ * (paths relative to the reference root, src/saev/...).  The Python host in saev_amd/ binds these
+ * with ctypes (see INTEGRATION.md for the stub a saev maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers + sizes; all pointers are DEVICE pointers unless the name ends in _host;
+ *   - every call returns 0 or a negative saev_status; saev_last_error() gives the message;
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*; NULL = default stream);
+ *     nothing synchronises unless documented;
+ *   - the library never frees caller memory; scratch is owned by the context;
+ *   - a context is bound to one device and is not thread-safe.
+ *
+ * Layout of the flat parameter-sized buffers (params, grads, Adam m, Adam v), fp32, in
+ * state_dict order (nn/modeling.py:312-327):
+ *   [ W_dec (d_sae x d_model, row-major) | b_dec (d_model) | W_enc (d_model x d_sae) | b_enc (d_sae) ]
+ */
+#ifndef SAEV_AMD_H
+#define SAEV_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAEV_AMD_ABI_VERSION 1
+
+typedef enum {
+    SAEV_OK = 0,
+    SAEV_INVALID_ARG = -1,
+    SAEV_HIP_ERROR = -2,
+    SAEV_UNSUPPORTED = -3,
+    SAEV_NOT_BOUND = -4
+} saev_status;
+
+/* Static configuration of one SAE (nn/modeling.py:259-284 SparseAutoencoderConfig, :119-130 TopK,
+ * :66-73 AuxK; nn/objectives.py:13-25 Matryoshka). */
+typedef struct {
+    int32_t d_model;
+    int32_t d_sae;
+    int32_t top_k;
+    int32_t k_aux;                 /* 0 = no auxiliary loss (NoAux)                         */
+    float alpha;                   /* AuxK scale                                            */
+    int64_t dead_threshold_tokens; /* objectives.py:24                                      */
+    int32_t normalize_w_dec;       /* modeling.py:283                                       */
+    int32_t remove_parallel_grads; /* modeling.py:281                                       */
+    int32_t max_batch;             /* scratch is sized for this many activation rows        */
+    int32_t reserved;
+} saev_cfg;
+
+/* Scalars of one step (nn/objectives.py:57-89 MatryoshkaLoss + train.py:356-362 grad norm). */
+typedef struct {
+    float mse;
+    float aux;
+    float l0;
+    float l1;
+    float grad_norm; /* pre-clip global L2 norm                                             */
+    float upper;     /* max |x| of the batch (objectives.py:227)                            */
+    int32_t n_dead;
+    int32_t n_overflow_rows; /* rows whose candidate list overflowed and took the exact slow path */
+    double sse;      /* sum (x - x_hat)^2 accumulated in fp64 (train.py:398-401, :561-562)  */
+    double sum_sq;   /* sum x^2 in fp64 (train.py:383, :554)                                */
+} saev_step_stats;
+
+typedef struct saev_ctx saev_ctx;
+
+int saev_abi_version(void);
+const char* saev_last_error(const saev_ctx* ctx);
+
+/* Lifetime.  `device` is the HIP device ordinal. */
+int saev_create(const saev_cfg* cfg, int device, saev_ctx** out);
+void saev_destroy(saev_ctx* ctx);
+
+/* Borrow the caller's flat buffers (see layout above).  grads/adam_m/adam_v may be NULL for a
+ * forward-only context.  Pointers must stay valid until re-bound or destroy. */
+int saev_bind(saev_ctx* ctx, float* params, float* grads, float* adam_m, float* adam_v);
+
+/* Dead-latent tracker state, (d_sae) int64, owned by the context (objectives.py:99,107-120).
+ * Exposed so the host can read/seed it (it is not part of the checkpoint in the reference). */
+int64_t* saev_toks_since_active(saev_ctx* ctx);
+/* Per-latent "fired this step" flags, (d_sae) int32 0/1; in data-parallel runs the host
+ * max-all-reduces this buffer between saev_step_forward and saev_step_dead. */
+int32_t* saev_fired_flags(saev_ctx* ctx);
+/* Let the host own the tracker state instead (both buffers d_sae long, zero-initialised by the
+ * caller): lets a torch tensor alias them for all-reduce / inspection. */
+int saev_bind_tracker(saev_ctx* ctx, int64_t* toks_since_active, int32_t* fired_flags);
+/* Device copy of the current step's saev_step_stats (valid after the producing call completes). */
+const saev_step_stats* saev_stats_device(saev_ctx* ctx);
+/* Blocking read-back of the stats (synchronises `stream`). */
+int saev_read_stats(saev_ctx* ctx, saev_step_stats* out_host, void* stream);
+
+/* ---- single ops (API-compat surface of SparseAutoencoder) ---------------------------------- */
+
+/* modeling.py:411-417  W_dec[i,:] /= ||W_dec[i,:]||  (no-op when cfg.normalize_w_dec == 0). */
+int saev_normalize_w_dec(saev_ctx* ctx, void* stream);
+/* modeling.py:343-347  h = x @ W_enc + b_enc, dense (n_rows x d_sae) output. */
+int saev_encode_dense(saev_ctx* ctx, const float* x, int32_t n_rows, float* h_out, void* stream);
+/* modeling.py:169-179  per-row top-k of a dense (n_rows x d_sae) matrix -> idx/val (n_rows x k),
+ * unsorted.  `mask` (d_sae int32, may be NULL) restricts candidates to latents with mask != 0. */
+int saev_topk_dense(saev_ctx* ctx, const float* h, int32_t n_rows, int32_t k, const int32_t* mask,
+                    int32_t* idx_out, float* val_out, void* stream);
+/* encode + TopK without materialising h (the fast path): idx/val (n_rows x top_k). */
+int saev_encode_topk(saev_ctx* ctx, const float* x, int32_t n_rows, int32_t* idx_out, float* val_out,
+                     void* stream);
+/* scatter codes into a dense zero-initialised (n_rows x d_sae) matrix (f_x for API compat). */
+int saev_scatter_dense(saev_ctx* ctx, const int32_t* idx, const float* val, int32_t n_rows, int32_t k,
+                       float* f_out, void* stream);
+/* modeling.py:351-409 with sparse input: x_hat[b, p, :] = b_dec + sum_{j: idx < prefixes[p]} val*W_dec[idx].
+ * `prefixes_host` has n_prefixes ascending cut points ending at d_sae (NULL => one prefix). */
+int saev_decode_sparse(saev_ctx* ctx, const int32_t* idx, const float* val, int32_t n_rows, int32_t k,
+                       const int64_t* prefixes_host, int32_t n_prefixes, float* x_hats_out, void* stream);
+/* modeling.py:419-445 on the bound grad buffer. */
+int saev_remove_parallel_grads(saev_ctx* ctx, void* stream);
+/* Row gather out of a device-resident activation pool (replaces ReservoirBuffer.get,
+ * data/buffers.py:179-216): out[r,:] = pool[rows[r],:]. */
+int saev_gather_rows(saev_ctx* ctx, const float* pool, const int64_t* rows, int32_t n_rows, float* out,
+                     void* stream);
+
+/* ---- the train step, in phases (framework/train.py:332-460) --------------------------------- */
+
+/* Phase 1: renormalise W_dec (train.py:334-335), encode + TopK, fired flags, sparse decode, MSE,
+ * main-path gradient pieces.  `training` = 0 gives the eval-mode forward (no tracker, no aux).
+ * `n_rows_global` = rows of this step summed over all data-parallel ranks (= n_rows on one GPU);
+ * it must equal the value later passed to saev_step_dead. */
+int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_rows_global, int32_t training,
+                      void* stream);
+/* Phase 2: tracker update with `n_rows_global` tokens (objectives.py:118-120), dead mask, AuxK
+ * forward (modeling.py:75-103).  Training mode only. */
+int saev_step_dead(saev_ctx* ctx, int64_t n_rows_global, void* stream);
+/* Phase 3: all four parameter gradients into the bound grad buffer (replaces autograd,
+ * train.py:347-348), un-projected and un-clipped. */
+int saev_step_backward(saev_ctx* ctx, void* stream);
+/* Phase 4: grads *= grad_scale (1/world_size after a sum all-reduce), remove_parallel_grads
+ * (train.py:351-352), global-norm clip (train.py:356-362, max_norm <= 0 disables), Adam with torch
+ * defaults (train.py:294,444-446). `adam_step` is the 1-based step count. */
+int saev_step_tail(saev_ctx* ctx, float lr, float max_norm, float grad_scale, int64_t adam_step, void* stream);
+/* Phases 1-4 back to back for the single-GPU case. */
+int saev_train_step(saev_ctx* ctx, const float* x, int32_t n_rows, float lr, float max_norm,
+                    int64_t adam_step, void* stream);
+
+/* Codes / reconstruction of the last saev_step_forward (device pointers into context scratch):
+ * idx,val (n_rows x top_k); x_hat (n_rows x d_model). */
+const int32_t* saev_last_idx(saev_ctx* ctx);
+const float* saev_last_val(saev_ctx* ctx);
+const float* saev_last_x_hat(saev_ctx* ctx);
+
+/* Device-to-device copies of the same into caller buffers (any may be NULL). */
+int saev_copy_last(saev_ctx* ctx, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream);
+
+/* Timing hooks for bench.py: wall duration in ms of the encoder kernel of the last step, measured
+ * with HIP events on `stream` (call after the stream has been synchronised). */
+int saev_enable_kernel_timing(saev_ctx* ctx, int32_t enable);
+float saev_last_encoder_ms(saev_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAEV_AMD_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libsaev_amd.so (the C ABI declared in include/saev_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing or a HIP device is not
+present, everything here raises.  Build the library with ``make`` (or ``__graft_entry__.build()``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
+
+ABI_VERSION = 1
+
+
+class SaevCfg(C.Structure):
+    _fields_ = [
+        ("d_model", C.c_int32), ("d_sae", C.c_int32), ("top_k", C.c_int32), ("k_aux", C.c_int32),
+        ("alpha", C.c_float), ("dead_threshold_tokens", C.c_int64),
+        ("normalize_w_dec", C.c_int32), ("remove_parallel_grads", C.c_int32),
+        ("max_batch", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class SaevStepStats(C.Structure):
+    _fields_ = [
+        ("mse", C.c_float), ("aux", C.c_float), ("l0", C.c_float), ("l1", C.c_float),
+        ("grad_norm", C.c_float), ("upper", C.c_float), ("n_dead", C.c_int32),
+        ("n_overflow_rows", C.c_int32), ("sse", C.c_double), ("sum_sq", C.c_double),
+    ]
+
+
+class SaevError(RuntimeError):
+    pass
+
+
+P = C.c_void_p
+_SIGNATURES = {
+    "saev_abi_version": (C.c_int, []),
+    "saev_last_error": (C.c_char_p, [P]),
+    "saev_create": (C.c_int, [C.POINTER(SaevCfg), C.c_int, C.POINTER(P)]),
+    "saev_destroy": (None, [P]),
+    "saev_bind": (C.c_int, [P, P, P, P, P]),
+    "saev_bind_tracker": (C.c_int, [P, P, P]),
+    "saev_toks_since_active": (P, [P]),
+    "saev_fired_flags": (P, [P]),
+    "saev_stats_device": (P, [P]),
+    "saev_read_stats": (C.c_int, [P, C.POINTER(SaevStepStats), P]),
+    "saev_normalize_w_dec": (C.c_int, [P, P]),
+    "saev_encode_dense": (C.c_int, [P, P, C.c_int32, P, P]),
+    "saev_topk_dense": (C.c_int, [P, P, C.c_int32, C.c_int32, P, P, P, P]),
+    "saev_encode_topk": (C.c_int, [P, P, C.c_int32, P, P, P]),
+    "saev_scatter_dense": (C.c_int, [P, P, P, C.c_int32, C.c_int32, P, P]),
+    "saev_decode_sparse": (C.c_int, [P, P, P, C.c_int32, C.c_int32, P, C.c_int32, P, P]),
+    "saev_remove_parallel_grads": (C.c_int, [P, P]),
+    "saev_gather_rows": (C.c_int, [P, P, P, C.c_int32, P, P]),
+    "saev_step_forward": (C.c_int, [P, P, C.c_int32, C.c_int64, C.c_int32, P]),
+    "saev_step_dead": (C.c_int, [P, C.c_int64, P]),
+    "saev_step_backward": (C.c_int, [P, P]),
+    "saev_step_tail": (C.c_int, [P, C.c_float, C.c_float, C.c_float, C.c_int64, P]),
+    "saev_train_step": (C.c_int, [P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
+    "saev_last_idx": (P, [P]),
+    "saev_last_val": (P, [P]),
+    "saev_last_x_hat": (P, [P]),
+    "saev_copy_last": (C.c_int, [P, P, P, P, P]),
+    "saev_enable_kernel_timing": (C.c_int, [P, C.c_int32]),
+    "saev_last_encoder_ms": (C.c_float, [P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libsaev_amd.so and attach argument types.  Raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise SaevError(
+                f"{LIB_PATH} not found: build the HIP extension first (`make` in the repo root or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.saev_abi_version()
+        if got != ABI_VERSION:
+            raise SaevError(f"libsaev_amd.so ABI version {got} != expected {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(lib: C.CDLL, ctx, rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.saev_last_error(ctx)
+        raise SaevError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,568 @@
+// C ABI of libsaev_amd.so (see include/saev_amd.h): context, scratch, and the launch sequences of
+// the train step.  No torch types; plain device pointers and a hipStream_t per call.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+constexpr int CAND_CAP = 1024;
+constexpr int TIMING_RING = 512;
+}
+
+struct saev_ctx {
+    saev_cfg cfg{};
+    int device = 0;
+    std::string err;
+    // bound buffers
+    float* params = nullptr;
+    float* grads = nullptr;
+    float* adam_m = nullptr;
+    float* adam_v = nullptr;
+    // derived
+    long n_params = 0;
+    long off_W_dec = 0, off_b_dec = 0, off_W_enc = 0, off_b_enc = 0;
+    // scratch
+    std::vector<void*> allocs;
+    int32_t *cand_cnt = nullptr, *row_tau = nullptr, *cand_idx = nullptr;
+    float* cand_val = nullptr;
+    float* h_dense = nullptr;
+    int32_t *idx = nullptr, *aux_idx = nullptr;
+    float *val = nullptr, *dval = nullptr, *aux_val = nullptr, *aux_dval = nullptr;
+    float *x_hat = nullptr, *g = nullptr, *g_aux = nullptr;
+    RowStats* rowstats = nullptr;
+    uint32_t* bitmap = nullptr;
+    int bitmap_words = 0;
+    int32_t *counts = nullptr, *starts = nullptr;
+    int2* pairs = nullptr;
+    float* colsum_partials = nullptr;
+    double *sumsq_partials = nullptr, *sumsq_total = nullptr;
+    int64_t* toks = nullptr;
+    int32_t *fired = nullptr, *dead = nullptr;
+    int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] n_dead [4] k_use
+    float* upper = nullptr;
+    saev_step_stats* stats = nullptr;
+    // state of the step in flight
+    const float* x_last = nullptr;
+    int n_last = 0;
+    int training_last = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev_start[TIMING_RING], ev_stop[TIMING_RING];
+    bool ev_created = false;
+    long ev_count = 0;
+};
+
+#define HIPCHK(ctx, expr)                                                                    \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                  \
+            return SAEV_HIP_ERROR;                                                           \
+        }                                                                                    \
+    } while (0)
+
+#define REQUIRE(ctx, cond, code, msg)                                                        \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            (ctx)->err = (msg);                                                              \
+            return (code);                                                                   \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+template <typename T>
+int alloc(saev_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+        return SAEV_HIP_ERROR;
+    }
+    c->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return SAEV_OK;
+}
+
+int encoder_splits(int n_rows, int S) {
+    const int nb = (n_rows + 127) / 128;
+    const int nst = (S + 255) / 256;
+    int sp = (256 + nb - 1) / nb;
+    return std::max(1, std::min(sp, nst));
+}
+
+bool fused_supported(const saev_cfg& c) { return c.top_k <= 64; }
+
+void timing_begin(saev_ctx* c, hipStream_t s) {
+    if (c->timing) hipEventRecord(c->ev_start[c->ev_count % TIMING_RING], s);
+}
+void timing_end(saev_ctx* c, hipStream_t s) {
+    if (c->timing) {
+        hipEventRecord(c->ev_stop[c->ev_count % TIMING_RING], s);
+        c->ev_count++;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int saev_abi_version(void) { return SAEV_AMD_ABI_VERSION; }
+
+const char* saev_last_error(const saev_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
+    if (!cfg || !out) return SAEV_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->d_model <= 0 || cfg->d_sae <= 0 || cfg->top_k <= 0 || cfg->max_batch <= 0) return SAEV_INVALID_ARG;
+    if (cfg->d_model % 4 != 0 || cfg->d_sae % 4 != 0 || cfg->d_model > 2048) return SAEV_UNSUPPORTED;
+    if (cfg->k_aux < 0 || cfg->k_aux > 1024) return SAEV_UNSUPPORTED;
+    saev_ctx* c = new saev_ctx();
+    c->cfg = *cfg;
+    c->cfg.top_k = std::min(cfg->top_k, cfg->d_sae);
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return SAEV_HIP_ERROR;
+    }
+    const long S = cfg->d_sae, D = cfg->d_model, MB = cfg->max_batch, K = c->cfg.top_k, KA = cfg->k_aux;
+    c->off_W_dec = 0;
+    c->off_b_dec = S * D;
+    c->off_W_enc = S * D + D;
+    c->off_b_enc = S * D + D + D * S;
+    c->n_params = 2 * S * D + S + D;
+    int rc = SAEV_OK;
+#define A(p, n) if (rc == SAEV_OK) rc = alloc(c, &c->p, (size_t)(n))
+    A(cand_cnt, MB); A(row_tau, MB); A(cand_idx, MB * CAND_CAP); A(cand_val, MB * CAND_CAP);
+    A(h_dense, MB * S);
+    A(idx, MB * K); A(val, MB * K); A(dval, MB * K);
+    if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(aux_dval, MB * KA); A(g_aux, MB * D); }
+    A(x_hat, MB * D); A(g, MB * D);
+    A(rowstats, MB);
+    c->bitmap_words = (int)((MB + 31) / 32);
+    A(bitmap, S * c->bitmap_words);
+    A(counts, S); A(starts, S + 1); A(pairs, MB * std::max(K, KA));
+    A(colsum_partials, ((MB + 63) / 64) * D);
+    A(sumsq_partials, 1024); A(sumsq_total, 1);
+    A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
+#undef A
+    if (rc != SAEV_OK) {
+        // keep the context so the caller can read the message, but report failure
+        for (void* p : c->allocs) hipFree(p);
+        delete c;
+        return rc;
+    }
+    hipMemset(c->toks, 0, S * sizeof(int64_t));
+    hipMemset(c->fired, 0, S * sizeof(int32_t));
+    hipMemset(c->dead, 0, S * sizeof(int32_t));
+    hipMemset(c->flags, 0, 8 * sizeof(int32_t));
+    hipMemset(c->stats, 0, sizeof(saev_step_stats));
+    hipMemset(c->rowstats, 0, MB * sizeof(RowStats));
+    hipDeviceSynchronize();
+    *out = c;
+    return SAEV_OK;
+}
+
+void saev_destroy(saev_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void* p : c->allocs) hipFree(p);
+    if (c->ev_created)
+        for (int i = 0; i < TIMING_RING; ++i) {
+            hipEventDestroy(c->ev_start[i]);
+            hipEventDestroy(c->ev_stop[i]);
+        }
+    delete c;
+}
+
+int saev_bind(saev_ctx* c, float* params, float* grads, float* adam_m, float* adam_v) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, params != nullptr, SAEV_INVALID_ARG, "saev_bind: params is NULL");
+    REQUIRE(c, ((uintptr_t)params % 16) == 0, SAEV_INVALID_ARG, "saev_bind: params must be 16-byte aligned");
+    c->params = params;
+    c->grads = grads;
+    c->adam_m = adam_m;
+    c->adam_v = adam_v;
+    return SAEV_OK;
+}
+
+int saev_bind_tracker(saev_ctx* c, int64_t* toks, int32_t* fired) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, toks && fired, SAEV_INVALID_ARG, "saev_bind_tracker: NULL buffer");
+    c->toks = toks;
+    c->fired = fired;
+    return SAEV_OK;
+}
+
+int saev_copy_last(saev_ctx* c, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->n_last > 0, SAEV_INVALID_ARG, "saev_copy_last: no forward has run");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nk = (size_t)c->n_last * c->cfg.top_k, nd = (size_t)c->n_last * c->cfg.d_model;
+    if (idx_out) HIPCHK(c, hipMemcpyAsync(idx_out, c->idx, nk * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (val_out) HIPCHK(c, hipMemcpyAsync(val_out, c->val, nk * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (x_hat_out) HIPCHK(c, hipMemcpyAsync(x_hat_out, c->x_hat, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SAEV_OK;
+}
+
+int64_t* saev_toks_since_active(saev_ctx* c) { return c ? c->toks : nullptr; }
+int32_t* saev_fired_flags(saev_ctx* c) { return c ? c->fired : nullptr; }
+const saev_step_stats* saev_stats_device(saev_ctx* c) { return c ? c->stats : nullptr; }
+const int32_t* saev_last_idx(saev_ctx* c) { return c ? c->idx : nullptr; }
+const float* saev_last_val(saev_ctx* c) { return c ? c->val : nullptr; }
+const float* saev_last_x_hat(saev_ctx* c) { return c ? c->x_hat : nullptr; }
+
+int saev_read_stats(saev_ctx* c, saev_step_stats* out_host, void* stream) {
+    if (!c || !out_host) return SAEV_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipMemcpyAsync(out_host, c->stats, sizeof(saev_step_stats), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return SAEV_OK;
+}
+
+int saev_enable_kernel_timing(saev_ctx* c, int32_t enable) {
+    if (!c) return SAEV_INVALID_ARG;
+    if (enable && !c->ev_created) {
+        for (int i = 0; i < TIMING_RING; ++i) {
+            HIPCHK(c, hipEventCreate(&c->ev_start[i]));
+            HIPCHK(c, hipEventCreate(&c->ev_stop[i]));
+        }
+        c->ev_created = true;
+    }
+    c->timing = enable != 0;
+    c->ev_count = 0;
+    return SAEV_OK;
+}
+
+// mean duration (ms) of the encoder kernel over the steps recorded since timing was enabled
+// (at most the last TIMING_RING); caller must have synchronised the stream.
+float saev_last_encoder_ms(saev_ctx* c) {
+    if (!c || !c->ev_created || c->ev_count == 0) return -1.f;
+    const long n = std::min<long>(c->ev_count, TIMING_RING);
+    double tot = 0;
+    for (long i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]) != hipSuccess) return -1.f;
+        tot += ms;
+    }
+    return (float)(tot / n);
+}
+
+// ------------------------------------------------------------------------------------------
+// single ops
+// ------------------------------------------------------------------------------------------
+
+int saev_normalize_w_dec(saev_ctx* c, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params, SAEV_NOT_BOUND, "parameters not bound");
+    if (!c->cfg.normalize_w_dec) return SAEV_OK;
+    HIPCHK(c, launch_normalize_rows(c->params + c->off_W_dec, c->cfg.d_sae, c->cfg.d_model, (hipStream_t)stream));
+    return SAEV_OK;
+}
+
+static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out, const int32_t* flag, int when,
+                       hipStream_t s) {
+    EncodeArgs a{};
+    a.x = x;
+    a.W_enc = c->params + c->off_W_enc;
+    a.b_enc = c->params + c->off_b_enc;
+    a.n_rows = n;
+    a.D = c->cfg.d_model;
+    a.S = c->cfg.d_sae;
+    a.s_splits = encoder_splits(n, a.S);
+    a.h_out = h_out;
+    a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
+    a.row_tau = c->row_tau;
+    a.cand_cnt = c->cand_cnt;
+    a.cand_val = c->cand_val;
+    a.cand_idx = c->cand_idx;
+    a.cand_cap = CAND_CAP;
+    a.enable_flag = flag;
+    a.enable_when = when;
+    HIPCHK(c, launch_encode_gemm(a, epi, s));
+    return SAEV_OK;
+}
+
+int saev_encode_dense(saev_ctx* c, const float* x, int32_t n, float* h_out, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params, SAEV_NOT_BOUND, "parameters not bound");
+    REQUIRE(c, x && h_out && n > 0, SAEV_INVALID_ARG, "saev_encode_dense: bad arguments");
+    return run_encoder(c, x, n, EPI_DENSE, h_out, nullptr, 0, (hipStream_t)stream);
+}
+
+int saev_topk_dense(saev_ctx* c, const float* h, int32_t n, int32_t k, const int32_t* mask, int32_t* idx_out,
+                    float* val_out, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, h && idx_out && val_out && n > 0 && k > 0, SAEV_INVALID_ARG, "saev_topk_dense: bad arguments");
+    REQUIRE(c, k <= c->cfg.d_sae, SAEV_INVALID_ARG, "saev_topk_dense: k > d_sae");
+    SelectDenseArgs a{};
+    a.h = h; a.n_rows = n; a.S = c->cfg.d_sae; a.k = k; a.mask = mask;
+    a.idx_out = idx_out; a.val_out = val_out; a.out_stride = k;
+    HIPCHK(c, launch_select_dense(a, (hipStream_t)stream));
+    return SAEV_OK;
+}
+
+// encode + top-k into (idx_out, val_out); fused path with exact dense fallback on overflow
+static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out, float* val_out,
+                            const int32_t* pre_flag, hipStream_t s) {
+    const int K = c->cfg.top_k;
+    int32_t* need_dense = c->flags + 1;
+    timing_begin(c, s);
+    if (fused_supported(c->cfg)) {
+        HIPCHK(c, hipMemsetAsync(c->cand_cnt, 0, (size_t)n * sizeof(int32_t), s));
+        HIPCHK(c, launch_init_i32(c->row_tau, INT32_MIN, n, s));
+        int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
+        if (rc != SAEV_OK) return rc;
+        HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, s));
+    } else {
+        HIPCHK(c, launch_init_i32(need_dense, 1, 1, s));
+        HIPCHK(c, hipMemsetAsync(c->flags + 2, 0, sizeof(int32_t), s));
+    }
+    int rc = run_encoder(c, x, n, EPI_DENSE, c->h_dense, need_dense, 1, s);
+    if (rc != SAEV_OK) return rc;
+    timing_end(c, s);
+    if (fused_supported(c->cfg)) {
+        SelectCandArgs sc{};
+        sc.cand_cnt = c->cand_cnt; sc.cand_val = c->cand_val; sc.cand_idx = c->cand_idx;
+        sc.cand_cap = CAND_CAP; sc.n_rows = n; sc.k = K;
+        sc.idx_out = idx_out; sc.val_out = val_out; sc.out_stride = K;
+        sc.enable_flag = need_dense; sc.enable_when = 0;
+        HIPCHK(c, launch_select_cand(sc, s));
+    }
+    SelectDenseArgs sd{};
+    sd.h = c->h_dense; sd.n_rows = n; sd.S = c->cfg.d_sae; sd.k = K;
+    sd.idx_out = idx_out; sd.val_out = val_out; sd.out_stride = K;
+    sd.enable_flag = need_dense; sd.enable_when = 1;
+    HIPCHK(c, launch_select_dense(sd, s));
+    return SAEV_OK;
+}
+
+int saev_encode_topk(saev_ctx* c, const float* x, int32_t n, int32_t* idx_out, float* val_out, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params, SAEV_NOT_BOUND, "parameters not bound");
+    REQUIRE(c, x && idx_out && val_out && n > 0 && n <= c->cfg.max_batch, SAEV_INVALID_ARG,
+            "saev_encode_topk: bad arguments (n_rows must be in 1..max_batch)");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int32_t), s));
+    return encode_topk_impl(c, x, n, idx_out, val_out, c->flags, s);
+}
+
+int saev_scatter_dense(saev_ctx* c, const int32_t* idx, const float* val, int32_t n, int32_t k, float* f_out,
+                       void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, idx && val && f_out && n > 0 && k > 0, SAEV_INVALID_ARG, "saev_scatter_dense: bad arguments");
+    HIPCHK(c, launch_scatter_dense(idx, val, n, k, k, c->cfg.d_sae, f_out, (hipStream_t)stream));
+    return SAEV_OK;
+}
+
+int saev_decode_sparse(saev_ctx* c, const int32_t* idx, const float* val, int32_t n, int32_t k,
+                       const int64_t* prefixes_host, int32_t n_prefixes, float* x_hats_out, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params, SAEV_NOT_BOUND, "parameters not bound");
+    REQUIRE(c, idx && val && x_hats_out && n > 0 && k > 0, SAEV_INVALID_ARG, "saev_decode_sparse: bad arguments");
+    const int S = c->cfg.d_sae, D = c->cfg.d_model;
+    int64_t single = S;
+    if (!prefixes_host) { prefixes_host = &single; n_prefixes = 1; }
+    REQUIRE(c, n_prefixes >= 1 && prefixes_host[n_prefixes - 1] == S && prefixes_host[0] >= 1, SAEV_INVALID_ARG,
+            "prefixes must end at d_sae and start at >= 1");
+    for (int p = 1; p < n_prefixes; ++p)
+        REQUIRE(c, prefixes_host[p] > prefixes_host[p - 1], SAEV_INVALID_ARG, "prefixes must be strictly increasing");
+    // x_hats is (n, P, D).  One decode launch per prefix (cut = prefixes[p]); with P > 1 each prefix is
+    // decoded into (n, D) scratch and copied into its strided slot.
+    REQUIRE(c, n <= c->cfg.max_batch || n_prefixes == 1, SAEV_INVALID_ARG, "n_rows > max_batch");
+    hipStream_t s = (hipStream_t)stream;
+    for (int p = 0; p < n_prefixes; ++p) {
+        DecodeArgs a{};
+        a.x = nullptr;  // reconstruction only
+        a.idx = idx; a.val = val; a.code_stride = k; a.k = k;
+        a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
+        a.n_rows = n; a.D = D; a.S = S; a.idx_limit = (int)prefixes_host[p];
+        a.x_hat = (n_prefixes == 1) ? x_hats_out : c->g;
+        HIPCHK(c, launch_decode(a, s));
+        if (n_prefixes > 1)
+            HIPCHK(c, hipMemcpy2DAsync(x_hats_out + (size_t)p * D, (size_t)n_prefixes * D * sizeof(float), c->g,
+                                       (size_t)D * sizeof(float), (size_t)D * sizeof(float), n,
+                                       hipMemcpyDeviceToDevice, s));
+    }
+    return SAEV_OK;
+}
+
+int saev_remove_parallel_grads(saev_ctx* c, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params && c->grads, SAEV_NOT_BOUND, "parameters/grads not bound");
+    if (!c->cfg.remove_parallel_grads) return SAEV_OK;
+    HIPCHK(c, launch_rpg(c->grads + c->off_W_dec, c->params + c->off_W_dec, c->cfg.d_sae, c->cfg.d_model,
+                         (hipStream_t)stream));
+    return SAEV_OK;
+}
+
+int saev_gather_rows(saev_ctx* c, const float* pool, const int64_t* rows, int32_t n, float* out, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, pool && rows && out && n > 0, SAEV_INVALID_ARG, "saev_gather_rows: bad arguments");
+    HIPCHK(c, launch_gather_rows(pool, rows, n, c->cfg.d_model, out, (hipStream_t)stream));
+    return SAEV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// the step
+// ------------------------------------------------------------------------------------------
+
+int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_global, int32_t training,
+                      void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params, SAEV_NOT_BOUND, "parameters not bound");
+    REQUIRE(c, x && n > 0 && n <= c->cfg.max_batch, SAEV_INVALID_ARG,
+            "saev_step_forward: n_rows must be in 1..max_batch");
+    REQUIRE(c, ((uintptr_t)x % 16) == 0, SAEV_INVALID_ARG, "x must be 16-byte aligned");
+    REQUIRE(c, n_rows_global >= n, SAEV_INVALID_ARG, "n_rows_global < n_rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k;
+    c->x_last = x;
+    c->n_last = n;
+    c->training_last = training;
+    if (training) {
+        int rc = saev_normalize_w_dec(c, stream);
+        if (rc != SAEV_OK) return rc;
+    }
+    HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(saev_step_stats), s));
+    HIPCHK(c, hipMemsetAsync(c->upper, 0, sizeof(float), s));
+    HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
+    // AuxK needs the pre-activations of dead latents, which the fused encoder never materialises: if any
+    // latent can be dead after this step's tracker update (age + global batch >= threshold), take the
+    // dense-h route.  The flag is a device value; both encoder variants are launched and one exits at once.
+    HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int32_t), s));
+    if (training && c->cfg.k_aux > 0) {
+        HIPCHK(c, launch_predead_flag(c->toks, S, n_rows_global, c->cfg.dead_threshold_tokens, c->flags, s));
+    }
+    int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s);
+    if (rc != SAEV_OK) return rc;
+
+    DecodeArgs a{};
+    a.x = x; a.idx = c->idx; a.val = c->val; a.code_stride = K; a.k = K;
+    a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
+    a.n_rows = n; a.D = D; a.S = S; a.idx_limit = S;
+    a.upper = c->upper;
+    a.gscale = 2.0f / ((float)n * (float)D);
+    a.training = training ? 1 : 0;
+    a.g = c->g; a.x_hat = c->x_hat; a.dval = c->dval; a.fired = c->fired; a.rowstats = c->rowstats;
+    HIPCHK(c, launch_decode(a, s));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->cfg.alpha, 0, c->upper, c->flags + 2, c->stats, s));
+    return SAEV_OK;
+}
+
+int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_step_dead: no training forward in flight");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, n = c->n_last;
+    DeadArgs d{};
+    d.toks = c->toks; d.fired = c->fired; d.dead = c->dead; d.S = S;
+    d.add_tokens = n_rows_global; d.threshold = c->cfg.dead_threshold_tokens; d.k_aux = c->cfg.k_aux;
+    d.n_dead = c->flags + 3; d.k_use = c->flags + 4; d.stats = c->stats;
+    HIPCHK(c, launch_dead_update(d, s));
+    if (c->cfg.k_aux > 0) {
+        SelectDenseArgs sd{};
+        sd.h = c->h_dense; sd.n_rows = n; sd.S = S; sd.k = c->cfg.k_aux; sd.k_dev = c->flags + 4; sd.mask = c->dead;
+        sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
+        HIPCHK(c, launch_select_dense(sd, s));
+        AuxDecodeArgs a{};
+        a.x = c->x_last; a.x_hat = c->x_hat; a.idx = c->aux_idx; a.val = c->aux_val; a.code_stride = c->cfg.k_aux;
+        a.k_use = c->flags + 4; a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
+        a.n_rows = n; a.D = D; a.gscale = c->cfg.alpha * 2.0f / ((float)n * (float)D);
+        a.g_aux = c->g_aux; a.dval = c->aux_dval; a.rowstats = c->rowstats;
+        HIPCHK(c, launch_aux_decode(a, s));
+        HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
+    }
+    return SAEV_OK;
+}
+
+int saev_step_backward(saev_ctx* c, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_step_backward: no training forward in flight");
+    REQUIRE(c, c->grads, SAEV_NOT_BOUND, "gradient buffer not bound");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
+    const size_t bm_bytes = (size_t)S * c->bitmap_words * sizeof(uint32_t);
+    const int words = (n + 31) / 32;
+
+    auto build = [&](const int32_t* idx, int stride, int k, const int32_t* k_dev) -> int {
+        HIPCHK(c, hipMemsetAsync(c->bitmap, 0, (size_t)S * words * sizeof(uint32_t), s));
+        HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)S * sizeof(int32_t), s));
+        CscArgs a{};
+        a.idx = idx; a.code_stride = stride; a.k = k; a.k_dev = k_dev; a.n_rows = n; a.S = S;
+        a.bitmap = c->bitmap; a.words = words; a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
+        HIPCHK(c, launch_csc_build(a, s));
+        return SAEV_OK;
+    };
+    (void)bm_bytes;
+    int rc = build(c->idx, K, K, nullptr);
+    if (rc != SAEV_OK) return rc;
+    {
+        DwDecArgs a{};
+        a.starts = c->starts; a.pairs = c->pairs; a.coef = c->val; a.coef2 = c->dval; a.rows = c->g;
+        a.D = D; a.S = S; a.accumulate = 0; a.dW = c->grads + c->off_W_dec; a.db = c->grads + c->off_b_enc;
+        HIPCHK(c, launch_dw_dec(a, s));
+        DwEncArgs e{};
+        e.starts = c->starts; e.pairs = c->pairs; e.coef = c->dval; e.rows = c->x_last; e.D = D; e.S = S;
+        e.accumulate = 0; e.dW = c->grads + c->off_W_enc;
+        HIPCHK(c, launch_dw_enc(e, s));
+        HIPCHK(c, launch_colsum(c->g, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s));
+    }
+    if (c->cfg.k_aux > 0) {
+        const int32_t* k_dev = c->flags + 4;
+        rc = build(c->aux_idx, c->cfg.k_aux, c->cfg.k_aux, k_dev);
+        if (rc != SAEV_OK) return rc;
+        DwDecArgs a{};
+        a.starts = c->starts; a.pairs = c->pairs; a.coef = c->aux_val; a.coef2 = c->aux_dval; a.rows = c->g_aux;
+        a.D = D; a.S = S; a.k_dev = k_dev; a.accumulate = 1; a.dW = c->grads + c->off_W_dec;
+        a.db = c->grads + c->off_b_enc;
+        HIPCHK(c, launch_dw_dec(a, s));
+        DwEncArgs e{};
+        e.starts = c->starts; e.pairs = c->pairs; e.coef = c->aux_dval; e.rows = c->x_last; e.D = D; e.S = S;
+        e.k_dev = k_dev; e.accumulate = 1; e.dW = c->grads + c->off_W_enc;
+        HIPCHK(c, launch_dw_enc(e, s));
+        HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, k_dev, s));
+    }
+    return SAEV_OK;
+}
+
+int saev_step_tail(saev_ctx* c, float lr, float max_norm, float grad_scale, int64_t adam_step, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params && c->grads && c->adam_m && c->adam_v, SAEV_NOT_BOUND,
+            "saev_step_tail: params/grads/adam state not bound");
+    REQUIRE(c, adam_step >= 1, SAEV_INVALID_ARG, "adam_step is 1-based");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = saev_remove_parallel_grads(c, stream);
+    if (rc != SAEV_OK) return rc;
+    HIPCHK(c, launch_sumsq(c->grads, c->n_params, c->sumsq_partials, c->sumsq_total, s));
+    AdamArgs a{};
+    a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = c->n_params;
+    a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
+    a.bc1 = (float)(1.0 - std::pow(0.9, (double)adam_step));
+    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, (double)adam_step));
+    a.grad_scale = grad_scale; a.max_norm = max_norm; a.sumsq = c->sumsq_total; a.stats = c->stats;
+    HIPCHK(c, launch_adam(a, s));
+    return SAEV_OK;
+}
+
+int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_norm, int64_t adam_step,
+                    void* stream) {
+    int rc = saev_step_forward(c, x, n, n, 1, stream);
+    if (rc != SAEV_OK) return rc;
+    rc = saev_step_dead(c, n, stream);
+    if (rc != SAEV_OK) return rc;
+    rc = saev_step_backward(c, stream);
+    if (rc != SAEV_OK) return rc;
+    return saev_step_tail(c, lr, max_norm, 1.0f, adam_step, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// Internal launch interface between ctx.hip (the C ABI) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/saev_amd.h"
+
+enum { EPI_DENSE = 0, EPI_TOPK = 1 };
+
+struct EncodeArgs {
+    const float* x;       // (n_rows, D)
+    const float* W_enc;   // (D, S)
+    const float* b_enc;   // (S)
+    int n_rows, D, S;
+    int s_splits;         // latent ranges per batch block (grid = n_bblocks * s_splits)
+    // EPI_DENSE
+    float* h_out;         // (n_rows, S)
+    // EPI_TOPK
+    int ngroups;          // 32 or 64, >= top_k
+    int32_t* row_tau;     // (n_rows) ordered-int keys, init INT32_MIN
+    int32_t* cand_cnt;    // (n_rows) init 0
+    float* cand_val;      // (n_rows, cand_cap)
+    int32_t* cand_idx;    // (n_rows, cand_cap)
+    int cand_cap;
+    // optional device-side predicate: run only when (*enable_flag != 0) == enable_when
+    const int32_t* enable_flag;
+    int enable_when;
+};
+
+size_t encode_gemm_smem_bytes();
+hipError_t launch_encode_gemm(const EncodeArgs& a, int epi, hipStream_t stream);
+
+struct SelectDenseArgs {
+    const float* h;        // (n_rows, S)
+    int n_rows, S;
+    int k;                 // host-side k (upper bound when k_dev != NULL)
+    const int32_t* k_dev;  // optional device-side k (AuxK: min(k_aux, n_dead)); <= 0 -> kernel exits
+    const int32_t* mask;   // optional (S) int32; only latents with mask != 0 are eligible
+    int32_t* idx_out;      // (n_rows, out_stride)
+    float* val_out;
+    int out_stride;
+    const int32_t* enable_flag;
+    int enable_when;
+};
+hipError_t launch_select_dense(const SelectDenseArgs& a, hipStream_t stream);
+
+struct SelectCandArgs {
+    const int32_t* cand_cnt;
+    const float* cand_val;
+    const int32_t* cand_idx;
+    int cand_cap, n_rows, k;
+    int32_t* idx_out;
+    float* val_out;
+    int out_stride;
+    const int32_t* enable_flag;
+    int enable_when;
+};
+hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
+hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
+hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
+                                 int32_t* need_dense, int32_t* n_overflow, hipStream_t stream);
+
+// per-row statistics produced by the decode kernels (reduced by stats_reduce)
+struct __attribute__((aligned(8))) RowStats {
+    float sse_scaled;  // sum_d ((x_hat/u - x/u)^2 * u * u)      objectives.py:227-237
+    float l0;          // count(val != 0)                         objectives.py:150
+    float l1;          // sum |val|                               objectives.py:151
+    float aux_sse;     // sum_d (aux_recon - residual)^2          modeling.py:103
+    double sse64;      // sum_d (x - x_hat)^2 in fp64             train.py:398-401
+    double sumsq64;    // sum_d x^2 in fp64                       train.py:383
+};
+
+struct DecodeArgs {
+    const float* x;         // (n_rows, D)
+    const int32_t* idx;     // (n_rows, code_stride) ascending, -1 padded
+    const float* val;
+    int code_stride, k;
+    const float* W_dec;     // (S, D)
+    const float* b_dec;     // (D)
+    int n_rows, D, S;
+    int idx_limit;          // only latents < idx_limit contribute (Matryoshka prefix); S = all
+    const float* upper;     // device scalar max|x|
+    float gscale;           // 2 / (n_rows * D)
+    int training;           // write g/dval/fired
+    float* g;               // (n_rows, D)   d loss / d x_hat
+    float* x_hat;           // (n_rows, D) or NULL
+    float* dval;            // (n_rows, code_stride)
+    int32_t* fired;         // (S)
+    RowStats* rowstats;     // (n_rows) or NULL
+};
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
+
+struct AuxDecodeArgs {
+    const float* x;         // (n_rows, D)
+    const float* x_hat;     // (n_rows, D) main reconstruction (detached target = x - x_hat)
+    const int32_t* idx;     // (n_rows, code_stride) aux codes
+    const float* val;
+    int code_stride;
+    const int32_t* k_use;   // device: min(k_aux, n_dead); 0 -> kernel exits
+    const float* W_dec;
+    const float* b_dec;
+    int n_rows, D;
+    float gscale;           // alpha * 2 / (n_rows * D)
+    float* g_aux;           // (n_rows, D)
+    float* dval;            // (n_rows, code_stride)
+    RowStats* rowstats;
+};
+hipError_t launch_aux_decode(const AuxDecodeArgs& a, hipStream_t stream);
+
+// CSC (latent-major) view of the codes, built deterministically through a (S x n_rows)-bit map.
+struct CscArgs {
+    const int32_t* idx;     // (n_rows, code_stride)
+    int code_stride, k;     // k = host upper bound of codes per row
+    const int32_t* k_dev;   // optional device-side count (aux); <= 0 -> kernels exit
+    int n_rows, S;
+    uint32_t* bitmap;       // (S, words) zeroed by the caller
+    int words;              // ceil(n_rows / 32)
+    int32_t* counts;        // (S) zeroed by the caller
+    int32_t* starts;        // (S + 1)
+    int2* pairs;            // (n_rows * k) -> {row b, flat code position b*code_stride + j}
+};
+hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream);
+
+struct DwDecArgs {
+    const int32_t* starts;  // (S + 1)
+    const int2* pairs;
+    const float* coef;      // val, indexed by pairs[].y
+    const float* coef2;     // dval (for db_enc), indexed by pairs[].y; may be NULL
+    const float* rows;      // g (n_rows, D)
+    int D, S;
+    const int32_t* k_dev;   // optional predicate (aux)
+    int accumulate;
+    float* dW;              // (S, D)
+    float* db;              // (S) db_enc or NULL
+};
+hipError_t launch_dw_dec(const DwDecArgs& a, hipStream_t stream);
+
+struct DwEncArgs {
+    const int32_t* starts;
+    const int2* pairs;
+    const float* coef;      // dval
+    const float* rows;      // x (n_rows, D)
+    int D, S;
+    const int32_t* k_dev;
+    int accumulate;
+    float* dW;              // (D, S)  -- latent is the fast axis
+};
+hipError_t launch_dw_enc(const DwEncArgs& a, hipStream_t stream);
+
+// out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats
+hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
+                         const int32_t* k_dev, hipStream_t stream);
+
+// ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
+hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream);
+hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream);
+// total[0] = sum of squares of g[0..n) (deterministic two-stage; `partials` >= 1024 floats... doubles)
+hipError_t launch_sumsq(const float* g, long n, double* partials, double* total, hipStream_t stream);
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    long n;
+    float lr, beta1, beta2, eps, bc1, bc2_sqrt;  // bias corrections for this step
+    float grad_scale;       // applied to g before everything else (1/world_size)
+    float max_norm;         // <= 0 disables clipping
+    const double* sumsq;    // device: sum of squares of the *unscaled* grads
+    saev_step_stats* stats; // grad_norm written here by block 0
+};
+hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
+
+struct DeadArgs {
+    int64_t* toks;          // (S)
+    int32_t* fired;         // (S) consumed and reset to 0
+    int32_t* dead;          // (S) out: 1 if dead this step
+    int S;
+    int64_t add_tokens, threshold;
+    int k_aux;
+    int32_t* n_dead;        // device scalar out
+    int32_t* k_use;         // device scalar out: min(k_aux, n_dead)
+    saev_step_stats* stats;
+};
+hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream);
+// flag = any(toks[i] + add_tokens >= threshold)
+hipError_t launch_predead_flag(const int64_t* toks, int S, int64_t add_tokens, int64_t threshold, int32_t* flag,
+                               hipStream_t stream);
+hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream);
+hipError_t launch_gather_rows(const float* pool, const int64_t* rows, int n_rows, int D, float* out, hipStream_t stream);
+hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows, int k, int stride, int S, float* f,
+                                hipStream_t stream);
+// reduce rowstats[0..n_rows) into *stats (mse, l0, l1, aux, sse, sum_sq)
+hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, float alpha, int with_aux, const float* upper,
+                               const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream);

@@ -1,0 +1,299 @@
+// Exact per-row top-k selection (modeling.py:169-179: torch.topk(h, k, sorted=False) + scatter).
+//
+//   select_dense_kernel : one workgroup per row of a dense (n_rows x S) matrix; 4-pass MSB radix
+//                         select (8 bits per pass, LDS histogram) on order-preserving uint keys,
+//                         then an index-ordered compaction.  Optional latent mask (AuxK: dead only)
+//                         and device-side k (AuxK: min(k_aux, n_dead)).
+//   select_cand_kernel  : one wave per row over the short candidate list the fused encoder left
+//                         behind; bitwise threshold search in registers, ties broken towards the
+//                         smaller latent index, output ordered by latent index.
+//
+// Both emit exactly k (idx, val) pairs per row in ascending idx order (deterministic, and what the
+// sparse backward's binary search relies on).  Ties on the k-th value: lowest indices win ("any k"
+// is acceptable to the reference: tests/test_nn_activations.py:41-52).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int SD_THREADS = 256;
+
+__device__ __forceinline__ int block_excl_scan_256(int v, int* lds_wave_tot, int& total) {
+    // exclusive scan of one int per thread over 256 threads (4 waves)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) lds_wave_tot[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = lds_wave_tot[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(SD_THREADS) void select_dense_kernel(SelectDenseArgs a) {
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+    __shared__ int hist[256];
+    __shared__ int sh_digit, sh_need;
+    __shared__ int wave_tot[4];
+
+    const int row = blockIdx.x;
+    const int S = a.S;
+    int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
+    if (a.k_dev && k <= 0) return;
+    const float* h = a.h + (size_t)row * S;
+    const int tid = threadIdx.x;
+    const int S4 = S >> 2;
+
+    // number of eligible elements (mask) bounds k
+    // (without a mask, k <= S is enforced by the host)
+    uint32_t prefix = 0, pmask = 0;
+    int need = k;
+
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int q = tid; q < S4; q += SD_THREADS) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(h + 4 * q);
+            int4 mk = {1, 1, 1, 1};
+            if (a.mask) mk = *reinterpret_cast<const int4*>(a.mask + 4 * q);
+            const int m[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t key = f2ukey(v[e]);
+                if (m[e] != 0 && (key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins 4l..4l+3; suffix sums from the top
+            const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const int c = c0 + c1 + c2 + c3;
+            int suf = c;  // inclusive suffix sum over lanes >= tid
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int n = __shfl_down(suf, o, 64);
+                if (tid + o < 64) suf += n;
+            }
+            const unsigned long long ge = __ballot(suf >= need);
+            const int L = 63 - __builtin_clzll(ge | 1ull);  // highest lane whose suffix reaches `need`
+            if (tid == L) {
+                int running = suf - c;  // elements in bins above this lane's
+                const int cs[4] = {c0, c1, c2, c3};
+                int d = 4 * tid, nn = need;
+                for (int j = 3; j >= 0; --j) {
+                    if (running + cs[j] >= need) { d = 4 * tid + j; nn = need - running; break; }
+                    running += cs[j];
+                }
+                sh_digit = d;
+                sh_need = nn;
+            }
+        }
+        __syncthreads();
+        prefix |= (uint32_t)sh_digit << shift;
+        pmask |= 0xFFu << shift;
+        need = sh_need;
+        __syncthreads();
+    }
+    // prefix == key of the k-th largest; take all keys > prefix and the first `need` equal keys.
+    const uint32_t T = prefix;
+    int base_gt = 0, base_eq = 0;
+    int32_t* oi = a.idx_out + (size_t)row * a.out_stride;
+    float* ov = a.val_out + (size_t)row * a.out_stride;
+    for (int q0 = 0; q0 < S4; q0 += SD_THREADS) {
+        const int q = q0 + tid;
+        f32x4 v = {0, 0, 0, 0};
+        int flg[4] = {0, 0, 0, 0}, feq[4] = {0, 0, 0, 0};
+        if (q < S4) {
+            v = *reinterpret_cast<const f32x4*>(h + 4 * q);
+            int4 mk = {1, 1, 1, 1};
+            if (a.mask) mk = *reinterpret_cast<const int4*>(a.mask + 4 * q);
+            const int m[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t key = f2ukey(v[e]);
+                flg[e] = (m[e] != 0 && key > T);
+                feq[e] = (m[e] != 0 && key == T);
+            }
+        }
+        const int ngt = flg[0] + flg[1] + flg[2] + flg[3];
+        const int neq = feq[0] + feq[1] + feq[2] + feq[3];
+        int tot;
+        const int ex = block_excl_scan_256(ngt | (neq << 16), wave_tot, tot);
+        int gt_before = base_gt + (ex & 0xFFFF);
+        int eq_before = base_eq + (ex >> 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (flg[e]) {
+                const int pos = gt_before + min(eq_before, need);
+                oi[pos] = 4 * q + e;
+                ov[pos] = v[e];
+                ++gt_before;
+            } else if (feq[e]) {
+                if (eq_before < need) {
+                    const int pos = gt_before + eq_before;
+                    oi[pos] = 4 * q + e;
+                    ov[pos] = v[e];
+                }
+                ++eq_before;
+            }
+        }
+        base_gt += tot & 0xFFFF;
+        base_eq += tot >> 16;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+template <int EPL>  // elements per lane; list capacity = 64*EPL
+__global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+    __shared__ int32_t s_idx[4][64];
+    __shared__ float s_val[4][64];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= a.n_rows) return;
+    const int n = min(a.cand_cnt[row], a.cand_cap);
+    const int k = min(a.k, n);
+    const float* cv = a.cand_val + (size_t)row * a.cand_cap;
+    const int32_t* ci = a.cand_idx + (size_t)row * a.cand_cap;
+
+    uint32_t key[EPL];
+    int32_t idx[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int p = e * 64 + lane;
+        if (p < n) { key[e] = f2ukey(cv[p]); idx[e] = ci[p]; }
+        else { key[e] = 0u; idx[e] = 0x7fffffff; }  // key 0 sorts below every real float key
+    }
+    // largest T with count(key >= T) >= k
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = T | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) c += (key[e] >= trial);
+        c = wave_sum_i(c);
+        if (c >= k) T = trial;
+    }
+    int cgt = 0, ceq = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { cgt += (key[e] > T); ceq += (key[e] == T); }
+    cgt = wave_sum_i(cgt);
+    ceq = wave_sum_i(ceq);
+    const int need = k - cgt;  // ties to keep (>= 1 when k > 0)
+    int32_t idx_cut = 0x7fffffff;  // keep ties with idx <= idx_cut
+    if (ceq > need) {
+        // largest X with count(tie && idx < X) < need; latent indices are distinct, so
+        // count(tie && idx <= X) == need exactly.
+        int32_t X = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+            const int32_t trial = X | (1 << bit);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) c += (key[e] == T && idx[e] < trial);
+            c = wave_sum_i(c);
+            if (c < need) X = trial;
+        }
+        idx_cut = X;
+    }
+    // compact the k winners into one element per lane (k <= 64)
+    s_idx[w][lane] = 0x7fffffff;
+    s_val[w][lane] = 0.f;
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const bool sel = (key[e] > T) || (key[e] == T && idx[e] <= idx_cut);
+        const unsigned long long m = __ballot(sel);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (sel && pos < 64) { s_idx[w][pos] = idx[e]; s_val[w][pos] = ukey2f(key[e]); }
+        base += __popcll(m);
+    }
+    int32_t my_idx = s_idx[w][lane];
+    float my_val = s_val[w][lane];
+    // bitonic sort of 64 lanes by idx ascending (unused lanes carry INT_MAX and end up last)
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int32_t o_idx = __shfl_xor(my_idx, stride, 64);
+            const float o_val = __shfl_xor(my_val, stride, 64);
+            const bool up = ((lane & size) == 0);          // ascending block
+            const bool lower = ((lane & stride) == 0);     // this lane keeps the smaller one (if up)
+            const bool take_other = (lower == up) ? (o_idx < my_idx) : (o_idx > my_idx);
+            if (take_other) { my_idx = o_idx; my_val = o_val; }
+        }
+    }
+    if (lane < a.k) {
+        const bool ok = lane < k;
+        a.idx_out[(size_t)row * a.out_stride + lane] = ok ? my_idx : -1;
+        a.val_out[(size_t)row * a.out_stride + lane] = ok ? my_val : 0.f;
+    }
+}
+
+__global__ void init_i32_kernel(int32_t* p, int32_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// need_dense = pre_flag || any(cand_cnt > cap); also counts overflowing rows
+__global__ void overflow_check_kernel(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
+                                      int32_t* need_dense, int32_t* n_overflow) {
+    __shared__ int sh;
+    if (threadIdx.x == 0) sh = 0;
+    __syncthreads();
+    int c = 0;
+    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) c += (cand_cnt[i] > cap);
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&sh, c);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *n_overflow = sh;
+        *need_dense = ((pre_flag && *pre_flag) || sh > 0) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_select_dense(const SelectDenseArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(select_dense_kernel, dim3(a.n_rows), dim3(SD_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    dim3 grid((a.n_rows + 3) / 4), block(256);
+    if (a.cand_cap <= 512)
+        hipLaunchKernelGGL(select_cand_kernel<8>, grid, block, 0, stream, a);
+    else if (a.cand_cap <= 1024)
+        hipLaunchKernelGGL(select_cand_kernel<16>, grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL(select_cand_kernel<32>, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(init_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
+                                 int32_t* need_dense, int32_t* n_overflow, hipStream_t stream) {
+    hipLaunchKernelGGL(overflow_check_kernel, dim3(1), dim3(1024), 0, stream, cand_cnt, n_rows, cap, pre_flag,
+                       need_dense, n_overflow);
+    return hipGetLastError();
+}

@@ -1,0 +1,467 @@
+// The k-sparse half of the step: everything the reference does with dense (B,S) x (S,D) GEMMs on a
+// matrix that has k non-zeros per row (modeling.py:351-409 decode; autograd backward of it,
+// train.py:347-348) done as index-gathered row operations.
+//
+//   decode_kernel     x_hat = b_dec + sum_j val_j W_dec[idx_j]; scaled MSE (objectives.py:223-237);
+//                     g = dL/dx_hat; dval_j = <W_dec[idx_j], g>; fired flags; per-row stats.
+//   aux_decode_kernel AuxK reconstruction of the detached residual (modeling.py:89-103).
+//   csc_*             latent-major ordering of the (row, latent) pairs, deterministic (row-ascending
+//                     inside a latent) via an S x B bit map: atomicOr fill, per-latent enumeration.
+//   dw_dec_kernel     dW_dec[i,:] = sum_{b in latent i} val * g[b,:]   (+ db_enc[i] = sum dval)
+//   dw_enc_kernel     dW_enc[:,i] = sum_{b in latent i} dval * x[b,:]  (32 latents per workgroup,
+//                     transposed through LDS so global stores are 128-byte rows of the (D,S) matrix)
+//   colsum            db_dec = sum_b g[b,:]
+//
+// One wave owns one activation row / one latent; lanes stride the d_model axis in float4s.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int NV>
+__device__ __forceinline__ void gather_rows_accum(f32x4 (&acc)[NV], const float* __restrict__ W, int D, int D4,
+                                                  const int32_t* idx_row, const float* val_row, int k, int limit,
+                                                  int lane) {
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int cnt = min(64, k - j0);
+        int32_t my_i = -1;
+        float my_v = 0.f;
+        if (lane < cnt) { my_i = idx_row[j0 + lane]; my_v = val_row[j0 + lane]; }
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int32_t i = __shfl(my_i, jj, 64);
+            const float v = __shfl(my_v, jj, 64);
+            if (i < 0 || i >= limit) continue;
+            const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                if (q < D4) {
+                    const f32x4 w = wr[q];
+                    acc[n] += v * w;
+                }
+            }
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void row_dots(const f32x4 (&g)[NV], const float* __restrict__ W, int D, int D4,
+                                         const int32_t* idx_row, float* dval_row, int k, int limit, int lane) {
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int cnt = min(64, k - j0);
+        int32_t my_i = -1;
+        if (lane < cnt) my_i = idx_row[j0 + lane];
+        float my_d = 0.f;
+#pragma unroll 2
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int32_t i = __shfl(my_i, jj, 64);
+            if (i < 0 || i >= limit) continue;
+            const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
+            float p = 0.f;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                if (q < D4) {
+                    const f32x4 w = wr[q];
+                    p += w[0] * g[n][0] + w[1] * g[n][1] + w[2] * g[n][2] + w[3] * g[n][3];
+                }
+            }
+            p = wave_sum(p);
+            if (lane == jj) my_d = p;
+        }
+        if (lane < cnt) dval_row[j0 + lane] = my_d;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int D = a.D, D4 = D >> 2;
+    const int32_t* idx_row = a.idx + (size_t)row * a.code_stride;
+    const float* val_row = a.val + (size_t)row * a.code_stride;
+
+    f32x4 acc[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        acc[n] = (q < D4) ? reinterpret_cast<const f32x4*>(a.b_dec)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    gather_rows_accum<NV>(acc, a.W_dec, D, D4, idx_row, val_row, a.k, a.idx_limit, lane);
+
+    if (a.x == nullptr) {  // reconstruction only (API decode)
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) reinterpret_cast<f32x4*>(a.x_hat + (size_t)row * D)[q] = acc[n];
+        }
+        return;
+    }
+    const float u = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
+    float sse_scaled = 0.f;
+    double sse64 = 0.0, sumsq64 = 0.0;
+    f32x4 g[NV];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(a.x + (size_t)row * D);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        g[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < D4) {
+            const f32x4 xv = xr[q];
+            if (a.x_hat) reinterpret_cast<f32x4*>(a.x_hat + (size_t)row * D)[q] = acc[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = acc[n][e] / u - xv[e] / u;
+                sse_scaled += t * t * u * u;
+                g[n][e] = a.gscale * t * u;
+                const float r = xv[e] - acc[n][e];
+                sse64 += (double)r * (double)r;
+                sumsq64 += (double)xv[e] * (double)xv[e];
+            }
+            if (a.training) reinterpret_cast<f32x4*>(a.g + (size_t)row * D)[q] = g[n];
+        }
+    }
+    if (a.training) {
+        row_dots<NV>(g, a.W_dec, D, D4, idx_row, a.dval + (size_t)row * a.code_stride, a.k, a.idx_limit, lane);
+    }
+    // code statistics + fired flags
+    float l0 = 0.f, l1 = 0.f;
+    for (int j = lane; j < a.k; j += 64) {
+        const int32_t i = idx_row[j];
+        const float v = val_row[j];
+        if (i >= 0 && v != 0.f) {
+            l0 += 1.f;
+            l1 += fabsf(v);
+            if (a.training && a.fired) a.fired[i] = 1;
+        }
+    }
+    if (a.rowstats) {
+        sse_scaled = wave_sum(sse_scaled);
+        l0 = wave_sum(l0);
+        l1 = wave_sum(l1);
+        sse64 = wave_sum_d(sse64);
+        sumsq64 = wave_sum_d(sumsq64);
+        if (lane == 0) {
+            RowStats rs;
+            rs.sse_scaled = sse_scaled; rs.l0 = l0; rs.l1 = l1; rs.aux_sse = 0.f;
+            rs.sse64 = sse64; rs.sumsq64 = sumsq64;
+            a.rowstats[row] = rs;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void aux_decode_kernel(AuxDecodeArgs a) {
+    const int k = *a.k_use;
+    if (k <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int D = a.D, D4 = D >> 2;
+    const int32_t* idx_row = a.idx + (size_t)row * a.code_stride;
+    const float* val_row = a.val + (size_t)row * a.code_stride;
+    f32x4 acc[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        acc[n] = (q < D4) ? reinterpret_cast<const f32x4*>(a.b_dec)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    gather_rows_accum<NV>(acc, a.W_dec, D, D4, idx_row, val_row, k, 0x7fffffff, lane);
+    float sse = 0.f;
+    f32x4 g[NV];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(a.x + (size_t)row * D);
+    const f32x4* hr = reinterpret_cast<const f32x4*>(a.x_hat + (size_t)row * D);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        g[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < D4) {
+            const f32x4 xv = xr[q], hv = hr[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float resid = xv[e] - hv[e];
+                const float diff = acc[n][e] - resid;
+                sse += diff * diff;
+                g[n][e] = a.gscale * diff;
+            }
+            reinterpret_cast<f32x4*>(a.g_aux + (size_t)row * D)[q] = g[n];
+        }
+    }
+    row_dots<NV>(g, a.W_dec, D, D4, idx_row, a.dval + (size_t)row * a.code_stride, k, 0x7fffffff, lane);
+    sse = wave_sum(sse);
+    if (lane == 0) a.rowstats[row].aux_sse = sse;
+}
+
+// ------------------------------- CSC build -------------------------------------------------
+
+__global__ void csc_fill_kernel(CscArgs a) {
+    const int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
+    if (k <= 0) return;
+    const long n = (long)a.n_rows * k;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(p / k), j = (int)(p % k);
+        const int32_t i = a.idx[(size_t)b * a.code_stride + j];
+        if (i >= 0 && i < a.S) {
+            atomicOr(&a.bitmap[(size_t)i * a.words + (b >> 5)], 1u << (b & 31));
+            atomicAdd(&a.counts[i], 1);
+        }
+    }
+}
+
+// exclusive scan of counts[0..S) -> starts[0..S]; single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void csc_scan_kernel(CscArgs a) {
+    if (a.k_dev && *a.k_dev <= 0) return;
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.S; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < a.S) ? a.counts[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        if (lane == 63) wave_tot[w] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int j = 0; j < w; ++j) off += wave_tot[j];
+        if (i < a.S) a.starts[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) a.starts[a.S] = carry;
+}
+
+// one wave per latent: enumerate the set bits of its bitmap row in ascending row order, look the
+// latent up in that row's (ascending) code list, emit {row, flat position}.
+__global__ __launch_bounds__(256) void csc_emit_kernel(CscArgs a) {
+    const int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
+    if (k <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.S) return;
+    const int total = a.counts[i];
+    if (total == 0) return;
+    int out = a.starts[i];
+    const uint32_t* bm = a.bitmap + (size_t)i * a.words;
+    for (int w0 = 0; w0 < a.words; w0 += 64) {
+        uint32_t word = (w0 + lane < a.words) ? bm[w0 + lane] : 0u;
+        const int c = __popc(word);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        const int chunk_total = __shfl(incl, 63, 64);
+        if (chunk_total == 0) continue;
+        int pos = out + incl - c;
+        while (word) {
+            const int bit = __ffs(word) - 1;
+            word &= word - 1;
+            const int b = (w0 + lane) * 32 + bit;
+            // binary search for latent i in row b's ascending code list [0, k)
+            const int32_t* r = a.idx + (size_t)b * a.code_stride;
+            int lo = 0, hi = k - 1, j = 0;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const int32_t v = r[mid];
+                if (v == i) { j = mid; break; }
+                if (v < i && v >= 0) lo = mid + 1; else hi = mid - 1;
+            }
+            a.pairs[pos] = int2{b, (int)((size_t)b * a.code_stride + j)};
+            ++pos;
+        }
+        out += chunk_total;
+    }
+}
+
+// ------------------------------- weight gradients ------------------------------------------
+
+template <int NV>
+__global__ __launch_bounds__(256) void dw_dec_kernel(DwDecArgs a) {
+    if (a.k_dev && *a.k_dev <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.S) return;
+    const int D = a.D, D4 = D >> 2;
+    const int beg = a.starts[i], end = a.starts[i + 1];
+    f32x4 acc[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbsum = 0.f;
+    for (int p0 = beg; p0 < end; p0 += 64) {
+        const int cnt = min(64, end - p0);
+        int my_b = 0;
+        float my_c = 0.f;
+        if (lane < cnt) {
+            const int2 pr = a.pairs[p0 + lane];
+            my_b = pr.x;
+            my_c = a.coef[pr.y];
+            if (a.coef2) dbsum += a.coef2[pr.y];
+        }
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int b = __shfl(my_b, jj, 64);
+            const float c = __shfl(my_c, jj, 64);
+            const f32x4* gr = reinterpret_cast<const f32x4*>(a.rows + (size_t)b * D);
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                if (q < D4) acc[n] += c * gr[q];
+            }
+        }
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(a.dW + (size_t)i * D);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        if (q < D4) o[q] = a.accumulate ? (o[q] + acc[n]) : acc[n];
+    }
+    if (a.db) {
+        // lanes hold partial sums in segment order; fixed-shape tree => deterministic
+        dbsum = wave_sum(dbsum);
+        if (lane == 0) a.db[i] = a.accumulate ? (a.db[i] + dbsum) : dbsum;
+    }
+}
+
+constexpr int ENC_LAT = 32;    // latents per workgroup
+constexpr int ENC_DCH = 256;   // d_model columns per workgroup
+
+__global__ __launch_bounds__(256) void dw_enc_kernel(DwEncArgs a) {
+    if (a.k_dev && *a.k_dev <= 0) return;
+    __shared__ float tile[ENC_LAT][ENC_DCH + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * ENC_LAT;
+    const int d0 = blockIdx.y * ENC_DCH;
+    const int D = a.D;
+    const int dq = d0 + 4 * lane;  // this lane's 4 columns
+    const bool dok = dq < D;
+    for (int t = 0; t < ENC_LAT / 4; ++t) {
+        const int il = w * (ENC_LAT / 4) + t;
+        const int i = i0 + il;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (i < a.S) {
+            const int beg = a.starts[i], end = a.starts[i + 1];
+            for (int p0 = beg; p0 < end; p0 += 64) {
+                const int cnt = min(64, end - p0);
+                int my_b = 0;
+                float my_c = 0.f;
+                if (lane < cnt) {
+                    const int2 pr = a.pairs[p0 + lane];
+                    my_b = pr.x;
+                    my_c = a.coef[pr.y];
+                }
+#pragma unroll 4
+                for (int jj = 0; jj < cnt; ++jj) {
+                    const int b = __shfl(my_b, jj, 64);
+                    const float c = __shfl(my_c, jj, 64);
+                    if (dok) acc += c * *reinterpret_cast<const f32x4*>(a.rows + (size_t)b * D + dq);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[il][4 * lane + e] = acc[e];
+    }
+    __syncthreads();
+    // transposed store: 32 consecutive threads write 32 consecutive latents of one d row
+    const int il = threadIdx.x & 31;
+    const int i = i0 + il;
+    for (int dl = threadIdx.x >> 5; dl < ENC_DCH; dl += 8) {
+        const int d = d0 + dl;
+        if (d < D && i < a.S) {
+            float* o = a.dW + (size_t)d * a.S + i;
+            const float v = tile[il][dl];
+            *o = a.accumulate ? (*o + v) : v;
+        }
+    }
+}
+
+// ------------------------------- column sums -----------------------------------------------
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int n_rows, int D, float* partials,
+                                                             const int32_t* k_dev) {
+    if (k_dev && *k_dev <= 0) return;
+    const int r0 = blockIdx.x * 64;
+    const int r1 = min(n_rows, r0 + 64);
+    for (int q = threadIdx.x; q < (D >> 2); q += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int r = r0; r < r1; ++r) s += reinterpret_cast<const f32x4*>(m + (size_t)r * D)[q];
+        reinterpret_cast<f32x4*>(partials + (size_t)blockIdx.x * D)[q] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partials, int n_blocks, int D, float* out,
+                                                           int accumulate, const int32_t* k_dev) {
+    if (k_dev && *k_dev <= 0) return;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f;
+    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * D + d];
+    out[d] = accumulate ? out[d] + s : s;
+}
+
+template <typename F>
+hipError_t dispatch_nv(int D, F&& f) {
+    const int nv = (D / 4 + 63) / 64;
+    switch (nv) {
+        case 1: f(std::integral_constant<int, 1>()); break;
+        case 2: f(std::integral_constant<int, 2>()); break;
+        case 3: f(std::integral_constant<int, 3>()); break;
+        case 4: f(std::integral_constant<int, 4>()); break;
+        case 5: f(std::integral_constant<int, 5>()); break;
+        case 6: f(std::integral_constant<int, 6>()); break;
+        case 7: case 8: f(std::integral_constant<int, 8>()); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    return dispatch_nv(a.D, [&](auto nv) {
+        hipLaunchKernelGGL(decode_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
+    });
+}
+hipError_t launch_aux_decode(const AuxDecodeArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    return dispatch_nv(a.D, [&](auto nv) {
+        hipLaunchKernelGGL(aux_decode_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
+    });
+}
+hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    const long n = (long)a.n_rows * a.k;
+    const int blocks = (int)std::min<long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(csc_emit_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_dw_dec(const DwDecArgs& a, hipStream_t stream) {
+    return dispatch_nv(a.D, [&](auto nv) {
+        hipLaunchKernelGGL(dw_dec_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+    });
+}
+hipError_t launch_dw_enc(const DwEncArgs& a, hipStream_t stream) {
+    dim3 grid((a.S + ENC_LAT - 1) / ENC_LAT, (a.D + ENC_DCH - 1) / ENC_DCH);
+    hipLaunchKernelGGL(dw_enc_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
+                         const int32_t* k_dev, hipStream_t stream) {
+    const int nb = (n_rows + 63) / 64;
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, partials, nb, D, out,
+                       accumulate, k_dev);
+    return hipGetLastError();
+}

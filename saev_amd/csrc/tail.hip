@@ -1,0 +1,307 @@
+// HBM-bound streaming kernels of the step: decoder-row renormalisation (modeling.py:411-417),
+// parallel-gradient removal (modeling.py:419-445), global gradient norm + clip (train.py:356-362),
+// fused Adam (train.py:294,444-446), the dead-latent tracker (objectives.py:107-120), and the small
+// reductions around them.  All are one pass over their operands with 16-byte accesses.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int NV>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, int D) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= S) return;
+    const int D4 = D >> 2;
+    f32x4* r = reinterpret_cast<f32x4*>(W + (size_t)i * D);
+    f32x4 v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        v[n] = (q < D4) ? r[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        ss += v[n][0] * v[n][0] + v[n][1] * v[n][1] + v[n][2] * v[n][2] + v[n][3] * v[n][3];
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        if (q < D4) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[n][e] / nrm;
+            r[q] = o;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void rpg_kernel(float* gW, const float* W, int S, int D) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= S) return;
+    const int D4 = D >> 2;
+    f32x4* gr = reinterpret_cast<f32x4*>(gW + (size_t)i * D);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
+    f32x4 g[NV], w[NV];
+    float dot = 0.f, nsq = 0.f;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        const bool ok = q < D4;
+        g[n] = ok ? gr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        w[n] = ok ? wr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dot += g[n][e] * w[n][e]; nsq += w[n][e] * w[n][e]; }
+    }
+    dot = wave_sum(dot);
+    nsq = wave_sum(nsq);
+    if (!(nsq > 0.f)) return;
+    const float sc = dot / nsq;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        if (q < D4) gr[q] = g[n] - sc * w[n];
+    }
+}
+
+constexpr int SUMSQ_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, double* partials) {
+    __shared__ double sh[4];
+    const long n4 = n >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(g)[q];
+        s0 += v[0] * v[0]; s1 += v[1] * v[1]; s2 += v[2] * v[2]; s3 += v[3] * v[3];
+    }
+    double s = (double)s0 + (double)s1 + (double)s2 + (double)s3;
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += (double)g[i] * (double)g[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* partials, int nb, double* total) {
+    __shared__ double sh[16];
+    double s = (threadIdx.x < nb) ? partials[threadIdx.x] : 0.0;
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += sh[i];
+        *total = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    // clip coefficient from the global norm of the (scaled) gradient; torch semantics
+    const float norm = a.grad_scale * (float)sqrt(*a.sumsq);
+    float coef = 1.f;
+    if (a.max_norm > 0.f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.stats) a.stats->grad_norm = norm;
+    const float gs = a.grad_scale * coef;
+    const float step_size = a.lr / a.bc1;
+    const long n4 = a.n >> 2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        f32x4 p = reinterpret_cast<f32x4*>(a.p)[q];
+        const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[q];
+        f32x4 m = reinterpret_cast<f32x4*>(a.m)[q];
+        f32x4 v = reinterpret_cast<f32x4*>(a.v)[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = g[e] * gs;
+            m[e] = m[e] + (ge - m[e]) * (1.f - a.beta1);
+            v[e] = a.beta2 * v[e] + (1.f - a.beta2) * ge * ge;
+            const float denom = sqrtf(v[e]) / a.bc2_sqrt + a.eps;
+            p[e] -= step_size * (m[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(a.p)[q] = p;
+        reinterpret_cast<f32x4*>(a.m)[q] = m;
+        reinterpret_cast<f32x4*>(a.v)[q] = v;
+    }
+    if (blockIdx.x == 0) {
+        for (long i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) {
+            const float ge = a.g[i] * gs;
+            const float m = a.m[i] + (ge - a.m[i]) * (1.f - a.beta1);
+            const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * ge * ge;
+            a.m[i] = m; a.v[i] = v;
+            a.p[i] -= step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void dead_update_kernel(DeadArgs a) {
+    __shared__ int sh[16];
+    int c = 0;
+    for (int i = threadIdx.x; i < a.S; i += 1024) {
+        int64_t t = a.toks[i] + a.add_tokens;
+        if (a.fired[i]) t = 0;
+        a.fired[i] = 0;
+        a.toks[i] = t;
+        const int d = (t >= a.threshold) ? 1 : 0;
+        a.dead[i] = d;
+        c += d;
+    }
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < 16; ++i) t += sh[i];
+        *a.n_dead = t;
+        *a.k_use = min(a.k_aux, t);
+        if (a.stats) a.stats->n_dead = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void predead_flag_kernel(const int64_t* toks, int S, int64_t add, int64_t thr,
+                                                            int32_t* flag) {
+    __shared__ int sh;
+    if (threadIdx.x == 0) sh = 0;
+    __syncthreads();
+    int any = 0;
+    for (int i = threadIdx.x; i < S; i += 1024) any |= (toks[i] + add >= thr);
+    if (__ballot(any) != 0ull && (threadIdx.x & 63) == 0) sh = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = sh;
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, float* out) {
+    const long n4 = n >> 2;
+    float m = 0.f;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[q];
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* pool, const int64_t* rows, int n_rows, int D,
+                                                          float* out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(pool + (size_t)rows[r] * D);
+    f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)r * D);
+    for (int q = lane; q < (D >> 2); q += 64) dst[q] = src[q];
+}
+
+__global__ __launch_bounds__(256) void scatter_dense_kernel(const int32_t* idx, const float* val, int n_rows, int k,
+                                                            int stride, int S, float* f) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)n_rows * k) return;
+    const int b = (int)(p / k), j = (int)(p % k);
+    const int32_t i = idx[(size_t)b * stride + j];
+    if (i >= 0 && i < S) f[(size_t)b * S + i] = val[(size_t)b * stride + j];
+}
+
+__global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, int n_rows, int D, float alpha,
+                                                            int with_aux, const float* upper,
+                                                            const int32_t* n_overflow, saev_step_stats* stats) {
+    __shared__ double sh[16][6];
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = threadIdx.x; r < n_rows; r += 1024) {
+        const RowStats v = rs[r];
+        s[0] += v.sse_scaled; s[1] += v.l0; s[2] += v.l1; s[3] += with_aux ? v.aux_sse : 0.f;
+        s[4] += v.sse64; s[5] += v.sumsq64;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = wave_sum_d(s[i]);
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 6; ++i) sh[threadIdx.x >> 6][i] = s[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 16; ++w)
+            for (int i = 0; i < 6; ++i) t[i] += sh[w][i];
+        const double nd = (double)n_rows * (double)D;
+        stats->mse = (float)(t[0] / nd);
+        stats->l0 = (float)(t[1] / n_rows);
+        stats->l1 = (float)(t[2] / n_rows);
+        if (with_aux) stats->aux = (float)((double)alpha * t[3] / nd);
+        stats->sse = t[4];
+        stats->sum_sq = t[5];
+        if (upper) stats->upper = *upper;
+        if (n_overflow) stats->n_overflow_rows = *n_overflow;
+    }
+}
+
+template <typename F>
+hipError_t dispatch_nv(int D, F&& f) {
+    const int nv = (D / 4 + 63) / 64;
+    switch (nv) {
+        case 1: f(std::integral_constant<int, 1>()); break;
+        case 2: f(std::integral_constant<int, 2>()); break;
+        case 3: f(std::integral_constant<int, 3>()); break;
+        case 4: f(std::integral_constant<int, 4>()); break;
+        case 5: f(std::integral_constant<int, 5>()); break;
+        case 6: f(std::integral_constant<int, 6>()); break;
+        case 7: case 8: f(std::integral_constant<int, 8>()); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream) {
+    return dispatch_nv(D, [&](auto nv) {
+        hipLaunchKernelGGL(normalize_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, W, S, D);
+    });
+}
+hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream) {
+    return dispatch_nv(D, [&](auto nv) {
+        hipLaunchKernelGGL(rpg_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, gW, W, S, D);
+    });
+}
+hipError_t launch_sumsq(const float* g, long n, double* partials, double* total, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, g, n, partials);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, stream, partials, SUMSQ_BLOCKS, total);
+    return hipGetLastError();
+}
+hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {
+    const long n4 = a.n >> 2;
+    const int blocks = (int)std::max<long>(1, std::min<long>((n4 + 255) / 256, 256 * 8));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(dead_update_kernel, dim3(1), dim3(1024), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_predead_flag(const int64_t* toks, int S, int64_t add, int64_t thr, int32_t* flag, hipStream_t stream) {
+    hipLaunchKernelGGL(predead_flag_kernel, dim3(1), dim3(1024), 0, stream, toks, S, add, thr, flag);
+    return hipGetLastError();
+}
+hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream) {
+    const int blocks = (int)std::max<long>(1, std::min<long>(((n >> 2) + 255) / 256, 2048));
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, n, out_zeroed);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows(const float* pool, const int64_t* rows, int n_rows, int D, float* out, hipStream_t stream) {
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, pool, rows, n_rows, D, out);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows, int k, int stride, int S, float* f,
+                                hipStream_t stream) {
+    const long n = (long)n_rows * k;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_dense_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, idx, val, n_rows, k,
+                       stride, S, f);
+    return hipGetLastError();
+}
+hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, float alpha, int with_aux, const float* upper,
+                               const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, rs, n_rows, D, alpha, with_aux, upper,
+                       n_overflow, stats);
+    return hipGetLastError();
+}

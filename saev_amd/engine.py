@@ -1,0 +1,228 @@
+"""Host-side owner of one SAE's device state and the C-ABI context that runs its train step.
+
+``SaeEngine`` allocates the four parameter-sized flat buffers (params, grads, Adam m, Adam v) as
+torch tensors on a HIP device, exposes ``W_dec / b_dec / W_enc / b_enc`` as views into the flat
+parameter buffer (state_dict order, reference nn/modeling.py:312-327), and forwards every compute
+call to libsaev_amd.so.  PyTorch is used for memory, streams and ``torch.distributed`` only.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+
+import torch
+
+from . import _lib
+
+
+@dataclasses.dataclass(frozen=True)
+class EngineConfig:
+    d_model: int
+    d_sae: int
+    top_k: int = 32
+    k_aux: int = 512           # 0 disables the auxiliary loss
+    alpha: float = 1.0 / 32.0
+    dead_threshold_tokens: int = 10_000_000
+    normalize_w_dec: bool = True
+    remove_parallel_grads: bool = True
+    max_batch: int = 16384
+
+
+@dataclasses.dataclass
+class StepStats:
+    mse: float
+    aux: float
+    l0: float
+    l1: float
+    grad_norm: float
+    upper: float
+    n_dead: int
+    n_overflow_rows: int
+    sse: float
+    sum_sq: float
+
+    @property
+    def loss(self) -> float:
+        return self.mse + self.aux
+
+
+def _ptr(t: torch.Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SaeEngine:
+    def __init__(self, cfg: EngineConfig, device: torch.device | str | int = "cuda", *, with_optim: bool = True):
+        if not torch.cuda.is_available():
+            raise _lib.SaevError("saev_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        S, D = cfg.d_sae, cfg.d_model
+        self.n_params = 2 * S * D + S + D
+        self.offsets = {"W_dec": 0, "b_dec": S * D, "W_enc": S * D + D, "b_enc": 2 * S * D + D}
+        self.shapes = {"W_dec": (S, D), "b_dec": (D,), "W_enc": (D, S), "b_enc": (S,)}
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(self.n_params, device=self.device, dtype=torch.float32)
+            self.grads = torch.zeros_like(self.params) if with_optim else None
+            self.adam_m = torch.zeros_like(self.params) if with_optim else None
+            self.adam_v = torch.zeros_like(self.params) if with_optim else None
+            self.toks_since_active = torch.zeros(S, device=self.device, dtype=torch.int64)
+            self.fired = torch.zeros(S, device=self.device, dtype=torch.int32)
+            ccfg = _lib.SaevCfg(
+                d_model=D, d_sae=S, top_k=cfg.top_k, k_aux=cfg.k_aux, alpha=cfg.alpha,
+                dead_threshold_tokens=cfg.dead_threshold_tokens,
+                normalize_w_dec=int(cfg.normalize_w_dec), remove_parallel_grads=int(cfg.remove_parallel_grads),
+                max_batch=cfg.max_batch, reserved=0,
+            )
+            ctx = C.c_void_p()
+            rc = self.lib.saev_create(C.byref(ccfg), self.device.index, C.byref(ctx))
+            if rc != 0:
+                raise _lib.SaevError(f"saev_create failed with status {rc} for {cfg}")
+            self.ctx = ctx
+            self._chk(self.lib.saev_bind(ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v)), "saev_bind")
+            self._chk(self.lib.saev_bind_tracker(ctx, _ptr(self.toks_since_active), _ptr(self.fired)), "saev_bind_tracker")
+        self.adam_steps = 0
+        self._x_keepalive = None
+
+    # ---- plumbing -------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        _lib.check(self.lib, self.ctx, rc, what)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.saev_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def view(self, name: str, flat: torch.Tensor | None = None) -> torch.Tensor:
+        flat = self.params if flat is None else flat
+        off, shape = self.offsets[name], self.shapes[name]
+        return flat[off : off + math.prod(shape)].view(shape)
+
+    def param_views(self) -> dict[str, torch.Tensor]:
+        return {k: self.view(k) for k in self.offsets}
+
+    def grad_views(self) -> dict[str, torch.Tensor]:
+        return {k: self.view(k, self.grads) for k in self.offsets}
+
+    def load_params(self, params: dict[str, torch.Tensor]) -> None:
+        for k in self.offsets:
+            self.view(k).copy_(params[k].to(self.device, torch.float32))
+
+    def _check_x(self, x: torch.Tensor) -> torch.Tensor:
+        if x.device != self.device or x.dtype != torch.float32:
+            raise _lib.SaevError(f"activations must be float32 on {self.device}, got {x.dtype} on {x.device}")
+        if x.ndim != 2 or x.shape[1] != self.cfg.d_model:
+            raise _lib.SaevError(f"activations must be (n, {self.cfg.d_model}), got {tuple(x.shape)}")
+        return x.contiguous()
+
+    # ---- single ops -----------------------------------------------------------------------
+    def normalize_w_dec(self):
+        self._chk(self.lib.saev_normalize_w_dec(self.ctx, _stream()), "saev_normalize_w_dec")
+
+    def encode_dense(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._check_x(x)
+        h = torch.empty(x.shape[0], self.cfg.d_sae, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.saev_encode_dense(self.ctx, _ptr(x), x.shape[0], _ptr(h), _stream()), "saev_encode_dense")
+        return h
+
+    def topk_dense(self, h: torch.Tensor, k: int, mask: torch.Tensor | None = None):
+        h = h.contiguous()
+        n = h.shape[0]
+        idx = torch.empty(n, k, device=self.device, dtype=torch.int32)
+        val = torch.empty(n, k, device=self.device, dtype=torch.float32)
+        if mask is not None:
+            mask = mask.to(self.device, torch.int32).contiguous()
+        self._chk(self.lib.saev_topk_dense(self.ctx, _ptr(h), n, k, _ptr(mask), _ptr(idx), _ptr(val), _stream()), "saev_topk_dense")
+        return idx, val
+
+    def encode_topk(self, x: torch.Tensor):
+        x = self._check_x(x)
+        n, k = x.shape[0], min(self.cfg.top_k, self.cfg.d_sae)
+        idx = torch.empty(n, k, device=self.device, dtype=torch.int32)
+        val = torch.empty(n, k, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.saev_encode_topk(self.ctx, _ptr(x), n, _ptr(idx), _ptr(val), _stream()), "saev_encode_topk")
+        return idx, val
+
+    def scatter_dense(self, idx: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
+        n, k = idx.shape
+        f = torch.zeros(n, self.cfg.d_sae, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.saev_scatter_dense(self.ctx, _ptr(idx.contiguous()), _ptr(val.contiguous()), n, k, _ptr(f), _stream()), "saev_scatter_dense")
+        return f
+
+    def decode_sparse(self, idx: torch.Tensor, val: torch.Tensor, prefixes=None) -> torch.Tensor:
+        n, k = idx.shape
+        if prefixes is None:
+            pre = [self.cfg.d_sae]
+        else:
+            pre = [int(p) for p in prefixes]
+        arr = (C.c_int64 * len(pre))(*pre)
+        out = torch.empty(n, len(pre), self.cfg.d_model, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.saev_decode_sparse(self.ctx, _ptr(idx.contiguous()), _ptr(val.contiguous()), n, k, arr, len(pre), _ptr(out), _stream()), "saev_decode_sparse")
+        return out
+
+    def remove_parallel_grads(self):
+        self._chk(self.lib.saev_remove_parallel_grads(self.ctx, _stream()), "saev_remove_parallel_grads")
+
+    def gather_rows(self, pool: torch.Tensor, rows: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        n = rows.shape[0]
+        if out is None:
+            out = torch.empty(n, self.cfg.d_model, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.saev_gather_rows(self.ctx, _ptr(pool), _ptr(rows), n, _ptr(out), _stream()), "saev_gather_rows")
+        return out
+
+    # ---- the step -------------------------------------------------------------------------
+    def step_forward(self, x: torch.Tensor, *, training: bool = True, n_rows_global: int | None = None):
+        x = self._check_x(x)
+        self._x_keepalive = x
+        n = x.shape[0]
+        self._chk(self.lib.saev_step_forward(self.ctx, _ptr(x), n, n_rows_global or n, int(training), _stream()), "saev_step_forward")
+
+    def step_dead(self, n_rows_global: int):
+        self._chk(self.lib.saev_step_dead(self.ctx, n_rows_global, _stream()), "saev_step_dead")
+
+    def step_backward(self):
+        self._chk(self.lib.saev_step_backward(self.ctx, _stream()), "saev_step_backward")
+
+    def step_tail(self, lr: float, max_norm: float = 1.0, grad_scale: float = 1.0):
+        self.adam_steps += 1
+        self._chk(self.lib.saev_step_tail(self.ctx, lr, max_norm, grad_scale, self.adam_steps, _stream()), "saev_step_tail")
+
+    def train_step(self, x: torch.Tensor, lr: float, max_norm: float = 1.0):
+        """Phases 1-4 on one GPU (reference train.py:332-460 loop body for one SAE)."""
+        x = self._check_x(x)
+        self._x_keepalive = x
+        self.adam_steps += 1
+        self._chk(self.lib.saev_train_step(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps, _stream()), "saev_train_step")
+
+    def read_stats(self) -> StepStats:
+        st = _lib.SaevStepStats()
+        self._chk(self.lib.saev_read_stats(self.ctx, C.byref(st), _stream()), "saev_read_stats")
+        return StepStats(**{f: getattr(st, f) for f, _ in _lib.SaevStepStats._fields_})
+
+    def last_codes(self, n_rows: int):
+        k = min(self.cfg.top_k, self.cfg.d_sae)
+        idx = torch.empty(n_rows, k, device=self.device, dtype=torch.int32)
+        val = torch.empty(n_rows, k, device=self.device, dtype=torch.float32)
+        x_hat = torch.empty(n_rows, self.cfg.d_model, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.saev_copy_last(self.ctx, _ptr(idx), _ptr(val), _ptr(x_hat), _stream()), "saev_copy_last")
+        return idx, val, x_hat
+
+    def enable_kernel_timing(self, on: bool = True):
+        self._chk(self.lib.saev_enable_kernel_timing(self.ctx, int(on)), "saev_enable_kernel_timing")
+
+    def encoder_ms(self) -> float:
+        return float(self.lib.saev_last_encoder_ms(self.ctx))

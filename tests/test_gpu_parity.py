@@ -1,0 +1,172 @@
+"""HIP path vs CPU oracle / golden fixtures, through the C ABI (needs an MI355X: -m gpu)."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import sae_ref as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(d, s, k, *, k_aux=512, alpha=1 / 32, thr=10_000_000, max_batch=512, **kw):
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    return SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, alpha=alpha, dead_threshold_tokens=thr,
+                                  max_batch=max_batch, **kw))
+
+
+def rand_params(d, s, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    p = R.init_params(R.RefConfig(d_model=d, d_sae=s), g)
+    p["b_enc"] = 0.05 * torch.randn(s, generator=g)
+    p["b_dec"] = 0.1 * torch.randn(d, generator=g)
+    p["W_enc"] = p["W_enc"] + 0.02 * torch.randn(d, s, generator=g)
+    return p
+
+
+def codes_to_dense(idx, val, s):
+    f = torch.zeros(idx.shape[0], s)
+    ok = idx >= 0
+    rows = torch.arange(idx.shape[0])[:, None].expand_as(idx)
+    f[rows[ok], idx[ok].long()] = val[ok]
+    return f
+
+
+@pytest.mark.parametrize("n,d,s", [(96, 48, 320), (128, 64, 512), (300, 128, 1024), (5, 16, 24), (257, 256, 768)])
+def test_encode_dense_matches_oracle(n, d, s):
+    p = rand_params(d, s, seed=n)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(n + 1))
+    eng = make_engine(d, s, 8, max_batch=max(n, 8))
+    eng.load_params(p)
+    h = eng.encode_dense(x.cuda()).cpu()
+    ref = R.encode_pre(x, p["W_enc"], p["b_enc"])
+    torch.testing.assert_close(h, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,s,k", [(64, 512, 8), (33, 1024, 32), (7, 24, 24), (16, 4096, 64), (9, 320, 100)])
+def test_topk_dense_matches_torch_topk(n, s, k):
+    h = torch.randn(n, s, generator=torch.Generator().manual_seed(s + k))
+    eng = make_engine(16, s, min(k, 64), max_batch=64)
+    idx, val = eng.topk_dense(h.cuda(), k)
+    idx, val = idx.cpu(), val.cpu()
+    want = torch.topk(h, k, dim=-1).values.sort(dim=-1).values
+    torch.testing.assert_close(val.sort(dim=-1).values, want, rtol=0, atol=0)
+    assert torch.equal(h.gather(1, idx.long()), val)
+    assert (idx[:, 1:] > idx[:, :-1]).all(), "codes come out in ascending latent order"
+
+
+def test_topk_dense_ties_and_mask():
+    eng = make_engine(16, 64, 4, max_batch=8)
+    h = torch.full((2, 64), 2.0)
+    idx, val = eng.topk_dense(h.cuda(), 4)
+    assert (val.cpu() == 2.0).all() and idx.cpu().tolist() == [[0, 1, 2, 3]] * 2
+    h = torch.arange(64.0).repeat(2, 1)
+    mask = torch.zeros(64, dtype=torch.int32)
+    mask[[3, 10, 50, 7, 20]] = 1
+    idx, val = eng.topk_dense(h.cuda(), 3, mask=mask)
+    assert idx.cpu().tolist() == [[10, 20, 50]] * 2
+
+
+@pytest.mark.parametrize("n,d,s,k", [(96, 48, 320, 8), (128, 64, 512, 8), (300, 128, 1024, 16), (5, 16, 24, 64),
+                                     (200, 64, 2048, 32), (130, 32, 4096, 64)])
+def test_fused_encode_topk_matches_oracle(n, d, s, k):
+    p = rand_params(d, s, seed=7 * n)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(n + 2))
+    eng = make_engine(d, s, k, max_batch=max(n, 8))
+    eng.load_params(p)
+    idx, val = eng.encode_topk(x.cuda())
+    idx, val = idx.cpu(), val.cpu()
+    h = R.encode_pre(x, p["W_enc"], p["b_enc"])
+    kk = min(k, s)
+    want = torch.topk(h, kk, dim=-1).values.sort(dim=-1).values
+    torch.testing.assert_close(val.sort(dim=-1).values, want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(h.gather(1, idx.long()), val, rtol=1e-5, atol=1e-5)
+    assert (idx[:, 1:] > idx[:, :-1]).all()
+
+
+def test_g1_golden_encode_topk():
+    g = load_golden("g1_encode_topk")
+    eng = make_engine(48, 320, 8, max_batch=96)
+    eng.load_params({k: g["p_" + k] for k in R.PARAM_ORDER})
+    idx, val = eng.encode_topk(g["x"].cuda())
+    f = codes_to_dense(idx.cpu(), val.cpu(), 320)
+    torch.testing.assert_close(f, g["f"], rtol=1e-5, atol=1e-5)
+
+
+def test_g2_golden_decode_with_prefixes():
+    g = load_golden("g2_decode")
+    eng = make_engine(48, 320, 8, max_batch=96)
+    eng.load_params({"W_dec": g["W_dec"], "b_dec": g["b_dec"], "W_enc": torch.zeros(48, 320), "b_enc": torch.zeros(320)})
+    idx, val = eng.topk_dense((g["f"].abs() + (g["f"] != 0)).cuda(), 8)  # positions of the 8 non-zeros
+    val = g["f"].gather(1, idx.cpu().long()).cuda()
+    torch.testing.assert_close(eng.decode_sparse(idx, val).cpu(), g["x_hats_p1"], rtol=1e-5, atol=1e-5)
+    out = eng.decode_sparse(idx, val, prefixes=g["prefixes"].tolist()).cpu()
+    torch.testing.assert_close(out, g["x_hats_p3"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["nodead", "dead", "dead_few"])
+def test_g5_golden_objective_forward_backward(tag):
+    g = load_golden(f"g5_objective_{tag}")
+    eng = make_engine(64, 512, int(g["k"]), k_aux=int(g["k_aux"]), alpha=float(g["alpha"]), thr=int(g["thr"]),
+                      max_batch=128, normalize_w_dec=False, remove_parallel_grads=False)
+    eng.load_params({k: g["p_" + k] for k in R.PARAM_ORDER})
+    eng.toks_since_active.copy_(g["toks_before"])
+    x = g["x"].cuda()
+    eng.step_forward(x, training=True)
+    eng.step_dead(x.shape[0])
+    eng.step_backward()
+    st = eng.read_stats()
+    assert torch.equal(eng.toks_since_active.cpu(), g["toks_after"])
+    assert st.n_dead == g["n_dead"]
+    assert math.isclose(st.mse, g["mse"], rel_tol=1e-4)
+    assert math.isclose(st.aux, g["aux"], rel_tol=1e-4, abs_tol=1e-9)
+    assert math.isclose(st.l0, g["l0"], rel_tol=1e-6) and math.isclose(st.l1, g["l1"], rel_tol=1e-5)
+    idx, val, x_hat = eng.last_codes(x.shape[0])
+    torch.testing.assert_close(codes_to_dense(idx.cpu(), val.cpu(), 512), g["f"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x_hat.cpu(), g["x_hat"], rtol=1e-5, atol=1e-5)
+    gv = eng.grad_views()
+    for k in R.PARAM_ORDER:
+        torch.testing.assert_close(gv[k].cpu(), g["g_" + k], rtol=1e-3, atol=1e-7, msg=lambda m: f"{k}: {m}")
+
+
+def test_g5_golden_eval_mode():
+    g = load_golden("g5_objective_eval")
+    eng = make_engine(64, 512, int(g["k"]), max_batch=128)
+    eng.load_params({k: g["p_" + k] for k in R.PARAM_ORDER})
+    eng.step_forward(g["x"].cuda(), training=False)
+    st = eng.read_stats()
+    assert st.aux == 0.0 and st.n_dead == 0
+    assert math.isclose(st.mse, g["mse"], rel_tol=1e-4)
+    assert (eng.toks_since_active == 0).all()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g9_golden_train_trajectory(tag):
+    g = load_golden(f"g9_train_{tag}")
+    d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
+    eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz)
+    eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
+    sched = R.WarmupCosine(0.0, int(g["n_warm"]), float(g["lr"]), math.ceil(int(g["n_train"]) / bsz), 0.0)
+    batches = [b.cuda() for b in g["acts"].split(bsz)]
+    lr, log = 0.0, []
+    for x in R.limited_batches(batches, int(g["n_train"]), bsz, drop_last=False):
+        eng.train_step(x, lr, 1.0)
+        st = eng.read_stats()
+        log.append((st.mse, st.aux, st.l0, st.l1, st.n_dead, st.grad_norm, lr))
+        lr = sched.step()
+    assert len(log) == g["n_steps"]
+    got = np.array(log, dtype=np.float64)
+    np.testing.assert_allclose(got[:, 0], g["log_loss_mse"].numpy(), rtol=1e-4, err_msg="mse")
+    np.testing.assert_allclose(got[:, 1], g["log_loss_aux"].numpy(), rtol=1e-3, atol=1e-8, err_msg="aux")
+    np.testing.assert_allclose(got[:, 2], g["log_loss_l0"].numpy(), rtol=1e-6, err_msg="l0")
+    np.testing.assert_allclose(got[:, 3], g["log_loss_l1"].numpy(), rtol=1e-4, err_msg="l1")
+    np.testing.assert_allclose(got[:, 5], g["log_metrics_grad_norm"].numpy(), rtol=1e-3, err_msg="grad_norm")
+    assert got[:, 4].astype(int).tolist() == [int(v) for v in g["log_loss_n_dead"].tolist()]
+    assert torch.equal(eng.toks_since_active.cpu(), g["toks_final"])
+    pv = eng.param_views()
+    for key in R.PARAM_ORDER:
+        torch.testing.assert_close(pv[key].cpu(), g["final_" + key], rtol=2e-3, atol=2e-5, msg=lambda m: f"{key}: {m}")

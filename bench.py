@@ -1,0 +1,159 @@
+"""Headline benchmark: activations/sec of the TopK-SAE train step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): d_in = 1024, 32x expansion (d_sae = 32768), k = 32,
+batch 16384 activations per GPU, fp32, synthetic N(mu, 1) activations held in a device-resident pool
+of 64 batches (the reference's reservoir capacity, data/shuffled.py:45-63).  One step = draw a batch
+from the pool (row gather) + the full train step (renorm, encode+TopK, sparse decode, MSE, AuxK
+bookkeeping, backward, rpg, clip, Adam).  With N > 1 ranks (launched by torch.distributed.run) the
+batch is per-GPU (weak scaling) and each step all-reduces the 268 MB gradient buffer and the
+fired-latent flags over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  "roofline":     the encoder MFMA kernel's achieved TFLOP/s (algorithmic 2*B*D*S flops / mean
+                  kernel duration from HIP events on the launch stream) against the 157.3 TFLOP/s
+                  fp32 matrix peak of MI355X_MICROARCH.md;
+  "cpu_baseline": the CPU oracle (oracle/sae_ref.py, a restatement of the reference's PyTorch-CPU
+                  step) timed on this box's host cores on a bounded sample of the same workload.
+"""
+
+import argparse
+import json
+import math
+import os
+import pathlib
+import sys
+import time
+
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+D_MODEL, D_SAE, TOP_K, BATCH = 1024, 32768, 32, 16384
+POOL_BATCHES = 64
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def cpu_baseline(n_rows: int = 2048, steps: int = 2):
+    """Time the CPU oracle's train step on a bounded sample: same d_model/d_sae/k, `n_rows` rows."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import sae_ref as R
+
+    cfg = R.RefConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K)
+    gen = torch.Generator().manual_seed(42)
+    state = R.TrainState.create(R.init_params(cfg, gen))
+    sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, 1000, 0.0)
+    x = torch.randn(n_rows, D_MODEL, generator=torch.Generator().manual_seed(17))
+    R.train_step(state, x, cfg, sched)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R.train_step(state, x, cfg, sched)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_rows * steps / dt, "unit": "activations/sec", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{steps} timed steps (+1 warm-up) of {n_rows} rows, d_model={D_MODEL}, d_sae={D_SAE}, k={TOP_K}, "
+                  "fp32 PyTorch-CPU oracle (dense GEMMs + autograd, as the reference does)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from saev_amd.engine import EngineConfig, SaeEngine
+    from saev_amd.framework.ddp import DataParallelStepper
+
+    B = args.batch
+    eng = SaeEngine(EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B), dev)
+    # random-init weights of the reference architecture (modeling.py:306-329), model seed 42
+    g = torch.Generator(device=dev).manual_seed(42)
+    W = (torch.rand(D_SAE, D_MODEL, device=dev, generator=g) * 2 - 1) * math.sqrt(6.0 / D_MODEL)
+    W /= W.norm(dim=1, keepdim=True)
+    eng.view("W_dec").copy_(W)
+    eng.view("W_enc").copy_(W.t())
+    del W
+    # synthetic activation pool: x = z + mu, generator seed 17 (+rank)
+    g = torch.Generator(device=dev).manual_seed(17 + rank)
+    mu = torch.randn(D_MODEL, device=dev, generator=torch.Generator(device=dev).manual_seed(17))
+    pool = torch.randn(POOL_BATCHES * B, D_MODEL, device=dev, generator=g) + mu
+    perm = torch.randperm(pool.shape[0], device=dev, generator=g)
+    x = torch.empty(B, D_MODEL, device=dev)
+    stepper = DataParallelStepper(eng, dist, world)
+    lr_sched = lambda i: 4e-4 * min(1.0, i / 500)  # noqa: E731  warm-up region of the reference schedule
+
+    def one_step(i):
+        rows = perm[(i % POOL_BATCHES) * B : (i % POOL_BATCHES + 1) * B]
+        eng.gather_rows(pool, rows, out=x)
+        stepper.train_step(x, lr_sched(i), 1.0)
+
+    for i in range(args.warmup):
+        one_step(i)
+    eng.enable_kernel_timing(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    enc_ms = eng.encoder_ms()
+    stats = eng.read_stats()
+
+    if rank == 0:
+        flops = 2.0 * B * D_MODEL * D_SAE
+        achieved = flops / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else None
+        out = {
+            "metric": "activations/sec (train step), d_in=1024 x32 k=32",
+            "value": B * world * args.steps / dt,
+            "unit": "activations/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: d_in={D_MODEL}, d_sae={D_SAE} (32x), k={TOP_K}, batch={B}/GPU, "
+                                   "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "mse_last": stats.mse, "n_overflow_rows": stats.n_overflow_rows,
+            "roofline": {"bound": "mfma", "kernel": "encode_gemm_kernel<EPI_TOPK> (f32 MFMA 32x32x2)",
+                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / F32_MFMA_PEAK_TFLOPS) if achieved else None,
+                         "kernel_ms": enc_ms, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

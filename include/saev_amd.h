@@ -61,7 +61,9 @@ typedef struct {
     float grad_norm; /* pre-clip global L2 norm                                             */
     float upper;     /* max |x| of the batch (objectives.py:227)                            */
     int32_t n_dead;
-    int32_t n_overflow_rows; /* rows whose candidate list overflowed and took the exact slow path */
+    int32_t n_overflow_rows; /* rows whose candidate list overflowed (step re-ran on the exact dense route) */
+    int32_t cand_max;        /* longest per-row candidate list the fused encoder produced              */
+    int32_t reserved;
     double sse;      /* sum (x - x_hat)^2 accumulated in fp64 (train.py:398-401, :561-562)  */
     double sum_sq;   /* sum x^2 in fp64 (train.py:383, :554)                                */
 } saev_step_stats;

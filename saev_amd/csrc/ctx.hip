@@ -12,7 +12,7 @@
 #include "kernels.h"
 
 namespace {
-constexpr int CAND_CAP = 1024;
+constexpr int CAND_CAP = 4096;
 constexpr int TIMING_RING = 512;
 }
 
@@ -45,7 +45,10 @@ struct saev_ctx {
     double *sumsq_partials = nullptr, *sumsq_total = nullptr;
     int64_t* toks = nullptr;
     int32_t *fired = nullptr, *dead = nullptr;
-    int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] n_dead [4] k_use
+    int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use
+    int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
+    float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
+    int max_work = 0, max_part = 0;
     float* upper = nullptr;
     saev_step_stats* stats = nullptr;
     // state of the step in flight
@@ -150,6 +153,13 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     c->bitmap_words = (int)((MB + 31) / 32);
     A(bitmap, S * c->bitmap_words);
     A(counts, S); A(starts, S + 1); A(pairs, MB * std::max(K, KA));
+    {
+        const long max_pairs = MB * std::max(K, KA);
+        c->max_work = (int)(S + (max_pairs + DW_CHUNK - 1) / DW_CHUNK);
+        c->max_part = (int)(2 * ((max_pairs + DW_CHUNK - 1) / DW_CHUNK) + 2);
+    }
+    A(chunk_starts, S + 1); A(part_starts, S); A(work_latent, c->max_work);
+    A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part);
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 1024); A(sumsq_total, 1);
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
@@ -322,10 +332,10 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         HIPCHK(c, launch_init_i32(c->row_tau, INT32_MIN, n, s));
         int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
         if (rc != SAEV_OK) return rc;
-        HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, s));
+        HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
     } else {
         HIPCHK(c, launch_init_i32(need_dense, 1, 1, s));
-        HIPCHK(c, hipMemsetAsync(c->flags + 2, 0, sizeof(int32_t), s));
+        HIPCHK(c, hipMemsetAsync(c->flags + 2, 0, 2 * sizeof(int32_t), s));
     }
     int rc = run_encoder(c, x, n, EPI_DENSE, c->h_dense, need_dense, 1, s);
     if (rc != SAEV_OK) return rc;
@@ -467,16 +477,16 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     DeadArgs d{};
     d.toks = c->toks; d.fired = c->fired; d.dead = c->dead; d.S = S;
     d.add_tokens = n_rows_global; d.threshold = c->cfg.dead_threshold_tokens; d.k_aux = c->cfg.k_aux;
-    d.n_dead = c->flags + 3; d.k_use = c->flags + 4; d.stats = c->stats;
+    d.n_dead = c->flags + 4; d.k_use = c->flags + 5; d.stats = c->stats;
     HIPCHK(c, launch_dead_update(d, s));
     if (c->cfg.k_aux > 0) {
         SelectDenseArgs sd{};
-        sd.h = c->h_dense; sd.n_rows = n; sd.S = S; sd.k = c->cfg.k_aux; sd.k_dev = c->flags + 4; sd.mask = c->dead;
+        sd.h = c->h_dense; sd.n_rows = n; sd.S = S; sd.k = c->cfg.k_aux; sd.k_dev = c->flags + 5; sd.mask = c->dead;
         sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
         HIPCHK(c, launch_select_dense(sd, s));
         AuxDecodeArgs a{};
         a.x = c->x_last; a.x_hat = c->x_hat; a.idx = c->aux_idx; a.val = c->aux_val; a.code_stride = c->cfg.k_aux;
-        a.k_use = c->flags + 4; a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
+        a.k_use = c->flags + 5; a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
         a.n_rows = n; a.D = D; a.gscale = c->cfg.alpha * 2.0f / ((float)n * (float)D);
         a.g_aux = c->g_aux; a.dval = c->aux_dval; a.rowstats = c->rowstats;
         HIPCHK(c, launch_aux_decode(a, s));
@@ -491,7 +501,6 @@ int saev_step_backward(saev_ctx* c, void* stream) {
     REQUIRE(c, c->grads, SAEV_NOT_BOUND, "gradient buffer not bound");
     hipStream_t s = (hipStream_t)stream;
     const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
-    const size_t bm_bytes = (size_t)S * c->bitmap_words * sizeof(uint32_t);
     const int words = (n + 31) / 32;
 
     auto build = [&](const int32_t* idx, int stride, int k, const int32_t* k_dev) -> int {
@@ -500,38 +509,36 @@ int saev_step_backward(saev_ctx* c, void* stream) {
         CscArgs a{};
         a.idx = idx; a.code_stride = stride; a.k = k; a.k_dev = k_dev; a.n_rows = n; a.S = S;
         a.bitmap = c->bitmap; a.words = words; a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
+        a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
         HIPCHK(c, launch_csc_build(a, s));
         return SAEV_OK;
     };
-    (void)bm_bytes;
+    auto rows = [&](const float* val, const float* dval, const float* g, int k, const int32_t* k_dev,
+                    int accumulate) -> int {
+        DwRowsArgs a{};
+        a.starts = c->starts; a.chunk_starts = c->chunk_starts; a.work_latent = c->work_latent;
+        a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = val; a.dval = dval; a.g = g; a.x = c->x_last;
+        a.D = D; a.S = S; a.k_dev = k_dev; a.accumulate = accumulate;
+        a.dW_dec = c->grads + c->off_W_dec; a.dW_encT = c->dW_encT; a.db_enc = c->grads + c->off_b_enc;
+        a.partials = c->partials; a.db_partials = c->db_partials;
+        const int max_work = S + (int)(((long)n * k + DW_CHUNK - 1) / DW_CHUNK);
+        HIPCHK(c, launch_dw_rows(a, max_work, s));
+        return SAEV_OK;
+    };
     int rc = build(c->idx, K, K, nullptr);
     if (rc != SAEV_OK) return rc;
-    {
-        DwDecArgs a{};
-        a.starts = c->starts; a.pairs = c->pairs; a.coef = c->val; a.coef2 = c->dval; a.rows = c->g;
-        a.D = D; a.S = S; a.accumulate = 0; a.dW = c->grads + c->off_W_dec; a.db = c->grads + c->off_b_enc;
-        HIPCHK(c, launch_dw_dec(a, s));
-        DwEncArgs e{};
-        e.starts = c->starts; e.pairs = c->pairs; e.coef = c->dval; e.rows = c->x_last; e.D = D; e.S = S;
-        e.accumulate = 0; e.dW = c->grads + c->off_W_enc;
-        HIPCHK(c, launch_dw_enc(e, s));
-        HIPCHK(c, launch_colsum(c->g, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s));
-    }
+    rc = rows(c->val, c->dval, c->g, K, nullptr, 0);
+    if (rc != SAEV_OK) return rc;
+    HIPCHK(c, launch_colsum(c->g, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s));
     if (c->cfg.k_aux > 0) {
-        const int32_t* k_dev = c->flags + 4;
+        const int32_t* k_dev = c->flags + 5;
         rc = build(c->aux_idx, c->cfg.k_aux, c->cfg.k_aux, k_dev);
         if (rc != SAEV_OK) return rc;
-        DwDecArgs a{};
-        a.starts = c->starts; a.pairs = c->pairs; a.coef = c->aux_val; a.coef2 = c->aux_dval; a.rows = c->g_aux;
-        a.D = D; a.S = S; a.k_dev = k_dev; a.accumulate = 1; a.dW = c->grads + c->off_W_dec;
-        a.db = c->grads + c->off_b_enc;
-        HIPCHK(c, launch_dw_dec(a, s));
-        DwEncArgs e{};
-        e.starts = c->starts; e.pairs = c->pairs; e.coef = c->aux_dval; e.rows = c->x_last; e.D = D; e.S = S;
-        e.k_dev = k_dev; e.accumulate = 1; e.dW = c->grads + c->off_W_enc;
-        HIPCHK(c, launch_dw_enc(e, s));
+        rc = rows(c->aux_val, c->aux_dval, c->g_aux, c->cfg.k_aux, k_dev, 1);
+        if (rc != SAEV_OK) return rc;
         HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, k_dev, s));
     }
+    HIPCHK(c, launch_transpose(c->dW_encT, c->grads + c->off_W_enc, S, D, s));
     return SAEV_OK;
 }
 

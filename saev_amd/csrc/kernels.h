@@ -58,7 +58,7 @@ struct SelectCandArgs {
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
-                                 int32_t* need_dense, int32_t* n_overflow, hipStream_t stream);
+                                 int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);
 
 // per-row statistics produced by the decode kernels (reduced by stats_reduce)
 struct __attribute__((aligned(8))) RowStats {
@@ -118,34 +118,35 @@ struct CscArgs {
     int32_t* counts;        // (S) zeroed by the caller
     int32_t* starts;        // (S + 1)
     int2* pairs;            // (n_rows * k) -> {row b, flat code position b*code_stride + j}
+    int32_t* chunk_starts;  // (S + 1) or NULL
+    int32_t* part_starts;   // (S) partial-sum slot of each multi-chunk latent (with chunk_starts)
+    int32_t* work_latent;   // (max_work) or NULL
 };
 hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream);
 
-struct DwDecArgs {
-    const int32_t* starts;  // (S + 1)
-    const int2* pairs;
-    const float* coef;      // val, indexed by pairs[].y
-    const float* coef2;     // dval (for db_enc), indexed by pairs[].y; may be NULL
-    const float* rows;      // g (n_rows, D)
-    int D, S;
-    const int32_t* k_dev;   // optional predicate (aux)
-    int accumulate;
-    float* dW;              // (S, D)
-    float* db;              // (S) db_enc or NULL
-};
-hipError_t launch_dw_dec(const DwDecArgs& a, hipStream_t stream);
+constexpr int DW_CHUNK = 64;   // pairs per work item of the weight-gradient kernels
 
-struct DwEncArgs {
-    const int32_t* starts;
+struct DwRowsArgs {
+    const int32_t* starts;        // (S + 1) pair offsets per latent
+    const int32_t* chunk_starts;  // (S + 1) work-item offsets per latent
+    const int32_t* work_latent;   // (n_work) latent of each work item
+    const int32_t* part_starts;   // (S) first partial slot of a multi-chunk latent
     const int2* pairs;
-    const float* coef;      // dval
-    const float* rows;      // x (n_rows, D)
+    const float* val;             // coefficient of g rows   (indexed by pairs[].y)
+    const float* dval;            // coefficient of x rows and db_enc
+    const float* g;               // (n_rows, D)
+    const float* x;               // (n_rows, D)
     int D, S;
-    const int32_t* k_dev;
+    const int32_t* k_dev;         // optional predicate (aux)
     int accumulate;
-    float* dW;              // (D, S)  -- latent is the fast axis
+    float* dW_dec;                // (S, D)
+    float* dW_encT;               // (S, D) scratch, transposed into the (D, S) gradient afterwards
+    float* db_enc;                // (S)
+    float* partials;              // (max_part, 2, D)
+    float* db_partials;           // (max_part)
 };
-hipError_t launch_dw_enc(const DwEncArgs& a, hipStream_t stream);
+hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream);
+hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream);
 
 // out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
@@ -188,4 +189,4 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
                                 hipStream_t stream);
 // reduce rowstats[0..n_rows) into *stats (mse, l0, l1, aux, sse, sum_sq)
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, float alpha, int with_aux, const float* upper,
-                               const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream);
+                               const int32_t* n_overflow_and_max, saev_step_stats* stats, hipStream_t stream);

@@ -250,17 +250,20 @@ __global__ void init_i32_kernel(int32_t* p, int32_t v, int n) {
 
 // need_dense = pre_flag || any(cand_cnt > cap); also counts overflowing rows
 __global__ void overflow_check_kernel(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
-                                      int32_t* need_dense, int32_t* n_overflow) {
-    __shared__ int sh;
-    if (threadIdx.x == 0) sh = 0;
+                                      int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max) {
+    __shared__ int sh, shmax;
+    if (threadIdx.x == 0) { sh = 0; shmax = 0; }
     __syncthreads();
-    int c = 0;
-    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) c += (cand_cnt[i] > cap);
+    int c = 0, m = 0;
+    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) { const int v = cand_cnt[i]; c += (v > cap); m = max(m, v); }
     c = wave_sum_i(c);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&sh, c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) { if (c) atomicAdd(&sh, c); atomicMax(&shmax, m); }
     __syncthreads();
     if (threadIdx.x == 0) {
         *n_overflow = sh;
+        *cand_max = shmax;
         *need_dense = ((pre_flag && *pre_flag) || sh > 0) ? 1 : 0;
     }
 }
@@ -280,8 +283,10 @@ hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(select_cand_kernel<8>, grid, block, 0, stream, a);
     else if (a.cand_cap <= 1024)
         hipLaunchKernelGGL(select_cand_kernel<16>, grid, block, 0, stream, a);
-    else
+    else if (a.cand_cap <= 2048)
         hipLaunchKernelGGL(select_cand_kernel<32>, grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL(select_cand_kernel<64>, grid, block, 0, stream, a);
     return hipGetLastError();
 }
 
@@ -292,8 +297,8 @@ hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream) {
 }
 
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
-                                 int32_t* need_dense, int32_t* n_overflow, hipStream_t stream) {
+                                 int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream) {
     hipLaunchKernelGGL(overflow_check_kernel, dim3(1), dim3(1024), 0, stream, cand_cnt, n_rows, cap, pre_flag,
-                       need_dense, n_overflow);
+                       need_dense, n_overflow, cand_max);
     return hipGetLastError();
 }

@@ -237,6 +237,56 @@ __global__ __launch_bounds__(1024) void csc_scan_kernel(CscArgs a) {
         __syncthreads();
     }
     if (tid == 0) a.starts[a.S] = carry;
+    __syncthreads();
+    // second scan: chunks per latent = max(1, ceil(count / DW_CHUNK)) -> chunk_starts[0..S]
+    if (a.chunk_starts == nullptr) return;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.S; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < a.S) ? max(1, (a.counts[i] + DW_CHUNK - 1) / DW_CHUNK) : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        if (lane == 63) wave_tot[w] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int j = 0; j < w; ++j) off += wave_tot[j];
+        if (i < a.S) a.chunk_starts[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) a.chunk_starts[a.S] = carry;
+    __syncthreads();
+    // third scan: partial-sum slots, only latents with more than one chunk get any
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.S; base += 1024) {
+        const int i = base + tid;
+        int v = 0;
+        if (i < a.S) {
+            const int nch = (a.counts[i] + DW_CHUNK - 1) / DW_CHUNK;
+            v = nch > 1 ? nch : 0;
+        }
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        if (lane == 63) wave_tot[w] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int j = 0; j < w; ++j) off += wave_tot[j];
+        if (i < a.S) a.part_starts[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = off + incl;
+        __syncthreads();
+    }
 }
 
 // one wave per latent: enumerate the set bits of its bitmap row in ascending row order, look the
@@ -247,6 +297,10 @@ __global__ __launch_bounds__(256) void csc_emit_kernel(CscArgs a) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.S) return;
+    if (a.chunk_starts) {
+        const int c0 = a.chunk_starts[i], c1 = a.chunk_starts[i + 1];
+        for (int c = c0 + lane; c < c1; c += 64) a.work_latent[c] = i;
+    }
     const int total = a.counts[i];
     if (total == 0) return;
     int out = a.starts[i];
@@ -284,103 +338,157 @@ __global__ __launch_bounds__(256) void csc_emit_kernel(CscArgs a) {
 }
 
 // ------------------------------- weight gradients ------------------------------------------
+//
+// Work is cut into chunks of <= DW_CHUNK pairs of one latent so that dense latents (which fire on a
+// large share of the batch) do not serialise on one wave.  A chunk wave accumulates BOTH
+//     dec[:] += val  * g[b,:]      (row i of dW_dec)
+//     enc[:] += dval * x[b,:]      (row i of dW_enc^T, transposed into the (D,S) layout afterwards)
+// Single-chunk latents write their rows directly; multi-chunk latents write per-chunk partials that
+// dw_combine_kernel adds up in chunk order (deterministic).
 
 template <int NV>
-__global__ __launch_bounds__(256) void dw_dec_kernel(DwDecArgs a) {
+__global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
+    if (a.k_dev && *a.k_dev <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_work = a.chunk_starts[a.S];
+    if (wi >= n_work) return;
+    const int i = a.work_latent[wi];
+    const int c = wi - a.chunk_starts[i];
+    const int nch = a.chunk_starts[i + 1] - a.chunk_starts[i];
+    const int D = a.D, D4 = D >> 2;
+    const int seg_beg = a.starts[i], seg_end = a.starts[i + 1];
+    const int beg = seg_beg + c * DW_CHUNK;
+    const int end = min(seg_end, beg + DW_CHUNK);
+    f32x4 accd[NV], acce[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) { accd[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acce[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    int my_b = 0;
+    float my_v = 0.f, my_dv = 0.f;
+    const int cnt = end - beg;  // 0..64
+    if (lane < cnt) {
+        const int2 pr = a.pairs[beg + lane];
+        my_b = pr.x;
+        my_v = a.val[pr.y];
+        my_dv = a.dval[pr.y];
+    }
+    int jj = 0;
+    for (; jj + 2 <= cnt; jj += 2) {
+        const int b0 = __shfl(my_b, jj, 64), b1 = __shfl(my_b, jj + 1, 64);
+        const float v0 = __shfl(my_v, jj, 64), v1 = __shfl(my_v, jj + 1, 64);
+        const float e0 = __shfl(my_dv, jj, 64), e1 = __shfl(my_dv, jj + 1, 64);
+        const f32x4* g0 = reinterpret_cast<const f32x4*>(a.g + (size_t)b0 * D);
+        const f32x4* g1 = reinterpret_cast<const f32x4*>(a.g + (size_t)b1 * D);
+        const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
+        const f32x4* x1 = reinterpret_cast<const f32x4*>(a.x + (size_t)b1 * D);
+        f32x4 tg0[NV], tg1[NV], tx0[NV], tx1[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            const bool ok = q < D4;
+            tg0[n] = ok ? g0[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            tg1[n] = ok ? g1[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            tx0[n] = ok ? x0[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            tx1[n] = ok ? x1[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            accd[n] += v0 * tg0[n];
+            acce[n] += e0 * tx0[n];
+            accd[n] += v1 * tg1[n];
+            acce[n] += e1 * tx1[n];
+        }
+    }
+    if (jj < cnt) {
+        const int b0 = __shfl(my_b, jj, 64);
+        const float v0 = __shfl(my_v, jj, 64), e0 = __shfl(my_dv, jj, 64);
+        const f32x4* g0 = reinterpret_cast<const f32x4*>(a.g + (size_t)b0 * D);
+        const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) { accd[n] += v0 * g0[q]; acce[n] += e0 * x0[q]; }
+        }
+    }
+    // db_enc partial: sum of dval over this chunk, fixed-shape tree
+    const float dbs = wave_sum(lane < cnt ? my_dv : 0.f);
+
+    float *od, *oe;
+    bool direct = (nch == 1);
+    if (direct) {
+        od = a.dW_dec + (size_t)i * D;
+        oe = a.dW_encT + (size_t)i * D;
+    } else {
+        od = a.partials + (size_t)(a.part_starts[i] + c) * 2 * D;
+        oe = od + D;
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        if (q < D4) {
+            f32x4* pd = reinterpret_cast<f32x4*>(od) + q;
+            f32x4* pe = reinterpret_cast<f32x4*>(oe) + q;
+            if (direct && a.accumulate) { *pd = *pd + accd[n]; *pe = *pe + acce[n]; }
+            else { *pd = accd[n]; *pe = acce[n]; }
+        }
+    }
+    if (lane == 0) {
+        if (direct) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
+        else a.db_partials[a.part_starts[i] + c] = dbs;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.S) return;
+    const int nch = a.chunk_starts[i + 1] - a.chunk_starts[i];
+    if (nch <= 1) return;
+    const int c0 = a.part_starts[i], c1 = c0 + nch;
     const int D = a.D, D4 = D >> 2;
-    const int beg = a.starts[i], end = a.starts[i + 1];
-    f32x4 acc[NV];
+    f32x4 accd[NV], acce[NV];
 #pragma unroll
-    for (int n = 0; n < NV; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbsum = 0.f;
-    for (int p0 = beg; p0 < end; p0 += 64) {
-        const int cnt = min(64, end - p0);
-        int my_b = 0;
-        float my_c = 0.f;
-        if (lane < cnt) {
-            const int2 pr = a.pairs[p0 + lane];
-            my_b = pr.x;
-            my_c = a.coef[pr.y];
-            if (a.coef2) dbsum += a.coef2[pr.y];
-        }
-#pragma unroll 4
-        for (int jj = 0; jj < cnt; ++jj) {
-            const int b = __shfl(my_b, jj, 64);
-            const float c = __shfl(my_c, jj, 64);
-            const f32x4* gr = reinterpret_cast<const f32x4*>(a.rows + (size_t)b * D);
+    for (int n = 0; n < NV; ++n) { accd[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acce[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float dbs = 0.f;
+    for (int c = c0; c < c1; ++c) {
+        const f32x4* pd = reinterpret_cast<const f32x4*>(a.partials + (size_t)c * 2 * D);
+        const f32x4* pe = pd + D4;
 #pragma unroll
-            for (int n = 0; n < NV; ++n) {
-                const int q = lane + 64 * n;
-                if (q < D4) acc[n] += c * gr[q];
-            }
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) { accd[n] += pd[q]; acce[n] += pe[q]; }
         }
+        dbs += a.db_partials[c];
     }
-    f32x4* o = reinterpret_cast<f32x4*>(a.dW + (size_t)i * D);
+    f32x4* od = reinterpret_cast<f32x4*>(a.dW_dec + (size_t)i * D);
+    f32x4* oe = reinterpret_cast<f32x4*>(a.dW_encT + (size_t)i * D);
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int q = lane + 64 * n;
-        if (q < D4) o[q] = a.accumulate ? (o[q] + acc[n]) : acc[n];
+        if (q < D4) {
+            if (a.accumulate) { od[q] = od[q] + accd[n]; oe[q] = oe[q] + acce[n]; }
+            else { od[q] = accd[n]; oe[q] = acce[n]; }
+        }
     }
-    if (a.db) {
-        // lanes hold partial sums in segment order; fixed-shape tree => deterministic
-        dbsum = wave_sum(dbsum);
-        if (lane == 0) a.db[i] = a.accumulate ? (a.db[i] + dbsum) : dbsum;
-    }
+    if (lane == 0) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
 }
 
-constexpr int ENC_LAT = 32;    // latents per workgroup
-constexpr int ENC_DCH = 256;   // d_model columns per workgroup
-
-__global__ __launch_bounds__(256) void dw_enc_kernel(DwEncArgs a) {
-    if (a.k_dev && *a.k_dev <= 0) return;
-    __shared__ float tile[ENC_LAT][ENC_DCH + 1];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i0 = blockIdx.x * ENC_LAT;
-    const int d0 = blockIdx.y * ENC_DCH;
-    const int D = a.D;
-    const int dq = d0 + 4 * lane;  // this lane's 4 columns
-    const bool dok = dq < D;
-    for (int t = 0; t < ENC_LAT / 4; ++t) {
-        const int il = w * (ENC_LAT / 4) + t;
-        const int i = i0 + il;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (i < a.S) {
-            const int beg = a.starts[i], end = a.starts[i + 1];
-            for (int p0 = beg; p0 < end; p0 += 64) {
-                const int cnt = min(64, end - p0);
-                int my_b = 0;
-                float my_c = 0.f;
-                if (lane < cnt) {
-                    const int2 pr = a.pairs[p0 + lane];
-                    my_b = pr.x;
-                    my_c = a.coef[pr.y];
-                }
-#pragma unroll 4
-                for (int jj = 0; jj < cnt; ++jj) {
-                    const int b = __shfl(my_b, jj, 64);
-                    const float c = __shfl(my_c, jj, 64);
-                    if (dok) acc += c * *reinterpret_cast<const f32x4*>(a.rows + (size_t)b * D + dq);
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tile[il][4 * lane + e] = acc[e];
+// out (D, S) = in (S, D)^T, 64 x 64 tiles through LDS (padded: conflict-free both ways)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int S,
+                                                        int D) {
+    __shared__ float tile[64][65];
+    const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int s = s0 + r, d = d0 + tx;
+        tile[r][tx] = (s < S && d < D) ? in[(size_t)s * D + d] : 0.f;
     }
     __syncthreads();
-    // transposed store: 32 consecutive threads write 32 consecutive latents of one d row
-    const int il = threadIdx.x & 31;
-    const int i = i0 + il;
-    for (int dl = threadIdx.x >> 5; dl < ENC_DCH; dl += 8) {
-        const int d = d0 + dl;
-        if (d < D && i < a.S) {
-            float* o = a.dW + (size_t)d * a.S + i;
-            const float v = tile[il][dl];
-            *o = a.accumulate ? (*o + v) : v;
-        }
+    for (int r = ty; r < 64; r += 4) {
+        const int d = d0 + r, s = s0 + tx;
+        if (d < D && s < S) out[(size_t)d * S + s] = tile[tx][r];
     }
 }
 
@@ -446,14 +554,14 @@ hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(csc_emit_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
-hipError_t launch_dw_dec(const DwDecArgs& a, hipStream_t stream) {
+hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream) {
     return dispatch_nv(a.D, [&](auto nv) {
-        hipLaunchKernelGGL(dw_dec_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(dw_rows_kernel<decltype(nv)::value>, dim3((max_work + 3) / 4), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
     });
 }
-hipError_t launch_dw_enc(const DwEncArgs& a, hipStream_t stream) {
-    dim3 grid((a.S + ENC_LAT - 1) / ENC_LAT, (a.D + ENC_DCH - 1) / ENC_DCH);
-    hipLaunchKernelGGL(dw_enc_kernel, grid, dim3(256), 0, stream, a);
+hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((S + 63) / 64, (D + 63) / 64), dim3(256), 0, stream, in, out, S, D);
     return hipGetLastError();
 }
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,

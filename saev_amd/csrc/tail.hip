@@ -180,8 +180,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, flo
     if (blockIdx.x == 0)
         for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
     m = wave_max(m);
-    // non-negative floats order like their bit patterns
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+    __shared__ float shm[4];
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // non-negative floats order like their bit patterns; one atomic per workgroup
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(out),
+                  __float_as_uint(fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* pool, const int64_t* rows, int n_rows, int D,
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
         stats->sse = t[4];
         stats->sum_sq = t[5];
         if (upper) stats->upper = *upper;
-        if (n_overflow) stats->n_overflow_rows = *n_overflow;
+        if (n_overflow) { stats->n_overflow_rows = n_overflow[0]; stats->cand_max = n_overflow[1]; }
     }
 }
 
@@ -282,7 +287,7 @@ hipError_t launch_predead_flag(const int64_t* toks, int S, int64_t add, int64_t 
     return hipGetLastError();
 }
 hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream) {
-    const int blocks = (int)std::max<long>(1, std::min<long>(((n >> 2) + 255) / 256, 2048));
+    const int blocks = (int)std::max<long>(1, std::min<long>(((n >> 2) + 255) / 256, 1024));
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, n, out_zeroed);
     return hipGetLastError();
 }

@@ -40,6 +40,8 @@ class StepStats:
     upper: float
     n_dead: int
     n_overflow_rows: int
+    cand_max: int
+    reserved: int
     sse: float
     sum_sq: float
 

@@ -146,6 +146,11 @@ def test_g5_golden_eval_mode():
 
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_g9_golden_train_trajectory(tag):
+    """Free-running trajectory vs the reference's.  TopK is discontinuous at near-ties: a last-bit
+    difference in h can swap one selected latent for another, which moves the batch loss by about
+    1/(B*k) relative (one of B*k selected terms changes) -- 2.4e-4 at B=256,k=16 -- without being an
+    error.  So the free-running comparison allows a few such flips; the tight per-step check is
+    test_teacher_forced_steps_match_oracle below."""
     g = load_golden(f"g9_train_{tag}")
     d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
     eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz)
@@ -160,13 +165,57 @@ def test_g9_golden_train_trajectory(tag):
         lr = sched.step()
     assert len(log) == g["n_steps"]
     got = np.array(log, dtype=np.float64)
-    np.testing.assert_allclose(got[:, 0], g["log_loss_mse"].numpy(), rtol=1e-4, err_msg="mse")
-    np.testing.assert_allclose(got[:, 1], g["log_loss_aux"].numpy(), rtol=1e-3, atol=1e-8, err_msg="aux")
+    flip = 4.0 / (bsz * k)
+    np.testing.assert_allclose(got[:, 0], g["log_loss_mse"].numpy(), rtol=max(1e-4, flip), err_msg="mse")
+    np.testing.assert_allclose(got[:, 1], g["log_loss_aux"].numpy(), rtol=max(1e-3, flip), atol=1e-8, err_msg="aux")
     np.testing.assert_allclose(got[:, 2], g["log_loss_l0"].numpy(), rtol=1e-6, err_msg="l0")
-    np.testing.assert_allclose(got[:, 3], g["log_loss_l1"].numpy(), rtol=1e-4, err_msg="l1")
-    np.testing.assert_allclose(got[:, 5], g["log_metrics_grad_norm"].numpy(), rtol=1e-3, err_msg="grad_norm")
-    assert got[:, 4].astype(int).tolist() == [int(v) for v in g["log_loss_n_dead"].tolist()]
-    assert torch.equal(eng.toks_since_active.cpu(), g["toks_final"])
+    np.testing.assert_allclose(got[:, 3], g["log_loss_l1"].numpy(), rtol=max(1e-4, flip), err_msg="l1")
+    np.testing.assert_allclose(got[:, 5], g["log_metrics_grad_norm"].numpy(), rtol=2e-3, err_msg="grad_norm")
+    np.testing.assert_allclose(got[:, 6], g["log_progress_learning_rate"].numpy(), rtol=0, atol=0, err_msg="lr")
+    # most steps agree to rounding; only isolated flip steps may use the wide band
+    rel = np.abs(got[:, 0] - g["log_loss_mse"].numpy()) / g["log_loss_mse"].numpy()
+    assert np.median(rel) < 1e-5 and (rel > 1e-5).sum() <= 4, rel
+    assert np.abs(got[:, 4] - g["log_loss_n_dead"].numpy()).max() <= 1
+    # a flipped selection can change which latent fired; the tracker may differ on a handful of latents
+    assert (eng.toks_since_active.cpu() != g["toks_final"]).float().mean() < 0.01
     pv = eng.param_views()
     for key in R.PARAM_ORDER:
-        torch.testing.assert_close(pv[key].cpu(), g["final_" + key], rtol=2e-3, atol=2e-5, msg=lambda m: f"{key}: {m}")
+        torch.testing.assert_close(pv[key].cpu(), g["final_" + key], rtol=2e-3, atol=5e-5, msg=lambda m: f"{key}: {m}")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_teacher_forced_steps_match_oracle(tag):
+    """Every step: copy the HIP engine's state to the CPU oracle, run ONE oracle step and ONE HIP step
+    from that identical state, compare losses, gradients norm and updated parameters tightly."""
+    g = load_golden(f"g9_train_{tag}")
+    d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=int(g["k_aux"]), dead_threshold_tokens=int(g["thr"]))
+    eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz)
+    eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
+    sched = R.WarmupCosine(0.0, int(g["n_warm"]), float(g["lr"]), math.ceil(int(g["n_train"]) / bsz), 0.0)
+    batches = list(g["acts"].split(bsz))
+    lr = 0.0
+    n_flip_steps = 0
+    for i, x in enumerate(R.limited_batches(batches, int(g["n_train"]), bsz, drop_last=False)):
+        state = R.TrainState(
+            params={k_: v.cpu().clone() for k_, v in eng.param_views().items()},
+            m={k_: eng.view(k_, eng.adam_m).cpu().clone() for k_ in R.PARAM_ORDER},
+            v={k_: eng.view(k_, eng.adam_v).cpu().clone() for k_ in R.PARAM_ORDER},
+            toks_since_active=eng.toks_since_active.cpu().clone(), adam_steps=eng.adam_steps, lr=lr,
+        )
+        ref = R.train_step(state, x, cfg)
+        eng.train_step(x.cuda(), lr, 1.0)
+        st = eng.read_stats()
+        flipped = not math.isclose(st.mse, ref["mse"], rel_tol=2e-6)
+        n_flip_steps += flipped
+        assert math.isclose(st.mse, ref["mse"], rel_tol=4.0 / (bsz * k)), (i, st.mse, ref["mse"])
+        assert st.n_dead == ref["n_dead"] and math.isclose(st.l0, ref["l0"], rel_tol=1e-6)
+        assert torch.equal(eng.toks_since_active.cpu(), state.toks_since_active)
+        if not flipped:
+            assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-9), (i, st.aux, ref["aux"])
+            assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-4), (i, st.grad_norm, ref["grad_norm"])
+            for key in R.PARAM_ORDER:
+                torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6,
+                                           msg=lambda m: f"step {i} {key}: {m}")
+        lr = sched.step()
+    assert n_flip_steps <= 2

@@ -1,0 +1,457 @@
+"""saev.framework.train's training surface (reference: src/saev/framework/train.py) on the HIP engine.
+
+Kept from the reference: ``Config`` (same fields and defaults, train.py:50-105), ``make_saes``
+(train.py:108-189), ``train`` (train.py:238-462), ``evaluate`` + ``EvalMetrics`` (train.py:465-618),
+``split_cfgs`` (train.py:626-695), ``worker_fn`` (train.py:192-235) and the metric key names of the
+log block (train.py:419-432).  Step order is the reference's: renormalise decoder rows -> objective ->
+backward -> remove parallel grads -> clip -> (log) -> Adam with the lr set at the end of the previous
+step (first step lr = 0) -> scheduler step.
+
+Different by design: each SAE's step is ONE call into libsaev_amd.so (``saev_train_step``) instead of
+autograd over dense GEMMs; activations come from a device-resident pool (saev_amd.data); with
+``torch.distributed`` initialised (one process per GPU, RCCL) the batch is sharded over ranks and the
+gradient buffer / fired flags are all-reduced (saev_amd.framework.ddp).  Slurm/submitit launching
+(train.py:705-797) is out of scope; ``main`` runs groups in-process.
+"""
+
+from __future__ import annotations
+
+import collections
+import dataclasses
+import json
+import logging
+import math
+import os
+import pathlib
+import time
+import typing as tp
+import uuid
+
+import torch
+from torch import Tensor
+
+from .. import data as saev_data
+from .. import nn
+from ..nn import modeling, objectives
+from ..utils import scheduling
+from .ddp import DataParallelStepper
+
+logger = logging.getLogger("train")
+
+
+@dataclasses.dataclass(frozen=True, slots=True)
+class Config:
+    """Configuration for training a sparse autoencoder on transformer activations (train.py:50-105)."""
+
+    train_data: saev_data.ShuffledConfig = saev_data.ShuffledConfig()
+    val_data: saev_data.ShuffledConfig = saev_data.ShuffledConfig()
+    n_train: int = 100_000_000
+    n_val: int = 10_000_000
+    sae: nn.SparseAutoencoderConfig = nn.SparseAutoencoderConfig()
+    objective: nn.ObjectiveConfig = objectives.Matryoshka()
+    n_sparsity_warmup: int = 0
+    optim: tp.Literal["adam", "muon"] = "adam"
+    lr: float = 0.0004
+    n_lr_warmup: int = 500
+    grad_clip: float = 1.0
+    track: bool = True
+    wandb_project: str = "saev"
+    tags: tuple[str, ...] = ()
+    log_every: int = 25
+    runs_root: pathlib.Path = pathlib.Path("$SAEV_NFS/saev/runs")
+    device: tp.Literal["cuda", "cpu"] = "cuda"
+    seed: int = 42
+    slurm_acct: str = ""
+    slurm_partition: str = ""
+    n_hours: float = 24.0
+    mem_gb: int = 128
+    log_to: str = os.path.join(".", "logs")
+    # additive (not in the reference): the S x S dictionary-coherence metric costs 2*S^2*D flops per log step
+    log_coherence: bool = True
+
+
+# ------------------------------------------------------------------------------------------------
+# run logging (the reference multiplexes W&B runs, utils/wandb.py; here: W&B if importable and
+# track=True, else a JSONL file per SAE under runs_root)
+# ------------------------------------------------------------------------------------------------
+
+
+class RunLog:
+    def __init__(self, cfgs: list[Config], n: int):
+        self.ids = [uuid.uuid4().hex[:8] for _ in range(n)]
+        self.records: list[list[tuple[int, dict]]] = [[] for _ in range(n)]
+        self.summary: dict[str, object] = {}
+
+    def log(self, metrics: list[dict[str, object]], *, step: int):
+        for rec, m in zip(self.records, metrics):
+            rec.append((step, m))
+
+    def set_summary(self, key: str, value: object):
+        self.summary[key] = value
+
+    def finish(self) -> list[str]:
+        return self.ids
+
+
+# ------------------------------------------------------------------------------------------------
+# distributed context
+# ------------------------------------------------------------------------------------------------
+
+
+def _dist():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+# ------------------------------------------------------------------------------------------------
+# init
+# ------------------------------------------------------------------------------------------------
+
+
+def make_saes(
+    cfgs: list[tuple[nn.SparseAutoencoderConfig, nn.ObjectiveConfig]], dl, device: torch.device | str = "cuda"
+) -> tuple[torch.nn.ModuleList, torch.nn.ModuleList, list[dict[str, object]]]:
+    """Build SAEs + objectives; optional datapoint initialisation (train.py:108-189): rows of
+    (mean-centred, shuffled) activations blended with a Kaiming matrix become encoder columns, the
+    decoder is their transpose, decoder rows are unit-normalised and the encoder is re-synced to the
+    normalised decoder."""
+    saes, objs, param_groups = [], [], []
+    for sae_cfg, obj_cfg in cfgs:
+        sae = nn.SparseAutoencoder(sae_cfg)
+        saes.append(sae)
+        param_groups.append({"params": sae.parameters(), "lr": 0.0})
+        objs.append(nn.get_objective(obj_cfg))
+    if all(s.cfg.reinit_blend == 0 for s in saes):
+        logger.info("No datapoint initialization necessary; skipping.")
+        return torch.nn.ModuleList(saes), torch.nn.ModuleList(objs), param_groups
+    assert saes, "Need at least one SAE to initialize."
+    d_sae = saes[0].cfg.d_sae
+    assert all(s.cfg.d_sae == d_sae for s in saes), "All SAEs must have same .d_sae"
+    if hasattr(dl, "n_samples"):
+        assert dl.n_samples >= d_sae, f"Need {d_sae} samples for datapoint init; dataloader has {dl.n_samples}."
+    n_samples = min(max(d_sae, 65_536), dl.n_samples)
+    with torch.no_grad():
+        got, n_seen = [], 0
+        for batch in dl:
+            got.append(batch["act"])
+            n_seen += len(batch["act"])
+            if n_seen >= n_samples:
+                break
+        assert n_seen >= n_samples, f"Datapoint init requested {n_samples} samples but saw {n_seen}."
+        acts = torch.cat(got, dim=0)
+        acts = acts[torch.randperm(n_samples, device=acts.device)]
+        centred = acts[:d_sae] - acts.mean(dim=0, keepdim=True)
+        kaiming = torch.nn.init.kaiming_uniform_(torch.empty_like(centred))
+        for sae in saes:
+            p = sae.cfg.reinit_blend
+            assert 0.0 <= p <= 1.0, f"reinit_blend must be in [0, 1], got {p}."
+            order = torch.randperm(d_sae, device=acts.device)
+            rows = (p * centred[order] + (1 - p) * kaiming[order]).to("cpu")
+            sae.W_enc.data.copy_(rows.T)
+            if sae.cfg.reinit_enc_dec_tranpose:
+                sae.W_dec.data.copy_(sae.W_enc.data.T)
+            if sae.cfg.normalize_w_dec:
+                sae.W_dec.data /= torch.norm(sae.W_dec.data, dim=1, keepdim=True)
+            sae.W_enc.data.copy_(sae.W_dec.data.T)
+    logger.info("Initialized %d SAEs with avg(p)=%.2f", len(saes), sum(s.cfg.reinit_blend for s in saes) / len(saes))
+    return torch.nn.ModuleList(saes), torch.nn.ModuleList(objs), param_groups
+
+
+# ------------------------------------------------------------------------------------------------
+# train
+# ------------------------------------------------------------------------------------------------
+
+
+def _make_loader(cfg_data, device, rank, world, pool=None):
+    return saev_data.ShuffledDataLoader(cfg_data, device=device, rank=rank, world_size=world, pool=pool)
+
+
+def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torch.nn.ModuleList, torch.nn.ModuleList, RunLog, int]:
+    """Train all SAEs of one parallel group on the same batches (train.py:238-462).
+
+    ``train_pool`` optionally supplies an in-memory (n, d_model) activation pool instead of a shard dir."""
+    if len(split_cfgs(cfgs)) != 1:
+        raise ValueError(f"Configs are not parallelizeable: {cfgs}.")
+    cfg = cfgs[0]
+    if cfg.device != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("saev_amd trains on a HIP device only (Config.device must be 'cuda'); there is no CPU path")
+    for c in cfgs:
+        if c.optim != "adam":
+            raise NotImplementedError("optim='muon' is outside the MI355X hot path (Adam only)")
+    dist, rank, world = _dist()
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    dataloader = _make_loader(cfg.train_data, device, rank, world, train_pool)
+    limiter = scheduling.BatchLimiter(dataloader, cfg.n_train)
+    torch.manual_seed(cfg.seed)
+    saes, objs, _ = make_saes([(c.sae, c.objective) for c in cfgs], limiter, device)
+    run = RunLog(cfgs, len(cfgs))
+
+    saes.train()
+    saes = saes.to(device)
+    objs.train()
+    steppers, scheds, lrs = [], [], []
+    for sae, obj, c in zip(saes, objs, cfgs):
+        if c.objective.n_prefixes > 1:
+            raise NotImplementedError("Matryoshka n_prefixes > 1 is not on the HIP path yet; set n_prefixes=1")
+        eng = obj._bind(sae, dataloader.local_batch)
+        if world > 1:  # identical replicas: rank 0's initial parameters everywhere
+            dist.broadcast(eng.params, src=0)
+        steppers.append(DataParallelStepper(eng, dist, world))
+        scheds.append(scheduling.WarmupCosine(0.0, c.n_lr_warmup, c.lr, len(limiter), 0.0))
+        lrs.append(0.0)  # first optimizer step is pure warm-up (train.py:118)
+    dataloader.engine = steppers[0].engine
+
+    global_step, n_patches_seen = 0, 0
+    t_start = time.time()
+    for batch in limiter:
+        x = batch["act"]
+        n_patches_seen += len(x) * world
+        log_now = (global_step + 1) % cfg.log_every == 0
+        metrics = []
+        for i, (sae, st, c) in enumerate(zip(saes, steppers, cfgs)):
+            st.train_step(x, lrs[i], c.grad_clip)
+            if log_now:
+                metrics.append(_log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c))
+            lrs[i] = scheds[i].step()
+        if log_now and rank == 0:
+            run.log(metrics, step=global_step)
+            logger.info("step %d: %s", global_step, ", ".join(f"{k}: {v:.5f}" for k, v in metrics[0].items()
+                                                                if k.startswith("loss/") and isinstance(v, float)))
+        global_step += 1
+    logger.info("trained %d steps in %.1fs", global_step, time.time() - t_start)
+    return saes, objs, run, global_step
+
+
+@torch.no_grad()
+def _log_metrics(sae, eng, x: Tensor, lr: float, n_patches_seen: int, cfg: Config) -> dict[str, object]:
+    """The reference's log block (train.py:365-442), from the step's device-side statistics."""
+    st = eng.read_stats()
+    n = x.shape[0]
+    idx, val, x_hat = eng.last_codes(n)
+    sum_vec = x.to(torch.float64).sum(dim=0)
+    sse_baseline = st.sum_sq - torch.dot(sum_vec, sum_vec).item() / n
+    assert sse_baseline > 0, f"Batch baseline variance non-positive: sse_baseline={sse_baseline:.6e}"
+    residual = x - x_hat
+    explained = 1 - residual.var() / x.var()
+    live = torch.zeros(sae.cfg.d_sae, device=x.device, dtype=torch.bool)
+    live[idx[val.abs() > 1e-12].long()] = True
+    out = {
+        "loss/loss": st.mse + st.aux, "loss/mse": st.mse, "loss/l0": st.l0, "loss/l1": st.l1, "loss/sparsity": 0.0,
+        "loss/aux": st.aux, "loss/n_dead": st.n_dead,
+        "progress/n_patches_seen": n_patches_seen, "progress/learning_rate": lr,
+        "metrics/explained_variance": explained.item(),
+        "metrics/dead_unit_pct": (~live).float().mean().item(),
+        "metrics/avg_decoder_row_norm": sae.W_dec.norm(dim=1).mean().item(),
+        "metrics/grad_norm": st.grad_norm,
+        "metrics/sse_sae": st.sse, "metrics/sse_baseline": sse_baseline,
+        "metrics/normalized_mse": st.sse / sse_baseline,
+        "loader/buffer_fill": 1.0,
+    }
+    if cfg.log_coherence:
+        out["metrics/dictionary_coherence"] = _coherence(sae.W_dec)
+    return out
+
+
+def _coherence(W: Tensor, block: int = 4096) -> float:
+    """max_{i<j} |<w_i, w_j>| over unit-normalised decoder rows (train.py:410-414), in row blocks."""
+    Wn = W / W.norm(dim=1, keepdim=True)
+    best = 0.0
+    S = Wn.shape[0]
+    for lo in range(0, S, block):
+        g = (Wn[lo : lo + block] @ Wn[lo:].T).abs()
+        g = torch.triu(g, diagonal=1)
+        best = max(best, g.max().item())
+    return best
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluate
+# ------------------------------------------------------------------------------------------------
+
+
+@dataclasses.dataclass(frozen=True)
+class EvalMetrics:
+    """train.py:465-507."""
+
+    l0: float
+    l1: float
+    mse: float
+    normalized_mse: float
+    sse_sae: float
+    sse_baseline: float
+    n_dead: int
+    n_almost_dead: int
+    n_dense: int
+    freqs: Tensor
+    mean_values: Tensor
+    almost_dead_threshold: float
+    dense_threshold: float
+
+    def for_wandb(self) -> dict[str, object]:
+        d = dataclasses.asdict(self)
+        d["freqs"] = d["freqs"].tolist()
+        d["mean_values"] = d["mean_values"].tolist()
+        return {f"eval/{k}": v for k, v in d.items()}
+
+
+@torch.no_grad()
+def evaluate(cfgs: list[Config], saes: torch.nn.ModuleList, objs: torch.nn.ModuleList, *,
+             val_pool: Tensor | None = None) -> list[EvalMetrics]:
+    """Eval-mode pass over the validation feed (train.py:510-618): fp64 baseline sums, SAE SSE, per-latent
+    firing counts (f > 0) and value sums, dead / almost-dead (<1e-7) / dense (>1e-2) counts."""
+    if len(split_cfgs(cfgs)) != 1:
+        raise ValueError(f"Configs are not parallelizeable: {cfgs}.")
+    saes.eval()
+    objs.eval()
+    cfg = cfgs[0]
+    dist, rank, world = _dist()
+    device = torch.device("cuda", torch.cuda.current_device())
+    dataloader = _make_loader(cfg.val_data, device, rank, world, val_pool)
+    n_val = min(dataloader.n_samples, cfg.n_val)
+    limiter = scheduling.BatchLimiter(dataloader, n_val)
+    S, D = saes[0].cfg.d_sae, saes[0].cfg.d_model
+    n_fired = torch.zeros(len(cfgs), S, device=device)
+    values = torch.zeros(len(cfgs), S, device=device)
+    acc = torch.zeros(len(cfgs), 4, dtype=torch.float64, device=device)  # l0*b, l1*b, mse*b, sse
+    sum_sq = torch.zeros((), dtype=torch.float64, device=device)
+    sum_vec = torch.zeros(D, dtype=torch.float64, device=device)
+    n_tokens = 0
+    for batch in limiter:
+        x = batch["act"]
+        b = x.shape[0]
+        x64 = x.to(torch.float64)
+        sum_vec += x64.sum(dim=0)
+        n_tokens += b
+        for i, (sae, obj) in enumerate(zip(saes, objs)):
+            eng = obj._bind(sae, b)
+            eng.step_forward(x, training=False)
+            st = eng.read_stats()
+            if i == 0:
+                sum_sq += st.sum_sq
+            idx, val, _ = eng.last_codes(b)
+            pos = val > 0
+            n_fired[i].index_add_(0, idx[pos].long(), torch.ones_like(val[pos]))
+            values[i].index_add_(0, idx.reshape(-1).long().clamp_min(0), val.reshape(-1))
+            acc[i] += torch.tensor([st.l0 * b, st.l1 * b, st.mse * b, st.sse], dtype=torch.float64, device=device)
+    if dist is not None:
+        t = torch.tensor([float(n_tokens)], dtype=torch.float64, device=device)
+        for buf in (n_fired, values, acc, sum_sq, sum_vec, t):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        n_tokens = int(t.item())
+    assert n_tokens > 0, "Validation dataloader yielded zero tokens; cannot compute normalized MSE."
+    sse_baseline = (sum_sq - torch.dot(sum_vec, sum_vec) / n_tokens).item()
+    assert sse_baseline > 0, f"Validation baseline variance non-positive: sse_baseline={sse_baseline:.6e}"
+    freqs = (n_fired / n_tokens).cpu()
+    mean_values = (values / n_fired).cpu()
+    acc = acc.cpu()
+    out = []
+    for i in range(len(cfgs)):
+        out.append(EvalMetrics(
+            l0=acc[i, 0].item() / n_tokens, l1=acc[i, 1].item() / n_tokens, mse=acc[i, 2].item() / n_tokens,
+            normalized_mse=acc[i, 3].item() / sse_baseline, sse_sae=acc[i, 3].item(), sse_baseline=sse_baseline,
+            n_dead=int((freqs[i] == 0).sum()), n_almost_dead=int((freqs[i] < 1e-7).sum()),
+            n_dense=int((freqs[i] > 1e-2).sum()), freqs=freqs[i], mean_values=mean_values[i],
+            almost_dead_threshold=1e-7, dense_threshold=1e-2,
+        ))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# grouping / entry points
+# ------------------------------------------------------------------------------------------------
+
+CANNOT_PARALLELIZE = {
+    "train_data", "val_data", "n_train", "n_val", "track", "wandb_project", "tags", "log_every", "runs_root",
+    "device", "slurm_acct", "slurm_partition", "n_hours", "mem_gb", "log_to", "sae.d_sae", "sae.d_model",
+    "sae.reinit_blend", "sae.reinit_enc_dec_tranpose",
+}
+
+
+def _hashable(v):
+    if isinstance(v, dict):
+        return tuple(sorted((k, _hashable(x)) for k, x in v.items()))
+    if isinstance(v, (list, tuple)):
+        return tuple(_hashable(x) for x in v)
+    return v
+
+
+def _get(d: dict, dotted: str):
+    for part in dotted.split("."):
+        d = d[part]
+    return d
+
+
+def _parallel_key(cfg: Config):
+    d = dataclasses.asdict(cfg)
+    for split in ("train_data", "val_data"):
+        d[split] = dict(d[split], seed="IGNORED_FOR_PARALLEL")
+    return tuple((k, _hashable(_get(d, k))) for k in sorted(CANNOT_PARALLELIZE))
+
+
+def split_cfgs(cfgs: list[Config]) -> list[list[Config]]:
+    """Group configs that may share one data stream (train.py:669-695): equal on every key in
+    CANNOT_PARALLELIZE, loader seeds ignored for grouping and then set from ``cfg.seed``."""
+    groups = collections.defaultdict(list)
+    for cfg in cfgs:
+        groups[_parallel_key(cfg)].append(cfg)
+    return [
+        [dataclasses.replace(c, train_data=dataclasses.replace(c.train_data, seed=c.seed),
+                             val_data=dataclasses.replace(c.val_data, seed=c.seed)) for c in group]
+        for _, group in sorted(groups.items(), key=lambda kv: repr(kv[0]))
+    ]
+
+
+def _jsonable(o):
+    if dataclasses.is_dataclass(o) and not isinstance(o, type):
+        return {f.name: _jsonable(getattr(o, f.name)) for f in dataclasses.fields(o)}
+    if isinstance(o, pathlib.PurePath):
+        return str(o)
+    if isinstance(o, (list, tuple)):
+        return [_jsonable(x) for x in o]
+    if isinstance(o, dict):
+        return {k: _jsonable(v) for k, v in o.items()}
+    return o
+
+
+def worker_fn(cfgs: list[Config], *, train_pool: Tensor | None = None, val_pool: Tensor | None = None) -> list[str]:
+    """Train, evaluate, and write ``<runs_root>/<id>/checkpoint/{sae.pt, config.json}`` per SAE
+    (train.py:192-235; run-dir layout of disk.py:98-128)."""
+    logging.basicConfig(level=logging.INFO, format="[%(asctime)s] [%(levelname)s] [%(name)s] %(message)s")
+    saes, objs, run, steps = train(cfgs, train_pool=train_pool)
+    evals = evaluate(cfgs, saes, objs, val_pool=val_pool)
+    run.log([m.for_wandb() for m in evals], step=steps)
+    ids = run.finish()
+    _, rank, _ = _dist()
+    if rank != 0:
+        return ids
+    for cfg, rid, metric, sae, rec in zip(cfgs, ids, evals, saes, run.records):
+        logger.info("Checkpoint %s has %d dense, %d dead, %d almost dead features", rid, metric.n_dense, metric.n_dead,
+                    metric.n_almost_dead)
+        run_dir = pathlib.Path(os.path.expandvars(str(cfg.runs_root))) / rid
+        (run_dir / "checkpoint").mkdir(parents=True, exist_ok=True)
+        (run_dir / "links").mkdir(exist_ok=True)
+        (run_dir / "inference").mkdir(exist_ok=True)
+        for name, target in (("train-shards", cfg.train_data.shards), ("val-shards", cfg.val_data.shards)):
+            link = run_dir / "links" / name
+            if not link.exists() and pathlib.Path(os.path.expandvars(str(target))).exists():
+                link.symlink_to(pathlib.Path(os.path.expandvars(str(target))))
+        nn.dump(run_dir / "checkpoint" / "sae.pt", sae)
+        with open(run_dir / "checkpoint" / "config.json", "w") as fd:
+            json.dump(_jsonable(cfg), fd, indent=2)
+        with open(run_dir / "metrics.jsonl", "w") as fd:
+            for step, m in rec:
+                fd.write(json.dumps({"step": step, **{k: v for k, v in m.items() if not isinstance(v, list)}}) + "\n")
+        logger.info("Dumped checkpoint to '%s'.", run_dir / "checkpoint" / "sae.pt")
+    return ids
+
+
+def main(cfgs: list[Config]) -> list[str]:
+    """Run every parallel group in-process (the reference submits them to Slurm, train.py:705-797)."""
+    ids: list[str] = []
+    for group in split_cfgs(cfgs):
+        ids.extend(worker_fn(group))
+    return ids

@@ -1,0 +1,418 @@
+"""saev.nn.modeling's public surface (reference: src/saev/nn/modeling.py) over the HIP engine.
+
+Same names, fields, defaults and checkpoint format as the reference so configs, sweeps and ``sae.pt``
+files move between the two unchanged:
+
+* config dataclasses ``NoSparsity / L1Sparsity / NoAux / AuxK / Relu / TopK / BatchTopK /
+  SparseAutoencoderConfig`` (modeling.py:23-146, 259-284);
+* ``SparseAutoencoder`` — a ``torch.nn.Module`` with Parameters ``W_dec (S,D), b_dec (D), W_enc (D,S),
+  b_enc (S)`` in that state_dict order (modeling.py:306-329) and methods ``encode / decode / forward /
+  normalize_w_dec / remove_parallel_grads`` (modeling.py:331-445);
+* ``dump`` / ``load`` — one JSON header line + ``torch.save(state_dict)`` (modeling.py:548-658).
+
+What differs: every compute method runs hand-written HIP kernels through libsaev_amd.so on the
+module's parameters, which are views into one flat device buffer owned by ``saev_amd.engine.SaeEngine``.
+There is no CPU implementation: calling a compute method on CPU tensors raises.  Only the TopK
+activation is on the accelerated path (BASELINE.json north_star); ``Relu`` and ``BatchTopK`` configs
+still parse and round-trip through checkpoints but raise ``NotImplementedError`` when run.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import io
+import json
+import logging
+import pathlib
+import typing as tp
+
+import torch
+from torch import Tensor
+
+from .. import __version__
+from ..engine import EngineConfig, SaeEngine
+
+SCHEMA_VERSION = 5
+
+
+# ------------------------------------------------------------------------------------------------
+# configs
+# ------------------------------------------------------------------------------------------------
+
+
+@dataclasses.dataclass(frozen=True)
+class NoSparsity:
+    """No explicit sparsity penalty (modeling.py:25-31)."""
+
+    key: tp.Literal["no-sparsity"] = "no-sparsity"
+
+
+@dataclasses.dataclass(frozen=True)
+class L1Sparsity:
+    key: tp.Literal["l1-sparsity"] = "l1-sparsity"
+    coeff: float = 1e-4
+
+
+Sparsity = tp.Union[NoSparsity, L1Sparsity]
+
+
+@dataclasses.dataclass(frozen=True)
+class NoAux:
+    key: tp.Literal["no-aux"] = "no-aux"
+
+
+@dataclasses.dataclass(frozen=True)
+class AuxK:
+    """AuxK dead-latent reconstruction loss (modeling.py:66-103)."""
+
+    key: tp.Literal["auxk"] = "auxk"
+    k_aux: int = 512
+    alpha: float = 1 / 32
+
+
+Aux = tp.Union[AuxK, NoAux]
+
+
+@dataclasses.dataclass(frozen=True)
+class Relu:
+    key: tp.Literal["relu"] = "relu"
+    sparsity: Sparsity = L1Sparsity(coeff=4e-4)
+    aux: Aux = NoAux()
+
+
+@dataclasses.dataclass(frozen=True)
+class TopK:
+    key: tp.Literal["top-k"] = "top-k"
+    top_k: int = 32
+    sparsity: Sparsity = NoSparsity()
+    aux: Aux = AuxK()
+
+    def __post_init__(self):
+        assert self.top_k > 0, "top_k must be a positive integer."
+
+
+@dataclasses.dataclass(frozen=True)
+class BatchTopK:
+    key: tp.Literal["batch-top-k"] = "batch-top-k"
+    top_k: int = 32
+    sparsity: Sparsity = NoSparsity()
+    momentum: float = 0.1
+    aux: AuxK = AuxK()
+
+    def __post_init__(self):
+        assert self.top_k > 0, "top_k must be a positive integer."
+
+
+ActivationConfig = tp.Union[Relu, TopK, BatchTopK]
+
+
+@dataclasses.dataclass(frozen=True)
+class SparseAutoencoderConfig:
+    d_model: int = 1024
+    d_sae: int = 1024 * 16
+    activation: ActivationConfig = TopK()
+    reinit_blend: float = 0.8
+    reinit_enc_dec_tranpose: bool = True  # (sic) spelling kept: it is a checkpoint/config key
+    remove_parallel_grads: bool = True
+    normalize_w_dec: bool = True
+
+
+_CONFIG_CLASSES = {c.__name__: c for c in (NoSparsity, L1Sparsity, NoAux, AuxK, Relu, TopK, BatchTopK)}
+
+
+# ------------------------------------------------------------------------------------------------
+# outputs
+# ------------------------------------------------------------------------------------------------
+
+
+class EncodeOut(tp.NamedTuple):
+    """Dense pre-activations and activated latents (modeling.py:292-296)."""
+
+    h_x: Tensor
+    f_x: Tensor
+
+
+class Output:
+    """Forward outputs with the reference's field names (modeling.py:299-304).
+
+    The HIP path keeps the k-sparse codes ``idx`` / ``val`` (batch, top_k); the dense ``h_x`` / ``f_x``
+    (batch, d_sae) matrices are materialised only when read."""
+
+    def __init__(self, sae: "SparseAutoencoder", x: Tensor, idx: Tensor, val: Tensor, x_hats: Tensor,
+                 h_x: Tensor | None = None):
+        self._sae, self._x, self.idx, self.val, self.x_hats = sae, x, idx, val, x_hats
+        self._h_x, self._f_x = h_x, None
+
+    @property
+    def h_x(self) -> Tensor:
+        if self._h_x is None:
+            self._h_x = self._sae._eng().encode_dense(self._x)
+        return self._h_x
+
+    @property
+    def f_x(self) -> Tensor:
+        if self._f_x is None:
+            self._f_x = self._sae._eng().scatter_dense(self.idx, self.val)
+        return self._f_x
+
+
+# ------------------------------------------------------------------------------------------------
+# module
+# ------------------------------------------------------------------------------------------------
+
+
+class TopKActivation(torch.nn.Module):
+    """Per-row top-k of signed pre-activations (modeling.py:160-179), on the HIP select kernel."""
+
+    def __init__(self, cfg: TopK, sae: "SparseAutoencoder | None" = None):
+        super().__init__()
+        self.cfg = cfg
+        self.__dict__["_sae"] = sae  # not a submodule
+
+    def forward(self, x: Tensor) -> Tensor:
+        sae = self.__dict__["_sae"]
+        if sae is None:
+            raise RuntimeError("TopKActivation needs its owning SparseAutoencoder to reach the HIP engine")
+        eng = sae._eng()
+        k = min(self.cfg.top_k, x.shape[-1])
+        idx, val = eng.topk_dense(x, k)
+        return eng.scatter_dense(idx, val)
+
+
+class _Unsupported(torch.nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+    def forward(self, x):
+        raise NotImplementedError(
+            f"{type(self.cfg).__name__} is outside the MI355X hot path (TopK only); the config is kept so "
+            "sweeps/checkpoints parse.")
+
+
+class SparseAutoencoder(torch.nn.Module):
+    """Sparse auto-encoder (modeling.py:287-445)."""
+
+    EncodeOut = EncodeOut
+    Output = Output
+
+    def __init__(self, cfg: SparseAutoencoderConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.logger = logging.getLogger("sae")
+        # Kaiming-uniform decoder rows, unit-normalised; the encoder is an independent copy of its transpose.
+        W_dec = torch.nn.init.kaiming_uniform_(torch.empty(cfg.d_sae, cfg.d_model))
+        if cfg.normalize_w_dec:
+            W_dec /= torch.norm(W_dec, dim=1, keepdim=True)
+        self.W_dec = torch.nn.Parameter(W_dec)
+        self.b_dec = torch.nn.Parameter(torch.zeros(cfg.d_model))
+        self.W_enc = torch.nn.Parameter(W_dec.T.clone())
+        self.b_enc = torch.nn.Parameter(torch.zeros(cfg.d_sae))
+        if isinstance(cfg.activation, TopK):
+            self.activation = TopKActivation(cfg.activation, self)
+        else:
+            self.activation = _Unsupported(cfg.activation)
+        self.__dict__["_engine"] = None
+        self.__dict__["_engine_max_batch"] = 0
+
+    # ---- engine binding ---------------------------------------------------------------------
+    def _engine_cfg(self, max_batch: int, objective_cfg=None) -> EngineConfig:
+        act = self.cfg.activation
+        if not isinstance(act, TopK):
+            raise NotImplementedError(f"{type(act).__name__} activation is not on the HIP path (TopK only)")
+        if not isinstance(act.sparsity, NoSparsity):
+            raise NotImplementedError("TopK with an explicit sparsity penalty is not on the HIP path")
+        aux = act.aux
+        thr = getattr(self, "_dead_threshold_tokens", 10_000_000)
+        return EngineConfig(
+            d_model=self.cfg.d_model, d_sae=self.cfg.d_sae, top_k=act.top_k,
+            k_aux=aux.k_aux if isinstance(aux, AuxK) else 0, alpha=aux.alpha if isinstance(aux, AuxK) else 0.0,
+            dead_threshold_tokens=thr, normalize_w_dec=self.cfg.normalize_w_dec,
+            remove_parallel_grads=self.cfg.remove_parallel_grads, max_batch=max_batch,
+        )
+
+    def _eng(self, max_batch: int = 0) -> SaeEngine:
+        """The engine whose flat buffer backs the four Parameters; (re)built when the module moved
+        device, a larger batch arrives or the tracker threshold changed."""
+        dev = self.W_dec.device
+        if dev.type != "cuda":
+            raise RuntimeError("saev_amd runs on a HIP device only: move the module with .to('cuda') first "
+                               "(there is no CPU path)")
+        eng: SaeEngine | None = self.__dict__["_engine"]
+        want_batch = max(max_batch, self.__dict__["_engine_max_batch"], 1)
+        stale = (
+            eng is None or eng.device != dev or eng.cfg.max_batch < want_batch
+            or eng.cfg.dead_threshold_tokens != getattr(self, "_dead_threshold_tokens", eng.cfg.dead_threshold_tokens)
+            or any(getattr(self, n).data_ptr() != eng.view(n).data_ptr() for n in eng.offsets)
+        )
+        if stale:
+            old = eng
+            values = {n: getattr(self, n).detach().clone() for n in ("W_dec", "b_dec", "W_enc", "b_enc")}
+            eng = SaeEngine(self._engine_cfg(max(want_batch, 1024)), dev)
+            eng.load_params(values)
+            if old is not None and old.device == dev:
+                eng.toks_since_active.copy_(old.toks_since_active)
+                eng.adam_m.copy_(old.adam_m)
+                eng.adam_v.copy_(old.adam_v)
+                eng.adam_steps = old.adam_steps
+                old.close()
+            for n in eng.offsets:
+                getattr(self, n).data = eng.view(n)
+            self.__dict__["_engine"] = eng
+            self.__dict__["_engine_max_batch"] = eng.cfg.max_batch
+        return eng
+
+    # ---- reference API ----------------------------------------------------------------------
+    def forward(self, x: Tensor) -> Output:
+        eng = self._eng(x.shape[0])
+        eng.step_forward(x, training=False)
+        idx, val, x_hat = eng.last_codes(x.shape[0])
+        return Output(self, x, idx, val, x_hat[:, None, :])
+
+    def encode(self, x: Tensor) -> EncodeOut:
+        eng = self._eng(x.shape[0])
+        h_x = eng.encode_dense(x.reshape(-1, self.cfg.d_model))
+        f_x = self.activation(h_x)
+        shape = (*x.shape[:-1], self.cfg.d_sae)
+        return EncodeOut(h_x=h_x.reshape(shape), f_x=f_x.reshape(shape))
+
+    def encode_sparse(self, x: Tensor) -> tuple[Tensor, Tensor]:
+        """(idx, val) codes, (batch, top_k) each, without materialising the dense matrices."""
+        return self._eng(x.shape[0]).encode_topk(x)
+
+    def decode(self, f_x: Tensor, *, prefixes: Tensor | None = None) -> Tensor:
+        """(batch, n_prefixes, d_model) Matryoshka reconstructions of dense latents (modeling.py:351-409)."""
+        b, d_sae = f_x.shape
+        if prefixes is None:
+            prefixes = torch.tensor([d_sae], dtype=torch.int64)
+        pre = [int(p) for p in prefixes]
+        assert all(b_ > a_ for a_, b_ in zip(pre[:-1], pre[1:]))
+        assert 1 <= pre[0] and pre[-1] == d_sae
+        eng = self._eng(b)
+        nz = f_x != 0
+        k = max(int(nz.sum(dim=1).max().item()), 1)
+        idx, _ = eng.topk_dense(nz.to(torch.float32), k)  # ties -> lowest index first: all non-zeros, then zeros
+        val = f_x.gather(1, idx.long())
+        return eng.decode_sparse(idx, val, prefixes=pre)
+
+    @torch.no_grad()
+    def normalize_w_dec(self):
+        if self.cfg.normalize_w_dec:
+            self._eng().normalize_w_dec()
+
+    @torch.no_grad()
+    def remove_parallel_grads(self):
+        if not self.cfg.remove_parallel_grads or self.W_dec.grad is None:
+            return
+        eng = self._eng()
+        g = eng.view("W_dec", eng.grads)
+        if self.W_dec.grad.data_ptr() != g.data_ptr():
+            g.copy_(self.W_dec.grad)
+            self.W_dec.grad = g
+        eng.remove_parallel_grads()
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint I/O (modeling.py:448-658)
+# ------------------------------------------------------------------------------------------------
+
+
+def _ser(value: tp.Any) -> tp.Any:
+    if dataclasses.is_dataclass(value) and not isinstance(value, type):
+        return {"cls": type(value).__name__,
+                "params": {f.name: _ser(getattr(value, f.name)) for f in dataclasses.fields(value)}}
+    if isinstance(value, (tuple, list)):
+        return [_ser(v) for v in value]
+    if isinstance(value, dict):
+        return {k: _ser(v) for k, v in value.items()}
+    return value
+
+
+def _deser(value: tp.Any, *, field: str = "", legacy: bool = False) -> tp.Any:
+    if isinstance(value, dict):
+        if "cls" in value and "params" in value:
+            cls = _CONFIG_CLASSES.get(value["cls"])
+            assert cls is not None, f"Unknown activation class '{value['cls']}' in payload."
+            kwargs = {}
+            for raw, v in value["params"].items():
+                key = "key" if raw == "kind" else raw
+                assert key not in kwargs, f"Duplicate key '{key}' after legacy normalization."
+                kwargs[key] = _deser(v, field=key, legacy=legacy)
+            return cls(**kwargs)
+        if legacy and field == "sparsity":
+            if not value:
+                return NoSparsity()
+            if set(value) <= {"coeff"}:
+                return L1Sparsity(**value)
+        return {k: _deser(v, field=field, legacy=legacy) for k, v in value.items()}
+    if isinstance(value, list):
+        return [_deser(v, field=field, legacy=legacy) for v in value]
+    return value
+
+
+def _cfg_kwargs(d: dict) -> dict:
+    d = dict(d)
+    d.pop("n_reinit_samples", None)
+    d.pop("seed", None)
+    if "exp_factor" in d and "d_sae" not in d:
+        if d.get("d_model") is None:
+            raise ValueError("Cannot infer d_sae from exp_factor without d_model in checkpoint.")
+        d["d_sae"] = d["d_model"] * d.pop("exp_factor")
+    return d
+
+
+def _git_commit() -> str:
+    import subprocess
+
+    try:
+        out = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, timeout=5,
+                             cwd=pathlib.Path(__file__).parent)
+        return out.stdout.strip() or "unknown"
+    except Exception:
+        return "unknown"
+
+
+def dump(fpath: pathlib.Path | str, sae: SparseAutoencoder):
+    """Write ``sae.pt``: header line ``{"schema":5,"cfg":...,"commit":...,"lib":...}\\n`` then
+    ``torch.save(state_dict)`` with four independent CPU tensors, keys ``W_dec,b_dec,W_enc,b_enc``."""
+    cfg_dict = dataclasses.asdict(sae.cfg)
+    cfg_dict["activation"] = _ser(sae.cfg.activation)
+    header = {"schema": SCHEMA_VERSION, "cfg": cfg_dict, "commit": _git_commit(), "lib": __version__}
+    fpath = pathlib.Path(fpath)
+    fpath.parent.mkdir(exist_ok=True, parents=True)
+    state = {k: v.detach().to("cpu").clone() for k, v in sae.state_dict().items()}
+    with open(fpath, "wb") as fd:
+        fd.write(json.dumps(header, separators=(",", ":")).encode() + b"\n")
+        torch.save(state, fd)
+
+
+def load(fpath: pathlib.Path | str, *, device="cpu") -> SparseAutoencoder:
+    """Read a checkpoint written by this package or by the reference (schemas 1-5 and pre-schema)."""
+    with open(fpath, "rb") as fd:
+        header = json.loads(fd.readline())
+        buffer = io.BytesIO(fd.read())
+    if "schema" not in header:
+        for stale in ("sparsity_coeff", "ghost_grads", "l1_coeff", "use_ghost_grads", "seed"):
+            header.pop(stale, None)
+        header["d_model"] = header.pop("d_vit")
+        cfg = SparseAutoencoderConfig(**_cfg_kwargs(header), activation=Relu())
+    elif header["schema"] == 1:
+        cls_name = header.get("cls", "SparseAutoencoderConfig")
+        cfg_dict = dict(header["cfg"])
+        if cls_name in ("Relu", "TopK", "BatchTopK"):
+            act_cls = _CONFIG_CLASSES[cls_name]
+            act = act_cls(top_k=cfg_dict.pop("top_k", 32)) if cls_name != "Relu" else act_cls()
+            cfg = SparseAutoencoderConfig(**_cfg_kwargs(cfg_dict), activation=act)
+        else:
+            if "activation" in cfg_dict:
+                cfg_dict["activation"] = _deser(cfg_dict["activation"], legacy=True)
+            cfg = SparseAutoencoderConfig(**_cfg_kwargs(cfg_dict))
+    elif header["schema"] in (2, 3, 4, 5):
+        cfg_dict = dict(header["cfg"])
+        cfg_dict["activation"] = _deser(cfg_dict["activation"], legacy=header["schema"] != 5)
+        cfg = SparseAutoencoderConfig(**_cfg_kwargs(cfg_dict))
+    else:
+        raise ValueError(f"Unknown schema version: {header['schema']}")
+    model = SparseAutoencoder(cfg)
+    model.load_state_dict(torch.load(buffer, weights_only=True, map_location="cpu"))
+    return model.to(device)

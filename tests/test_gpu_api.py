@@ -1,0 +1,282 @@
+"""The reference's module-level API and known-answer tests, replayed through the HIP path
+(needs an MI355X: -m gpu).  Reference tests restated: tests/test_nn_activations.py:29-94,
+tests/test_auxk.py (scenarios reachable through the objective), tests/test_nn_modeling.py:60-67,
+:99-175, :323-338, tests/test_nn_objectives.py:102-146."""
+
+import dataclasses
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import sae_ref as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def M():
+    from saev_amd.nn import modeling
+
+    return modeling
+
+
+def O():
+    from saev_amd.nn import objectives
+
+    return objectives
+
+
+def identity_sae(d, top_k, k_aux=2, alpha=1.0):
+    m = M()
+    cfg = m.SparseAutoencoderConfig(d_model=d, d_sae=d, normalize_w_dec=False, remove_parallel_grads=False,
+                                    activation=m.TopK(top_k=top_k, aux=m.AuxK(k_aux=k_aux, alpha=alpha)))
+    sae = m.SparseAutoencoder(cfg)
+    with torch.no_grad():
+        sae.W_dec.copy_(torch.eye(d)); sae.W_enc.copy_(torch.eye(d)); sae.b_dec.zero_(); sae.b_enc.zero_()
+    return sae.cuda()
+
+
+def topk_act(k, width=4):
+    sae = identity_sae(width, k)
+    return sae.activation
+
+
+# ---- tests/test_nn_activations.py -------------------------------------------------------------
+
+
+def test_topk_basic_forward():
+    y = topk_act(2)(torch.tensor([[5.0, 1.0, 3.0, 2.0], [2.0, 4.0, 1.0, 3.0]]).cuda()).cpu()
+    torch.testing.assert_close(y, torch.tensor([[5.0, 0.0, 3.0, 0.0], [0.0, 4.0, 0.0, 3.0]]))
+
+
+def test_topk_ties():
+    y = topk_act(2)(torch.full((1, 4), 2.0).cuda()).cpu()
+    assert (y != 0).sum() == 2 and y[y != 0].unique().item() == 2.0
+
+
+def test_topk_k_equals_size():
+    x = torch.tensor([[5.0, 1.0, 3.0, 2.0]])
+    torch.testing.assert_close(topk_act(4)(x.cuda()).cpu(), x)
+
+
+def test_topk_negative_values():
+    y = topk_act(2)(torch.tensor([[-5.0, -1.0, -3.0, -2.0]]).cuda()).cpu()
+    torch.testing.assert_close(y, torch.tensor([[0.0, -1.0, 0.0, -2.0]]))
+
+
+# ---- module surface -----------------------------------------------------------------------------
+
+
+def test_encode_decode_forward_shapes_and_values():
+    sae = identity_sae(4, 2)
+    x = torch.tensor([[1.0, 2.0, 3.0, 4.0]]).cuda()
+    enc = sae.encode(x)
+    assert enc.h_x.cpu().tolist() == [[1.0, 2.0, 3.0, 4.0]] and enc.f_x.cpu().tolist() == [[0.0, 0.0, 3.0, 4.0]]
+    assert sae.decode(torch.ones(2, 4).cuda()).shape == (2, 1, 4)
+    out = sae(x)
+    assert out.x_hats.shape == (1, 1, 4) and out.f_x.shape == (1, 4) and out.h_x.shape == (1, 4)
+    assert out.x_hats.cpu().tolist() == [[[0.0, 0.0, 3.0, 4.0]]]
+    idx, val = sae.encode_sparse(x)
+    assert idx.cpu().tolist() == [[2, 3]] and val.cpu().tolist() == [[3.0, 4.0]]
+
+
+def test_decode_prefixes_match_oracle():
+    g = load_golden("g2_decode")
+    m = M()
+    sae = m.SparseAutoencoder(m.SparseAutoencoderConfig(d_model=48, d_sae=320, activation=m.TopK(top_k=8)))
+    with torch.no_grad():
+        sae.W_dec.copy_(g["W_dec"]); sae.b_dec.copy_(g["b_dec"])
+    sae = sae.cuda()
+    out = sae.decode(g["f"].cuda(), prefixes=g["prefixes"]).cpu()
+    torch.testing.assert_close(out, g["x_hats_p3"], rtol=1e-5, atol=1e-5)
+    with pytest.raises(AssertionError):
+        sae.decode(g["f"].cuda(), prefixes=torch.tensor([100, 7, 320]))
+
+
+def test_remove_parallel_grads_orthogonal_for_unnormalised_rows():
+    m = M()
+    sae = m.SparseAutoencoder(m.SparseAutoencoderConfig(d_model=4, d_sae=4, normalize_w_dec=False, remove_parallel_grads=True)).cuda()
+    with torch.no_grad():
+        sae.W_dec.copy_(torch.randn(4, 4))
+    sae.W_dec.grad = torch.randn(4, 4).cuda()
+    sae.remove_parallel_grads()
+    dots = (sae.W_dec.grad * sae.W_dec).sum(dim=1).cpu()
+    assert torch.allclose(dots, torch.zeros(4), atol=1e-6)
+
+
+def test_dump_load_roundtrip_from_gpu_module(tmp_path):
+    m = M()
+    sae = m.SparseAutoencoder(m.SparseAutoencoderConfig(d_model=64, d_sae=256, activation=m.TopK(top_k=8))).cuda()
+    x = torch.randn(32, 64).cuda()
+    before = sae(x).x_hats.cpu()
+    m.dump(tmp_path / "sae.pt", sae)
+    back = m.load(tmp_path / "sae.pt", device="cuda")
+    torch.testing.assert_close(back(x).x_hats.cpu(), before, rtol=0, atol=0)
+    w_dec = back.W_dec.detach().clone()
+    with torch.no_grad():
+        back.W_enc.mul_(2.0)
+    assert torch.equal(back.W_dec, w_dec), "W_enc and W_dec do not share storage"
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    sae = identity_sae(4, 2)
+    with pytest.raises(Exception, match="float32 on cuda|cuda"):
+        sae.encode(torch.zeros(1, 4))
+
+
+# ---- objective / AuxK ---------------------------------------------------------------------------
+
+
+def objective_for(sae, thr=10_000_000):
+    o = O()
+    return o.get_objective(o.Matryoshka(n_prefixes=1, dead_threshold_tokens=thr))
+
+
+def test_objective_total_and_eval_mode():
+    sae = identity_sae(4, 4)
+    obj = objective_for(sae)
+    loss, out = obj(sae, torch.randn(2, 4).cuda())
+    assert torch.allclose(loss.loss.detach(), loss.mse + loss.sparsity.to(loss.mse.device) + loss.aux)
+    assert set(loss.metrics()) == {"loss", "mse", "l0", "l1", "sparsity", "aux", "n_dead"}
+    sae.eval(); obj.eval()
+    loss, _ = obj(sae, torch.tensor([[1.0, 2.0, 3.0, 4.0]]).cuda())
+    assert loss.aux.item() == 0.0 and int(loss.n_dead) == 0
+    with pytest.raises(NotImplementedError):
+        O().get_objective(O().Matryoshka(n_prefixes=10))(sae, torch.zeros(1, 4).cuda())
+
+
+def test_n_dead_tracks_dead_latents():  # tests/test_auxk.py:304-353
+    thr = 10
+    sae = identity_sae(4, 2, k_aux=512, alpha=1 / 32).train()
+    obj = objective_for(sae, thr).train()
+    x = torch.tensor([[2.0, 1.0, 0.0, -1.0]] * 2).cuda()
+    loss, _ = obj(sae, x)
+    assert int(loss.n_dead) == 0
+    for _ in range(thr // 2 + 1):
+        loss, _ = obj(sae, x)
+    assert int(loss.n_dead) == 2
+    loss, _ = obj(sae, torch.tensor([[0.0, 1.0, 3.0, -1.0]] * 2).cuda())
+    assert int(loss.n_dead) == 1
+    assert obj.toks_since_active.tolist()[2] == 0
+
+
+def test_auxk_uses_preacts_of_dead_latents():  # tests/test_auxk.py:198-238
+    sae = identity_sae(4, 2, k_aux=2, alpha=1.0).train()
+    obj = objective_for(sae, thr=100).train()
+    obj.toks_since_active = torch.tensor([100, 100, 0, 0])
+    loss, out = obj(sae, torch.tensor([[1.0, 2.0, 3.0, 4.0]]).cuda())
+    assert out.f_x.cpu().tolist() == [[0.0, 0.0, 3.0, 4.0]]
+    assert int(loss.n_dead) == 2 and abs(loss.aux.item()) < 1e-6  # dead pre-acts [1,2] rebuild the residual exactly
+    # k_aux = 1: only latent 1 (h = 2) is used -> diff = [-1, 0, 0, 0] -> mean 1/4
+    sae1 = identity_sae(4, 2, k_aux=1, alpha=0.5).train()
+    obj1 = objective_for(sae1, thr=100).train()
+    obj1.toks_since_active = torch.tensor([100, 100, 0, 0])
+    loss1, _ = obj1(sae1, torch.tensor([[1.0, 2.0, 3.0, 4.0]]).cuda())
+    assert math.isclose(loss1.aux.item(), 0.5 * 0.25, rel_tol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["nodead", "dead", "dead_few"])
+def test_backward_populates_param_grads_like_autograd(tag):
+    g = load_golden(f"g5_objective_{tag}")
+    m, o = M(), O()
+    cfg = m.SparseAutoencoderConfig(d_model=64, d_sae=512, normalize_w_dec=False, remove_parallel_grads=False,
+                                    activation=m.TopK(top_k=int(g["k"]), aux=m.AuxK(k_aux=int(g["k_aux"]), alpha=float(g["alpha"]))))
+    sae = m.SparseAutoencoder(cfg)
+    sae.load_state_dict({k: g["p_" + k] for k in R.PARAM_ORDER})
+    sae = sae.cuda().train()
+    obj = o.get_objective(o.Matryoshka(n_prefixes=1, dead_threshold_tokens=int(g["thr"]))).train()
+    obj.toks_since_active = g["toks_before"]
+    loss, out = obj(sae, g["x"].cuda())
+    loss.loss.backward()
+    assert math.isclose(loss.mse.item(), g["mse"], rel_tol=1e-4) and int(loss.n_dead) == g["n_dead"]
+    for k in R.PARAM_ORDER:
+        torch.testing.assert_close(getattr(sae, k).grad.cpu(), g["g_" + k], rtol=1e-3, atol=1e-7, msg=lambda s: f"{k}: {s}")
+    torch.testing.assert_close(out.f_x.cpu(), g["f"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.h_x.cpu(), g["h"], rtol=1e-5, atol=1e-5)
+
+
+# ---- train() / evaluate() ---------------------------------------------------------------------
+
+
+def small_cfg(tmp_path, g, **kw):
+    from saev_amd import data
+    from saev_amd.framework import train as T
+
+    m, o = M(), O()
+    d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
+    dc = data.ShuffledConfig(batch_size=bsz, seed=3)
+    return T.Config(
+        train_data=dc, val_data=dc, n_train=int(g["n_train"]), n_val=10**9,
+        sae=m.SparseAutoencoderConfig(d_model=d, d_sae=s, reinit_blend=0.0,
+                                      activation=m.TopK(top_k=k, aux=m.AuxK(k_aux=int(g["k_aux"]), alpha=1 / 32))),
+        objective=o.Matryoshka(n_prefixes=1, dead_threshold_tokens=int(g["thr"])),
+        lr=float(g["lr"]), n_lr_warmup=int(g["n_warm"]), track=False, log_every=5, runs_root=tmp_path / "runs", **kw)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_evaluate_matches_reference_metrics(tmp_path, tag):
+    """evaluate() sums are batch-order independent: load the reference's trained parameters and compare
+    with the metrics the reference's evaluate() produced (golden G9)."""
+    from saev_amd.framework import train as T
+
+    g = load_golden(f"g9_train_{tag}")
+    cfg = small_cfg(tmp_path, g)
+    sae = M().SparseAutoencoder(cfg.sae)
+    sae.load_state_dict({k: g["final_" + k] for k in R.PARAM_ORDER})
+    saes = torch.nn.ModuleList([sae]).cuda()
+    objs = torch.nn.ModuleList([O().get_objective(cfg.objective)])
+    ev = T.evaluate([cfg], saes, objs, val_pool=g["val"])[0]
+    flip = 4.0 / (g["val"].shape[0] * int(g["k"]))
+    for key in ("l1", "mse", "normalized_mse", "sse_sae"):
+        assert math.isclose(getattr(ev, key), float(g["ev_" + key]), rel_tol=max(1e-4, flip)), key
+    assert math.isclose(ev.l0, float(g["ev_l0"]), rel_tol=1e-6)
+    assert math.isclose(ev.sse_baseline, float(g["ev_sse_baseline"]), rel_tol=1e-9)
+    assert abs(ev.n_dead - int(g["ev_n_dead"])) <= 1 and ev.n_dense == int(g["ev_n_dense"])
+    assert (ev.freqs - g["ev_freqs"]).abs().max() < 2.0 / g["val"].shape[0]
+
+
+def test_train_end_to_end_matches_oracle_on_same_batches(tmp_path):
+    from saev_amd import data
+    from saev_amd.framework import train as T
+    from saev_amd.utils import scheduling
+
+    g = load_golden("g9_train_a")
+    cfg = small_cfg(tmp_path, g)
+    ids = T.worker_fn([cfg], train_pool=g["acts"], val_pool=g["val"])
+    run_dir = tmp_path / "runs" / ids[0]
+    ckpt = M().load(run_dir / "checkpoint" / "sae.pt")
+    assert json.loads((run_dir / "checkpoint" / "config.json").read_text())["lr"] == cfg.lr
+    logs = [json.loads(line) for line in (run_dir / "metrics.jsonl").read_text().splitlines()]
+    assert logs[0]["step"] == 4 and "metrics/normalized_mse" in logs[0] and "eval/normalized_mse" in logs[-1]
+    # the same batches through the oracle
+    torch.manual_seed(cfg.seed)
+    init = M().SparseAutoencoder(cfg.sae)
+    rcfg = R.RefConfig(d_model=int(g["d"]), d_sae=int(g["s"]), top_k=int(g["k"]), k_aux=int(g["k_aux"]),
+                       dead_threshold_tokens=int(g["thr"]), lr=cfg.lr, n_lr_warmup=cfg.n_lr_warmup)
+    state = R.TrainState.create({k: getattr(init, k).detach() for k in R.PARAM_ORDER})
+    split = T.split_cfgs([cfg])[0][0]
+    dl = data.ShuffledDataLoader(split.train_data, device="cpu", pool=g["acts"])
+    lim = scheduling.BatchLimiter(dl, cfg.n_train)
+    sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, len(lim), 0.0)
+    mses = []
+    for batch in lim:
+        mses.append(R.train_step(state, batch["act"], rcfg, sched)["mse"])
+    for k in R.PARAM_ORDER:
+        torch.testing.assert_close(getattr(ckpt, k).detach(), state.params[k], rtol=2e-3, atol=5e-5, msg=lambda s: f"{k}: {s}")
+    assert math.isclose(logs[-2]["loss/mse"], mses[logs[-2]["step"]], rel_tol=1e-3)
+    assert mses[-1] < mses[0]
+
+
+def test_train_is_deterministic(tmp_path):
+    from saev_amd.framework import train as T
+
+    g = load_golden("g9_train_b")
+    outs = []
+    for run in range(2):
+        saes, objs, log, steps = T.train([small_cfg(tmp_path, g)], train_pool=g["acts"])
+        outs.append({k: v.detach().cpu().clone() for k, v in saes[0].state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"{k} differs between identical runs"

@@ -1,0 +1,259 @@
+"""CPU-only tests of the host side: C-ABI surface, schedules, checkpoints, config grouping, the shard
+cache reader and the device-resident loader (run on CPU tensors here)."""
+
+import dataclasses
+import json
+import math
+import pathlib
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import sae_ref as R
+from conftest import ROOT, load_golden
+
+
+# ---- C ABI ----------------------------------------------------------------------------------
+
+
+def header_functions():
+    text = (ROOT / "include" / "saev_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(saev_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    subprocess.run(["make", "-C", str(ROOT)], check=True, capture_output=True)
+    from saev_amd import _lib
+
+    lib = _lib.load()
+    assert lib.saev_abi_version() == _lib.ABI_VERSION
+    declared = header_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/saev_amd.h but not exported"
+    assert set(_lib.EXPORTED_SYMBOLS) == set(declared), set(_lib.EXPORTED_SYMBOLS) ^ set(declared)
+
+
+def test_struct_layouts_match_header():
+    import ctypes
+
+    from saev_amd import _lib
+
+    assert ctypes.sizeof(_lib.SaevCfg) == 48
+    assert ctypes.sizeof(_lib.SaevStepStats) == 56
+    assert _lib.SaevStepStats.sse.offset == 40
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from saev_amd import _lib
+    from saev_amd.engine import EngineConfig, SaeEngine
+    from saev_amd.nn import modeling as M
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.SaevError, match="no CPU path"):
+        SaeEngine(EngineConfig(d_model=16, d_sae=32, top_k=4))
+    sae = M.SparseAutoencoder(M.SparseAutoencoderConfig(d_model=16, d_sae=32, activation=M.TopK(top_k=4)))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        sae.encode(torch.zeros(2, 16))
+
+
+def test_product_package_never_imports_the_oracle():
+    for py in (ROOT / "saev_amd").rglob("*.py"):
+        src = py.read_text()
+        assert "sae_ref" not in src and "import oracle" not in src and "from oracle" not in src, py
+
+
+# ---- schedules -------------------------------------------------------------------------------
+
+
+def test_schedules_match_golden_and_oracle():
+    from saev_amd.utils import scheduling as S
+
+    g = load_golden("g11_schedule")
+    for tag in "abc":
+        a = g[f"args_{tag}"].tolist()
+        sc = S.WarmupCosine(a[0], int(a[1]), a[2], int(a[3]), a[4])
+        got = [sc.step() for _ in range(len(g[f"lr_{tag}"]))]
+        np.testing.assert_array_equal(got, g[f"lr_{tag}"].numpy())
+
+    class DL:
+        def __init__(self, n, b):
+            self.n, self.batch_size, self.drop_last = n, b, False
+
+        def __iter__(self):
+            for i in range(0, self.n, self.batch_size):
+                yield {"act": torch.zeros(min(self.batch_size, self.n - i), 1)}
+
+    for n_rows, bsz, n_train, ln, n_steps, n_seen in g["limiter"].tolist():
+        lim = S.BatchLimiter(DL(n_rows, bsz), n_train)
+        sizes = [len(b["act"]) for b in lim]
+        assert (len(lim), len(sizes), sum(sizes)) == (ln, n_steps, n_seen)
+    assert lim.batch_size == 128 and lim.n == 4096  # attribute pass-through
+    w = S.Warmup(0.0, 1.0, 4)
+    assert [w.step() for _ in range(5)] == [0.25, 0.5, 0.75, 1.0, 1.0]
+
+
+# ---- checkpoints -----------------------------------------------------------------------------
+
+
+def test_dump_matches_reference_header_and_roundtrips(tmp_path):
+    from saev_amd.nn import modeling as M
+
+    g = load_golden("g12_checkpoint")
+    want = json.loads(bytes(g["header_json"].numpy().tolist()).decode())
+    cfg = M.SparseAutoencoderConfig(d_model=16, d_sae=48, reinit_blend=0.0,
+                                    activation=M.TopK(top_k=4, aux=M.AuxK(k_aux=7, alpha=0.125)))
+    sae = M.SparseAutoencoder(cfg)
+    with torch.no_grad():
+        for k in R.PARAM_ORDER:
+            getattr(sae, k).copy_(g["sd_" + k])
+    M.dump(tmp_path / "sae.pt", sae)
+    raw = (tmp_path / "sae.pt").read_bytes()
+    header = json.loads(raw.split(b"\n", 1)[0])
+    assert header["schema"] == want["schema"] == 5
+    assert header["cfg"] == want["cfg"], "cfg block identical to what the reference's nn.dump writes"
+    assert set(header) == set(want)
+    back = M.load(tmp_path / "sae.pt")
+    assert back.cfg == cfg and list(back.state_dict()) == ["W_dec", "b_dec", "W_enc", "b_enc"]
+    for k in R.PARAM_ORDER:
+        assert torch.equal(getattr(back, k), g["sd_" + k])
+    assert back.W_enc.data_ptr() != back.W_dec.data_ptr()
+
+
+def test_load_reads_legacy_schemas(tmp_path):
+    import io
+
+    from saev_amd.nn import modeling as M
+
+    sae = M.SparseAutoencoder(M.SparseAutoencoderConfig(d_model=8, d_sae=16, activation=M.TopK(top_k=2)))
+    buf = io.BytesIO()
+    torch.save(sae.state_dict(), buf)
+    cases = {
+        "v1a": {"schema": 1, "cls": "TopK", "cfg": {"d_model": 8, "exp_factor": 2, "top_k": 2, "seed": 1}},
+        "v2": {"schema": 2, "cfg": {"d_model": 8, "d_sae": 16, "activation": {"cls": "TopK", "params": {"kind": "top-k", "top_k": 2, "sparsity": {}}}}},
+        "v4l1": {"schema": 4, "cfg": {"d_model": 8, "d_sae": 16, "activation": {"cls": "Relu", "params": {"sparsity": {"coeff": 0.01}}}}},
+    }
+    for name, hdr in cases.items():
+        p = tmp_path / f"{name}.pt"
+        p.write_bytes(json.dumps(hdr).encode() + b"\n" + buf.getvalue())
+        got = M.load(p)
+        assert got.cfg.d_sae == 16 and torch.equal(got.W_dec, sae.W_dec)
+    assert isinstance(M.load(tmp_path / "v4l1.pt").cfg.activation.sparsity, M.L1Sparsity)
+    (tmp_path / "bad.pt").write_bytes(json.dumps({"schema": 99, "cfg": {}}).encode() + b"\n")
+    with pytest.raises(ValueError, match="Unknown schema"):
+        M.load(tmp_path / "bad.pt")
+
+
+def test_reference_loader_reads_our_checkpoint(tmp_path):
+    import _refshim
+
+    if not _refshim.available():
+        pytest.skip("reference checkout not present (GPU box)")
+    from saev_amd.nn import modeling as M
+
+    ref = _refshim.install()
+    sae = M.SparseAutoencoder(M.SparseAutoencoderConfig(d_model=16, d_sae=48, activation=M.TopK(top_k=4)))
+    M.dump(tmp_path / "ours.pt", sae)
+    theirs = ref.modeling.load(tmp_path / "ours.pt")
+    assert torch.equal(theirs.W_enc, sae.W_enc) and theirs.cfg.activation.top_k == 4
+    ref.modeling.dump(tmp_path / "theirs.pt", theirs)
+    again = M.load(tmp_path / "theirs.pt")
+    assert again.cfg == sae.cfg and torch.equal(again.b_dec, sae.b_dec)
+
+
+def test_module_surface_matches_reference_shapes():
+    from saev_amd.nn import modeling as M
+
+    cfg = M.SparseAutoencoderConfig()
+    assert (cfg.d_model, cfg.d_sae, cfg.reinit_blend, cfg.remove_parallel_grads, cfg.normalize_w_dec) == (1024, 16384, 0.8, True, True)
+    assert cfg.activation == M.TopK(top_k=32, sparsity=M.NoSparsity(), aux=M.AuxK(k_aux=512, alpha=1 / 32))
+    sae = M.SparseAutoencoder(M.SparseAutoencoderConfig(d_model=12, d_sae=40))
+    assert sae.W_dec.shape == (40, 12) and sae.W_enc.shape == (12, 40) and sae.b_dec.shape == (12,) and sae.b_enc.shape == (40,)
+    torch.testing.assert_close(sae.W_dec.norm(dim=1), torch.ones(40))
+    assert torch.equal(sae.W_enc, sae.W_dec.T) and (sae.b_enc == 0).all()
+    with pytest.raises(AssertionError):
+        M.TopK(top_k=0)
+
+
+# ---- config grouping (reference tests/test_framework_train.py:14-61) ------------------------------
+
+
+def test_split_cfgs_groups_by_data_not_by_hyperparams():
+    from saev_amd import data
+    from saev_amd.framework import train as T
+
+    def mk(path):
+        return T.Config(train_data=data.ShuffledConfig(shards=pathlib.Path(path)), val_data=data.ShuffledConfig(shards=pathlib.Path(path)))
+
+    a1, a2 = dataclasses.replace(mk("/p/a"), lr=1e-3), dataclasses.replace(mk("/p/a"), lr=2e-3, seed=7)
+    b = mk("/p/b")
+    groups = T.split_cfgs([a1, a2, b])
+    assert sorted(len(g) for g in groups) == [1, 2]
+    for grp in groups:
+        assert len({c.train_data.shards for c in grp}) == 1
+        for c in grp:
+            assert c.train_data.seed == c.seed == c.val_data.seed
+    assert len(T.split_cfgs([a1, dataclasses.replace(a1, lr=3e-3), dataclasses.replace(a1, lr=4e-3)])) == 1
+    c = T.Config()
+    assert (c.n_train, c.lr, c.n_lr_warmup, c.grad_clip, c.log_every, c.seed, c.optim) == (100_000_000, 4e-4, 500, 1.0, 25, 42, "adam")
+
+
+# ---- shard cache + loader ---------------------------------------------------------------------
+
+
+def test_shard_cache_roundtrip_and_loader_semantics(tmp_path):
+    from saev_amd import data
+    from saev_amd.data import shards as SH
+
+    rng = np.random.default_rng(0)
+    acts = rng.standard_normal((10, 2, 5, 8)).astype(np.float32)  # 10 examples, 2 layers, CLS + 4 patches, d=8
+    d = data.write_shards(tmp_path, acts, layers=(6, 11), cls_token=True, max_tokens_per_shard=30)
+    md = data.Metadata.load(d)
+    assert d.name == md.hash and d.parent.name == "shards" and d.parent.parent.name == "saev"
+    assert (md.tokens_per_example, md.examples_per_shard, md.n_shards) == (5, 3, 4)
+    info = data.ShardInfo.load(d)
+    assert [n for _, n in info] == [3, 3, 3, 1] and info.shards[2][0] == "acts000002.bin"
+    mm = SH.open_shard(d, md, *info.shards[1])
+    np.testing.assert_array_equal(np.asarray(mm), acts[3:6])
+
+    cfg = data.ShuffledConfig(shards=d, layer=11, tokens="content", batch_size=16, seed=3)
+    dl = data.ShuffledDataLoader(cfg, device="cpu")
+    assert dl.n_samples == 40 and len(dl) == 3 and dl.batch_size == 16
+    seen = {}
+    for batch in dl:
+        assert batch["act"].dtype == torch.float32 and batch["example_idx"].dtype == torch.int32
+        for a, e, t in zip(batch["act"], batch["example_idx"].tolist(), batch["token_idx"].tolist()):
+            assert (e, t) not in seen
+            seen[(e, t)] = a
+            np.testing.assert_array_equal(a.numpy(), acts[e, 1, t + 1])  # content token t sits after the CLS slot
+    assert len(seen) == 40, "every row exactly once per epoch"
+    first_epoch_order = list(seen)
+    assert [k for b in dl for k in zip(b["example_idx"].tolist(), b["token_idx"].tolist())] != first_epoch_order
+    # drop_last and data-parallel sharding
+    dl2 = data.ShuffledDataLoader(dataclasses.replace(cfg, drop_last=True), device="cpu")
+    assert [len(b["act"]) for b in dl2] == [16, 16]
+    parts = [data.ShuffledDataLoader(cfg, device="cpu", rank=r, world_size=2) for r in range(2)]
+    ex = [set(p.example_idx.tolist()) for p in parts]
+    assert ex[0].isdisjoint(ex[1]) and len(ex[0] | ex[1]) == 10 and parts[0].local_batch == 8
+    cls = data.ShuffledDataLoader(dataclasses.replace(cfg, tokens="special", layer=6), device="cpu")
+    b = next(iter(cls))
+    np.testing.assert_array_equal(b["act"][0].numpy(), acts[b["example_idx"][0].item(), 0, 0])
+    with pytest.raises(ValueError, match="not in recorded layers"):
+        data.ShuffledDataLoader(dataclasses.replace(cfg, layer=3), device="cpu")
+
+
+def test_sample_prefixes_contract():
+    from saev_amd.nn import objectives as O
+
+    assert O.sample_prefixes(64, 1).tolist() == [64]
+    torch.manual_seed(0)
+    p = O.sample_prefixes(512, 10)
+    assert p.dtype == torch.int64 and len(p) == 10 and p[-1] == 512 and (p[1:] > p[:-1]).all() and p[0] >= 1
+    torch.manual_seed(0)
+    assert torch.equal(p, R.sample_prefixes(512, 10)), "same draw as the oracle restatement under the same seed"
+    assert O.Matryoshka() == O.Matryoshka(n_prefixes=10, dead_threshold_tokens=10_000_000)

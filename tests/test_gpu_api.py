@@ -257,8 +257,7 @@ def test_train_end_to_end_matches_oracle_on_same_batches(tmp_path):
     rcfg = R.RefConfig(d_model=int(g["d"]), d_sae=int(g["s"]), top_k=int(g["k"]), k_aux=int(g["k_aux"]),
                        dead_threshold_tokens=int(g["thr"]), lr=cfg.lr, n_lr_warmup=cfg.n_lr_warmup)
     state = R.TrainState.create({k: getattr(init, k).detach() for k in R.PARAM_ORDER})
-    split = T.split_cfgs([cfg])[0][0]
-    dl = data.ShuffledDataLoader(split.train_data, device="cpu", pool=g["acts"])
+    dl = data.ShuffledDataLoader(cfg.train_data, device="cpu", pool=g["acts"])
     lim = scheduling.BatchLimiter(dl, cfg.n_train)
     sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, len(lim), 0.0)
     mses = []

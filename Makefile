@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := saev_amd/csrc
-SRCS  := $(CSRC)/ctx.hip $(CSRC)/gemm_encode.hip $(CSRC)/select.hip $(CSRC)/sparse.hip $(CSRC)/tail.hip
+SRCS  := $(CSRC)/ctx.hip $(CSRC)/gemm_encode.hip $(CSRC)/gemm_encode_f16x3.hip $(CSRC)/split.hip $(CSRC)/select.hip $(CSRC)/sparse.hip $(CSRC)/tail.hip
 OBJS  := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-value -Iinclude
 

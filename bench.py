@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--encoder", choices=["f32", "f16x3"], default=None, help="encoder arithmetic (default: engine default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,7 +87,12 @@ def main():
     from saev_amd.framework.ddp import DataParallelStepper
 
     B = args.batch
-    eng = SaeEngine(EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B), dev)
+    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B)
+    if args.encoder:
+        import dataclasses
+
+        ecfg = dataclasses.replace(ecfg, encoder=args.encoder)
+    eng = SaeEngine(ecfg, dev)
     # random-init weights of the reference architecture (modeling.py:306-329), model seed 42
     g = torch.Generator(device=dev).manual_seed(42)
     W = (torch.rand(D_SAE, D_MODEL, device=dev, generator=g) * 2 - 1) * math.sqrt(6.0 / D_MODEL)

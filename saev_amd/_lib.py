@@ -21,7 +21,7 @@ class SaevCfg(C.Structure):
         ("d_model", C.c_int32), ("d_sae", C.c_int32), ("top_k", C.c_int32), ("k_aux", C.c_int32),
         ("alpha", C.c_float), ("dead_threshold_tokens", C.c_int64),
         ("normalize_w_dec", C.c_int32), ("remove_parallel_grads", C.c_int32),
-        ("max_batch", C.c_int32), ("reserved", C.c_int32),
+        ("max_batch", C.c_int32), ("encoder_mode", C.c_int32),
     ]
 
 

@@ -49,6 +49,9 @@ struct saev_ctx {
     int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use
     int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
     float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
+    // f16x3 encoder operands
+    _Float16 *xh = nullptr, *xl = nullptr, *wh = nullptr, *wl = nullptr;
+    int Dp = 0, S_pad = 0, MB_pad = 0;
     int max_work = 0, max_part = 0;
     float* upper = nullptr;
     saev_step_stats* stats = nullptr;
@@ -96,11 +99,10 @@ int alloc(saev_ctx* c, T** p, size_t count) {
     return SAEV_OK;
 }
 
-int encoder_splits(int n_rows, int S) {
-    // two workgroups per CU: aim for ~512 workgroups
-    const int nb = (n_rows + encode_gemm_tile_rows() - 1) / encode_gemm_tile_rows();
-    const int nst = (S + encode_gemm_tile_latents() - 1) / encode_gemm_tile_latents();
-    int sp = (512 + nb - 1) / nb;
+int encoder_splits(int n_rows, int S, int tile_rows, int tile_latents, int target_wgs) {
+    const int nb = (n_rows + tile_rows - 1) / tile_rows;
+    const int nst = (S + tile_latents - 1) / tile_latents;
+    int sp = (target_wgs + nb - 1) / nb;
     return std::max(1, std::min(sp, nst));
 }
 
@@ -130,6 +132,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     if (cfg->d_model <= 0 || cfg->d_sae <= 0 || cfg->top_k <= 0 || cfg->max_batch <= 0) return SAEV_INVALID_ARG;
     if (cfg->d_model % 4 != 0 || cfg->d_sae % 4 != 0 || cfg->d_model > 2048) return SAEV_UNSUPPORTED;
     if (cfg->k_aux < 0 || cfg->k_aux > 1024) return SAEV_UNSUPPORTED;
+    if (cfg->encoder_mode != SAEV_ENCODER_F32 && cfg->encoder_mode != SAEV_ENCODER_F16X3) return SAEV_INVALID_ARG;
     saev_ctx* c = new saev_ctx();
     c->cfg = *cfg;
     c->cfg.top_k = std::min(cfg->top_k, cfg->d_sae);
@@ -164,6 +167,13 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part);
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 1024); A(sumsq_total, 1);
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+        c->Dp = (int)((D + 31) / 32 * 32);
+        c->S_pad = (int)((S + 255) / 256 * 256);
+        c->MB_pad = (int)((MB + 255) / 256 * 256);
+        A(xh, (size_t)c->MB_pad * c->Dp); A(xl, (size_t)c->MB_pad * c->Dp);
+        A(wh, (size_t)c->S_pad * c->Dp); A(wl, (size_t)c->S_pad * c->Dp);
+    }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
 #undef A
     if (rc != SAEV_OK) {
@@ -178,6 +188,10 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     hipMemset(c->flags, 0, 8 * sizeof(int32_t));
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
     hipMemset(c->rowstats, 0, MB * sizeof(RowStats));
+    if (c->xh) {
+        hipMemset(c->xh, 0, (size_t)c->MB_pad * c->Dp * sizeof(_Float16));
+        hipMemset(c->xl, 0, (size_t)c->MB_pad * c->Dp * sizeof(_Float16));
+    }
     hipDeviceSynchronize();
     *out = c;
     return SAEV_OK;
@@ -281,8 +295,31 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
     return SAEV_OK;
 }
 
+// operand preparation for the f16x3 encoder: split x and W_enc^T into fp16 hi/lo (no-op for the f32 encoder)
+static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s) {
+    if (c->cfg.encoder_mode != SAEV_ENCODER_F16X3) return SAEV_OK;
+    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xh, c->xl, s));
+    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, c->cfg.d_model, c->cfg.d_sae, c->S_pad, c->Dp, 256.0f, c->wh,
+                              c->wl, s));
+    return SAEV_OK;
+}
+
 static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out, const int32_t* flag, int when,
                        hipStream_t s) {
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+        EncodeF16Args a{};
+        a.xh = c->xh; a.xl = c->xl; a.wh = c->wh; a.wl = c->wl;
+        a.b_enc = c->params + c->off_b_enc;
+        a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = 256.0f;
+        a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
+        a.h_out = h_out;
+        a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
+        a.row_tau = c->row_tau; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
+        a.cand_cap = CAND_CAP;
+        a.enable_flag = flag; a.enable_when = when;
+        HIPCHK(c, launch_encode_f16x3(a, epi, s));
+        return SAEV_OK;
+    }
     EncodeArgs a{};
     a.x = x;
     a.W_enc = c->params + c->off_W_enc;
@@ -290,7 +327,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
     a.n_rows = n;
     a.D = c->cfg.d_model;
     a.S = c->cfg.d_sae;
-    a.s_splits = encoder_splits(n, a.S);
+    a.s_splits = encoder_splits(n, a.S, encode_gemm_tile_rows(), encode_gemm_tile_latents(), 512);
     a.h_out = h_out;
     a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
     a.row_tau = c->row_tau;
@@ -308,6 +345,10 @@ int saev_encode_dense(saev_ctx* c, const float* x, int32_t n, float* h_out, void
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, c->params, SAEV_NOT_BOUND, "parameters not bound");
     REQUIRE(c, x && h_out && n > 0, SAEV_INVALID_ARG, "saev_encode_dense: bad arguments");
+    REQUIRE(c, n <= c->cfg.max_batch || c->cfg.encoder_mode == SAEV_ENCODER_F32, SAEV_INVALID_ARG,
+            "saev_encode_dense: n_rows > max_batch");
+    int rc = prepare_encoder(c, x, n, (hipStream_t)stream);
+    if (rc != SAEV_OK) return rc;
     return run_encoder(c, x, n, EPI_DENSE, h_out, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -328,6 +369,10 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                             const int32_t* pre_flag, hipStream_t s) {
     const int K = c->cfg.top_k;
     int32_t* need_dense = c->flags + 1;
+    {
+        int rc0 = prepare_encoder(c, x, n, s);
+        if (rc0 != SAEV_OK) return rc0;
+    }
     timing_begin(c, s);
     if (fused_supported(c->cfg)) {
         HIPCHK(c, hipMemsetAsync(c->cand_cnt, 0, (size_t)n * sizeof(int32_t), s));

@@ -192,3 +192,28 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
 // reduce rowstats[0..n_rows) into *stats (mse, l0, l1, aux, sse, sum_sq)
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, float alpha, int with_aux, const float* upper,
                                const int32_t* n_overflow_and_max, saev_step_stats* stats, hipStream_t stream);
+
+// ---- f16x3 encoder (fp32-accurate split-fp16 MFMA) -------------------------------------------------
+struct EncodeF16Args {
+    const _Float16 *xh, *xl;  // (rows padded to 256, Dp)
+    const _Float16 *wh, *wl;  // (S padded to 256, Dp), W_enc transposed, scaled by w_scale
+    const float* b_enc;       // (S)
+    int n_rows, Dp, S;
+    float w_scale;
+    int s_splits;
+    float* h_out;             // EPI_DENSE
+    int ngroups;              // EPI_TOPK
+    int32_t* row_tau;
+    int32_t* cand_cnt;
+    float* cand_val;
+    int32_t* cand_idx;
+    int cand_cap;
+    const int32_t* enable_flag;
+    int enable_when;
+};
+hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream);
+int encode_f16x3_tile_rows();
+int encode_f16x3_tile_latents();
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xh, void* xl, hipStream_t stream);
+hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* wh, void* wl,
+                           hipStream_t stream);

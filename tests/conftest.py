@@ -40,3 +40,15 @@ def load_golden(name: str) -> dict:
 @pytest.fixture
 def golden():
     return load_golden
+
+
+@pytest.fixture(params=["f32", "f16x3"], autouse=True)
+def encoder_mode(request, monkeypatch):
+    """GPU tests run once per encoder arithmetic (both are fp32-accurate); CPU tests ignore it."""
+    if "gpu" not in request.keywords:
+        if request.param != "f32":
+            pytest.skip("encoder mode only matters on the GPU")
+        yield request.param
+        return
+    monkeypatch.setenv("SAEV_AMD_ENCODER", request.param)
+    yield request.param

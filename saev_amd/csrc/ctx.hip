@@ -50,7 +50,7 @@ struct saev_ctx {
     int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
     float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
     // f16x3 encoder operands
-    _Float16 *xh = nullptr, *xl = nullptr, *wh = nullptr, *wl = nullptr;
+    _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
     int max_work = 0, max_part = 0;
     float* upper = nullptr;
@@ -171,8 +171,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         c->Dp = (int)((D + 31) / 32 * 32);
         c->S_pad = (int)((S + 255) / 256 * 256);
         c->MB_pad = (int)((MB + 255) / 256 * 256);
-        A(xh, (size_t)c->MB_pad * c->Dp); A(xl, (size_t)c->MB_pad * c->Dp);
-        A(wh, (size_t)c->S_pad * c->Dp); A(wl, (size_t)c->S_pad * c->Dp);
+        A(xs, (size_t)c->MB_pad * 2 * c->Dp);
+        A(ws, (size_t)c->S_pad * 2 * c->Dp);
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
 #undef A
@@ -188,10 +188,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     hipMemset(c->flags, 0, 8 * sizeof(int32_t));
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
     hipMemset(c->rowstats, 0, MB * sizeof(RowStats));
-    if (c->xh) {
-        hipMemset(c->xh, 0, (size_t)c->MB_pad * c->Dp * sizeof(_Float16));
-        hipMemset(c->xl, 0, (size_t)c->MB_pad * c->Dp * sizeof(_Float16));
-    }
+    if (c->xs) hipMemset(c->xs, 0, (size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
     hipDeviceSynchronize();
     *out = c;
     return SAEV_OK;
@@ -298,9 +295,8 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
 // operand preparation for the f16x3 encoder: split x and W_enc^T into fp16 hi/lo (no-op for the f32 encoder)
 static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s) {
     if (c->cfg.encoder_mode != SAEV_ENCODER_F16X3) return SAEV_OK;
-    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xh, c->xl, s));
-    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, c->cfg.d_model, c->cfg.d_sae, c->S_pad, c->Dp, 256.0f, c->wh,
-                              c->wl, s));
+    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xs, s));
+    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, c->cfg.d_model, c->cfg.d_sae, c->S_pad, c->Dp, 256.0f, c->ws, s));
     return SAEV_OK;
 }
 
@@ -308,7 +304,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
                        hipStream_t s) {
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
         EncodeF16Args a{};
-        a.xh = c->xh; a.xl = c->xl; a.wh = c->wh; a.wl = c->wl;
+        a.xs = c->xs; a.ws = c->ws;
         a.b_enc = c->params + c->off_b_enc;
         a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = 256.0f;
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);

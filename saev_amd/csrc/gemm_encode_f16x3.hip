@@ -9,16 +9,18 @@
 // section 3.1) -- three orders of magnitude tighter than the TF32 the reference enables on CUDA
 // (framework/train.py:253-257).  The f16 MFMA rate is 16x the f32 MFMA rate, so three products cost 3/16.
 //
-// Inputs are the pre-split operands produced by split.hip:
-//   xh, xl   (rows padded to 256, Dp = d_model padded to 32) fp16, row-major           [b][k]
-//   wh, wl   (d_sae padded to 256, Dp) fp16, row-major -- i.e. W_enc TRANSPOSED         [s][k]
-// so both MFMA operands are k-contiguous: one ds_read_b128 = one 8-wide k fragment.
+// Inputs are the pre-split operands produced by split.hip, already in LDS image order: for every block of
+// 256 rows (batch rows of x; latents of W_enc^T) and every 16-wide k-step one contiguous 16 KB image
+//   [row 0..255][4 chunks of 8 halfs: (hi|lo) x (k 0-7 | k 8-15), chunk c of row r at position c ^ ((r>>2)&3)]
+// so a k-step slot is filled by straight 1 KB-per-wave copies (every global_load_lds touches 8 full lines)
+// and every MFMA fragment is one conflict-free ds_read_b128.
 //
 // Tile: 256 latents x 256 batch rows per 512-thread workgroup, 8 waves as 2 (s) x 4 (b), 128 x 64 per wave
-// (4 x 2 MFMA blocks, 128 accumulator registers), BK = 32 halfs, two 64 KB LDS stages filled by
-// global_load_lds.  Rows of the LDS images are 64 bytes (4 chunks of 16 B); chunk c of row r is stored at
-// slot c ^ ((r >> 2) & 3), applied on the global source address, which makes the fragment reads
-// conflict-free.  Orientation and the TopK epilogue are those of gemm_encode.hip (lanes own batch rows).
+// (4 x 2 MFMA blocks, 128 accumulator registers).  LDS is a ring of four 32 KB k-step slots filled by
+// global_load_lds three k-steps ahead; the loop never drains the load queue (counted s_waitcnt vmcnt + raw
+// s_barrier, one per k-step).  Rows of a slot are 64 bytes = 4 chunks of 16 B (hi/lo x lane-half); chunk c of
+// row r sits at position c ^ ((r >> 2) & 3) (applied on the global source address), which makes the fragment
+// reads conflict-free.  Orientation and the TopK epilogue are those of gemm_encode.hip (lanes own batch rows).
 #include "common.h"
 #include "kernels.h"
 
@@ -28,27 +30,33 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int HTS = 256;  // latents per tile
 constexpr int HTB = 256;  // batch rows per tile
-constexpr int HBK = 32;   // halfs of k per stage
 constexpr int HTHREADS = 512;
+constexpr int NSLOTS = 4;  // k-step ring
 
-struct __attribute__((aligned(16))) HStage {
-    _Float16 ah[HTS][HBK];  // W^T hi   16 KB
-    _Float16 al[HTS][HBK];  // W^T lo
-    _Float16 bh[HTB][HBK];  // x hi
-    _Float16 bl[HTB][HBK];  // x lo
+struct __attribute__((aligned(16))) KSlot {
+    _Float16 a[HTS][32];  // W^T: [hi 16 | lo 16] per row, chunks swizzled     16 KB
+    _Float16 b[HTB][32];  // x                                                  16 KB
 };
 struct __attribute__((aligned(16))) HSmem {
     union {
-        HStage st[2];  // 128 KB
+        KSlot slot[NSLOTS];  // 128 KB
         struct {
-            HStage keep;                   // stage 0 stays usable during the NG == 32 epilogue
-            int32_t slots32[2][32][HTB];   // 64 KB
+            KSlot keep[2];                 // slots 0,1 receive the next tile's first k-steps during the epilogue
+            int32_t slots32[2][32][HTB];   // NG == 32 scratch: 64 KB (slots 2,3)
         } e32;
-        int32_t slots64[2][64][HTB];       // 128 KB
+        int32_t slots64[2][64][HTB];       // NG == 64 scratch: 128 KB
     };
     float tau[HTB];
     float bias[HTS];
 };
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>());
+    }
+}
 
 __device__ __forceinline__ void glds16h(const char* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -100,22 +108,25 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             for (int r = 0; r < NSLOT; ++r) smax[jb][r] = NEG_INF;
     }
 
-    const int nk = Dp / HBK;
+    const int nks = Dp / 16;  // k-steps per tile
+    // Workgroups that share an operand image (same latent range -> same W images, same batch block -> same x
+    // images) walk the k-steps in rotated order so that they do not hit the same 16 KB at the same moment (the sum
+    // over k does not care); neighbours stay within a few k-steps of each other, so the images remain L2-resident.
+    const int rot = ((bb & 7) + 8 * sp) % nks;
+    auto kmap = [&](int t) { const int k = t + rot; return k >= nks ? k - nks : k; };
 
-    // one global_load_lds call = 16 rows x 64 B; lane -> row (lane >> 2), physical chunk (lane & 3) holding
-    // logical chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
-    const uint32_t g_off = (uint32_t)(((size_t)(lane >> 2) * Dp + 8 * ((lane & 3) ^ ((lane >> 4) & 3))) * sizeof(_Float16));
-    auto stage_async = [&](int buf, int s0, int k0) {
-        HStage& st = sm.st[buf];
-        const size_t wrow = (size_t)(s0 + wid * 32) * Dp + k0;
-        const size_t xrow = (size_t)(b0 + wid * 32) * Dp + k0;
+    // a slot image is 16 KB per operand; wave w copies bytes [2 KB * w, +2 KB) of each with two 1 KB calls
+    const uint32_t g_off = (uint32_t)(wid * 2048 + lane * 16);
+    const size_t img = (size_t)256 * 32;  // halfs per image
+    const _Float16* x_imgs = a.xs + (size_t)bb * nks * img;
+    auto stage_kstep = [&](int slot, int s0, int ks) {
+        KSlot& st = sm.slot[slot];
+        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * nks + ks) * img) + g_off;
+        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + g_off;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const size_t d = (size_t)(16 * j) * Dp;
-            glds16h(reinterpret_cast<const char*>(a.wh + wrow + d) + g_off, &st.ah[wid * 32 + 16 * j][0]);
-            glds16h(reinterpret_cast<const char*>(a.wl + wrow + d) + g_off, &st.al[wid * 32 + 16 * j][0]);
-            glds16h(reinterpret_cast<const char*>(a.xh + xrow + d) + g_off, &st.bh[wid * 32 + 16 * j][0]);
-            glds16h(reinterpret_cast<const char*>(a.xl + xrow + d) + g_off, &st.bl[wid * 32 + 16 * j][0]);
+            glds16h(wsrc + 1024 * j, &st.a[wid * 32 + 16 * j][0]);
+            glds16h(xsrc + 1024 * j, &st.b[wid * 32 + 16 * j][0]);
         }
     };
 
@@ -125,7 +136,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     const int asw = (l31 >> 2) & 3;               // ((arow0 + 32*sb) >> 2) & 3 is independent of sb, ws
     const int bsw = (l31 >> 2) & 3;
 
-    if (st_begin < st_end) stage_async(0, st_begin * HTS, 0);
+    // k-steps 0 and 1 of a tile are requested by the previous tile's epilogue (or here for the first tile)
+    if (st_begin < st_end) {
+        stage_kstep(0, st_begin * HTS, kmap(0));
+        if (nks > 1) stage_kstep(1, st_begin * HTS, kmap(1));
+    }
 
     for (int st = st_begin; st < st_end; ++st) {
         const int s0 = st * HTS;
@@ -140,37 +155,55 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
         if (tid < HTS) sm.bias[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : 0.f;
         int32_t tau_other = INT32_MIN;
         if (EPI == EPI_TOPK && tid < HTB && a.s_splits > 1 && b0 + tid < B) tau_other = a.row_tau[b0 + tid];
-        __syncthreads();  // stage 0 of this tile has landed
+        __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
+        if (nks > 2) stage_kstep(2, s0, kmap(2));
 
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) stage_async(buf ^ 1, s0, (kt + 1) * HBK);
-            const HStage& cs = sm.st[buf];
+        for (int t = 0; t < nks; ++t) {
+            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));
+            const KSlot& cs = sm.slot[t & 3];
+            // 4 groups of 6 MFMAs (latent block sb).  The fragments of group sb+1 are requested right after the
+            // first MFMA of group sb, so their LDS latency hides behind the other five.
+            half8 fa[3][2];  // [ring][hi, lo]   A fragments of one latent block, requested two groups ahead
+            half8 fb[2][2];  // [jb][hi, lo]     B fragments of this k-step
+            auto load_a = [&](int set, int sb) {
+                fa[set][0] = *reinterpret_cast<const half8*>(&cs.a[arow0 + 32 * sb][8 * ((0 + half) ^ asw)]);
+                fa[set][1] = *reinterpret_cast<const half8*>(&cs.a[arow0 + 32 * sb][8 * ((2 + half) ^ asw)]);
+            };
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int c = 2 * ks + half;
-                half8 bh[2], bl[2];
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) {
-                    bh[jb] = *reinterpret_cast<const half8*>(&cs.bh[brow0 + 32 * jb][8 * (c ^ bsw)]);
-                    bl[jb] = *reinterpret_cast<const half8*>(&cs.bl[brow0 + 32 * jb][8 * (c ^ bsw)]);
-                }
-#pragma unroll
-                for (int sb = 0; sb < 4; ++sb) {
-                    const half8 ah = *reinterpret_cast<const half8*>(&cs.ah[arow0 + 32 * sb][8 * (c ^ asw)]);
-                    const half8 al = *reinterpret_cast<const half8*>(&cs.al[arow0 + 32 * sb][8 * (c ^ asw)]);
-#pragma unroll
-                    for (int jb = 0; jb < 2; ++jb) {
-                        acc[sb][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[jb], acc[sb][jb], 0, 0, 0);
-                        acc[sb][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[jb], acc[sb][jb], 0, 0, 0);
-                        acc[sb][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[jb], acc[sb][jb], 0, 0, 0);
-                    }
-                }
+            for (int jb = 0; jb < 2; ++jb) {
+                fb[jb][0] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((0 + half) ^ bsw)]);
+                fb[jb][1] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((2 + half) ^ bsw)]);
             }
-            __syncthreads();
+            load_a(0, 0);
+            load_a(1, 1);
+            static_for<4>([&](auto G) {
+                constexpr int sb = decltype(G)::value;
+                constexpr int as = sb % 3;
+                acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[0][0], acc[sb][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (sb + 2 < 4) load_a((sb + 2) % 3, sb + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[0][1], acc[sb][0], 0, 0, 0);
+                acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[1][0], acc[sb][1], 0, 0, 0);
+                acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[1][1], acc[sb][1], 0, 0, 0);
+                acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[0][0], acc[sb][0], 0, 0, 0);
+                acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[1][0], acc[sb][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // k-step t+1 must have landed (this wave's part) before the barrier publishes it; newer requests
+            // (t+2, t+3: 4 loads each) stay in flight.  Raw barrier: __syncthreads() would drain the queue.
+            if (t + 3 < nks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (t + 2 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
+        // all slots are free.  Request the next tile's first two k-steps so they land during the epilogue
+        // (the NG == 32 scratch only uses slots 2,3).
         const bool prefetched = (NG == 32 || EPI == EPI_DENSE) && (st + 1 < st_end);
-        if (prefetched) stage_async(0, s0 + HTS, 0);
+        if (prefetched) {
+            stage_kstep(0, s0 + HTS, kmap(0));
+            if (nks > 1) stage_kstep(1, s0 + HTS, kmap(1));
+        }
 
         // ---------------- epilogue ----------------
         // lane owns batch rows bl(jb) = wb*64 + jb*32 + l31; latent of acc[sb][jb][r]:
@@ -280,8 +313,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             }
         }
         if (!prefetched && st + 1 < st_end) {
-            __syncthreads();
-            stage_async(0, s0 + HTS, 0);
+            __syncthreads();  // NG == 64: the scratch covered every slot
+            stage_kstep(0, s0 + HTS, kmap(0));
+            if (nks > 1) stage_kstep(1, s0 + HTS, kmap(1));
         }
     }
 }

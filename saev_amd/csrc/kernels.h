@@ -195,8 +195,8 @@ hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, float alph
 
 // ---- f16x3 encoder (fp32-accurate split-fp16 MFMA) -------------------------------------------------
 struct EncodeF16Args {
-    const _Float16 *xh, *xl;  // (rows padded to 256, Dp)
-    const _Float16 *wh, *wl;  // (S padded to 256, Dp), W_enc transposed, scaled by w_scale
+    const _Float16* xs;       // (rows padded to 256, 2*Dp): per 16-wide k-step [hi 16 | lo 16]
+    const _Float16* ws;       // (S padded to 256, 2*Dp): W_enc transposed, scaled by w_scale, same interleave
     const float* b_enc;       // (S)
     int n_rows, Dp, S;
     float w_scale;
@@ -214,6 +214,5 @@ struct EncodeF16Args {
 hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream);
 int encode_f16x3_tile_rows();
 int encode_f16x3_tile_latents();
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xh, void* xl, hipStream_t stream);
-hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* wh, void* wl,
-                           hipStream_t stream);
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, hipStream_t stream);
+hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, hipStream_t stream);

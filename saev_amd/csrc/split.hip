@@ -1,67 +1,91 @@
-// fp32 -> (hi, lo) fp16 operand splitting for the f16x3 encoder (gemm_encode_f16x3.hip).
-//   split_rows_kernel : x (n, D) fp32 -> xh, xl (n_pad, Dp) fp16; columns D..Dp are zero.
-//   split_wT_kernel   : W_enc (D, S) fp32 -> wh, wl (S_pad, Dp) fp16, TRANSPOSED and scaled by `scale`;
-//                       64 x 64 tiles through LDS so both the fp32 reads and the fp16 writes are coalesced.
+// fp32 -> (hi, lo) fp16 operand splitting for the f16x3 encoder (gemm_encode_f16x3.hip), written directly in
+// the encoder's LDS image order so the encoder can stream it with perfectly coalesced global_load_lds:
+//
+//   operand (rows R, k) -> blocks of 256 rows x one 16-wide k-step = one 16 KB "slot image":
+//       image(blk, ks) at  ((blk * nks + ks) * 256 * 32) halfs,   nks = Dp / 16
+//       inside: row rl (0..255) owns 32 halfs = 4 chunks of 8; logical chunk c = 2*part + h
+//               (part 0 = hi, 1 = lo; h = which half of the k-step: k%16 < 8 or >= 8)
+//               is stored at position c ^ ((rl >> 2) & 3)   <- the bank-conflict swizzle of the fragment reads
+//
+//   split_rows_kernel : x (n, D) fp32            -> xs images (rows padded to 256)
+//   split_wT_kernel   : W_enc (D, S) fp32, i.e. k-major -> ws images of W_enc^T * scale (rows = latents)
 // hi = fp16(a*scale) (round to nearest even), lo = fp16(a*scale - hi): together 22 significand bits.
+// Rows beyond n / S and k beyond D are written as zeros where the kernels cover them; x padding rows are
+// zeroed once at context creation.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int n, int D, int Dp,
-                                                         _Float16* __restrict__ xh, _Float16* __restrict__ xl) {
-    // one thread handles 4 consecutive k of one row
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    const int per_row = Dp >> 2;
-    const long total = (long)n * per_row;
-    if (q >= total) return;
-    const int r = (int)(q / per_row), c = (int)(q % per_row) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (c < D) v = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + c);  // D % 4 == 0
-    _Float16 h[4], l[4];
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ half8 split8(const float (&v)[8], int part) {
+    half8 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = (_Float16)v[e];
-        l[e] = (_Float16)(v[e] - (float)h[e]);
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        o[e] = part == 0 ? h : (_Float16)(v[e] - (float)h);
     }
-    *reinterpret_cast<uint2*>(xh + (size_t)r * Dp + c) = *reinterpret_cast<uint2*>(h);
-    *reinterpret_cast<uint2*>(xl + (size_t)r * Dp + c) = *reinterpret_cast<uint2*>(l);
+    return o;
 }
 
-__global__ __launch_bounds__(256) void split_wT_kernel(const float* __restrict__ W, int D, int S, int Dp, float scale,
-                                                       _Float16* __restrict__ wh, _Float16* __restrict__ wl) {
-    __shared__ float tile[64][65];
-    const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {
-        const int d = d0 + r, s = s0 + tx;
-        tile[r][tx] = (d < D && s < S) ? W[(size_t)d * S + s] * scale : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int s = s0 + r, d = d0 + tx;
-        if (d < Dp) {  // rows s >= S are written too (zeros): the padded buffer is fully defined
-            const float v = tile[tx][r];
-            const _Float16 h = (_Float16)v;
-            wh[(size_t)s * Dp + d] = h;
-            wl[(size_t)s * Dp + d] = (_Float16)(v - (float)h);
+// one thread = one 16-byte chunk of the image; grid.x = ceil(n/256) * nks images, 1024 threads each
+__global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks,
+                                                          _Float16* __restrict__ xs) {
+    const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
+    const int i = threadIdx.x;           // chunk index inside the image
+    const int rl = i >> 2, p = i & 3;
+    const int c = p ^ ((rl >> 2) & 3);
+    const int part = c >> 1, h = c & 1;
+    const int r = blk * 256 + rl, k = ks * 16 + h * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < n && k < D) {  // D % 4 == 0: load in two float4s, the second may fall off the end
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        if (k + 4 < D) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k + 4);
+            v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
         }
     }
+    reinterpret_cast<half8*>(xs + (size_t)blockIdx.x * 256 * 32)[i] = split8(v, part);
+}
+
+// one workgroup = one image of W_enc^T: 256 latents x 16 k.  The 16 k-rows of W_enc (1 KB each) are read
+// coalesced into LDS, then every thread assembles its chunk from a column.
+__global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict__ W, int D, int S, int nks, float scale,
+                                                        _Float16* __restrict__ ws) {
+    __shared__ float tile[16][257];
+    const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
+    const int s0 = blk * 256, k0 = ks * 16;
+    for (int q = threadIdx.x; q < 16 * 256; q += 1024) {
+        const int kk = q >> 8, sl = q & 255;
+        const int k = k0 + kk, s = s0 + sl;
+        tile[kk][sl] = (k < D && s < S) ? W[(size_t)k * S + s] * scale : 0.f;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    const int rl = i >> 2, p = i & 3;
+    const int c = p ^ ((rl >> 2) & 3);
+    const int part = c >> 1, h = c & 1;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[h * 8 + e][rl];
+    reinterpret_cast<half8*>(ws + (size_t)blockIdx.x * 256 * 32)[i] = split8(v, part);
 }
 
 }  // namespace
 
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xh, void* xl, hipStream_t stream) {
-    const long total = (long)n * (Dp >> 2);
-    if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, n, D, Dp,
-                       reinterpret_cast<_Float16*>(xh), reinterpret_cast<_Float16*>(xl));
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, hipStream_t stream) {
+    const int nks = Dp / 16, nblk = (n + 255) / 256;
+    if (nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL(split_rows_kernel, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks,
+                       reinterpret_cast<_Float16*>(xs));
     return hipGetLastError();
 }
 
-hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* wh, void* wl,
-                           hipStream_t stream) {
-    hipLaunchKernelGGL(split_wT_kernel, dim3(S_pad / 64, (Dp + 63) / 64), dim3(256), 0, stream, W, D, S, Dp, scale,
-                       reinterpret_cast<_Float16*>(wh), reinterpret_cast<_Float16*>(wl));
+hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, hipStream_t stream) {
+    const int nks = Dp / 16;
+    hipLaunchKernelGGL(split_wT_kernel, dim3((S_pad / 256) * nks), dim3(1024), 0, stream, W, D, S, nks, scale,
+                       reinterpret_cast<_Float16*>(ws));
     return hipGetLastError();
 }

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 
 
-DEFAULT_ENCODER = "f32"
+DEFAULT_ENCODER = "f16x3"
 
 
 @dataclasses.dataclass(frozen=True)

@@ -547,8 +547,6 @@ int saev_step_backward(saev_ctx* c, void* stream) {
     const int words = (n + 31) / 32;
 
     auto build = [&](const int32_t* idx, int stride, int k, const int32_t* k_dev) -> int {
-        HIPCHK(c, hipMemsetAsync(c->bitmap, 0, (size_t)S * words * sizeof(uint32_t), s));
-        HIPCHK(c, hipMemsetAsync(c->counts, 0, (size_t)S * sizeof(int32_t), s));
         CscArgs a{};
         a.idx = idx; a.code_stride = stride; a.k = k; a.k_dev = k_dev; a.n_rows = n; a.S = S;
         a.bitmap = c->bitmap; a.words = words; a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;

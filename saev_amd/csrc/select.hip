@@ -156,16 +156,11 @@ __global__ __launch_bounds__(SD_THREADS) void select_dense_kernel(SelectDenseArg
 
 // ---------------------------------------------------------------------------------------------
 
-template <int EPL>  // elements per lane; list capacity = 64*EPL
-__global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
-    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
-    __shared__ int32_t s_idx[4][64];
-    __shared__ float s_val[4][64];
+template <int EPL>  // elements per lane: handles lists of up to 64*EPL candidates
+__device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row, int n, int32_t (&s_idx)[4][64],
+                                                float (&s_val)[4][64]) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + w;
-    if (row >= a.n_rows) return;
-    const int n = min(a.cand_cnt[row], a.cand_cap);
     const int k = min(a.k, n);
     const float* cv = a.cand_val + (size_t)row * a.cand_cap;
     const int32_t* ci = a.cand_idx + (size_t)row * a.cand_cap;
@@ -243,6 +238,20 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     }
 }
 
+// one wave per row; the register footprint of the search is chosen from the row's list length
+__global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+    __shared__ int32_t s_idx[4][64];
+    __shared__ float s_val[4][64];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int n = min(a.cand_cnt[row], a.cand_cap);  // wave-uniform
+    if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val);
+    else if (n <= 1024) select_cand_row<16>(a, row, n, s_idx, s_val);
+    else if (n <= 2048) select_cand_row<32>(a, row, n, s_idx, s_val);
+    else select_cand_row<64>(a, row, n, s_idx, s_val);
+}
+
 __global__ void init_i32_kernel(int32_t* p, int32_t v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -278,15 +287,8 @@ hipError_t launch_select_dense(const SelectDenseArgs& a, hipStream_t stream) {
 
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
-    dim3 grid((a.n_rows + 3) / 4), block(256);
-    if (a.cand_cap <= 512)
-        hipLaunchKernelGGL(select_cand_kernel<8>, grid, block, 0, stream, a);
-    else if (a.cand_cap <= 1024)
-        hipLaunchKernelGGL(select_cand_kernel<16>, grid, block, 0, stream, a);
-    else if (a.cand_cap <= 2048)
-        hipLaunchKernelGGL(select_cand_kernel<32>, grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL(select_cand_kernel<64>, grid, block, 0, stream, a);
+    if (a.cand_cap > 4096) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(select_cand_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

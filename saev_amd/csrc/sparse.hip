@@ -196,6 +196,17 @@ __global__ __launch_bounds__(256) void aux_decode_kernel(AuxDecodeArgs a) {
 
 // ------------------------------- CSC build -------------------------------------------------
 
+// zero the bit map and the per-latent counts; skipped entirely when the (device-side) code count is 0
+__global__ __launch_bounds__(256) void csc_clear_kernel(CscArgs a) {
+    if (a.k_dev && *a.k_dev <= 0) return;
+    const size_t n4 = ((size_t)a.S * a.words) >> 2;  // words is a multiple of 4 for the sizes used; tail below
+    uint4* bm = reinterpret_cast<uint4*>(a.bitmap);
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) bm[q] = uint4{0, 0, 0, 0};
+    for (size_t q = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)a.S * a.words; q += (size_t)gridDim.x * 256)
+        a.bitmap[q] = 0;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)a.S; q += (size_t)gridDim.x * 256) a.counts[q] = 0;
+}
+
 __global__ void csc_fill_kernel(CscArgs a) {
     const int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
     if (k <= 0) return;
@@ -210,82 +221,57 @@ __global__ void csc_fill_kernel(CscArgs a) {
     }
 }
 
-// exclusive scan of counts[0..S) -> starts[0..S]; single workgroup of 1024 threads
+// exclusive scans over the latents, one sweep of a single 1024-thread workgroup:
+//   starts[i]       pair offset            (sum of counts)
+//   chunk_starts[i] work-item offset       (sum of max(1, ceil(count / DW_CHUNK)))
+//   part_starts[i]  partial-sum slot       (sum of chunks of latents with more than one chunk)
 __global__ __launch_bounds__(1024) void csc_scan_kernel(CscArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
-    __shared__ int wave_tot[16];
-    __shared__ int carry;
+    __shared__ int wave_tot[16][3];
+    __shared__ int carry[3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry = 0;
+    if (tid < 3) carry[tid] = 0;
     __syncthreads();
     for (int base = 0; base < a.S; base += 1024) {
         const int i = base + tid;
-        const int v = (i < a.S) ? a.counts[i] : 0;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int n = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += n;
-        }
-        if (lane == 63) wave_tot[w] = incl;
-        __syncthreads();
-        int off = carry;
-        for (int j = 0; j < w; ++j) off += wave_tot[j];
-        if (i < a.S) a.starts[i] = off + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry = off + incl;
-        __syncthreads();
-    }
-    if (tid == 0) a.starts[a.S] = carry;
-    __syncthreads();
-    // second scan: chunks per latent = max(1, ceil(count / DW_CHUNK)) -> chunk_starts[0..S]
-    if (a.chunk_starts == nullptr) return;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < a.S; base += 1024) {
-        const int i = base + tid;
-        const int v = (i < a.S) ? max(1, (a.counts[i] + DW_CHUNK - 1) / DW_CHUNK) : 0;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int n = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += n;
-        }
-        if (lane == 63) wave_tot[w] = incl;
-        __syncthreads();
-        int off = carry;
-        for (int j = 0; j < w; ++j) off += wave_tot[j];
-        if (i < a.S) a.chunk_starts[i] = off + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry = off + incl;
-        __syncthreads();
-    }
-    if (tid == 0) a.chunk_starts[a.S] = carry;
-    __syncthreads();
-    // third scan: partial-sum slots, only latents with more than one chunk get any
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < a.S; base += 1024) {
-        const int i = base + tid;
-        int v = 0;
+        int v[3] = {0, 0, 0};
         if (i < a.S) {
-            const int nch = (a.counts[i] + DW_CHUNK - 1) / DW_CHUNK;
-            v = nch > 1 ? nch : 0;
+            const int c = a.counts[i];
+            const int nch = (c + DW_CHUNK - 1) / DW_CHUNK;
+            v[0] = c;
+            v[1] = max(1, nch);
+            v[2] = nch > 1 ? nch : 0;
         }
-        int incl = v;
+        int incl[3] = {v[0], v[1], v[2]};
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            int n = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += n;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int n = __shfl_up(incl[q], o, 64);
+                if (lane >= o) incl[q] += n;
+            }
         }
-        if (lane == 63) wave_tot[w] = incl;
+        if (lane == 63)
+            for (int q = 0; q < 3; ++q) wave_tot[w][q] = incl[q];
         __syncthreads();
-        int off = carry;
-        for (int j = 0; j < w; ++j) off += wave_tot[j];
-        if (i < a.S) a.part_starts[i] = off + incl - v;
+        int off[3] = {carry[0], carry[1], carry[2]};
+        for (int j = 0; j < w; ++j)
+            for (int q = 0; q < 3; ++q) off[q] += wave_tot[j][q];
+        if (i < a.S) {
+            a.starts[i] = off[0] + incl[0] - v[0];
+            if (a.chunk_starts) {
+                a.chunk_starts[i] = off[1] + incl[1] - v[1];
+                a.part_starts[i] = off[2] + incl[2] - v[2];
+            }
+        }
         __syncthreads();
-        if (tid == 1023) carry = off + incl;
+        if (tid == 1023)
+            for (int q = 0; q < 3; ++q) carry[q] = off[q] + incl[q];
         __syncthreads();
+    }
+    if (tid == 0) {
+        a.starts[a.S] = carry[0];
+        if (a.chunk_starts) a.chunk_starts[a.S] = carry[1];
     }
 }
 
@@ -549,6 +535,7 @@ hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
     const long n = (long)a.n_rows * a.k;
     const int blocks = (int)std::min<long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(csc_emit_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);

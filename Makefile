@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := saev_amd/csrc
-SRCS  := $(CSRC)/ctx.hip $(CSRC)/gemm_encode.hip $(CSRC)/gemm_encode_f16x3.hip $(CSRC)/split.hip $(CSRC)/select.hip $(CSRC)/sparse.hip $(CSRC)/tail.hip
+SRCS  := $(CSRC)/ctx.hip $(CSRC)/gemm_encode.hip $(CSRC)/gemm_encode_f16x3.hip $(CSRC)/split.hip $(CSRC)/select.hip $(CSRC)/sparse.hip $(CSRC)/tail.hip $(CSRC)/auxk.hip
 OBJS  := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-value -Iinclude
 
@@ -13,7 +13,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/common.h include/saev_amd.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 saev_amd/libsaev_amd.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib -o $@
 
 clean:
 	rm -rf build saev_amd/libsaev_amd.so

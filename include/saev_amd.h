@@ -97,6 +97,9 @@ int32_t* saev_fired_flags(saev_ctx* ctx);
 /* Let the host own the tracker state instead (both buffers d_sae long, zero-initialised by the
  * caller): lets a torch tensor alias them for all-reduce / inspection. */
 int saev_bind_tracker(saev_ctx* ctx, int64_t* toks_since_active, int32_t* fired_flags);
+/* Tell the context that the host wrote the tracker buffer (so dead latents may exist before
+ * dead_threshold_tokens tokens have been processed). */
+int saev_tracker_touched(saev_ctx* ctx);
 /* Device copy of the current step's saev_step_stats (valid after the producing call completes). */
 const saev_step_stats* saev_stats_device(saev_ctx* ctx);
 /* Blocking read-back of the stats (synchronises `stream`). */
@@ -138,7 +141,8 @@ int saev_gather_rows(saev_ctx* ctx, const float* pool, const int64_t* rows, int3
 int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_rows_global, int32_t training,
                       void* stream);
 /* Phase 2: tracker update with `n_rows_global` tokens (objectives.py:118-120), dead mask, AuxK
- * forward (modeling.py:75-103).  Training mode only. */
+ * forward (modeling.py:75-103).  Training mode only.  Once dead latents are possible this call reads
+ * n_dead back (one stream synchronisation per step, as the reference's `.item()` does). */
 int saev_step_dead(saev_ctx* ctx, int64_t n_rows_global, void* stream);
 /* Phase 3: all four parameter gradients into the bound grad buffer (replaces autograd,
  * train.py:347-348), un-projected and un-clipped. */

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "saev_destroy": (None, [P]),
     "saev_bind": (C.c_int, [P, P, P, P, P]),
     "saev_bind_tracker": (C.c_int, [P, P, P]),
+    "saev_tracker_touched": (C.c_int, [P]),
     "saev_toks_since_active": (P, [P]),
     "saev_fired_flags": (P, [P]),
     "saev_stats_device": (P, [P]),

@@ -1,6 +1,7 @@
 // C ABI of libsaev_amd.so (see include/saev_amd.h): context, scratch, and the launch sequences of
 // the train step.  No torch types; plain device pointers and a hipStream_t per call.
 #include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <cmath>
@@ -35,7 +36,7 @@ struct saev_ctx {
     float* cand_val = nullptr;
     float* h_dense = nullptr;
     int32_t *idx = nullptr, *aux_idx = nullptr;
-    float *val = nullptr, *dval = nullptr, *aux_val = nullptr, *aux_dval = nullptr;
+    float *val = nullptr, *dval = nullptr, *aux_val = nullptr;
     float *x_hat = nullptr, *g = nullptr, *g_aux = nullptr;
     RowStats* rowstats = nullptr;
     uint32_t* bitmap = nullptr;
@@ -49,6 +50,17 @@ struct saev_ctx {
     int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use
     int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
     float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
+    // AuxK dense-over-dead-set path (auxk.hip)
+    rocblas_handle blas = nullptr;
+    int n_dead_host = 0, k_use_host = 0;
+    int64_t tokens_seen = 0;
+    bool tracker_dirty = false;
+    int nd_cap = 0;
+    std::vector<void*> aux_allocs;
+    int32_t* dead_list = nullptr;
+    float *Wenc_dead = nullptr, *Wdec_dead = nullptr, *H_dead = nullptr, *A_dead = nullptr, *dWd = nullptr, *dWe = nullptr,
+          *dbe = nullptr, *aux_partials = nullptr;
+    uint8_t* A_mask = nullptr;
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -152,14 +164,14 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(cand_cnt, MB); A(row_tau, MB); A(cand_idx, MB * CAND_CAP); A(cand_val, MB * CAND_CAP);
     A(h_dense, MB * S);
     A(idx, MB * K); A(val, MB * K); A(dval, MB * K);
-    if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(aux_dval, MB * KA); A(g_aux, MB * D); }
+    if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(g_aux, MB * D); A(dead_list, S); }
     A(x_hat, MB * D); A(g, MB * D);
     A(rowstats, MB);
     c->bitmap_words = (int)((MB + 31) / 32);
     A(bitmap, S * c->bitmap_words);
-    A(counts, S); A(starts, S + 1); A(pairs, MB * std::max(K, KA));
+    A(counts, S); A(starts, S + 1); A(pairs, MB * K);
     {
-        const long max_pairs = MB * std::max(K, KA);
+        const long max_pairs = MB * K;
         c->max_work = (int)(S + (max_pairs + DW_CHUNK - 1) / DW_CHUNK);
         c->max_part = (int)(2 * ((max_pairs + DW_CHUNK - 1) / DW_CHUNK) + 2);
     }
@@ -199,6 +211,8 @@ void saev_destroy(saev_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (void* p : c->allocs) hipFree(p);
+    for (void* p : c->aux_allocs) hipFree(p);
+    if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_created)
         for (int i = 0; i < TIMING_RING; ++i) {
             hipEventDestroy(c->ev_start[i]);
@@ -223,6 +237,13 @@ int saev_bind_tracker(saev_ctx* c, int64_t* toks, int32_t* fired) {
     REQUIRE(c, toks && fired, SAEV_INVALID_ARG, "saev_bind_tracker: NULL buffer");
     c->toks = toks;
     c->fired = fired;
+    c->tracker_dirty = true;
+    return SAEV_OK;
+}
+
+int saev_tracker_touched(saev_ctx* c) {
+    if (!c) return SAEV_INVALID_ARG;
+    c->tracker_dirty = true;
     return SAEV_OK;
 }
 
@@ -489,13 +510,8 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(saev_step_stats), s));
     HIPCHK(c, hipMemsetAsync(c->upper, 0, sizeof(float), s));
     HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
-    // AuxK needs the pre-activations of dead latents, which the fused encoder never materialises: if any
-    // latent can be dead after this step's tracker update (age + global batch >= threshold), take the
-    // dense-h route.  The flag is a device value; both encoder variants are launched and one exits at once.
-    HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int32_t), s));
-    if (training && c->cfg.k_aux > 0) {
-        HIPCHK(c, launch_predead_flag(c->toks, S, n_rows_global, c->cfg.dead_threshold_tokens, c->flags, s));
-    }
+    HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int32_t), s));  // [0]: force-dense flag, unused by the step
+    (void)n_rows_global;
     int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s);
     if (rc != SAEV_OK) return rc;
 
@@ -512,28 +528,148 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     return SAEV_OK;
 }
 
+namespace {
+
+#define BLASCHK(ctx, expr)                                                                   \
+    do {                                                                                     \
+        rocblas_status _st = (expr);                                                         \
+        if (_st != rocblas_status_success) {                                                 \
+            (ctx)->err = std::string(#expr) + ": rocblas status " + std::to_string((int)_st); \
+            return SAEV_HIP_ERROR;                                                           \
+        }                                                                                    \
+    } while (0)
+
+// row-major GEMM helpers on top of column-major rocBLAS
+int gemm_nn(saev_ctx* c, int M, int N, int K, const float* A, const float* B, float* C) {  // C = A (MxK) B (KxN)
+    const float one = 1.f, zero = 0.f;
+    BLASCHK(c, rocblas_sgemm(c->blas, rocblas_operation_none, rocblas_operation_none, N, M, K, &one, B, N, A, K, &zero, C, N));
+    return SAEV_OK;
+}
+int gemm_nt(saev_ctx* c, int M, int N, int K, const float* A, const float* B, float* C) {  // C = A (MxK) B^T, B is (NxK)
+    const float one = 1.f, zero = 0.f;
+    BLASCHK(c, rocblas_sgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, B, K, A, K, &zero, C, N));
+    return SAEV_OK;
+}
+int gemm_tn(saev_ctx* c, int M, int N, int K, const float* A, const float* B, float* C) {  // C = A^T B, A is (KxM), B (KxN)
+    const float one = 1.f, zero = 0.f;
+    BLASCHK(c, rocblas_sgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, M, K, &one, B, N, A, M, &zero, C, N));
+    return SAEV_OK;
+}
+
+int ensure_aux_capacity(saev_ctx* c, int ndp) {
+    if (!c->blas) {
+        BLASCHK(c, rocblas_create_handle(&c->blas));
+        BLASCHK(c, rocblas_set_atomics_mode(c->blas, rocblas_atomics_not_allowed));  // deterministic sums
+        BLASCHK(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+    }
+    if (ndp <= c->nd_cap) return SAEV_OK;
+    int cap = std::max(256, c->nd_cap);
+    while (cap < ndp) cap *= 2;
+    cap = std::min(cap, (c->cfg.d_sae + 3) / 4 * 4);
+    hipDeviceSynchronize();
+    for (void* p : c->aux_allocs) hipFree(p);
+    c->aux_allocs.clear();
+    const size_t MB = c->cfg.max_batch, D = c->cfg.d_model;
+    auto grab = [&](size_t bytes) -> void* {
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+        c->aux_allocs.push_back(q);
+        return q;
+    };
+    c->Wenc_dead = (float*)grab(D * cap * 4);
+    c->Wdec_dead = (float*)grab((size_t)cap * D * 4);
+    c->H_dead = (float*)grab(MB * cap * 4);
+    c->A_dead = (float*)grab(MB * cap * 4);
+    c->A_mask = (uint8_t*)grab(MB * cap);
+    c->dWd = (float*)grab((size_t)cap * D * 4);
+    c->dWe = (float*)grab((size_t)cap * D * 4);
+    c->dbe = (float*)grab((size_t)cap * 4);
+    c->aux_partials = (float*)grab(((MB + 63) / 64) * (size_t)cap * 4);
+    if (!c->Wenc_dead || !c->Wdec_dead || !c->H_dead || !c->A_dead || !c->A_mask || !c->dWd || !c->dWe || !c->dbe ||
+        !c->aux_partials) {
+        c->err = "AuxK: out of device memory for the dead-set buffers";
+        c->nd_cap = 0;
+        return SAEV_HIP_ERROR;
+    }
+    c->nd_cap = cap;
+    return SAEV_OK;
+}
+
+// forward of the auxiliary loss for n_dead_host > 0 dead latents (see auxk.hip)
+int auxk_forward(saev_ctx* c, hipStream_t s) {
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, n = c->n_last;
+    const int nd = c->n_dead_host, ku = c->k_use_host;
+    const int ndp = (nd + 3) / 4 * 4;
+    int rc = ensure_aux_capacity(c, ndp);
+    if (rc != SAEV_OK) return rc;
+    BLASCHK(c, rocblas_set_stream(c->blas, s));
+    HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
+    HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
+                                 c->Wenc_dead, c->Wdec_dead, s));
+    rc = gemm_nn(c, n, ndp, D, c->x_last, c->Wenc_dead, c->H_dead);  // H = x W_enc[:, dl]
+    if (rc != SAEV_OK) return rc;
+    HIPCHK(c, launch_dead_bias(c->H_dead, n, nd, ndp, c->params + c->off_b_enc, c->dead_list, s));
+    SelectDenseArgs sd{};
+    sd.h = c->H_dead; sd.n_rows = n; sd.S = ndp; sd.k = ku;
+    sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
+    HIPCHK(c, launch_select_dense(sd, s));
+    HIPCHK(c, hipMemsetAsync(c->A_dead, 0, (size_t)n * ndp * sizeof(float), s));
+    HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
+    HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
+    rc = gemm_nn(c, n, D, ndp, c->A_dead, c->Wdec_dead, c->g_aux);  // E = A W_dec[dl]
+    if (rc != SAEV_OK) return rc;
+    HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
+                               c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
+    return SAEV_OK;
+}
+
+// gradients of the auxiliary loss, accumulated into the gradient buffer / the transposed W_enc scratch
+int auxk_backward(saev_ctx* c, hipStream_t s) {
+    const int D = c->cfg.d_model, n = c->n_last;
+    const int nd = c->n_dead_host;
+    const int ndp = (nd + 3) / 4 * 4;
+    BLASCHK(c, rocblas_set_stream(c->blas, s));
+    float* dA = c->H_dead;  // H is dead after the select
+    int rc = gemm_nt(c, n, ndp, D, c->g_aux, c->Wdec_dead, dA);  // dA = g_aux W_dec[dl]^T
+    if (rc != SAEV_OK) return rc;
+    HIPCHK(c, launch_mask_apply(dA, c->A_mask, (long)n * ndp, s));
+    rc = gemm_tn(c, ndp, D, n, c->A_dead, c->g_aux, c->dWd);  // dW_dec[dl] = A^T g_aux
+    if (rc != SAEV_OK) return rc;
+    rc = gemm_tn(c, ndp, D, n, dA, c->x_last, c->dWe);  // dW_enc^T[dl] = dA^T x
+    if (rc != SAEV_OK) return rc;
+    HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));
+    HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
+    HIPCHK(c, launch_scatter_add_dead(c->dead_list, nd, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec, c->dW_encT,
+                                      c->grads + c->off_b_enc, s));
+    return SAEV_OK;
+}
+
+}  // namespace
+
 int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_step_dead: no training forward in flight");
     hipStream_t s = (hipStream_t)stream;
-    const int S = c->cfg.d_sae, D = c->cfg.d_model, n = c->n_last;
+    const int S = c->cfg.d_sae;
     DeadArgs d{};
     d.toks = c->toks; d.fired = c->fired; d.dead = c->dead; d.S = S;
     d.add_tokens = n_rows_global; d.threshold = c->cfg.dead_threshold_tokens; d.k_aux = c->cfg.k_aux;
     d.n_dead = c->flags + 4; d.k_use = c->flags + 5; d.stats = c->stats;
     HIPCHK(c, launch_dead_update(d, s));
-    if (c->cfg.k_aux > 0) {
-        SelectDenseArgs sd{};
-        sd.h = c->h_dense; sd.n_rows = n; sd.S = S; sd.k = c->cfg.k_aux; sd.k_dev = c->flags + 5; sd.mask = c->dead;
-        sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
-        HIPCHK(c, launch_select_dense(sd, s));
-        AuxDecodeArgs a{};
-        a.x = c->x_last; a.x_hat = c->x_hat; a.idx = c->aux_idx; a.val = c->aux_val; a.code_stride = c->cfg.k_aux;
-        a.k_use = c->flags + 5; a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
-        a.n_rows = n; a.D = D; a.gscale = c->cfg.alpha * 2.0f / ((float)n * (float)D);
-        a.g_aux = c->g_aux; a.dval = c->aux_dval; a.rowstats = c->rowstats;
-        HIPCHK(c, launch_aux_decode(a, s));
-        HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
+    c->n_dead_host = 0;
+    c->k_use_host = 0;
+    c->tokens_seen += n_rows_global;
+    // A latent can only be dead once `threshold` tokens went by since the tracker was last known to be all-zero.
+    // Until then nothing is read back; afterwards n_dead comes to the host once per step (the reference does the
+    // same: modeling.py:92).
+    if (c->cfg.k_aux > 0 && (c->tracker_dirty || c->tokens_seen >= c->cfg.dead_threshold_tokens)) {
+        int32_t host[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(host, c->flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->n_dead_host = host[0];
+        c->k_use_host = host[1];
+        if (c->n_dead_host > 0) return auxk_forward(c, s);
     }
     return SAEV_OK;
 }
@@ -571,13 +707,9 @@ int saev_step_backward(saev_ctx* c, void* stream) {
     rc = rows(c->val, c->dval, c->g, K, nullptr, 0);
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_colsum(c->g, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s));
-    if (c->cfg.k_aux > 0) {
-        const int32_t* k_dev = c->flags + 5;
-        rc = build(c->aux_idx, c->cfg.k_aux, c->cfg.k_aux, k_dev);
+    if (c->n_dead_host > 0) {
+        rc = auxk_backward(c, s);
         if (rc != SAEV_OK) return rc;
-        rc = rows(c->aux_val, c->aux_dval, c->g_aux, c->cfg.k_aux, k_dev, 1);
-        if (rc != SAEV_OK) return rc;
-        HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, k_dev, s));
     }
     HIPCHK(c, launch_transpose(c->dW_encT, c->grads + c->off_W_enc, S, D, s));
     return SAEV_OK;

@@ -216,3 +216,16 @@ int encode_f16x3_tile_rows();
 int encode_f16x3_tile_latents();
 hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, hipStream_t stream);
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, hipStream_t stream);
+
+// ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------
+hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s);
+hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int32_t* dl, int nd, int ndp, int D, int S,
+                              float* Wenc_dead, float* Wdec_dead, hipStream_t s);
+hipError_t launch_dead_bias(float* H, int n_rows, int nd, int ndp, const float* b_enc, const int32_t* dl, hipStream_t s);
+hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, int k, int stride, int ndp, float* A,
+                              uint8_t* mask, hipStream_t s);
+hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const float* b_dec, int n_rows, int D,
+                            float gscale, RowStats* rowstats, hipStream_t s);
+hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
+hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
+                                   float* gW_dec, float* gW_encT, float* gb_enc, hipStream_t s);

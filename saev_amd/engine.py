@@ -127,6 +127,14 @@ class SaeEngine:
     def grad_views(self) -> dict[str, torch.Tensor]:
         return {k: self.view(k, self.grads) for k in self.offsets}
 
+    def set_tracker(self, toks: torch.Tensor | None) -> None:
+        """Overwrite the dead-latent tracker (``None`` zeroes it) and tell the context it changed."""
+        if toks is None:
+            self.toks_since_active.zero_()
+        else:
+            self.toks_since_active.copy_(toks.to(self.device, torch.int64))
+        self._chk(self.lib.saev_tracker_touched(self.ctx), "saev_tracker_touched")
+
     def load_params(self, params: dict[str, torch.Tensor]) -> None:
         for k in self.offsets:
             self.view(k).copy_(params[k].to(self.device, torch.float32))

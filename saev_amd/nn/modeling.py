@@ -251,7 +251,7 @@ class SparseAutoencoder(torch.nn.Module):
             eng = SaeEngine(self._engine_cfg(max(want_batch, 1024)), dev)
             eng.load_params(values)
             if old is not None and old.device == dev:
-                eng.toks_since_active.copy_(old.toks_since_active)
+                eng.set_tracker(old.toks_since_active)
                 eng.adam_m.copy_(old.adam_m)
                 eng.adam_v.copy_(old.adam_v)
                 eng.adam_steps = old.adam_steps

@@ -112,10 +112,8 @@ class MatryoshkaObjective(Objective):
         eng = self.__dict__["_eng_ref"]
         if eng is None:
             self.__dict__["_pending_toks"] = value
-        elif value is None:
-            eng.toks_since_active.zero_()
         else:
-            eng.toks_since_active.copy_(value.to(eng.device, torch.int64))
+            eng.set_tracker(value)
 
     def _bind(self, sae: modeling.SparseAutoencoder, n_rows: int):
         sae.__dict__["_dead_threshold_tokens"] = self.cfg.dead_threshold_tokens
@@ -124,7 +122,7 @@ class MatryoshkaObjective(Objective):
             self.__dict__["_eng_ref"] = eng
             pending = self.__dict__["_pending_toks"]
             if pending is not None:
-                eng.toks_since_active.copy_(pending.to(eng.device, torch.int64))
+                eng.set_tracker(pending)
                 self.__dict__["_pending_toks"] = None
         return eng
 

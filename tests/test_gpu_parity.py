@@ -114,7 +114,7 @@ def test_g5_golden_objective_forward_backward(tag):
     eng = make_engine(64, 512, int(g["k"]), k_aux=int(g["k_aux"]), alpha=float(g["alpha"]), thr=int(g["thr"]),
                       max_batch=128, normalize_w_dec=False, remove_parallel_grads=False)
     eng.load_params({k: g["p_" + k] for k in R.PARAM_ORDER})
-    eng.toks_since_active.copy_(g["toks_before"])
+    eng.set_tracker(g["toks_before"])
     x = g["x"].cuda()
     eng.step_forward(x, training=True)
     eng.step_dead(x.shape[0])

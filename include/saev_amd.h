@@ -134,6 +134,11 @@ int saev_gather_rows(saev_ctx* ctx, const float* pool, const int64_t* rows, int3
 
 /* ---- the train step, in phases (framework/train.py:332-460) --------------------------------- */
 
+/* Matryoshka prefix cut points for the following steps (objectives.py:125-138): n ascending latent counts ending at
+ * d_sae, n <= 16; the loss is the mean over all n nested reconstructions.  NULL / n = 1 restores the plain
+ * objective.  (The host samples them per step: objectives.py:159-201.) */
+int saev_set_prefixes(saev_ctx* ctx, const int64_t* prefixes_host, int32_t n);
+
 /* Phase 1: renormalise W_dec (train.py:334-335), encode + TopK, fired flags, sparse decode, MSE,
  * main-path gradient pieces.  `training` = 0 gives the eval-mode forward (no tracker, no aux).
  * `n_rows_global` = rows of this step summed over all data-parallel ranks (= n_rows on one GPU);

@@ -20,6 +20,7 @@ Fixture index:
   G9  train_a/train_b  20ish-step train() trajectories + evaluate() metrics
   G11 schedule         WarmupCosine lr lists and BatchLimiter step counts
   G12 checkpoint       header bytes/JSON written by the reference's nn.dump
+  G13 matryoshka       objective fwd/bwd with 4 fixed prefixes (with and without dead latents)
 """
 
 import dataclasses
@@ -159,6 +160,35 @@ def g5_objective(ref):
         loss, out = obj(sae, x)
     npz("g5_objective_eval", x=x, **params_of(sae), k=k, mse=loss.mse, aux=loss.aux, l0=loss.l0, l1=loss.l1,
         n_dead=int(loss.n_dead), f=out.f_x, x_hat=out.x_hats[:, -1])
+
+
+def g13_matryoshka(ref):
+    """Objective fwd/bwd with FIXED Matryoshka prefixes (the sampler is patched to return them)."""
+    d, s, k, b = 64, 512, 8, 128
+    fixed = torch.tensor([5, 60, 200, 512], dtype=torch.int64)
+    orig = ref.objectives.sample_prefixes
+    ref.objectives.sample_prefixes = lambda d_sae, n_prefixes, *a, **kw: fixed
+    try:
+        for tag, thr, k_aux in (("nodead", 10_000_000, 512), ("dead", 300, 24)):
+            sae = make_sae(ref, d, s, k, k_aux=k_aux, seed=90)
+            sae.train()
+            obj = ref.objectives.get_objective(ref.objectives.Matryoshka(n_prefixes=4, dead_threshold_tokens=thr))
+            obj.train()
+            toks0 = torch.zeros(s, dtype=torch.int64)
+            if tag == "dead":
+                toks0[torch.randperm(s, generator=torch.Generator().manual_seed(91))[:150]] = 250
+            obj.toks_since_active = toks0.clone()
+            x = lowrank_data(b, d, seed=92)
+            loss, out = obj(sae, x)
+            loss.loss.backward()
+            npz(
+                f"g13_matryoshka_{tag}", x=x, **params_of(sae), prefixes=fixed, toks_before=toks0,
+                toks_after=obj.toks_since_active, thr=thr, k=k, k_aux=k_aux, alpha=1 / 32, mse=loss.mse, aux=loss.aux,
+                l0=loss.l0, l1=loss.l1, n_dead=int(loss.n_dead), x_hats=out.x_hats, f=out.f_x,
+                g_W_dec=sae.W_dec.grad, g_b_dec=sae.b_dec.grad, g_W_enc=sae.W_enc.grad, g_b_enc=sae.b_enc.grad,
+            )
+    finally:
+        ref.objectives.sample_prefixes = orig
 
 
 def g6_g7_g8(ref):
@@ -351,6 +381,7 @@ def main():
     g9_train(ref, "b", d=128, s=1024, k=16, bsz=256, n_rows=2048, n_train=6144, thr=512, k_aux=32, lr=2e-3, n_warm=4)
     g11_schedule(ref)
     g12_checkpoint(ref)
+    g13_matryoshka(ref)
 
 
 if __name__ == "__main__":

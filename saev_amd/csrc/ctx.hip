@@ -50,6 +50,11 @@ struct saev_ctx {
     int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use
     int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
     float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
+    // Matryoshka prefixes of the step (P == 1: plain objective)
+    int P = 1;
+    int32_t cuts[MAX_PREFIXES] = {0};
+    float* G = nullptr;  // (max_batch, P_cap, D)
+    int P_cap = 0;
     // AuxK dense-over-dead-set path (auxk.hip)
     rocblas_handle blas = nullptr;
     int n_dead_host = 0, k_use_host = 0;
@@ -71,6 +76,7 @@ struct saev_ctx {
     const float* x_last = nullptr;
     int n_last = 0;
     int training_last = 0;
+    int P_last = 1;
     // timing
     bool timing = false;
     hipEvent_t ev_start[TIMING_RING], ev_stop[TIMING_RING];
@@ -212,6 +218,7 @@ void saev_destroy(saev_ctx* c) {
     hipDeviceSynchronize();
     for (void* p : c->allocs) hipFree(p);
     for (void* p : c->aux_allocs) hipFree(p);
+    if (c->G) hipFree(c->G);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_created)
         for (int i = 0; i < TIMING_RING; ++i) {
@@ -238,6 +245,38 @@ int saev_bind_tracker(saev_ctx* c, int64_t* toks, int32_t* fired) {
     c->toks = toks;
     c->fired = fired;
     c->tracker_dirty = true;
+    return SAEV_OK;
+}
+
+int saev_set_prefixes(saev_ctx* c, const int64_t* prefixes_host, int32_t n) {
+    if (!c) return SAEV_INVALID_ARG;
+    const int S = c->cfg.d_sae;
+    if (prefixes_host == nullptr || n <= 1) {
+        REQUIRE(c, prefixes_host == nullptr || (n == 1 && prefixes_host[0] == S), SAEV_INVALID_ARG,
+                "a single prefix must equal d_sae");
+        c->P = 1;
+        return SAEV_OK;
+    }
+    REQUIRE(c, n <= MAX_PREFIXES, SAEV_UNSUPPORTED, "at most 16 Matryoshka prefixes are supported");
+    REQUIRE(c, prefixes_host[0] >= 1 && prefixes_host[n - 1] == S, SAEV_INVALID_ARG,
+            "prefixes must start at >= 1 and end at d_sae");
+    for (int p = 1; p < n; ++p)
+        REQUIRE(c, prefixes_host[p] > prefixes_host[p - 1], SAEV_INVALID_ARG, "prefixes must be strictly increasing");
+    if (n > c->P_cap) {
+        hipDeviceSynchronize();
+        if (c->G) hipFree(c->G);
+        c->G = nullptr;
+        c->P_cap = 0;
+        void* q = nullptr;
+        if (hipMalloc(&q, (size_t)c->cfg.max_batch * n * c->cfg.d_model * sizeof(float)) != hipSuccess) {
+            c->err = "out of device memory for the Matryoshka gradient buffer";
+            return SAEV_HIP_ERROR;
+        }
+        c->G = (float*)q;
+        c->P_cap = n;
+    }
+    c->P = n;
+    for (int p = 0; p < n; ++p) c->cuts[p] = (int32_t)prefixes_host[p];
     return SAEV_OK;
 }
 
@@ -520,11 +559,20 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
     a.n_rows = n; a.D = D; a.S = S; a.idx_limit = S;
     a.upper = c->upper;
-    a.gscale = 2.0f / ((float)n * (float)D);
+    a.gscale = 2.0f / ((float)n * (float)D * (float)c->P);
     a.training = training ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.dval = c->dval; a.fired = c->fired; a.rowstats = c->rowstats;
-    HIPCHK(c, launch_decode(a, s));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->cfg.alpha, 0, c->upper, c->flags + 2, c->stats, s));
+    if (c->P > 1) {
+        MatryArgs m{};
+        m.P = c->P;
+        for (int p = 0; p < c->P; ++p) m.cuts[p] = c->cuts[p];
+        m.G = c->G;
+        HIPCHK(c, launch_decode_matry(a, m, s));
+    } else {
+        HIPCHK(c, launch_decode(a, s));
+    }
+    c->P_last = c->P;
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper, c->flags + 2, c->stats, s));
     return SAEV_OK;
 }
 
@@ -620,7 +668,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
                                c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
     return SAEV_OK;
 }
 
@@ -696,6 +744,8 @@ int saev_step_backward(saev_ctx* c, void* stream) {
         a.starts = c->starts; a.chunk_starts = c->chunk_starts; a.work_latent = c->work_latent;
         a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = val; a.dval = dval; a.g = g; a.x = c->x_last;
         a.D = D; a.S = S; a.k_dev = k_dev; a.accumulate = accumulate;
+        a.P = c->P_last;
+        for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts[p];
         a.dW_dec = c->grads + c->off_W_dec; a.dW_encT = c->dW_encT; a.db_enc = c->grads + c->off_b_enc;
         a.partials = c->partials; a.db_partials = c->db_partials;
         const int max_work = S + (int)(((long)n * k + DW_CHUNK - 1) / DW_CHUNK);
@@ -704,9 +754,12 @@ int saev_step_backward(saev_ctx* c, void* stream) {
     };
     int rc = build(c->idx, K, K, nullptr);
     if (rc != SAEV_OK) return rc;
-    rc = rows(c->val, c->dval, c->g, K, nullptr, 0);
+    // Matryoshka: rows receive the suffix-summed gradients C_p (c->G); db_dec = column sums of C_0
+    const float* gmat = c->P_last > 1 ? c->G : c->g;
+    rc = rows(c->val, c->dval, gmat, K, nullptr, 0);
     if (rc != SAEV_OK) return rc;
-    HIPCHK(c, launch_colsum(c->g, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s));
+    HIPCHK(c, launch_colsum(gmat, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s,
+                            (long)c->P_last * D));
     if (c->n_dead_host > 0) {
         rc = auxk_backward(c, s);
         if (rc != SAEV_OK) return rc;

@@ -92,6 +92,16 @@ struct DecodeArgs {
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 
+// Matryoshka prefixes (objectives.py:125-138, modeling.py:369-409): P ascending cut points ending at S; prefix p
+// reconstructs from the codes with latent index < cuts[p].
+constexpr int MAX_PREFIXES = 16;
+struct MatryArgs {
+    int P;
+    int32_t cuts[MAX_PREFIXES];
+    float* G;  // (n_rows, P, D): first dL/dx_hat_p, then (in place) C_p = sum_{p' >= p} dL/dx_hat_p'
+};
+hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStream_t stream);
+
 struct AuxDecodeArgs {
     const float* x;         // (n_rows, D)
     const float* x_hat;     // (n_rows, D) main reconstruction (detached target = x - x_hat)
@@ -136,9 +146,11 @@ struct DwRowsArgs {
     const int2* pairs;
     const float* val;             // coefficient of g rows   (indexed by pairs[].y)
     const float* dval;            // coefficient of x rows and db_enc
-    const float* g;               // (n_rows, D)
+    const float* g;               // (n_rows, D), or (n_rows, P, D) suffix sums when P > 1
     const float* x;               // (n_rows, D)
     int D, S;
+    int P;                        // Matryoshka prefixes (1 = plain)
+    int32_t cuts[MAX_PREFIXES];
     const int32_t* k_dev;         // optional predicate (aux)
     int accumulate;
     float* dW_dec;                // (S, D)
@@ -152,7 +164,7 @@ hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream
 
 // out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
-                         const int32_t* k_dev, hipStream_t stream);
+                         const int32_t* k_dev, hipStream_t stream, long row_stride = 0);
 
 // ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
 hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream);
@@ -190,7 +202,7 @@ hipError_t launch_gather_rows(const float* pool, const int64_t* rows, int n_rows
 hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows, int k, int stride, int S, float* f,
                                 hipStream_t stream);
 // reduce rowstats[0..n_rows) into *stats (mse, l0, l1, aux, sse, sum_sq)
-hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, float alpha, int with_aux, const float* upper,
+hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
                                const int32_t* n_overflow_and_max, saev_step_stats* stats, hipStream_t stream);
 
 // ---- f16x3 encoder (fp32-accurate split-fp16 MFMA) -------------------------------------------------

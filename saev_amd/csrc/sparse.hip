@@ -152,6 +152,151 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     }
 }
 
+// Matryoshka variant of decode_kernel: P nested reconstructions per row.  Codes are in ascending latent order, so
+// one sweep emits prefix p whenever the next code's latent reaches cuts[p].  Writes g_p = dL/dx_hat_p for every
+// prefix, turns them into suffix sums C_p (what a code in prefix block p receives from all reconstructions that
+// contain it) in place, and takes dval_j = <W_dec[idx_j], C_{p(j)}>.
+template <int NV>
+__global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryArgs m) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int D = a.D, D4 = D >> 2, P = m.P;
+    const int32_t* idx_row = a.idx + (size_t)row * a.code_stride;
+    const float* val_row = a.val + (size_t)row * a.code_stride;
+    f32x4 acc[NV], xv[NV];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(a.x + (size_t)row * D);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        acc[n] = (q < D4) ? reinterpret_cast<const f32x4*>(a.b_dec)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv[n] = (q < D4) ? xr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float u = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
+    float sse_scaled = 0.f;
+    double sse64 = 0.0, sumsq64 = 0.0;
+    f32x4* Grow = reinterpret_cast<f32x4*>(m.G + (size_t)row * P * D);
+    auto emit = [&](int p) {
+        const bool last = (p == P - 1);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) {
+                f32x4 g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[n][e] / u - xv[n][e] / u;
+                    sse_scaled += t * t * u * u;
+                    g[e] = a.gscale * t * u;
+                    if (last) {
+                        const float r = xv[n][e] - acc[n][e];
+                        sse64 += (double)r * (double)r;
+                        sumsq64 += (double)xv[n][e] * (double)xv[n][e];
+                    }
+                }
+                if (a.training) Grow[(size_t)p * D4 + q] = g;
+                if (last && a.x_hat) reinterpret_cast<f32x4*>(a.x_hat + (size_t)row * D)[q] = acc[n];
+            }
+        }
+    };
+    int p = 0;
+    for (int j0 = 0; j0 < a.k; j0 += 64) {
+        const int cnt = min(64, a.k - j0);
+        int32_t my_i = -1;
+        float my_v = 0.f;
+        if (lane < cnt) { my_i = idx_row[j0 + lane]; my_v = val_row[j0 + lane]; }
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int32_t i = __shfl(my_i, jj, 64);
+            const float v = __shfl(my_v, jj, 64);
+            if (i < 0) continue;
+            while (p < P - 1 && i >= m.cuts[p]) { emit(p); ++p; }
+            const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                if (q < D4) acc[n] += v * wr[q];
+            }
+        }
+    }
+    while (p < P) { emit(p); ++p; }
+
+    if (a.training) {
+        // suffix sums in place (each lane re-reads only what it wrote)
+        f32x4 c[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) c[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pp = P - 1; pp >= 0; --pp) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                if (q < D4) {
+                    c[n] += Grow[(size_t)pp * D4 + q];
+                    Grow[(size_t)pp * D4 + q] = c[n];
+                }
+            }
+        }
+        // dval_j = <W_dec[idx_j], C_{p(j)}>; p(j) is non-decreasing along the (ascending) code list
+        int cur = -1;
+        float* dval_row = a.dval + (size_t)row * a.code_stride;
+        for (int j0 = 0; j0 < a.k; j0 += 64) {
+            const int cnt = min(64, a.k - j0);
+            int32_t my_i = -1;
+            if (lane < cnt) my_i = idx_row[j0 + lane];
+            float my_d = 0.f;
+            for (int jj = 0; jj < cnt; ++jj) {
+                const int32_t i = __shfl(my_i, jj, 64);
+                if (i < 0) continue;
+                int pj = 0;
+                while (pj < P - 1 && i >= m.cuts[pj]) ++pj;
+                if (pj != cur) {
+                    cur = pj;
+#pragma unroll
+                    for (int n = 0; n < NV; ++n) {
+                        const int q = lane + 64 * n;
+                        c[n] = (q < D4) ? Grow[(size_t)pj * D4 + q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+                float d = 0.f;
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const int q = lane + 64 * n;
+                    if (q < D4) {
+                        const f32x4 w = wr[q];
+                        d += w[0] * c[n][0] + w[1] * c[n][1] + w[2] * c[n][2] + w[3] * c[n][3];
+                    }
+                }
+                d = wave_sum(d);
+                if (lane == jj) my_d = d;
+            }
+            if (lane < cnt) dval_row[j0 + lane] = my_d;
+        }
+    }
+    float l0 = 0.f, l1 = 0.f;
+    for (int j = lane; j < a.k; j += 64) {
+        const int32_t i = idx_row[j];
+        const float v = val_row[j];
+        if (i >= 0 && v != 0.f) {
+            l0 += 1.f;
+            l1 += fabsf(v);
+            if (a.training && a.fired) a.fired[i] = 1;
+        }
+    }
+    if (a.rowstats) {
+        sse_scaled = wave_sum(sse_scaled);
+        l0 = wave_sum(l0);
+        l1 = wave_sum(l1);
+        sse64 = wave_sum_d(sse64);
+        sumsq64 = wave_sum_d(sumsq64);
+        if (lane == 0) {
+            RowStats rs;
+            rs.sse_scaled = sse_scaled; rs.l0 = l0; rs.l1 = l1; rs.aux_sse = 0.f;
+            rs.sse64 = sse64; rs.sumsq64 = sumsq64;
+            a.rowstats[row] = rs;
+        }
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void aux_decode_kernel(AuxDecodeArgs a) {
     const int k = *a.k_use;
@@ -344,6 +489,11 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
     const int nch = a.chunk_starts[i + 1] - a.chunk_starts[i];
     const int D = a.D, D4 = D >> 2;
     const int seg_beg = a.starts[i], seg_end = a.starts[i + 1];
+    // Matryoshka: latent i sits in prefix block p(i) and receives the suffix-summed gradient C_{p(i)} (row stride P*D)
+    int pblk = 0;
+    if (a.P > 1) while (pblk < a.P - 1 && i >= a.cuts[pblk]) ++pblk;
+    const size_t g_stride = (size_t)a.P * D;
+    const float* gbase = a.g + (size_t)pblk * D;
     const int beg = seg_beg + c * DW_CHUNK;
     const int end = min(seg_end, beg + DW_CHUNK);
     f32x4 accd[NV], acce[NV];
@@ -363,8 +513,8 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
         const int b0 = __shfl(my_b, jj, 64), b1 = __shfl(my_b, jj + 1, 64);
         const float v0 = __shfl(my_v, jj, 64), v1 = __shfl(my_v, jj + 1, 64);
         const float e0 = __shfl(my_dv, jj, 64), e1 = __shfl(my_dv, jj + 1, 64);
-        const f32x4* g0 = reinterpret_cast<const f32x4*>(a.g + (size_t)b0 * D);
-        const f32x4* g1 = reinterpret_cast<const f32x4*>(a.g + (size_t)b1 * D);
+        const f32x4* g0 = reinterpret_cast<const f32x4*>(gbase + (size_t)b0 * g_stride);
+        const f32x4* g1 = reinterpret_cast<const f32x4*>(gbase + (size_t)b1 * g_stride);
         const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
         const f32x4* x1 = reinterpret_cast<const f32x4*>(a.x + (size_t)b1 * D);
         f32x4 tg0[NV], tg1[NV], tx0[NV], tx1[NV];
@@ -388,7 +538,7 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
     if (jj < cnt) {
         const int b0 = __shfl(my_b, jj, 64);
         const float v0 = __shfl(my_v, jj, 64), e0 = __shfl(my_dv, jj, 64);
-        const f32x4* g0 = reinterpret_cast<const f32x4*>(a.g + (size_t)b0 * D);
+        const f32x4* g0 = reinterpret_cast<const f32x4*>(gbase + (size_t)b0 * g_stride);
         const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
@@ -481,13 +631,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // ------------------------------- column sums -----------------------------------------------
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int n_rows, int D, float* partials,
-                                                             const int32_t* k_dev) {
+                                                             const int32_t* k_dev, long row_stride) {
     if (k_dev && *k_dev <= 0) return;
     const int r0 = blockIdx.x * 64;
     const int r1 = min(n_rows, r0 + 64);
     for (int q = threadIdx.x; q < (D >> 2); q += 256) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int r = r0; r < r1; ++r) s += reinterpret_cast<const f32x4*>(m + (size_t)r * D)[q];
+        for (int r = r0; r < r1; ++r) s += reinterpret_cast<const f32x4*>(m + (size_t)r * row_stride)[q];
         reinterpret_cast<f32x4*>(partials + (size_t)blockIdx.x * D)[q] = s;
     }
 }
@@ -525,6 +675,12 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(decode_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     });
 }
+hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    return dispatch_nv(a.D, [&](auto nv) {
+        hipLaunchKernelGGL(decode_matry_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a, m);
+    });
+}
 hipError_t launch_aux_decode(const AuxDecodeArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
     return dispatch_nv(a.D, [&](auto nv) {
@@ -552,10 +708,11 @@ hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream
     return hipGetLastError();
 }
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
-                         const int32_t* k_dev, hipStream_t stream) {
+                         const int32_t* k_dev, hipStream_t stream, long row_stride) {
     const int nb = (n_rows + 63) / 64;
     if (nb <= 0) return hipSuccess;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev,
+                       row_stride > 0 ? row_stride : (long)D);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, partials, nb, D, out,
                        accumulate, k_dev);
     return hipGetLastError();

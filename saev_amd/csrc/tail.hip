@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void scatter_dense_kernel(const int32_t* idx, 
     if (i >= 0 && i < S) f[(size_t)b * S + i] = val[(size_t)b * stride + j];
 }
 
-__global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, int n_rows, int D, float alpha,
+__global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, int n_rows, int D, int P, float alpha,
                                                             int with_aux, const float* upper,
                                                             const int32_t* n_overflow, saev_step_stats* stats) {
     __shared__ double sh[16][6];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
         for (int w = 0; w < 16; ++w)
             for (int i = 0; i < 6; ++i) t[i] += sh[w][i];
         const double nd = (double)n_rows * (double)D;
-        stats->mse = (float)(t[0] / nd);
+        stats->mse = (float)(t[0] / (nd * (double)P));  // mean over rows x prefixes x d_model
         stats->l0 = (float)(t[1] / n_rows);
         stats->l1 = (float)(t[2] / n_rows);
         if (with_aux) stats->aux = (float)((double)alpha * t[3] / nd);
@@ -304,9 +304,9 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
                        stride, S, f);
     return hipGetLastError();
 }
-hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, float alpha, int with_aux, const float* upper,
+hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
                                const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream) {
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, rs, n_rows, D, alpha, with_aux, upper,
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, rs, n_rows, D, P, alpha, with_aux, upper,
                        n_overflow, stats);
     return hipGetLastError();
 }

@@ -135,6 +135,15 @@ class SaeEngine:
             self.toks_since_active.copy_(toks.to(self.device, torch.int64))
         self._chk(self.lib.saev_tracker_touched(self.ctx), "saev_tracker_touched")
 
+    def set_prefixes(self, prefixes) -> None:
+        """Matryoshka cut points for the following steps (ascending, last == d_sae); None / one entry = plain."""
+        if prefixes is None:
+            self._chk(self.lib.saev_set_prefixes(self.ctx, None, 0), "saev_set_prefixes")
+            return
+        pre = [int(p) for p in prefixes]
+        arr = (C.c_int64 * len(pre))(*pre)
+        self._chk(self.lib.saev_set_prefixes(self.ctx, arr, len(pre)), "saev_set_prefixes")
+
     def load_params(self, params: dict[str, torch.Tensor]) -> None:
         for k in self.offsets:
             self.view(k).copy_(params[k].to(self.device, torch.float32))

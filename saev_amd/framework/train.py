@@ -195,8 +195,6 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
     objs.train()
     steppers, scheds, lrs = [], [], []
     for sae, obj, c in zip(saes, objs, cfgs):
-        if c.objective.n_prefixes > 1:
-            raise NotImplementedError("Matryoshka n_prefixes > 1 is not on the HIP path yet; set n_prefixes=1")
         eng = obj._bind(sae, dataloader.local_batch)
         if world > 1:  # identical replicas: rank 0's initial parameters everywhere
             dist.broadcast(eng.params, src=0)
@@ -213,6 +211,10 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
         log_now = (global_step + 1) % cfg.log_every == 0
         metrics = []
         for i, (sae, st, c) in enumerate(zip(saes, steppers, cfgs)):
+            # Matryoshka cut points: sampled per SAE per step from torch's global CPU RNG, like the reference
+            # (objectives.py:125); every rank draws the same sequence (same seed, same call order)
+            if c.objective.n_prefixes > 1:
+                st.engine.set_prefixes(objectives.sample_prefixes(c.sae.d_sae, c.objective.n_prefixes))
             st.train_step(x, lrs[i], c.grad_clip)
             if log_now:
                 metrics.append(_log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c))
@@ -328,6 +330,8 @@ def evaluate(cfgs: list[Config], saes: torch.nn.ModuleList, objs: torch.nn.Modul
         n_tokens += b
         for i, (sae, obj) in enumerate(zip(saes, objs)):
             eng = obj._bind(sae, b)
+            n_pre = cfgs[i].objective.n_prefixes
+            eng.set_prefixes(objectives.sample_prefixes(sae.cfg.d_sae, n_pre) if n_pre > 1 else None)
             eng.step_forward(x, training=False)
             st = eng.read_stats()
             if i == 0:

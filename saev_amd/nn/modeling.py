@@ -138,10 +138,17 @@ class Output:
     The HIP path keeps the k-sparse codes ``idx`` / ``val`` (batch, top_k); the dense ``h_x`` / ``f_x``
     (batch, d_sae) matrices are materialised only when read."""
 
-    def __init__(self, sae: "SparseAutoencoder", x: Tensor, idx: Tensor, val: Tensor, x_hats: Tensor,
-                 h_x: Tensor | None = None):
-        self._sae, self._x, self.idx, self.val, self.x_hats = sae, x, idx, val, x_hats
-        self._h_x, self._f_x = h_x, None
+    def __init__(self, sae: "SparseAutoencoder", x: Tensor, idx: Tensor, val: Tensor, x_hats: Tensor | None,
+                 h_x: Tensor | None = None, prefixes: Tensor | None = None):
+        self._sae, self._x, self.idx, self.val, self._x_hats = sae, x, idx, val, x_hats
+        self._h_x, self._f_x, self.prefixes = h_x, None, prefixes
+
+    @property
+    def x_hats(self) -> Tensor:
+        """(batch, n_prefixes, d_model); with Matryoshka prefixes the nested reconstructions are decoded on demand."""
+        if self._x_hats is None:
+            self._x_hats = self._sae._eng().decode_sparse(self.idx, self.val, prefixes=self.prefixes)
+        return self._x_hats
 
     @property
     def h_x(self) -> Tensor:

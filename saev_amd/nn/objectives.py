@@ -6,9 +6,9 @@ tracking, decode, MSE with the max|x| rescale (objectives.py:223-237), AuxK (mod
 All of it runs in libsaev_amd.so; ``loss.loss.backward()`` runs the HIP sparse backward and leaves the
 four parameter gradients in ``param.grad`` (views of the engine's flat gradient buffer).
 
-Scope (BASELINE.json north_star): the TopK objective with ``n_prefixes == 1``.  The stochastic
-Matryoshka prefix sampler (objectives.py:159-201) is reproduced on the host for API parity, but
-training with more than one prefix is not on the HIP path yet and raises.
+Matryoshka prefixes (``n_prefixes > 1``, the reference default of 10): the cut points are sampled on the
+host every call exactly as the reference does (Pareto law, torch global RNG, objectives.py:159-201) and
+handed to the kernels, which form all nested reconstructions from the (latent-ordered) codes in one sweep.
 """
 
 from __future__ import annotations
@@ -127,12 +127,11 @@ class MatryoshkaObjective(Objective):
         return eng
 
     def forward(self, sae: modeling.SparseAutoencoder, x: Tensor):
-        if self.cfg.n_prefixes > 1:
-            raise NotImplementedError(
-                "Matryoshka training with n_prefixes > 1 is not on the HIP path yet; use Matryoshka(n_prefixes=1)")
         n = x.shape[0]
         eng = self._bind(sae, n)
         x = x.detach()
+        prefixes = sample_prefixes(sae.cfg.d_sae, self.cfg.n_prefixes)
+        eng.set_prefixes(prefixes if self.cfg.n_prefixes > 1 else None)
         if self.training:
             assert sae.training, "objective.train() with sae.eval(): AuxK needs a dead mask only in training"
             eng.step_forward(x, training=True)
@@ -150,6 +149,8 @@ class MatryoshkaObjective(Objective):
             n_dead=torch.tensor(st.n_dead, device=dev) if self.training else torch.tensor(0), total=total,
         )
         idx, val, x_hat = eng.last_codes(n)
+        if self.cfg.n_prefixes > 1:
+            return loss, modeling.Output(sae, x, idx, val, None, prefixes=prefixes)
         return loss, modeling.Output(sae, x, idx, val, x_hat[:, None, :])
 
 

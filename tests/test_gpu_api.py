@@ -144,8 +144,15 @@ def test_objective_total_and_eval_mode():
     sae.eval(); obj.eval()
     loss, _ = obj(sae, torch.tensor([[1.0, 2.0, 3.0, 4.0]]).cuda())
     assert loss.aux.item() == 0.0 and int(loss.n_dead) == 0
-    with pytest.raises(NotImplementedError):
-        O().get_objective(O().Matryoshka(n_prefixes=10))(sae, torch.zeros(1, 4).cuda())
+    # reference default: 10 Matryoshka prefixes (needs d_sae >= n_prefixes)
+    m = M()
+    big = m.SparseAutoencoder(m.SparseAutoencoderConfig(d_model=32, d_sae=256, activation=m.TopK(top_k=8))).cuda().train()
+    obj10 = O().get_objective(O().Matryoshka()).train()
+    torch.manual_seed(1)
+    loss10, out10 = obj10(big, torch.randn(16, 32).cuda())
+    assert out10.x_hats.shape == (16, 10, 32) and out10.prefixes.tolist()[-1] == 256 and torch.isfinite(loss10.mse)
+    loss10.loss.backward()
+    assert big.W_enc.grad is not None and big.W_enc.grad.abs().sum() > 0
 
 
 def test_n_dead_tracks_dead_latents():  # tests/test_auxk.py:304-353

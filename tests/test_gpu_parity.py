@@ -221,3 +221,34 @@ def test_teacher_forced_steps_match_oracle(tag):
                                            msg=lambda m: f"step {i} {key}: {m}")
         lr = sched.step()
     assert n_flip_steps <= 2
+
+
+@pytest.mark.parametrize("tag", ["nodead", "dead"])
+def test_g13_golden_matryoshka_forward_backward(tag):
+    """Nested-prefix objective (the reference default has 10 prefixes) with fixed cut points."""
+    g = load_golden(f"g13_matryoshka_{tag}")
+    eng = make_engine(64, 512, int(g["k"]), k_aux=int(g["k_aux"]), alpha=float(g["alpha"]), thr=int(g["thr"]),
+                      max_batch=128, normalize_w_dec=False, remove_parallel_grads=False)
+    eng.load_params({k: g["p_" + k] for k in R.PARAM_ORDER})
+    eng.set_tracker(g["toks_before"])
+    eng.set_prefixes(g["prefixes"].tolist())
+    x = g["x"].cuda()
+    eng.step_forward(x, training=True)
+    eng.step_dead(x.shape[0])
+    eng.step_backward()
+    st = eng.read_stats()
+    assert torch.equal(eng.toks_since_active.cpu(), g["toks_after"]) and st.n_dead == g["n_dead"]
+    assert math.isclose(st.mse, g["mse"], rel_tol=1e-4)
+    assert math.isclose(st.aux, g["aux"], rel_tol=1e-4, abs_tol=1e-9)
+    idx, val, x_hat = eng.last_codes(x.shape[0])
+    torch.testing.assert_close(x_hat.cpu(), g["x_hats"][:, -1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(eng.decode_sparse(idx, val, prefixes=g["prefixes"].tolist()).cpu(), g["x_hats"],
+                               rtol=1e-5, atol=1e-5)
+    gv = eng.grad_views()
+    for k in R.PARAM_ORDER:
+        torch.testing.assert_close(gv[k].cpu(), g["g_" + k], rtol=1e-3, atol=1e-7, msg=lambda m: f"{k}: {m}")
+    # back to the plain objective
+    eng.set_prefixes(None)
+    eng.step_forward(x, training=False)
+    plain = eng.read_stats().mse
+    assert plain < st.mse, "the full reconstruction is better than the average over nested prefixes"

@@ -175,3 +175,20 @@ def test_g12_checkpoint_header_shape():
     assert hdr["cfg"]["activation"]["cls"] == "TopK"
     assert hdr["cfg"]["activation"]["params"]["aux"] == {"cls": "AuxK", "params": {"key": "auxk", "k_aux": 7, "alpha": 0.125}}
     assert list(g["keys"]) == ["W_dec", "b_dec", "W_enc", "b_enc"]
+
+
+@pytest.mark.parametrize("tag", ["nodead", "dead"])
+def test_g13_matryoshka_fixed_prefixes(tag):
+    g = load_golden(f"g13_matryoshka_{tag}")
+    cfg = R.RefConfig(d_model=64, d_sae=512, top_k=int(g["k"]), k_aux=int(g["k_aux"]), alpha=float(g["alpha"]),
+                      dead_threshold_tokens=int(g["thr"]), n_prefixes=4)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params(g).items()}
+    toks = g["toks_before"].clone()
+    out = R.objective_forward(leaves, g["x"], cfg, toks_since_active=toks, training=True, prefixes=g["prefixes"])
+    out.loss.backward()
+    assert torch.equal(toks, g["toks_after"]) and out.n_dead == g["n_dead"]
+    torch.testing.assert_close(out.mse.detach(), torch.as_tensor(g["mse"]), **TIGHT)
+    torch.testing.assert_close(out.aux.detach(), torch.as_tensor(g["aux"]), **TIGHT)
+    torch.testing.assert_close(out.x_hats.detach(), g["x_hats"], rtol=1e-5, atol=1e-6)
+    for k in R.PARAM_ORDER:
+        torch.testing.assert_close(leaves[k].grad, g["g_" + k], rtol=1e-5, atol=1e-8)

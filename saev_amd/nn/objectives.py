@@ -14,6 +14,7 @@ handed to the kernels, which form all nested reconstructions from the (latent-or
 from __future__ import annotations
 
 import dataclasses
+import functools
 import typing as tp
 
 import torch
@@ -154,17 +155,25 @@ class MatryoshkaObjective(Objective):
         return loss, modeling.Output(sae, x, idx, val, x_hat[:, None, :])
 
 
-@torch.no_grad()
-def sample_prefixes(d_sae: int, n_prefixes: int, min_prefix_length: int = 1, pareto_power: float = 0.5) -> Tensor:
-    """Sorted prefix lengths ending in d_sae; lengths 1..d_sae-1 drawn without replacement from the
-    discretised Pareto law P(len <= L) = 1 - (min/L)^power (objectives.py:159-201; torch global RNG)."""
-    if n_prefixes <= 1:
-        return torch.tensor([d_sae], dtype=torch.int64)
-    assert n_prefixes <= d_sae
+@functools.lru_cache(maxsize=8)
+def _prefix_law(d_sae: int, min_prefix_length: int, pareto_power: float) -> tuple[Tensor, Tensor]:
+    """Lengths 1..d_sae-1 and their probabilities under the discretised Pareto law P(len <= L) = 1 - (min/L)^power
+    (objectives.py:183-186).  Deterministic, so it is computed once per d_sae; only the draw is per step."""
     lengths = torch.arange(1, d_sae)
     cdf = 1 - (min_prefix_length / lengths.float()) ** pareto_power
     pdf = torch.cat([cdf[:1], cdf[1:] - cdf[:-1]])
-    picks = torch.multinomial(pdf / pdf.sum(), num_samples=n_prefixes - 1, replacement=False)
+    return lengths, pdf / pdf.sum()
+
+
+@torch.no_grad()
+def sample_prefixes(d_sae: int, n_prefixes: int, min_prefix_length: int = 1, pareto_power: float = 0.5) -> Tensor:
+    """Sorted prefix lengths ending in d_sae; n_prefixes-1 lengths drawn without replacement from the Pareto law
+    with torch's global CPU RNG -- the same draw, consuming the same random numbers, as objectives.py:159-201."""
+    if n_prefixes <= 1:
+        return torch.tensor([d_sae], dtype=torch.int64)
+    assert n_prefixes <= d_sae
+    lengths, pdf = _prefix_law(d_sae, min_prefix_length, pareto_power)
+    picks = torch.multinomial(pdf, num_samples=n_prefixes - 1, replacement=False)
     out = torch.cat((lengths[picks], torch.tensor([d_sae])))
     return torch.sort(out).values.to(torch.int64)
 

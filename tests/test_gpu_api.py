@@ -286,3 +286,32 @@ def test_train_is_deterministic(tmp_path):
         outs.append({k: v.detach().cpu().clone() for k, v in saes[0].state_dict().items()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), f"{k} differs between identical runs"
+
+
+def test_train_matryoshka_matches_oracle_on_same_batches_and_prefix_draws(tmp_path):
+    """Default-style objective (several Matryoshka prefixes + AuxK): train() vs the oracle fed the same batches;
+    both draw the prefix cut points from torch's global CPU RNG, which is seeded identically."""
+    from saev_amd import data
+    from saev_amd.framework import train as T
+    from saev_amd.utils import scheduling
+
+    g = load_golden("g9_train_b")
+    cfg = small_cfg(tmp_path, g)
+    cfg = dataclasses.replace(cfg, objective=dataclasses.replace(cfg.objective, n_prefixes=5), n_train=3072)
+    saes, objs, log, steps = T.train([cfg], train_pool=g["acts"])
+    torch.manual_seed(cfg.seed)
+    init = M().SparseAutoencoder(cfg.sae)
+    rcfg = R.RefConfig(d_model=int(g["d"]), d_sae=int(g["s"]), top_k=int(g["k"]), k_aux=int(g["k_aux"]),
+                       dead_threshold_tokens=int(g["thr"]), lr=cfg.lr, n_lr_warmup=cfg.n_lr_warmup, n_prefixes=5)
+    state = R.TrainState.create({k: getattr(init, k).detach() for k in R.PARAM_ORDER})
+    dl = data.ShuffledDataLoader(cfg.train_data, device="cpu", pool=g["acts"])
+    lim = scheduling.BatchLimiter(dl, cfg.n_train)
+    sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, len(lim), 0.0)
+    recs = [R.train_step(state, batch["act"], rcfg, sched) for batch in lim]
+    assert len(recs) == steps and max(r["n_dead"] for r in recs) > 0
+    got = {k: v.detach().cpu() for k, v in saes[0].state_dict().items()}
+    for k in R.PARAM_ORDER:
+        bad = ~torch.isclose(got[k], state.params[k], rtol=2e-3, atol=5e-5)
+        assert bad.float().mean() < 5e-3, f"{k}: {bad.sum().item()} of {bad.numel()} elements off"
+    last = log.records[0][-1][1]
+    assert math.isclose(last["loss/mse"], recs[log.records[0][-1][0]]["mse"], rel_tol=2e-3)

@@ -109,10 +109,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     }
 
     const int nks = Dp / 16;  // k-steps per tile
-    // Workgroups that share an operand image (same latent range -> same W images, same batch block -> same x
-    // images) walk the k-steps in rotated order so that they do not hit the same 16 KB at the same moment (the sum
-    // over k does not care); neighbours stay within a few k-steps of each other, so the images remain L2-resident.
-    const int rot = ((bb & 7) + 8 * sp) % nks;
+    // The 8 workgroups of an XCD that stream the same W images (same latent range, different batch block) walk the
+    // k-steps in an order rotated by one step each, so they do not hit the same 16 KB at the same moment but stay
+    // within the L2 retention window; the workgroups that share an x block (same batch block) keep the same order.
+    // (Measured: 3.23 ms vs 3.40 ms unrotated; the sum over k does not care about the order.)
+    const int rot = (bb & 7) % nks;
     auto kmap = [&](int t) { const int k = t + rot; return k >= nks ? k - nks : k; };
 
     // a slot image is 16 KB per operand; wave w copies bytes [2 KB * w, +2 KB) of each with two 1 KB calls

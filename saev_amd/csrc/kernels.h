@@ -102,23 +102,6 @@ struct MatryArgs {
 };
 hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStream_t stream);
 
-struct AuxDecodeArgs {
-    const float* x;         // (n_rows, D)
-    const float* x_hat;     // (n_rows, D) main reconstruction (detached target = x - x_hat)
-    const int32_t* idx;     // (n_rows, code_stride) aux codes
-    const float* val;
-    int code_stride;
-    const int32_t* k_use;   // device: min(k_aux, n_dead); 0 -> kernel exits
-    const float* W_dec;
-    const float* b_dec;
-    int n_rows, D;
-    float gscale;           // alpha * 2 / (n_rows * D)
-    float* g_aux;           // (n_rows, D)
-    float* dval;            // (n_rows, code_stride)
-    RowStats* rowstats;
-};
-hipError_t launch_aux_decode(const AuxDecodeArgs& a, hipStream_t stream);
-
 // CSC (latent-major) view of the codes, built deterministically through a (S x n_rows)-bit map.
 struct CscArgs {
     const int32_t* idx;     // (n_rows, code_stride)
@@ -194,9 +177,6 @@ struct DeadArgs {
     saev_step_stats* stats;
 };
 hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream);
-// flag = any(toks[i] + add_tokens >= threshold)
-hipError_t launch_predead_flag(const int64_t* toks, int S, int64_t add_tokens, int64_t threshold, int32_t* flag,
-                               hipStream_t stream);
 hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream);
 hipError_t launch_gather_rows(const float* pool, const int64_t* rows, int n_rows, int D, float* out, hipStream_t stream);
 hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows, int k, int stride, int S, float* f,

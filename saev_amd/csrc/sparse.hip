@@ -4,7 +4,7 @@
 //
 //   decode_kernel     x_hat = b_dec + sum_j val_j W_dec[idx_j]; scaled MSE (objectives.py:223-237);
 //                     g = dL/dx_hat; dval_j = <W_dec[idx_j], g>; fired flags; per-row stats.
-//   aux_decode_kernel AuxK reconstruction of the detached residual (modeling.py:89-103).
+//   decode_matry_kernel the same for P nested Matryoshka prefixes (objectives.py:125-138).
 //   csc_*             latent-major ordering of the (row, latent) pairs, deterministic (row-ascending
 //                     inside a latent) via an S x B bit map: atomicOr fill, per-latent enumeration.
 //   dw_dec_kernel     dW_dec[i,:] = sum_{b in latent i} val * g[b,:]   (+ db_enc[i] = sum dval)
@@ -295,48 +295,6 @@ __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryAr
             a.rowstats[row] = rs;
         }
     }
-}
-
-template <int NV>
-__global__ __launch_bounds__(256) void aux_decode_kernel(AuxDecodeArgs a) {
-    const int k = *a.k_use;
-    if (k <= 0) return;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.n_rows) return;
-    const int D = a.D, D4 = D >> 2;
-    const int32_t* idx_row = a.idx + (size_t)row * a.code_stride;
-    const float* val_row = a.val + (size_t)row * a.code_stride;
-    f32x4 acc[NV];
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const int q = lane + 64 * n;
-        acc[n] = (q < D4) ? reinterpret_cast<const f32x4*>(a.b_dec)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    gather_rows_accum<NV>(acc, a.W_dec, D, D4, idx_row, val_row, k, 0x7fffffff, lane);
-    float sse = 0.f;
-    f32x4 g[NV];
-    const f32x4* xr = reinterpret_cast<const f32x4*>(a.x + (size_t)row * D);
-    const f32x4* hr = reinterpret_cast<const f32x4*>(a.x_hat + (size_t)row * D);
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const int q = lane + 64 * n;
-        g[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q < D4) {
-            const f32x4 xv = xr[q], hv = hr[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float resid = xv[e] - hv[e];
-                const float diff = acc[n][e] - resid;
-                sse += diff * diff;
-                g[n][e] = a.gscale * diff;
-            }
-            reinterpret_cast<f32x4*>(a.g_aux + (size_t)row * D)[q] = g[n];
-        }
-    }
-    row_dots<NV>(g, a.W_dec, D, D4, idx_row, a.dval + (size_t)row * a.code_stride, k, 0x7fffffff, lane);
-    sse = wave_sum(sse);
-    if (lane == 0) a.rowstats[row].aux_sse = sse;
 }
 
 // ------------------------------- CSC build -------------------------------------------------
@@ -679,12 +637,6 @@ hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStrea
     if (a.n_rows <= 0) return hipSuccess;
     return dispatch_nv(a.D, [&](auto nv) {
         hipLaunchKernelGGL(decode_matry_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a, m);
-    });
-}
-hipError_t launch_aux_decode(const AuxDecodeArgs& a, hipStream_t stream) {
-    if (a.n_rows <= 0) return hipSuccess;
-    return dispatch_nv(a.D, [&](auto nv) {
-        hipLaunchKernelGGL(aux_decode_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     });
 }
 hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream) {

@@ -158,18 +158,6 @@ __global__ __launch_bounds__(1024) void dead_update_kernel(DeadArgs a) {
     }
 }
 
-__global__ __launch_bounds__(1024) void predead_flag_kernel(const int64_t* toks, int S, int64_t add, int64_t thr,
-                                                            int32_t* flag) {
-    __shared__ int sh;
-    if (threadIdx.x == 0) sh = 0;
-    __syncthreads();
-    int any = 0;
-    for (int i = threadIdx.x; i < S; i += 1024) any |= (toks[i] + add >= thr);
-    if (__ballot(any) != 0ull && (threadIdx.x & 63) == 0) sh = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) *flag = sh;
-}
-
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, float* out) {
     const long n4 = n >> 2;
     float m = 0.f;
@@ -280,10 +268,6 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {
 }
 hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(dead_update_kernel, dim3(1), dim3(1024), 0, stream, a);
-    return hipGetLastError();
-}
-hipError_t launch_predead_flag(const int64_t* toks, int S, int64_t add, int64_t thr, int32_t* flag, hipStream_t stream) {
-    hipLaunchKernelGGL(predead_flag_kernel, dim3(1), dim3(1024), 0, stream, toks, S, add, thr, flag);
     return hipGetLastError();
 }
 hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream) {

@@ -252,3 +252,53 @@ def test_g13_golden_matryoshka_forward_backward(tag):
     eng.step_forward(x, training=False)
     plain = eng.read_stats().mse
     assert plain < st.mse, "the full reconstruction is better than the average over nested prefixes"
+
+
+def test_candidate_overflow_takes_the_exact_dense_route():
+    """Adversarial input for the fused TopK: when (almost) all pre-activations of a row are tied, every value
+    passes the running bound and the row's candidate list overflows (4096 entries).  The device-side flag must
+    then re-run the step on the exact dense route and still return a correct top-k."""
+    n, d, s, k = 40, 32, 16384, 16
+    p = rand_params(d, s, seed=3)
+    p["W_enc"] = torch.zeros(d, s)
+    p["b_enc"] = torch.ones(s)
+    p["b_enc"][7], p["b_enc"][9000] = 2.0, 3.0
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(4))
+    eng = make_engine(d, s, k, max_batch=64)
+    eng.load_params(p)
+    eng.step_forward(x.cuda(), training=False)
+    st = eng.read_stats()
+    assert st.n_overflow_rows == n and st.cand_max > 4096
+    idx, val, x_hat = (t.cpu() for t in eng.last_codes(n))
+    assert (idx[:, 1:] > idx[:, :-1]).all()
+    for row in range(n):
+        got = dict(zip(idx[row].tolist(), val[row].tolist()))
+        assert got.get(7) == 2.0 and got.get(9000) == 3.0, "the two strict maxima are always selected"
+        assert sorted(got.values())[:k - 2] == [1.0] * (k - 2), "the rest are ties at 1.0 (any k of them)"
+    # the step's loss is the loss of exactly those codes
+    want_hat = p["b_dec"] + torch.einsum("bk,bkd->bd", val, p["W_dec"][idx.long()])
+    torch.testing.assert_close(x_hat, want_hat, rtol=1e-5, atol=1e-5)
+    assert math.isclose(st.mse, ((want_hat - x) ** 2).mean().item(), rel_tol=1e-4)
+    eng.train_step(x.cuda(), 1e-3, 1.0)
+    st = eng.read_stats()
+    assert st.n_overflow_rows == n and math.isfinite(st.grad_norm) and st.grad_norm > 0
+
+
+@pytest.mark.parametrize("n", [1, 127, 129, 255, 257, 300])
+def test_ragged_batches_through_the_full_step(n):
+    """Batch sizes that do not fill the encoder's 128/256-row tiles (the loader's last batch, drop_last=False)."""
+    d, s, k = 64, 1024, 16
+    p = rand_params(d, s, seed=n)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(n + 5))
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k)
+    state = R.TrainState.create(p)
+    state.lr = 1e-3
+    ref = R.train_step(state, x, cfg)
+    eng = make_engine(d, s, k, max_batch=300)
+    eng.load_params(p)
+    eng.train_step(x.cuda(), 1e-3, 1.0)
+    st = eng.read_stats()
+    assert math.isclose(st.mse, ref["mse"], rel_tol=1e-4) and math.isclose(st.l0, ref["l0"], rel_tol=1e-6)
+    assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-3)
+    for key in R.PARAM_ORDER:
+        torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-3, atol=1e-5)

@@ -32,7 +32,8 @@ struct saev_ctx {
     long off_W_dec = 0, off_b_dec = 0, off_W_enc = 0, off_b_enc = 0;
     // scratch
     std::vector<void*> allocs;
-    int32_t *cand_cnt = nullptr, *row_tau = nullptr, *cand_idx = nullptr;
+    int32_t *cand_cnt = nullptr, *gmax = nullptr, *cand_idx = nullptr;
+    int gmax_stride = 0;
     float* cand_val = nullptr;
     float* h_dense = nullptr;
     int32_t *idx = nullptr, *aux_idx = nullptr;
@@ -167,7 +168,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     c->n_params = 2 * S * D + S + D;
     int rc = SAEV_OK;
 #define A(p, n) if (rc == SAEV_OK) rc = alloc(c, &c->p, (size_t)(n))
-    A(cand_cnt, MB); A(row_tau, MB); A(cand_idx, MB * CAND_CAP); A(cand_val, MB * CAND_CAP);
+    c->gmax_stride = (int)((MB + 255) / 256 * 256);
+    A(cand_cnt, MB); A(gmax, (size_t)64 * c->gmax_stride); A(cand_idx, MB * CAND_CAP); A(cand_val, MB * CAND_CAP);
     A(h_dense, MB * S);
     A(idx, MB * K); A(val, MB * K); A(dval, MB * K);
     if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(g_aux, MB * D); A(dead_list, S); }
@@ -370,7 +372,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
         a.h_out = h_out;
         a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
-        a.row_tau = c->row_tau; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
+        a.gmax = c->gmax; a.gmax_stride = c->gmax_stride; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
         a.cand_cap = CAND_CAP;
         a.enable_flag = flag; a.enable_when = when;
         HIPCHK(c, launch_encode_f16x3(a, epi, s));
@@ -386,7 +388,8 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
     a.s_splits = encoder_splits(n, a.S, encode_gemm_tile_rows(), encode_gemm_tile_latents(), 512);
     a.h_out = h_out;
     a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
-    a.row_tau = c->row_tau;
+    a.gmax = c->gmax;
+    a.gmax_stride = c->gmax_stride;
     a.cand_cnt = c->cand_cnt;
     a.cand_val = c->cand_val;
     a.cand_idx = c->cand_idx;
@@ -432,7 +435,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     timing_begin(c, s);
     if (fused_supported(c->cfg)) {
         HIPCHK(c, hipMemsetAsync(c->cand_cnt, 0, (size_t)n * sizeof(int32_t), s));
-        HIPCHK(c, launch_init_i32(c->row_tau, INT32_MIN, n, s));
+        HIPCHK(c, launch_init_i32(c->gmax, INT32_MIN, (c->cfg.top_k <= 32 ? 32 : 64) * c->gmax_stride, s));
         int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
         if (rc != SAEV_OK) return rc;
         HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));

@@ -46,7 +46,7 @@ struct __attribute__((aligned(16))) HSmem {
         } e32;
         int32_t slots64[2][64][HTB];       // NG == 64 scratch: 128 KB
     };
-    float tau[HTB];
+    int32_t tau_key[HTB];
     float bias[HTS];
 };
 
@@ -154,8 +154,6 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         if (tid < HTS) sm.bias[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : 0.f;
-        int32_t tau_other = INT32_MIN;
-        if (EPI == EPI_TOPK && tid < HTB && a.s_splits > 1 && b0 + tid < B) tau_other = a.row_tau[b0 + tid];
         __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
         if (nks > 2) stage_kstep(2, s0, kmap(2));
 
@@ -257,26 +255,51 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 }
             }
             __syncthreads();
-            if (tid < HTB) {
+            // bound per row = min over groups of the group maximum, where each group maximum is merged (a) across the
+            // two s-waves of this workgroup and (b) with what the row's other latent ranges have published so far in
+            // global memory (relaxed L2 reads: a stale value only gives a weaker, still valid bound).  Two threads per
+            // row, each owning half of the groups; improved maxima are published fire-and-forget.
+            if (tid < HTB) sm.tau_key[tid] = INT32_MAX;
+            __syncthreads();
+            {
+                const int row = tid % HTB;
+                const int part = __builtin_amdgcn_readfirstlane(tid / HTB);  // wave-uniform: group bases stay in SGPRs  // 512 threads = 2 x HTB rows
+                constexpr int GPT = NG / 2;                     // groups per thread
+                const int b = b0 + row;
+                const bool share = (a.s_splits > 1) && (b < B);
+                const uint32_t boff = (uint32_t)b * 4u;
                 int32_t m = INT32_MAX;
-#pragma unroll 8
-                for (int g = 0; g < NG; ++g) {
-                    const int32_t v0 = (NG == 32) ? sm.e32.slots32[0][g][tid] : sm.slots64[0][g][tid];
-                    const int32_t v1 = (NG == 32) ? sm.e32.slots32[1][g][tid] : sm.slots64[1][g][tid];
-                    m = min(m, max(v0, v1));
+#pragma unroll 1
+                for (int c0 = 0; c0 < GPT; c0 += 4) {  // four global reads in flight at a time (register pressure)
+                    int32_t v[4], old[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int g = part * GPT + c0 + i;
+                        const int32_t v0 = (NG == 32) ? sm.e32.slots32[0][g][row] : sm.slots64[0][g][row];
+                        const int32_t v1 = (NG == 32) ? sm.e32.slots32[1][g][row] : sm.slots64[1][g][row];
+                        v[i] = max(v0, v1);
+                        old[i] = INT32_MIN;
+                        if (share)
+                            old[i] = __hip_atomic_load(
+                                reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)g * a.gmax_stride) + boff),
+                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (share && v[i] > old[i])
+                            atomicMax(reinterpret_cast<int32_t*>(
+                                          reinterpret_cast<char*>(a.gmax + (size_t)(part * GPT + c0 + i) * a.gmax_stride) + boff),
+                                      v[i]);
+                        m = min(m, max(v[i], old[i]));
+                    }
                 }
-                const int b = b0 + tid;
-                if (b < B && a.s_splits > 1) {
-                    atomicMax(&a.row_tau[b], m);
-                    m = max(m, tau_other);
-                }
-                sm.tau[tid] = key2f(m);
+                atomicMin(&sm.tau_key[row], m);
             }
             __syncthreads();
             int npass[2], pos[2];
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
-                const float tau = sm.tau[wb * 64 + jb * 32 + l31];
+                const float tau = key2f(sm.tau_key[wb * 64 + jb * 32 + l31]);
                 int n = 0;
 #pragma unroll
                 for (int sb = 0; sb < 4; ++sb)
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             for (int jb = 0; jb < 2; ++jb) {
                 if (npass[jb] > 0) {
                     const int bl_ = wb * 64 + jb * 32 + l31;
-                    const float tau = sm.tau[bl_];
+                    const float tau = key2f(sm.tau_key[bl_]);
                     float* cv = a.cand_val + (size_t)(b0 + bl_) * a.cand_cap;
                     int32_t* ci = a.cand_idx + (size_t)(b0 + bl_) * a.cand_cap;
                     int p = pos[jb];

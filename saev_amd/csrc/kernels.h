@@ -17,7 +17,9 @@ struct EncodeArgs {
     float* h_out;         // (n_rows, S)
     // EPI_TOPK
     int ngroups;          // 32 or 64, >= top_k
-    int32_t* row_tau;     // (n_rows) ordered-int keys, init INT32_MIN
+    int32_t* gmax;        // (ngroups, gmax_stride) ordered-int keys, init INT32_MIN: per-row group maxima shared by
+                          // all latent ranges of the row
+    int gmax_stride;
     int32_t* cand_cnt;    // (n_rows) init 0
     float* cand_val;      // (n_rows, cand_cap)
     int32_t* cand_idx;    // (n_rows, cand_cap)
@@ -195,7 +197,8 @@ struct EncodeF16Args {
     int s_splits;
     float* h_out;             // EPI_DENSE
     int ngroups;              // EPI_TOPK
-    int32_t* row_tau;
+    int32_t* gmax;            // (ngroups, gmax_stride) shared per-row group maxima, init INT32_MIN
+    int gmax_stride;
     int32_t* cand_cnt;
     float* cand_val;
     int32_t* cand_idx;

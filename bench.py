@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--encoder", choices=["f32", "f16x3"], default=None, help="encoder arithmetic (default: engine default)")
+    ap.add_argument("--encoder", choices=["f32", "f16x3", "bf16"], default=None, help="encoder arithmetic (default: engine default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,10 +142,15 @@ def main():
         flops = 2.0 * B * D_MODEL * D_SAE
         achieved = flops / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else None
         f16x3 = eng.cfg.encoder == "f16x3"
-        peak = F16_MFMA_PEAK_TFLOPS if f16x3 else F32_MFMA_PEAK_TFLOPS
+        peak = F32_MFMA_PEAK_TFLOPS if eng.cfg.encoder == "f32" else F16_MFMA_PEAK_TFLOPS
+        kernel_name = {"f16x3": "encode_f16x3_kernel<EPI_TOPK,32,3> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)",
+                       "bf16": "encode_f16x3_kernel<EPI_TOPK,32,1> (v_mfma_f32_32x32x16_bf16)",
+                       "f32": "encode_gemm_kernel<EPI_TOPK> (v_mfma_f32_32x32x2_f32)"}[eng.cfg.encoder]
+        dtype_name = {"f16x3": "f32 (encoder products as 3 x f16 MFMA on fp16 hi/lo splits, fp32 accumulate; all else fp32)",
+                      "bf16": "bf16 encoder operands, fp32 accumulate; all else fp32 (NOT the headline precision)",
+                      "f32": "f32"}[eng.cfg.encoder]
         roof = {"bound": "mfma",
-                "kernel": "encode_f16x3_kernel<EPI_TOPK> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)" if f16x3
-                else "encode_gemm_kernel<EPI_TOPK> (v_mfma_f32_32x32x2_f32)",
+                "kernel": kernel_name,
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                 "kernel_ms": enc_ms, "traffic": None}
         if f16x3 and achieved:
@@ -158,7 +163,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (encoder products as 3 x f16 MFMA on fp16 hi/lo splits, fp32 accumulate; all else fp32)" if f16x3 else "f32",
+            "dtype": dtype_name,
             "data": "synthetic",
             "config": {"workload": f"configs[1]: d_in={D_MODEL}, d_sae={D_SAE} (32x), k={TOP_K}, batch={B}/GPU, "
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",

@@ -49,15 +49,19 @@ typedef struct {
     int32_t normalize_w_dec;       /* modeling.py:283                                       */
     int32_t remove_parallel_grads; /* modeling.py:281                                       */
     int32_t max_batch;             /* scratch is sized for this many activation rows        */
-    int32_t encoder_mode;          /* SAEV_ENCODER_F32 or SAEV_ENCODER_F16X3                */
+    int32_t encoder_mode;          /* SAEV_ENCODER_F32, _F16X3 or _BF16                     */
 } saev_cfg;
 
-/* Encoder arithmetic.  Both are fp32-accurate (error vs fp64 at the level of a native fp32 GEMM):
+/* Encoder arithmetic.  F32 and F16X3 are fp32-accurate (error vs fp64 at the level of a native fp32 GEMM):
  *   F32   : v_mfma_f32_32x32x2_f32, exact fp32 products;
  *   F16X3 : operands split into fp16 hi+lo (22 significand bits), three v_mfma_f32_32x32x16_f16 per
- *           product pair, fp32 accumulate -- 16/3 of the F32 matrix rate. */
+ *           product pair, fp32 accumulate -- 16/3 of the F32 matrix rate;
+ *   BF16  : x and W_enc rounded to bf16 (nearest even) for the encoder contraction only, one
+ *           v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; bias, TopK, decode, losses, all
+ *           gradients and Adam stay fp32 on the fp32 master weights (BASELINE.json configs[3]). */
 #define SAEV_ENCODER_F32 0
 #define SAEV_ENCODER_F16X3 1
+#define SAEV_ENCODER_BF16 2
 
 /* Scalars of one step (nn/objectives.py:57-89 MatryoshkaLoss + train.py:356-362 grad norm). */
 typedef struct {

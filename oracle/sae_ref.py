@@ -49,6 +49,10 @@ class RefConfig:
     lr: float = 4e-4
     n_lr_warmup: int = 500
     grad_clip: float = 1.0
+    # Not in the reference (it trains in fp32 / TF32 only): models BASELINE.json configs[3] "bf16" -- the encoder
+    # contraction that feeds TopK sees bf16-rounded x and W_enc (fp32 accumulate); everything else -- the AuxK branch's
+    # pre-activations of dead latents, decode, losses, all gradients, Adam -- is fp32.
+    encoder_bf16: bool = False
 
 
 PARAM_ORDER = ("W_dec", "b_dec", "W_enc", "b_enc")  # state_dict order, modeling.py:312-327
@@ -90,6 +94,18 @@ def normalize_w_dec(W_dec: Tensor) -> Tensor:
 def encode_pre(x: Tensor, W_enc: Tensor, b_enc: Tensor) -> Tensor:
     """Pre-activations h = x @ W_enc + b_enc.  modeling.py:343-347."""
     return torch.einsum("bd,ds->bs", x, W_enc) + b_enc
+
+
+def encode_pre_bf16(x: Tensor, W_enc: Tensor, b_enc: Tensor) -> Tensor:
+    """Pre-activations with bf16-rounded operands (round to nearest even) and fp32 accumulation.  The value is the
+    bf16 product; the gradient is that of the fp32 formula (straight-through), which is what the HIP path computes:
+    its backward uses the fp32 x and the fp32 master weights."""
+    h = encode_pre(x, W_enc, b_enc)
+    with torch.no_grad():
+        xb = x.to(torch.bfloat16).to(torch.float32)
+        wb = W_enc.to(torch.bfloat16).to(torch.float32)
+        delta = torch.einsum("bd,ds->bs", xb, wb) + b_enc - h
+    return h + delta
 
 
 def topk_mask(h: Tensor, k: int) -> Tensor:
@@ -202,7 +218,8 @@ def objective_forward(
 
     ``toks_since_active`` (S,) int64 is updated in place in training mode.  In eval mode there is no
     dead tracking and the auxiliary term is zero (modeling.py:83-87, objectives.py:121-122)."""
-    h = encode_pre(x, params["W_enc"], params["b_enc"])
+    enc = encode_pre_bf16 if cfg.encoder_bf16 else encode_pre
+    h = enc(x, params["W_enc"], params["b_enc"])
     f = topk_activation(h, cfg.top_k)
     dead_mask = None
     if training:
@@ -215,8 +232,9 @@ def objective_forward(
     P = x_hats.shape[1]
     mse = mean_squared_err(x_hats, x[:, None, :].expand(-1, P, -1)).mean()
     if training and cfg.use_aux:
+        h_aux = encode_pre(x, params["W_enc"], params["b_enc"]) if cfg.encoder_bf16 else h
         aux = auxk_loss(
-            x=x, h=h, x_hat_last=x_hats[:, -1, :], dead_mask=dead_mask,
+            x=x, h=h_aux, x_hat_last=x_hats[:, -1, :], dead_mask=dead_mask,
             W_dec=params["W_dec"], b_dec=params["b_dec"], k_aux=cfg.k_aux, alpha=cfg.alpha,
         )
     else:

@@ -151,7 +151,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     if (cfg->d_model <= 0 || cfg->d_sae <= 0 || cfg->top_k <= 0 || cfg->max_batch <= 0) return SAEV_INVALID_ARG;
     if (cfg->d_model % 4 != 0 || cfg->d_sae % 4 != 0 || cfg->d_model > 2048) return SAEV_UNSUPPORTED;
     if (cfg->k_aux < 0 || cfg->k_aux > 1024) return SAEV_UNSUPPORTED;
-    if (cfg->encoder_mode != SAEV_ENCODER_F32 && cfg->encoder_mode != SAEV_ENCODER_F16X3) return SAEV_INVALID_ARG;
+    if (cfg->encoder_mode != SAEV_ENCODER_F32 && cfg->encoder_mode != SAEV_ENCODER_F16X3 && cfg->encoder_mode != SAEV_ENCODER_BF16)
+        return SAEV_INVALID_ARG;
     saev_ctx* c = new saev_ctx();
     c->cfg = *cfg;
     c->cfg.top_k = std::min(cfg->top_k, cfg->d_sae);
@@ -187,7 +188,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part);
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 1024); A(sumsq_total, 1);
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+    if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
         c->Dp = (int)((D + 31) / 32 * 32);
         c->S_pad = (int)((S + 255) / 256 * 256);
         c->MB_pad = (int)((MB + 255) / 256 * 256);
@@ -356,19 +357,23 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
 
 // operand preparation for the f16x3 encoder: split x and W_enc^T into fp16 hi/lo (no-op for the f32 encoder)
 static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s) {
-    if (c->cfg.encoder_mode != SAEV_ENCODER_F16X3) return SAEV_OK;
-    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xs, s));
-    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, c->cfg.d_model, c->cfg.d_sae, c->S_pad, c->Dp, 256.0f, c->ws, s));
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F32) return SAEV_OK;
+    const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
+    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xs, bf, s));
+    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, c->cfg.d_model, c->cfg.d_sae, c->S_pad, c->Dp, bf ? 1.0f : 256.0f,
+                              c->ws, bf, s));
     return SAEV_OK;
 }
 
 static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out, const int32_t* flag, int when,
                        hipStream_t s) {
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+    if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
+        const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
         EncodeF16Args a{};
         a.xs = c->xs; a.ws = c->ws;
         a.b_enc = c->params + c->off_b_enc;
-        a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = 256.0f;
+        a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = bf ? 1.0f : 256.0f;
+        a.nprod = bf ? 1 : 3;
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
         a.h_out = h_out;
         a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;

@@ -58,12 +58,20 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf16(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ void glds16h(const char* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI, int NG>
+// NP = 3: the split-fp16 scheme above.  NP = 1: single-product bf16 (SAEV_ENCODER_BF16): the same 16 KB images hold 32
+// consecutive k of bf16(x) / bf16(W^T) per row, chunk pairs (0,1) and (2,3) feed two v_mfma_f32_32x32x16_bf16 per
+// block, fp32 accumulate; everything after the contraction is identical.
+template <int EPI, int NG, int NP>
 __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     HSmem& sm = *reinterpret_cast<HSmem*>(smem_raw);
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             for (int r = 0; r < NSLOT; ++r) smax[jb][r] = NEG_INF;
     }
 
-    const int nks = Dp / 16;  // k-steps per tile
+    const int nks = Dp / (NP == 3 ? 16 : 32);  // k-steps per tile
     // The 8 workgroups of an XCD that stream the same W images (same latent range, different batch block) walk the
     // k-steps in an order rotated by one step each, so they do not hit the same 16 KB at the same moment but stay
     // within the L2 retention window; the workgroups that share an x block (same batch block) keep the same order.
@@ -178,15 +186,25 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             static_for<4>([&](auto G) {
                 constexpr int sb = decltype(G)::value;
                 constexpr int as = sb % 3;
-                acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[0][0], acc[sb][0], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (sb + 2 < 4) load_a((sb + 2) % 3, sb + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[0][1], acc[sb][0], 0, 0, 0);
-                acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[1][0], acc[sb][1], 0, 0, 0);
-                acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[1][1], acc[sb][1], 0, 0, 0);
-                acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[0][0], acc[sb][0], 0, 0, 0);
-                acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[1][0], acc[sb][1], 0, 0, 0);
+                if constexpr (NP == 3) {
+                    acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[0][0], acc[sb][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (sb + 2 < 4) load_a((sb + 2) % 3, sb + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[0][1], acc[sb][0], 0, 0, 0);
+                    acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[1][0], acc[sb][1], 0, 0, 0);
+                    acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][0], fb[1][1], acc[sb][1], 0, 0, 0);
+                    acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[0][0], acc[sb][0], 0, 0, 0);
+                    acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[1][0], acc[sb][1], 0, 0, 0);
+                } else {
+                    acc[sb][0] = mfma_bf16(fa[as][0], fb[0][0], acc[sb][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (sb + 2 < 4) load_a((sb + 2) % 3, sb + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[sb][1] = mfma_bf16(fa[as][0], fb[1][0], acc[sb][1]);
+                    acc[sb][0] = mfma_bf16(fa[as][1], fb[0][1], acc[sb][0]);
+                    acc[sb][1] = mfma_bf16(fa[as][1], fb[1][1], acc[sb][1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             // k-step t+1 must have landed (this wave's part) before the barrier publishes it; newer requests
@@ -352,21 +370,28 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
     const size_t smem = sizeof(HSmem);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[3] = {reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32>),
-                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32>),
-                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64>)};
+        const void* fns[6] = {reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 3>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 3>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 3>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 1>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 1>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 1>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
         }
         attr_set = true;
     }
-    if (epi == EPI_DENSE)
-        hipLaunchKernelGGL((encode_f16x3_kernel<EPI_DENSE, 32>), grid, block, smem, stream, a);
-    else if (a.ngroups <= 32)
-        hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32>), grid, block, smem, stream, a);
-    else
-        hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 64>), grid, block, smem, stream, a);
+#define LAUNCH_ENC(E, G, N) hipLaunchKernelGGL((encode_f16x3_kernel<E, G, N>), grid, block, smem, stream, a)
+    const bool one = a.nprod == 1;
+    if (epi == EPI_DENSE) {
+        if (one) LAUNCH_ENC(EPI_DENSE, 32, 1); else LAUNCH_ENC(EPI_DENSE, 32, 3);
+    } else if (a.ngroups <= 32) {
+        if (one) LAUNCH_ENC(EPI_TOPK, 32, 1); else LAUNCH_ENC(EPI_TOPK, 32, 3);
+    } else {
+        if (one) LAUNCH_ENC(EPI_TOPK, 64, 1); else LAUNCH_ENC(EPI_TOPK, 64, 3);
+    }
+#undef LAUNCH_ENC
     return hipGetLastError();
 }
 

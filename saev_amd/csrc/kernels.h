@@ -194,6 +194,7 @@ struct EncodeF16Args {
     const float* b_enc;       // (S)
     int n_rows, Dp, S;
     float w_scale;
+    int nprod;                // 3: fp16 hi/lo split, three products (fp32-accurate); 1: bf16 operands, one product
     int s_splits;
     float* h_out;             // EPI_DENSE
     int ngroups;              // EPI_TOPK
@@ -209,8 +210,9 @@ struct EncodeF16Args {
 hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream);
 int encode_f16x3_tile_rows();
 int encode_f16x3_tile_latents();
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, hipStream_t stream);
-hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, hipStream_t stream);
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, bool bf16, hipStream_t stream);
+hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, bool bf16,
+                           hipStream_t stream);
 
 // ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------
 hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s);

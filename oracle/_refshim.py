@@ -10,6 +10,7 @@ to the GPU box, only the generated fixtures under ``tests/golden/`` do.
 """
 
 import dataclasses
+import enum
 import importlib
 import json
 import os
@@ -47,6 +48,8 @@ def _json_default(user_default):
             return dataclasses.asdict(o)
         if isinstance(o, pathlib.PurePath):
             return str(o)
+        if isinstance(o, enum.Enum):  # orjson serialises enums by value natively
+            return o.value
         if user_default is not None:
             return user_default(o)
         raise TypeError(type(o))
@@ -57,7 +60,8 @@ def _json_default(user_default):
 def _dumps(obj, default=None, option=None):
     indent = 2 if option and (option & 2) else None
     seps = (",", ": ") if indent else (",", ":")
-    out = json.dumps(obj, default=_json_default(default), indent=indent, separators=seps)
+    out = json.dumps(obj, default=_json_default(default), indent=indent, separators=seps,
+                     sort_keys=bool(option and (option & 4)), ensure_ascii=False)
     if option and (option & 1):
         out += "\n"
     return out.encode()

@@ -21,6 +21,9 @@ Fixture index:
   G11 schedule         WarmupCosine lr lists and BatchLimiter step counts
   G12 checkpoint       header bytes/JSON written by the reference's nn.dump
   G13 matryoshka       objective fwd/bwd with 4 fixed prefixes (with and without dead latents)
+  G14 inference        the reference's framework/inference.worker_fn over a small protocol-2.1 cache (with and
+                       without labels.bin / ignore_labels): CSR token_acts, mean_values, sparsity, distributions,
+                       metrics.json; plus Metadata.hash and IndexMap known answers for the same cache
 """
 
 import dataclasses
@@ -370,8 +373,84 @@ def g12_checkpoint(ref):
     buf.unlink()
 
 
+def g14_inference(ref, tag, with_labels):
+    """Runs the reference's inference pass (its own OrderedDataLoader, manager process included) on a cache written
+    by this repo's protocol-2.1 writer and a checkpoint written by the reference's nn.dump."""
+    import importlib
+    import shutil
+    import tempfile
+
+    import scipy.sparse
+
+    sys.path.insert(0, str(HERE.parent))
+    from saev_amd.data import shards as my_shards
+
+    ordered = importlib.import_module("saev.data.ordered")
+    ref.data.OrderedConfig, ref.data.OrderedDataLoader = ordered.Config, ordered.DataLoader
+    inf = importlib.import_module("saev.framework.inference")
+    rshards = importlib.import_module("saev.data.shards")
+
+    d, s, k, n_ex, n_tok, layers = 32, 256, 8, 13, 6, (5, 11)
+    rows = lowrank_data(n_ex * len(layers) * (n_tok + 1), d, seed=140 + with_labels)
+    acts = rows.reshape(n_ex, len(layers), n_tok + 1, d).numpy()
+    labels = None
+    if with_labels:
+        labels = np.random.default_rng(14).integers(0, 4, (n_ex, n_tok)).astype(np.uint8)
+    tmp = pathlib.Path(tempfile.mkdtemp(prefix="g14_"))
+    try:
+        shards_dir = my_shards.write_shards(tmp, acts, layers=layers, cls_token=True,
+                                            max_tokens_per_shard=4 * (n_tok + 1) * len(layers), labels=labels)
+        # the reference parses what this repo wrote, and agrees on the content hash
+        md = rshards.Metadata.load(shards_dir)
+        my_md = my_shards.Metadata.load(shards_dir)
+        imap = rshards.IndexMap(md, "content", 11)
+        probes = [0, 1, n_tok - 1, n_tok, 4 * n_tok - 1, 4 * n_tok, len(imap) - 1]
+        index_rows = []
+        for g in probes:
+            ix = imap.from_global(g)
+            index_rows.append([g, ix.example_idx, ix.content_token_idx, ix.shard_idx, ix.example_idx_in_shard,
+                               ix.layer_idx_in_shard, ix.token_idx_in_shard])
+        sae = make_sae(ref, d, s, k, k_aux=16, seed=141)
+        with torch.no_grad():
+            sae.b_enc.copy_(0.05 * torch.randn(s, generator=torch.Generator().manual_seed(142)))
+            sae.b_dec.copy_(rows.mean(dim=0))
+        run = ref_disk_new(tmp, shards_dir)
+        ref.modeling.dump(run / "checkpoint" / "sae.pt", sae)
+        cfg = inf.Config(run=run, data=ordered.Config(shards=shards_dir, layer=11, batch_size=4 * n_tok + 1),
+                         n_dists=5, ignore_labels=[2] if with_labels else [], device="cpu")
+        inf.worker_fn(cfg)
+        out = run / "inference" / md.hash
+        csr = scipy.sparse.load_npz(out / "token_acts.npz")
+        metrics = json.loads((out / "metrics.json").read_text())
+        npz(f"g14_inference_{tag}", acts=acts, labels=labels if labels is not None else np.zeros((0, 0), np.uint8),
+            layers=np.array(layers), k=k, k_aux=16, n_dists=5, batch_size=4 * n_tok + 1,
+            max_tokens_per_shard=4 * (n_tok + 1) * len(layers),
+            ignore_labels=np.array([2] if with_labels else [], dtype=np.int64),
+            ref_hash=np.frombuffer(md.hash.encode(), dtype=np.uint8), my_hash=np.frombuffer(my_md.hash.encode(), dtype=np.uint8),
+            index_probes=np.array(index_rows, dtype=np.int64),
+            csr_data=csr.data, csr_indices=csr.indices, csr_indptr=csr.indptr, csr_shape=np.array(csr.shape),
+            mean_values=torch.load(out / "mean_values.pt"), sparsity=torch.load(out / "sparsity.pt"),
+            distributions=torch.load(out / "distributions.pt"),
+            metrics_keys=np.array(list(metrics.keys())), metrics_vals=np.array([float(v) for v in metrics.values()]),
+            **params_of(sae))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def ref_disk_new(tmp, shards_dir):
+    import saev.disk as rdisk
+
+    runs_root = tmp / "saev" / "runs"
+    runs_root.mkdir(parents=True)
+    return rdisk.Run.new("gold0014", train_shards_dir=shards_dir, val_shards_dir=shards_dir, runs_root=runs_root).run_dir
+
+
 def main():
     ref = _refshim.install()
+    if "--only-g14" in sys.argv:
+        g14_inference(ref, "plain", False)
+        g14_inference(ref, "labels", True)
+        return
     torch.set_num_threads(8)
     g1_g2_g3(ref)
     g4_auxk(ref)
@@ -382,6 +461,8 @@ def main():
     g11_schedule(ref)
     g12_checkpoint(ref)
     g13_matryoshka(ref)
+    g14_inference(ref, "plain", False)
+    g14_inference(ref, "labels", True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,7 @@
+from .ordered import Config as OrderedConfig
+from .ordered import DataLoader as OrderedDataLoader
 from .shards import Metadata, ShardInfo, write_shards
 from .shuffled import Config as ShuffledConfig
 from .shuffled import DataLoader as ShuffledDataLoader
 
-__all__ = ["Metadata", "ShardInfo", "ShuffledConfig", "ShuffledDataLoader", "write_shards"]
+__all__ = ["Metadata", "OrderedConfig", "OrderedDataLoader", "ShardInfo", "ShuffledConfig", "ShuffledDataLoader", "write_shards"]

@@ -61,12 +61,14 @@ class Metadata:
     def to_json(self) -> dict:
         d = dataclasses.asdict(self)
         d["layers"] = list(self.layers)
-        d["dataset"] = str(self.dataset)
+        d["dataset"] = str(pathlib.Path(self.dataset))  # the reference holds a pathlib.Path here ("" reads back as ".")
         return d
 
     @property
     def hash(self) -> str:
-        blob = json.dumps(self.to_json(), sort_keys=True, separators=(",", ":")).encode("utf-8")
+        # protocol.md: sha256(json.dumps(metadata, sort_keys=True, separators=(',', ':'))); the reference produces the
+        # same bytes with orjson (compact, sorted keys, raw UTF-8), shards.py:126-135
+        blob = json.dumps(self.to_json(), sort_keys=True, separators=(",", ":"), ensure_ascii=False).encode("utf-8")
         return hashlib.sha256(blob).hexdigest()[:8]
 
     @classmethod
@@ -97,15 +99,29 @@ class ShardInfo:
         return len(self.shards)
 
 
+def locate_content_token(md: Metadata, g: int, layer: int) -> tuple[int, int, int, int, int, int]:
+    """Global content-token index -> (example, content token, shard, example in shard, layer slot, token slot in the
+    shard's token axis), the arithmetic of the reference's IndexMap.from_global for ("content", fixed layer)
+    (shards.py:1042-1067): tokens of an example are consecutive, examples fill shards in order, and the token axis of
+    a shard starts with the CLS token when there is one."""
+    T, eps = md.content_tokens_per_example, md.examples_per_shard
+    if not 0 <= g < md.n_examples * T:
+        raise IndexError(f"Index {g} out of range for dataset of length {md.n_examples * T}")
+    example, tok = divmod(g, T)
+    return example, tok, example // eps, example % eps, md.layers.index(layer), tok + (1 if md.cls_token else 0)
+
+
 def open_shard(shards_dir: pathlib.Path, md: Metadata, name: str, n_examples: int) -> np.memmap:
     shape = (n_examples, len(md.layers), md.tokens_per_example, md.d_model)
     return np.memmap(pathlib.Path(shards_dir) / name, mode="r", dtype=np.float32, shape=shape)
 
 
 def write_shards(root: pathlib.Path, acts: np.ndarray, *, layers: tuple[int, ...] = (0,), cls_token: bool = False,
-                 max_tokens_per_shard: int | None = None, family: str = "fake-clip", ckpt: str = "synthetic") -> pathlib.Path:
+                 max_tokens_per_shard: int | None = None, family: str = "fake-clip", ckpt: str = "synthetic",
+                 labels: np.ndarray | None = None) -> pathlib.Path:
     """Write ``acts`` (n_examples, n_layers, tokens_per_example, d_model) float32 as a protocol-2.1
-    cache under ``root/saev/shards/<hash>`` and return that directory (tests, synthetic runs)."""
+    cache under ``root/saev/shards/<hash>`` and return that directory (tests, synthetic runs).
+    ``labels`` (n_examples, content_tokens_per_example) uint8 becomes ``labels.bin`` (protocol.md section 2.3)."""
     acts = np.ascontiguousarray(acts, dtype=np.float32)
     n_ex, n_layers, tokens, d = acts.shape
     assert n_layers == len(layers)
@@ -121,10 +137,21 @@ def write_shards(root: pathlib.Path, acts: np.ndarray, *, layers: tuple[int, ...
     for i, lo in enumerate(range(0, n_ex, eps)):
         name = f"acts{i:06d}.bin"
         chunk = acts[lo : lo + eps]
-        chunk.tofile(out / name)
+        with open(out / name, "wb") as fd:
+            chunk.tofile(fd)
+            # every acts file has the full shard_shape on disk (the reference creates them as zero-filled
+            # np.memmap(mode="w+", shape=md.shard_shape), shards.py:522-524, and its readers map that shape);
+            # shards.json records how many examples are real
+            pad = (eps - chunk.shape[0]) * n_layers * tokens * d * 4
+            if pad:
+                fd.write(b"\0" * pad)
         infos.append({"name": name, "n_examples": int(chunk.shape[0])})
     with open(out / "metadata.json", "w") as fd:
         json.dump(md.to_json(), fd, indent=2)
     with open(out / "shards.json", "w") as fd:
         json.dump(infos, fd, indent=2)
+    if labels is not None:
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        assert labels.shape == (n_ex, md.content_tokens_per_example)
+        labels.tofile(out / "labels.bin")
     return out

@@ -1,0 +1,177 @@
+"""HBM-resident reservoir fed from the sharded cache by a background reader (the streaming half of the shuffled
+feed; replaces reference src/saev/data/buffers.py ReservoirBuffer + shuffled.py _io_worker/_manager_main for caches
+that do not fit in device memory).
+
+Reference behaviour kept (buffers.py:90-231, shuffled.py:131-376): shards are visited in a seeded permutation, rows
+enter a fixed-capacity reservoir (``buffer_size * batch_size`` rows) as they are read, a batch is B rows drawn
+uniformly without replacement from whatever the reservoir holds, every row is delivered exactly once per epoch, and
+``min_buffer_fill`` delays the first draw until the reservoir is that full.
+
+MI355X design: the reservoir is one (capacity, d_model) fp32 tensor in HBM plus an int32 (capacity, 2) tensor of
+(example_idx, token_idx).  A reader thread cuts whole (examples x tokens) blocks out of the memory-mapped shard,
+stages them in pinned host memory and scatters them into free slots with an asynchronous copy on its own HIP stream;
+slot bookkeeping (which slots hold unread rows) lives on the host, so a draw costs one index shuffle on the host and
+one row-gather kernel on the device -- not B Python-level pops under a lock.  Freed slots return to the reader once
+the gather that read them has finished (HIP event).
+"""
+
+from __future__ import annotations
+
+import threading
+import time
+
+import numpy as np
+import torch
+
+
+class StreamingReservoir:
+    """``blocks`` is a callable returning an iterator of ``(act (n, D) float32 ndarray, example_idx (n,) int32,
+    token_idx (n,) int32)`` for one epoch (host arrays, any n <= chunk_rows)."""
+
+    def __init__(self, blocks, *, d_model: int, capacity: int, chunk_rows: int, device: torch.device, seed: int,
+                 min_fill: float = 0.0, gather=None, timeout_s: float = 30.0):
+        assert capacity >= chunk_rows > 0
+        self.blocks = blocks
+        self.D, self.capacity, self.chunk_rows = d_model, capacity, chunk_rows
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.min_fill = min_fill
+        self.gather = gather  # HIP row gather (engine.gather_rows); torch indexing when None (CPU tests)
+        self.timeout_s = timeout_s
+        self.rng = np.random.default_rng(seed)
+        self.rows = torch.empty(capacity, d_model, dtype=torch.float32, device=self.device)
+        self.meta = torch.empty(capacity, 2, dtype=torch.int32, device=self.device)
+        self._cv = threading.Condition()
+        self._filled = np.empty(capacity, dtype=np.int64)
+        self._n_filled = 0
+        self._free = np.arange(capacity, dtype=np.int64)[::-1].copy()
+        self._n_free = capacity
+        self._pending: list[tuple[object, np.ndarray]] = []  # (event, slots) read by a gather still in flight
+        self._done = True
+        self._err: BaseException | None = None
+        self._thread: threading.Thread | None = None
+        self._stop = False
+        self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+
+    # ---- reader side -----------------------------------------------------------------------------------------------
+    def start_epoch(self):
+        self.stop()
+        with self._cv:
+            self._n_filled = 0
+            self._free = np.arange(self.capacity, dtype=np.int64)[::-1].copy()
+            self._n_free = self.capacity
+            self._pending.clear()
+            self._done, self._err, self._stop = False, None, False
+        self._thread = threading.Thread(target=self._reader, name="saev-reservoir-reader", daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            with self._cv:
+                self._stop = True
+                self._cv.notify_all()
+            self._thread.join()
+            self._thread = None
+
+    def _reclaim_locked(self):
+        keep = []
+        for ev, slots in self._pending:
+            if ev is None or ev.query():
+                n = slots.shape[0]
+                self._free[self._n_free : self._n_free + n] = slots
+                self._n_free += n
+            else:
+                keep.append((ev, slots))
+        self._pending = keep
+
+    def _take_free(self, n: int) -> np.ndarray | None:
+        with self._cv:
+            while True:
+                self._reclaim_locked()
+                if self._stop:
+                    return None
+                if self._n_free >= n:
+                    self._n_free -= n
+                    return self._free[self._n_free : self._n_free + n].copy()
+                self._cv.wait(timeout=0.002 if self._pending else 0.05)
+
+    def _reader(self):
+        try:
+            stage = [torch.empty(self.chunk_rows, self.D, dtype=torch.float32, pin_memory=self.on_gpu) for _ in range(2)]
+            stage_meta = [torch.empty(self.chunk_rows, 2, dtype=torch.int32, pin_memory=self.on_gpu) for _ in range(2)]
+            busy: list[object] = [None, None]
+            for i, (act, ex, tk) in enumerate(self.blocks()):
+                n = act.shape[0]
+                assert n <= self.chunk_rows
+                slots = self._take_free(n)
+                if slots is None:
+                    return
+                j = i & 1
+                if busy[j] is not None:
+                    busy[j].synchronize()
+                stage[j].numpy()[:n] = act
+                sm = stage_meta[j].numpy()
+                sm[:n, 0], sm[:n, 1] = ex, tk
+                slots_t = torch.from_numpy(slots)
+                if self.on_gpu:
+                    with torch.cuda.stream(self.copy_stream):
+                        sd = slots_t.to(self.device, non_blocking=True)
+                        self.rows.index_copy_(0, sd, stage[j][:n].to(self.device, non_blocking=True))
+                        self.meta.index_copy_(0, sd, stage_meta[j][:n].to(self.device, non_blocking=True))
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    busy[j] = ev
+                    ev.synchronize()  # rows are published only once they are in HBM
+                else:
+                    self.rows.index_copy_(0, slots_t, stage[j][:n])
+                    self.meta.index_copy_(0, slots_t, stage_meta[j][:n])
+                with self._cv:
+                    self._filled[self._n_filled : self._n_filled + n] = slots
+                    self._n_filled += n
+                    self._cv.notify_all()
+        except BaseException as e:  # surfaced to the consumer
+            self._err = e
+        finally:
+            with self._cv:
+                self._done = True
+                self._cv.notify_all()
+
+    # ---- consumer side ---------------------------------------------------------------------------------------------
+    def fill(self) -> float:
+        return self._n_filled / self.capacity
+
+    def get(self, batch_size: int):
+        """Up to ``batch_size`` rows drawn uniformly without replacement from the reservoir; fewer only when the epoch
+        is running out; ``None`` when it is exhausted."""
+        deadline = time.monotonic() + self.timeout_s
+        with self._cv:
+            while True:
+                if self._err is not None:
+                    raise RuntimeError("reservoir reader failed") from self._err
+                want = max(batch_size, int(self.min_fill * self.capacity)) if not self._done else 1
+                if self._n_filled >= min(want, self.capacity) or (self._done and self._n_filled > 0):
+                    break
+                if self._done:
+                    return None
+                if not self._cv.wait(timeout=0.5) and time.monotonic() > deadline:
+                    raise TimeoutError(f"no batch within {self.timeout_s}s (reservoir fill {self.fill():.3f})")
+            n = self._n_filled
+            b = min(batch_size, n)
+            pick = self.rng.choice(n, size=b, replace=False) if b < n else np.arange(n)
+            slots = self._filled[pick].copy()
+            # close the holes with the tail entries that were not drawn themselves
+            tail = np.setdiff1d(np.arange(n - b, n), pick, assume_unique=True)
+            holes = pick[pick < n - b]
+            self._filled[np.sort(holes)] = self._filled[tail]
+            self._n_filled = n - b
+        slots_t = torch.from_numpy(slots).to(self.device)
+        act = self.gather(self.rows, slots_t) if self.gather is not None else self.rows[slots_t]
+        meta = self.meta[slots_t]
+        ev = None
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
+        with self._cv:
+            self._pending.append((ev, slots))
+            self._cv.notify_all()
+        return act, meta[:, 0].contiguous(), meta[:, 1].contiguous()

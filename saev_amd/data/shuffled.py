@@ -10,14 +10,20 @@ serves batches with one HIP row-gather.  Semantics kept from the reference: ever
 exactly once per epoch; batches are dicts ``{"act" (B,D) f32, "example_idx" (B,) i32, "token_idx"
 (B,) i32}`` (shuffled.py:385-391); ``drop_last``; ``n_samples``; ``metadata``.
 
-``Config`` keeps the reference's field names and defaults (shuffled.py:31-70); fields that only tune
-the CPU reservoir (n_threads, buffer_size, ...) are accepted and ignored.
+Caches larger than the device budget (``SAEV_AMD_RESIDENT_GB``, default half of the device memory) are
+streamed instead: an HBM reservoir of ``buffer_size * batch_size`` rows (the reference's capacity,
+shuffled.py:45-63) is refilled from the shards by a background reader and batches are uniform draws from
+it -- see reservoir.py.  ``min_buffer_fill`` and ``batch_timeout_s`` apply to that mode.
+
+``Config`` keeps the reference's field names and defaults (shuffled.py:31-70); ``n_threads`` is accepted
+and ignored (one reader thread saturates the PCIe copy engine with whole-block reads).
 """
 
 from __future__ import annotations
 
 import dataclasses
 import math
+import os
 import pathlib
 import typing as tp
 
@@ -25,6 +31,7 @@ import numpy as np
 import torch
 
 from . import shards as shards_lib
+from .reservoir import StreamingReservoir
 
 
 @dataclasses.dataclass(frozen=True)
@@ -50,8 +57,10 @@ class DataLoader:
     """Iterable over shuffled batches of one epoch; re-iterable (a new permutation each epoch)."""
 
     def __init__(self, cfg: Config, *, device: torch.device | str = "cuda", rank: int = 0, world_size: int = 1,
-                 pool: torch.Tensor | None = None, engine=None):
+                 pool: torch.Tensor | None = None, engine=None, resident: bool | None = None):
         self.cfg = cfg
+        self.reservoir: StreamingReservoir | None = None
+        self._resident_arg = resident
         self.device = torch.device(device)
         self.rank, self.world = rank, world_size
         assert cfg.batch_size % world_size == 0, "global batch must divide evenly over ranks"
@@ -77,11 +86,9 @@ class DataLoader:
     # -------------------------------------------------------------------------------------
     def _load_shards(self):
         cfg = self.cfg
-        if cfg.ignore_labels:
-            raise NotImplementedError("ignore_labels (patch filtering) is not supported by the device-resident feed yet")
         if cfg.scale_norm:
-            raise NotImplementedError("scale_norm is not supported by the device-resident feed yet")
-        d = pathlib.Path(cfg.shards)
+            raise NotImplementedError("scale_norm not implemented.")  # nor in the reference (shuffled.py:414-415)
+        d = pathlib.Path(os.path.expandvars(str(cfg.shards)))
         if not (d / "metadata.json").exists():
             raise FileNotFoundError(f"no metadata.json under {d}")
         md = shards_lib.Metadata.load(d)
@@ -103,39 +110,110 @@ class DataLoader:
         else:
             tok = list(range(md.tokens_per_example))
         self.n_samples = md.n_examples * len(tok) * len(layer_ids)
+        # patch-label filtering (shuffled.py:207-216, 636-693): content tokens of one layer whose label is not ignored
+        labels = None
+        if cfg.ignore_labels:
+            if cfg.tokens != "content" or not isinstance(cfg.layer, int):
+                raise NotImplementedError("Patch label filtering only supports 'content' patches with fixed layer")
+            if not (d / "labels.bin").exists():
+                raise FileNotFoundError(f"ignore_labels filtering requested but labels.bin not found at {d / 'labels.bin'}")
+            labels = np.memmap(d / "labels.bin", mode="r", dtype=np.uint8, shape=(md.n_examples, md.content_tokens_per_example))
+            keep_all = ~np.isin(np.asarray(labels), cfg.ignore_labels)
+            self.n_samples = int(keep_all.sum())
         # shard order: seeded permutation, as the reference's manager does (shuffled.py:327-328);
         # ranks take shards round-robin
         order = np.random.default_rng(cfg.seed).permutation(len(info))
-        acts, exs, tks = [], [], []
+        mine = [int(si) for pos, si in enumerate(order) if pos % self.world == self.rank]
+        if not mine:
+            raise ValueError(f"rank {self.rank} of {self.world} received no shards ({len(info)} shards in cache)")
         ex_base = np.cumsum([0] + [n for _, n in info.shards])
-        for pos, si in enumerate(order):
-            if pos % self.world != self.rank:
-                continue
-            name, n_ex = info.shards[si]
-            mm = shards_lib.open_shard(d, md, name, n_ex)
-            for li in layer_ids:
-                block = np.ascontiguousarray(mm[:, li][:, tok])  # (n_ex, n_tok, D)
-                acts.append(torch.from_numpy(block.reshape(-1, md.d_model)).to(self.device))
-                ex = np.repeat((np.arange(n_ex) + ex_base[si]).astype(np.int32), len(tok))
-                tk = np.tile((np.asarray(tok) - first * (cfg.tokens == "content")).astype(np.int32), n_ex)
+        rows_per_example = len(tok) * len(layer_ids)
+        if labels is None:
+            self._n_local = sum(info.shards[si][1] for si in mine) * rows_per_example
+        else:
+            self._n_local = int(sum(keep_all[ex_base[si] : ex_base[si] + info.shards[si][1]].sum() for si in mine))
+        tok_arr = np.asarray(tok)
+        tok_out = (tok_arr - first * (cfg.tokens == "content")).astype(np.int32)
+
+        def blocks(epoch: int, max_rows: int | None):
+            """(act (n, D), example_idx (n,), token_idx (n,)) host blocks of this rank's shards, in the epoch's order."""
+            seq = mine if epoch == 0 else [mine[i] for i in np.random.default_rng(cfg.seed + epoch).permutation(len(mine))]
+            for si in seq:
+                name, n_ex = info.shards[si]
+                mm = shards_lib.open_shard(d, md, name, n_ex)
+                step = n_ex if max_rows is None else max(1, max_rows // len(tok))
+                for li in layer_ids:
+                    for lo in range(0, n_ex, step):
+                        hi = min(n_ex, lo + step)
+                        block = np.ascontiguousarray(mm[lo:hi, li][:, tok])  # (n, n_tok, D)
+                        rows = block.reshape(-1, md.d_model)
+                        ex = np.repeat((np.arange(lo, hi) + ex_base[si]).astype(np.int32), len(tok))
+                        tk = np.tile(tok_out, hi - lo)
+                        if labels is not None:
+                            keep = keep_all[ex_base[si] + lo : ex_base[si] + hi].reshape(-1)
+                            if not keep.any():
+                                continue
+                            rows, ex, tk = rows[keep], ex[keep], tk[keep]
+                        yield rows, ex, tk
+
+        resident = self._resident_arg
+        if resident is None:
+            budget = os.environ.get("SAEV_AMD_RESIDENT_GB")
+            if budget is not None:
+                limit = float(budget) * 1e9
+            elif self.device.type == "cuda":
+                limit = 0.5 * torch.cuda.get_device_properties(self.device).total_memory
+            else:
+                limit = float("inf")
+            resident = self._n_local * md.d_model * 4 <= limit
+        if resident:
+            acts, exs, tks = [], [], []
+            for a, ex, tk in blocks(0, None):
+                acts.append(torch.from_numpy(a).to(self.device))
                 exs.append(torch.from_numpy(ex))
                 tks.append(torch.from_numpy(tk))
-        if not acts:
-            raise ValueError(f"rank {self.rank} of {self.world} received no shards ({len(info)} shards in cache)")
-        self.pool = torch.cat(acts).contiguous()
-        self.example_idx = torch.cat(exs).to(self.device)
-        self.token_idx = torch.cat(tks).to(self.device)
+            self.pool = torch.cat(acts).contiguous()
+            self.example_idx = torch.cat(exs).to(self.device)
+            self.token_idx = torch.cat(tks).to(self.device)
+            return
+        self.pool = None
+        chunk = min(4 * self.local_batch, 65536)
+        capacity = max(cfg.buffer_size * self.local_batch, 2 * chunk)
+        self.reservoir = StreamingReservoir(
+            lambda: blocks(self._epoch - 1, chunk), d_model=md.d_model, capacity=capacity, chunk_rows=chunk,
+            device=self.device, seed=cfg.seed + 7919 * self.rank, min_fill=cfg.min_buffer_fill,
+            gather=lambda pool, rows: self.engine.gather_rows(pool, rows) if self.engine is not None else pool[rows],
+            timeout_s=cfg.batch_timeout_s)
 
     # -------------------------------------------------------------------------------------
     @property
     def n_local(self) -> int:
-        return self.pool.shape[0]
+        return self.pool.shape[0] if self.pool is not None else self._n_local
 
     def __len__(self) -> int:
         n = self.n_local
         return n // self.local_batch if self.drop_last else math.ceil(n / self.local_batch)
 
+    def _iter_streaming(self):
+        res = self.reservoir
+        self._epoch += 1
+        res.start_epoch()
+        try:
+            while True:
+                got = res.get(self.local_batch)
+                if got is None:
+                    return
+                act, ex, tk = got
+                if act.shape[0] < self.local_batch and self.drop_last:
+                    return
+                yield {"act": act, "example_idx": ex, "token_idx": tk}
+        finally:
+            res.stop()
+
     def __iter__(self):
+        if self.reservoir is not None:
+            yield from self._iter_streaming()
+            return
         # host-side permutation: the row order is then independent of the device type (tests replay it on CPU)
         g = torch.Generator().manual_seed(self.cfg.seed + 1000 * self._epoch + self.rank)
         self._epoch += 1

@@ -315,3 +315,33 @@ def test_train_matryoshka_matches_oracle_on_same_batches_and_prefix_draws(tmp_pa
         assert bad.float().mean() < 5e-3, f"{k}: {bad.sum().item()} of {bad.numel()} elements off"
     last = log.records[0][-1][1]
     assert math.isclose(last["loss/mse"], recs[log.records[0][-1][0]]["mse"], rel_tol=2e-3)
+
+
+@pytest.mark.parametrize("budget_gb", ["1000", "0"])  # resident pool / forced streaming reservoir
+def test_train_from_a_shard_directory(tmp_path, monkeypatch, budget_gb):
+    """worker_fn fed from a protocol-2.1 cache on disk (not an in-memory pool): every token is consumed once per
+    epoch in both feed modes, the loss falls, and the run directory links back to the cache."""
+    from saev_amd import data, disk
+    from saev_amd.framework import train as T
+
+    monkeypatch.setenv("SAEV_AMD_RESIDENT_GB", budget_gb)
+    g = load_golden("g9_train_a")
+    d, bsz = int(g["d"]), int(g["bsz"])
+    acts = g["acts"].numpy().reshape(-1, 1, 8, d)  # 128 examples x 8 content tokens, one layer, no CLS
+    shards = data.write_shards(tmp_path, acts, layers=(11,), cls_token=False, max_tokens_per_shard=8 * 20)
+    dc = data.ShuffledConfig(shards=shards, layer=11, batch_size=bsz, seed=3, buffer_size=4)
+    cfg = dataclasses.replace(small_cfg(tmp_path, g), train_data=dc, val_data=dc, runs_root=tmp_path / "saev" / "runs")
+    # the feed itself, on the device
+    dl = data.ShuffledDataLoader(dc, device="cuda")
+    assert (dl.reservoir is not None) == (budget_gb == "0")
+    rows = torch.cat([torch.stack([b["example_idx"], b["token_idx"]], 1) for b in dl]).cpu()
+    assert rows.shape[0] == acts.shape[0] * 8 and len({tuple(r) for r in rows.tolist()}) == rows.shape[0]
+    b = next(iter(dl))
+    torch.testing.assert_close(b["act"].cpu(), torch.from_numpy(acts[b["example_idx"].cpu(), 0, b["token_idx"].cpu()]),
+                               rtol=0, atol=0)
+    ids = T.worker_fn([cfg])
+    run = disk.Run(tmp_path / "saev" / "runs" / ids[0])
+    assert run.train_shards == shards.resolve() and run.ckpt.exists()
+    logs = [json.loads(line) for line in (run.run_dir / "metrics.jsonl").read_text().splitlines()]
+    mses = [rec["loss/mse"] for rec in logs if "loss/mse" in rec]
+    assert mses[-1] < mses[0] and all(math.isfinite(m) for m in mses)

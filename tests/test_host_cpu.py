@@ -247,6 +247,81 @@ def test_shard_cache_roundtrip_and_loader_semantics(tmp_path):
         data.ShuffledDataLoader(dataclasses.replace(cfg, layer=3), device="cpu")
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_streaming_reservoir_feed_delivers_every_row_once(tmp_path, world):
+    """Caches over the device budget stream through the reservoir (resident=False forces that mode): the reference's
+    contract is every row exactly once per epoch, random order, ragged last batch unless drop_last."""
+    from saev_amd import data
+
+    rng = np.random.default_rng(1)
+    acts = rng.standard_normal((37, 2, 5, 8)).astype(np.float32)
+    d = data.write_shards(tmp_path, acts, layers=(6, 11), cls_token=True, max_tokens_per_shard=5 * 5 * 2)
+    cfg = data.ShuffledConfig(shards=d, layer=11, tokens="content", batch_size=16, seed=3, buffer_size=3, min_buffer_fill=0.5)
+    seen_all = set()
+    for rank in range(world):
+        dl = data.ShuffledDataLoader(cfg, device="cpu", rank=rank, world_size=world, resident=False)
+        assert dl.reservoir is not None and dl.pool is None and dl.n_samples == 37 * 4
+        for epoch in range(2):
+            seen, sizes = {}, []
+            for batch in dl:
+                sizes.append(len(batch["act"]))
+                assert batch["act"].dtype == torch.float32 and batch["example_idx"].dtype == torch.int32
+                for a, e, t in zip(batch["act"], batch["example_idx"].tolist(), batch["token_idx"].tolist()):
+                    assert (e, t) not in seen
+                    seen[(e, t)] = True
+                    np.testing.assert_array_equal(a.numpy(), acts[e, 1, t + 1])
+            assert len(seen) == dl.n_local and len(sizes) == len(dl)
+            assert all(n == dl.local_batch for n in sizes[:-1]) and sizes[-1] <= dl.local_batch
+            if epoch == 0:
+                order0 = list(seen)
+            else:
+                assert list(seen) != order0
+        seen_all |= set(seen)
+    assert len(seen_all) == 37 * 4
+    # same rows, same once-per-epoch contract as the resident mode
+    res = data.ShuffledDataLoader(cfg, device="cpu")
+    assert res.reservoir is None and res.n_local == 37 * 4
+    # drop_last
+    dl = data.ShuffledDataLoader(dataclasses.replace(cfg, drop_last=True), device="cpu", resident=False)
+    assert [len(b["act"]) for b in dl] == [16] * (37 * 4 // 16)
+
+
+def test_streaming_reader_errors_reach_the_consumer():
+    from saev_amd.data.reservoir import StreamingReservoir
+
+    def blocks():
+        yield np.zeros((4, 8), np.float32), np.zeros(4, np.int32), np.zeros(4, np.int32)
+        raise OSError("disk went away")
+
+    r = StreamingReservoir(blocks, d_model=8, capacity=64, chunk_rows=8, device="cpu", seed=0)
+    r.start_epoch()
+    with pytest.raises(RuntimeError, match="reader failed"):
+        for _ in range(10):
+            r.get(4)
+    r.stop()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_ignore_labels_filters_patches(tmp_path, resident):
+    from saev_amd import data
+
+    rng = np.random.default_rng(2)
+    acts = rng.standard_normal((9, 1, 5, 8)).astype(np.float32)
+    labels = rng.integers(0, 3, (9, 4)).astype(np.uint8)
+    d = data.write_shards(tmp_path, acts, layers=(11,), cls_token=True, max_tokens_per_shard=4 * 5, labels=labels)
+    cfg = data.ShuffledConfig(shards=d, layer=11, batch_size=8, ignore_labels=[0, 2], buffer_size=2)
+    dl = data.ShuffledDataLoader(cfg, device="cpu", resident=resident)
+    want = {(e, t) for e in range(9) for t in range(4) if labels[e, t] == 1}
+    assert dl.n_samples == len(want) and len(dl) == -(-len(want) // 8)
+    got = [(e, t) for b in dl for e, t in zip(b["example_idx"].tolist(), b["token_idx"].tolist())]
+    assert len(got) == len(want) and set(got) == want
+    with pytest.raises(NotImplementedError):
+        data.ShuffledDataLoader(dataclasses.replace(cfg, tokens="all"), device="cpu")
+    d2 = data.write_shards(tmp_path / "nolabels", acts, layers=(11,), cls_token=True)
+    with pytest.raises(FileNotFoundError):
+        data.ShuffledDataLoader(dataclasses.replace(cfg, shards=d2), device="cpu")
+
+
 def test_sample_prefixes_contract():
     from saev_amd.nn import objectives as O
 

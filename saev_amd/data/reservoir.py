@@ -25,12 +25,15 @@ import torch
 
 
 class StreamingReservoir:
-    """``blocks`` is a callable returning an iterator of ``(act (n, D) float32 ndarray, example_idx (n,) int32,
-    token_idx (n,) int32)`` for one epoch (host arrays, any n <= chunk_rows)."""
+    """``blocks`` is a callable returning an iterator over one epoch whose items are either
+    ``(act (n, D) float32 ndarray, example_idx (n,) int32, token_idx (n,) int32)`` host arrays (n <= chunk_rows) or
+    callables ``read(out) -> (n, example_idx, token_idx)`` that write their rows into ``out[:n]`` (a pinned
+    ``(chunk_rows, D)`` staging buffer), so the memory-mapped read is the only host copy and happens in whichever of
+    the ``n_threads`` reader threads picked the item up."""
 
     def __init__(self, blocks, *, d_model: int, capacity: int, chunk_rows: int, device: torch.device, seed: int,
-                 min_fill: float = 0.0, gather=None, timeout_s: float = 30.0):
-        assert capacity >= chunk_rows > 0
+                 min_fill: float = 0.0, gather=None, timeout_s: float = 30.0, n_threads: int = 1):
+        assert chunk_rows > 0 and capacity >= chunk_rows * max(1, n_threads), "every reader must be able to place a block"
         self.blocks = blocks
         self.D, self.capacity, self.chunk_rows = d_model, capacity, chunk_rows
         self.device = torch.device(device)
@@ -49,9 +52,12 @@ class StreamingReservoir:
         self._pending: list[tuple[object, np.ndarray]] = []  # (event, slots) read by a gather still in flight
         self._done = True
         self._err: BaseException | None = None
-        self._thread: threading.Thread | None = None
+        self.n_threads = max(1, n_threads)
+        self._threads: list[threading.Thread] = []
+        self._n_running = 0
+        self._src = None
+        self._src_lock = threading.Lock()
         self._stop = False
-        self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
 
     # ---- reader side -----------------------------------------------------------------------------------------------
     def start_epoch(self):
@@ -62,16 +68,25 @@ class StreamingReservoir:
             self._n_free = self.capacity
             self._pending.clear()
             self._done, self._err, self._stop = False, None, False
-        self._thread = threading.Thread(target=self._reader, name="saev-reservoir-reader", daemon=True)
-        self._thread.start()
+            self._n_running = self.n_threads
+        self._src = iter(self.blocks())
+        self._threads = [threading.Thread(target=self._reader, name=f"saev-reservoir-reader-{i}", daemon=True)
+                         for i in range(self.n_threads)]
+        for t in self._threads:
+            t.start()
 
     def stop(self):
-        if self._thread is not None:
+        if self._threads:
             with self._cv:
                 self._stop = True
                 self._cv.notify_all()
-            self._thread.join()
-            self._thread = None
+            for t in self._threads:
+                t.join()
+            self._threads = []
+
+    def _next_item(self):
+        with self._src_lock:  # the generator itself only does index arithmetic; reads happen outside the lock
+            return next(self._src, None)
 
     def _reclaim_locked(self):
         keep = []
@@ -97,48 +112,88 @@ class StreamingReservoir:
 
     def _reader(self):
         try:
+            copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
             stage = [torch.empty(self.chunk_rows, self.D, dtype=torch.float32, pin_memory=self.on_gpu) for _ in range(2)]
             stage_meta = [torch.empty(self.chunk_rows, 2, dtype=torch.int32, pin_memory=self.on_gpu) for _ in range(2)]
-            busy: list[object] = [None, None]
-            for i, (act, ex, tk) in enumerate(self.blocks()):
-                n = act.shape[0]
-                assert n <= self.chunk_rows
+            inflight: list[tuple[object, np.ndarray] | None] = [None, None]
+
+            def publish(j):
+                if inflight[j] is None:
+                    return
+                ev, slots = inflight[j]
+                if ev is not None:
+                    ev.synchronize()  # rows are published only once they are in HBM
+                inflight[j] = None
+                with self._cv:
+                    n = slots.shape[0]
+                    self._filled[self._n_filled : self._n_filled + n] = slots
+                    self._n_filled += n
+                    self._cv.notify_all()
+
+            i = 0
+            while True:
+                item = self._next_item()
+                if item is None:
+                    break
+                j = i & 1
+                i += 1
+                publish(j)  # the copy that last used this staging buffer has landed
+                # host read (page cache / disk) straight into pinned memory; overlaps the other buffer's copy
+                if callable(item):
+                    n, ex, tk = item(stage[j].numpy())
+                else:
+                    act, ex, tk = item
+                    n = act.shape[0]
+                    assert n <= self.chunk_rows
+                    stage[j].numpy()[:n] = act
+                if n == 0:
+                    continue
+                sm = stage_meta[j].numpy()
+                sm[:n, 0], sm[:n, 1] = ex, tk
+                publish(1 - j)  # never wait for free slots while holding unpublished rows
                 slots = self._take_free(n)
                 if slots is None:
                     return
-                j = i & 1
-                if busy[j] is not None:
-                    busy[j].synchronize()
-                stage[j].numpy()[:n] = act
-                sm = stage_meta[j].numpy()
-                sm[:n, 0], sm[:n, 1] = ex, tk
                 slots_t = torch.from_numpy(slots)
+                ev = None
                 if self.on_gpu:
-                    with torch.cuda.stream(self.copy_stream):
+                    with torch.cuda.stream(copy_stream):
                         sd = slots_t.to(self.device, non_blocking=True)
                         self.rows.index_copy_(0, sd, stage[j][:n].to(self.device, non_blocking=True))
                         self.meta.index_copy_(0, sd, stage_meta[j][:n].to(self.device, non_blocking=True))
                         ev = torch.cuda.Event()
                         ev.record()
-                    busy[j] = ev
-                    ev.synchronize()  # rows are published only once they are in HBM
                 else:
                     self.rows.index_copy_(0, slots_t, stage[j][:n])
                     self.meta.index_copy_(0, slots_t, stage_meta[j][:n])
-                with self._cv:
-                    self._filled[self._n_filled : self._n_filled + n] = slots
-                    self._n_filled += n
-                    self._cv.notify_all()
+                inflight[j] = (ev, slots)
+            publish(0)
+            publish(1)
         except BaseException as e:  # surfaced to the consumer
             self._err = e
         finally:
             with self._cv:
-                self._done = True
+                self._n_running -= 1
+                if self._n_running == 0 or self._err is not None:
+                    self._done = True
                 self._cv.notify_all()
 
     # ---- consumer side ---------------------------------------------------------------------------------------------
     def fill(self) -> float:
         return self._n_filled / self.capacity
+
+    def _draw(self, n: int, b: int) -> np.ndarray:
+        """b distinct positions of range(n), uniform over all b-subsets, in O(b log b) (not O(n)) when b << n."""
+        if b >= n:
+            return np.arange(n)
+        if n < 4 * b:
+            return self.rng.permutation(n)[:b]
+        got = np.unique(self.rng.integers(0, n, size=b + b // 8 + 16))
+        while got.shape[0] < b:
+            got = np.unique(np.concatenate([got, self.rng.integers(0, n, size=b)]))
+        if got.shape[0] > b:  # drop a uniformly chosen surplus
+            got = np.delete(got, self.rng.choice(got.shape[0], got.shape[0] - b, replace=False))
+        return got
 
     def get(self, batch_size: int):
         """Up to ``batch_size`` rows drawn uniformly without replacement from the reservoir; fewer only when the epoch
@@ -148,8 +203,11 @@ class StreamingReservoir:
             while True:
                 if self._err is not None:
                     raise RuntimeError("reservoir reader failed") from self._err
-                want = max(batch_size, int(self.min_fill * self.capacity)) if not self._done else 1
-                if self._n_filled >= min(want, self.capacity) or (self._done and self._n_filled > 0):
+                # the fill threshold leaves room for every reader's next block, or nobody could make progress
+                room = self.capacity - self.chunk_rows * self.n_threads
+                assert room >= batch_size, "capacity must cover one batch plus one block per reader thread"
+                want = min(max(batch_size, int(self.min_fill * self.capacity)), max(room, 1)) if not self._done else 1
+                if self._n_filled >= want or (self._done and self._n_filled > 0):
                     break
                 if self._done:
                     return None
@@ -157,12 +215,13 @@ class StreamingReservoir:
                     raise TimeoutError(f"no batch within {self.timeout_s}s (reservoir fill {self.fill():.3f})")
             n = self._n_filled
             b = min(batch_size, n)
-            pick = self.rng.choice(n, size=b, replace=False) if b < n else np.arange(n)
+            pick = self._draw(n, b)
             slots = self._filled[pick].copy()
             # close the holes with the tail entries that were not drawn themselves
-            tail = np.setdiff1d(np.arange(n - b, n), pick, assume_unique=True)
-            holes = pick[pick < n - b]
-            self._filled[np.sort(holes)] = self._filled[tail]
+            in_tail = pick >= n - b
+            tail_kept = np.ones(b, dtype=bool)
+            tail_kept[pick[in_tail] - (n - b)] = False
+            self._filled[pick[~in_tail]] = self._filled[n - b : n][tail_kept]
             self._n_filled = n - b
         slots_t = torch.from_numpy(slots).to(self.device)
         act = self.gather(self.rows, slots_t) if self.gather is not None else self.rows[slots_t]

@@ -15,8 +15,8 @@ streamed instead: an HBM reservoir of ``buffer_size * batch_size`` rows (the ref
 shuffled.py:45-63) is refilled from the shards by a background reader and batches are uniform draws from
 it -- see reservoir.py.  ``min_buffer_fill`` and ``batch_timeout_s`` apply to that mode.
 
-``Config`` keeps the reference's field names and defaults (shuffled.py:31-70); ``n_threads`` is accepted
-and ignored (one reader thread saturates the PCIe copy engine with whole-block reads).
+``Config`` keeps the reference's field names and defaults (shuffled.py:31-70); ``n_threads`` is the number
+of reader threads of the streaming mode.
 """
 
 from __future__ import annotations
@@ -145,16 +145,27 @@ class DataLoader:
                 for li in layer_ids:
                     for lo in range(0, n_ex, step):
                         hi = min(n_ex, lo + step)
-                        block = np.ascontiguousarray(mm[lo:hi, li][:, tok])  # (n, n_tok, D)
-                        rows = block.reshape(-1, md.d_model)
-                        ex = np.repeat((np.arange(lo, hi) + ex_base[si]).astype(np.int32), len(tok))
-                        tk = np.tile(tok_out, hi - lo)
-                        if labels is not None:
-                            keep = keep_all[ex_base[si] + lo : ex_base[si] + hi].reshape(-1)
-                            if not keep.any():
-                                continue
-                            rows, ex, tk = rows[keep], ex[keep], tk[keep]
-                        yield rows, ex, tk
+                        def read(out=None, mm=mm, si=si, li=li, lo=lo, hi=hi):
+                            """Rows of examples [lo, hi) of one shard/layer into out[:n]; returns (n, example_idx, token_idx)
+                            (or (rows, example_idx, token_idx) when no output buffer is given)."""
+                            ex = np.repeat((np.arange(lo, hi) + ex_base[si]).astype(np.int32), len(tok))
+                            tk = np.tile(tok_out, hi - lo)
+                            src = mm[lo:hi, li][:, tok]  # (n_ex, n_tok, D) strided view of the mapped file
+                            keep = None
+                            if labels is not None:
+                                keep = keep_all[ex_base[si] + lo : ex_base[si] + hi].reshape(-1)
+                                ex, tk = ex[keep], tk[keep]
+                            n = ex.shape[0]
+                            if out is None:
+                                rows = np.ascontiguousarray(src).reshape(-1, md.d_model)
+                                return (rows if keep is None else rows[keep]), ex, tk
+                            if keep is None:
+                                np.copyto(out[:n].reshape(hi - lo, len(tok), md.d_model), src)
+                            elif n:
+                                out[:n] = np.ascontiguousarray(src).reshape(-1, md.d_model)[keep]
+                            return n, ex, tk
+
+                        yield read
 
         resident = self._resident_arg
         if resident is None:
@@ -168,7 +179,8 @@ class DataLoader:
             resident = self._n_local * md.d_model * 4 <= limit
         if resident:
             acts, exs, tks = [], [], []
-            for a, ex, tk in blocks(0, None):
+            for read in blocks(0, None):
+                a, ex, tk = read()
                 acts.append(torch.from_numpy(a).to(self.device))
                 exs.append(torch.from_numpy(ex))
                 tks.append(torch.from_numpy(tk))
@@ -178,12 +190,12 @@ class DataLoader:
             return
         self.pool = None
         chunk = min(4 * self.local_batch, 65536)
-        capacity = max(cfg.buffer_size * self.local_batch, 2 * chunk)
+        capacity = max(cfg.buffer_size * self.local_batch, (cfg.n_threads + 1) * chunk + self.local_batch)
         self.reservoir = StreamingReservoir(
             lambda: blocks(self._epoch - 1, chunk), d_model=md.d_model, capacity=capacity, chunk_rows=chunk,
             device=self.device, seed=cfg.seed + 7919 * self.rank, min_fill=cfg.min_buffer_fill,
             gather=lambda pool, rows: self.engine.gather_rows(pool, rows) if self.engine is not None else pool[rows],
-            timeout_s=cfg.batch_timeout_s)
+            timeout_s=cfg.batch_timeout_s, n_threads=cfg.n_threads)
 
     # -------------------------------------------------------------------------------------
     @property

@@ -45,6 +45,26 @@ __device__ __forceinline__ void gather_rows_accum(f32x4 (&acc)[NV], const float*
     }
 }
 
+// Reduce-scatter of KC per-lane partial sums across a wave: afterwards lane l holds the wave-wide sum of p[(l >> S) &
+// (KC-1)] in p[0], S = 6 - log2(KC).  KC + log2(64/KC) shuffles instead of 6 * KC for KC separate wave_sum()s.
+template <int KC>
+__device__ __forceinline__ float wave_reduce_scatter(float (&p)[KC], int lane) {
+    int bit = 32;
+#pragma unroll
+    for (int h = KC / 2; h >= 1; h >>= 1, bit >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const float keep = up ? p[i + h] : p[i];
+            const float send = up ? p[i] : p[i + h];
+            p[i] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    float r = p[0];
+    for (; bit >= 1; bit >>= 1) r += __shfl_xor(r, bit, 64);
+    return r;
+}
+
 template <int NV>
 __device__ __forceinline__ void row_dots(const f32x4 (&g)[NV], const float* __restrict__ W, int D, int D4,
                                          const int32_t* idx_row, float* dval_row, int k, int limit, int lane) {
@@ -53,22 +73,28 @@ __device__ __forceinline__ void row_dots(const f32x4 (&g)[NV], const float* __re
         int32_t my_i = -1;
         if (lane < cnt) my_i = idx_row[j0 + lane];
         float my_d = 0.f;
-#pragma unroll 2
-        for (int jj = 0; jj < cnt; ++jj) {
-            const int32_t i = __shfl(my_i, jj, 64);
-            if (i < 0 || i >= limit) continue;
-            const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
-            float p = 0.f;
+        // eight codes at a time: eight independent row loads in flight, then one reduce-scatter (11 shuffles
+        // instead of 48) leaves the dot product of code jj0 + ((lane >> 3) & 7) in every lane
+        for (int jj0 = 0; jj0 < cnt; jj0 += 8) {
+            float p[8];
 #pragma unroll
-            for (int n = 0; n < NV; ++n) {
-                const int q = lane + 64 * n;
-                if (q < D4) {
-                    const f32x4 w = wr[q];
-                    p += w[0] * g[n][0] + w[1] * g[n][1] + w[2] * g[n][2] + w[3] * g[n][3];
+            for (int t = 0; t < 8; ++t) {
+                const int32_t i = __shfl(my_i, min(jj0 + t, 63), 64);
+                p[t] = 0.f;
+                if (jj0 + t >= cnt || i < 0 || i >= limit) continue;
+                const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const int q = lane + 64 * n;
+                    if (q < D4) {
+                        const f32x4 w = wr[q];
+                        p[t] += w[0] * g[n][0] + w[1] * g[n][1] + w[2] * g[n][2] + w[3] * g[n][3];
+                    }
                 }
             }
-            p = wave_sum(p);
-            if (lane == jj) my_d = p;
+            const float r = wave_reduce_scatter<8>(p, lane);
+            const float mine = __shfl(r, (lane & 7) << 3, 64);  // lane l (jj0 <= l < jj0 + 8) takes code l's sum
+            if (lane >= jj0 && lane < jj0 + 8) my_d = mine;
         }
         if (lane < cnt) dval_row[j0 + lane] = my_d;
     }
@@ -599,14 +625,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int
         reinterpret_cast<f32x4*>(partials + (size_t)blockIdx.x * D)[q] = s;
     }
 }
+// 64 columns per workgroup, 4 threads per column each summing every 4th partial row with independent loads in
+// flight, then a fixed-order LDS combine (deterministic).
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partials, int n_blocks, int D, float* out,
                                                            int accumulate, const int32_t* k_dev) {
     if (k_dev && *k_dev <= 0) return;
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= D) return;
-    float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * D + d];
-    out[d] = accumulate ? out[d] + s : s;
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (d < D) {
+        int b = slice;
+        for (; b + 12 < n_blocks; b += 16) {
+            s0 += partials[(size_t)b * D + d];
+            s1 += partials[(size_t)(b + 4) * D + d];
+            s2 += partials[(size_t)(b + 8) * D + d];
+            s3 += partials[(size_t)(b + 12) * D + d];
+        }
+        for (; b < n_blocks; b += 4) s0 += partials[(size_t)b * D + d];
+    }
+    part[slice][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && d < D) {
+        const float s = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+        out[d] = accumulate ? out[d] + s : s;
+    }
 }
 
 template <typename F>
@@ -665,7 +708,7 @@ hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, flo
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev,
                        row_stride > 0 ? row_stride : (long)D);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, partials, nb, D, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out,
                        accumulate, k_dev);
     return hipGetLastError();
 }

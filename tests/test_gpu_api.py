@@ -344,4 +344,11 @@ def test_train_from_a_shard_directory(tmp_path, monkeypatch, budget_gb):
     assert run.train_shards == shards.resolve() and run.ckpt.exists()
     logs = [json.loads(line) for line in (run.run_dir / "metrics.jsonl").read_text().splitlines()]
     mses = [rec["loss/mse"] for rec in logs if "loss/mse" in rec]
-    assert mses[-1] < mses[0] and all(math.isfinite(m) for m in mses)
+    assert len(mses) >= 3 and all(math.isfinite(m) for m in mses)
+    # per-batch losses of a random feed are noisy; judge progress on the whole cache instead
+    x = g["acts"].cuda()
+    torch.manual_seed(cfg.seed)
+    before = M().SparseAutoencoder(cfg.sae).cuda()
+    after = M().load(run.ckpt, device="cuda")
+    mse = [((m(x).x_hats[:, -1] - x) ** 2).mean().item() for m in (before, after)]
+    assert mse[1] < mse[0], mse

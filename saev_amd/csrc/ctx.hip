@@ -41,6 +41,8 @@ struct saev_ctx {
     float *x_hat = nullptr, *g = nullptr, *g_aux = nullptr;
     RowStats* rowstats = nullptr;
     uint32_t* bitmap = nullptr;
+    int32_t* grp_prefix = nullptr;
+    int32_t* scan_totals = nullptr;
     int bitmap_words = 0;
     int32_t *counts = nullptr, *starts = nullptr;
     int2* pairs = nullptr;
@@ -176,8 +178,10 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(g_aux, MB * D); A(dead_list, S); }
     A(x_hat, MB * D); A(g, MB * D);
     A(rowstats, MB);
-    c->bitmap_words = (int)((MB + 31) / 32);
+    c->bitmap_words = (int)(((MB + 31) / 32 + 7) / 8 * 8);
     A(bitmap, S * c->bitmap_words);
+    A(grp_prefix, S * (c->bitmap_words / 8));
+    A(scan_totals, ((S + 1023) / 1024) * 3);
     A(counts, S); A(starts, S + 1); A(pairs, MB * K);
     {
         const long max_pairs = MB * K;
@@ -736,12 +740,12 @@ int saev_step_backward(saev_ctx* c, void* stream) {
     REQUIRE(c, c->grads, SAEV_NOT_BOUND, "gradient buffer not bound");
     hipStream_t s = (hipStream_t)stream;
     const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
-    const int words = (n + 31) / 32;
+    const int words = ((n + 31) / 32 + 7) / 8 * 8;
 
     auto build = [&](const int32_t* idx, int stride, int k, const int32_t* k_dev) -> int {
         CscArgs a{};
         a.idx = idx; a.code_stride = stride; a.k = k; a.k_dev = k_dev; a.n_rows = n; a.S = S;
-        a.bitmap = c->bitmap; a.words = words; a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
+        a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals; a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
         a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
         HIPCHK(c, launch_csc_build(a, s));
         return SAEV_OK;

@@ -110,9 +110,11 @@ struct CscArgs {
     int code_stride, k;     // k = host upper bound of codes per row
     const int32_t* k_dev;   // optional device-side count (aux); <= 0 -> kernels exit
     int n_rows, S;
-    uint32_t* bitmap;       // (S, words) zeroed by the caller
-    int words;              // ceil(n_rows / 32)
-    int32_t* counts;        // (S) zeroed by the caller
+    uint32_t* bitmap;       // (S, words)
+    int words;              // ceil(n_rows / 32) rounded up to a multiple of 8 (one 256-row group = 32 bytes)
+    int32_t* grp_prefix;    // (S, words / 8) codes of the latent in earlier 256-row groups
+    int32_t* counts;        // (S)
+    int32_t* scan_totals;   // (ceil(S / 1024), 3) scratch of the two-pass scan
     int32_t* starts;        // (S + 1)
     int2* pairs;            // (n_rows * k) -> {row b, flat code position b*code_stride + j}
     int32_t* chunk_starts;  // (S + 1) or NULL

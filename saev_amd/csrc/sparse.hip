@@ -6,7 +6,8 @@
 //                     g = dL/dx_hat; dval_j = <W_dec[idx_j], g>; fired flags; per-row stats.
 //   decode_matry_kernel the same for P nested Matryoshka prefixes (objectives.py:125-138).
 //   csc_*             latent-major ordering of the (row, latent) pairs, deterministic (row-ascending
-//                     inside a latent) via an S x B bit map: atomicOr fill, per-latent enumeration.
+//                     inside a latent) via an S x B bit map: atomicOr fill, per-latent popcounts + group
+//                     prefixes, scan, then every code computes its own slot from the bits below it.
 //   dw_dec_kernel     dW_dec[i,:] = sum_{b in latent i} val * g[b,:]   (+ db_enc[i] = sum dval)
 //   dw_enc_kernel     dW_enc[:,i] = sum_{b in latent i} dval * x[b,:]  (32 latents per workgroup,
 //                     transposed through LDS so global stores are 128-byte rows of the (D,S) matrix)
@@ -325,17 +326,16 @@ __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryAr
 
 // ------------------------------- CSC build -------------------------------------------------
 
-// zero the bit map and the per-latent counts; skipped entirely when the (device-side) code count is 0
+// zero the bit map; skipped entirely when the (device-side) code count is 0
 __global__ __launch_bounds__(256) void csc_clear_kernel(CscArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
-    const size_t n4 = ((size_t)a.S * a.words) >> 2;  // words is a multiple of 4 for the sizes used; tail below
+    const size_t n4 = ((size_t)a.S * a.words) >> 2;  // words is a multiple of 8
     uint4* bm = reinterpret_cast<uint4*>(a.bitmap);
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) bm[q] = uint4{0, 0, 0, 0};
-    for (size_t q = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)a.S * a.words; q += (size_t)gridDim.x * 256)
-        a.bitmap[q] = 0;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)a.S; q += (size_t)gridDim.x * 256) a.counts[q] = 0;
 }
 
+// bit (latent i, row b) for every code.  No per-latent counter here: a latent that fires on most rows would
+// serialise tens of thousands of same-address atomics; counts come from the bit map instead.
 __global__ void csc_fill_kernel(CscArgs a) {
     const int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
     if (k <= 0) return;
@@ -343,112 +343,133 @@ __global__ void csc_fill_kernel(CscArgs a) {
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
         const int b = (int)(p / k), j = (int)(p % k);
         const int32_t i = a.idx[(size_t)b * a.code_stride + j];
-        if (i >= 0 && i < a.S) {
-            atomicOr(&a.bitmap[(size_t)i * a.words + (b >> 5)], 1u << (b & 31));
-            atomicAdd(&a.counts[i], 1);
-        }
+        if (i >= 0 && i < a.S) atomicOr(&a.bitmap[(size_t)i * a.words + (b >> 5)], 1u << (b & 31));
     }
 }
 
-// exclusive scans over the latents, one sweep of a single 1024-thread workgroup:
-//   starts[i]       pair offset            (sum of counts)
-//   chunk_starts[i] work-item offset       (sum of max(1, ceil(count / DW_CHUNK)))
-//   part_starts[i]  partial-sum slot       (sum of chunks of latents with more than one chunk)
-__global__ __launch_bounds__(1024) void csc_scan_kernel(CscArgs a) {
+// one wave per latent: counts[i] = number of rows that use latent i, and grp_prefix[i][g] = how many of them lie in
+// row groups (256 rows = 8 bitmap words) before group g -- the rank of a code inside its latent is then one 2-byte
+// and one 32-byte read away (csc_place_kernel).
+__global__ __launch_bounds__(256) void csc_count_kernel(CscArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
-    __shared__ int wave_tot[16][3];
-    __shared__ int carry[3];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 3) carry[tid] = 0;
-    __syncthreads();
-    for (int base = 0; base < a.S; base += 1024) {
-        const int i = base + tid;
-        int v[3] = {0, 0, 0};
-        if (i < a.S) {
-            const int c = a.counts[i];
-            const int nch = (c + DW_CHUNK - 1) / DW_CHUNK;
-            v[0] = c;
-            v[1] = max(1, nch);
-            v[2] = nch > 1 ? nch : 0;
-        }
-        int incl[3] = {v[0], v[1], v[2]};
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int n = __shfl_up(incl[q], o, 64);
-                if (lane >= o) incl[q] += n;
-            }
-        }
-        if (lane == 63)
-            for (int q = 0; q < 3; ++q) wave_tot[w][q] = incl[q];
-        __syncthreads();
-        int off[3] = {carry[0], carry[1], carry[2]};
-        for (int j = 0; j < w; ++j)
-            for (int q = 0; q < 3; ++q) off[q] += wave_tot[j][q];
-        if (i < a.S) {
-            a.starts[i] = off[0] + incl[0] - v[0];
-            if (a.chunk_starts) {
-                a.chunk_starts[i] = off[1] + incl[1] - v[1];
-                a.part_starts[i] = off[2] + incl[2] - v[2];
-            }
-        }
-        __syncthreads();
-        if (tid == 1023)
-            for (int q = 0; q < 3; ++q) carry[q] = off[q] + incl[q];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        a.starts[a.S] = carry[0];
-        if (a.chunk_starts) a.chunk_starts[a.S] = carry[1];
-    }
-}
-
-// one wave per latent: enumerate the set bits of its bitmap row in ascending row order, look the
-// latent up in that row's (ascending) code list, emit {row, flat position}.
-__global__ __launch_bounds__(256) void csc_emit_kernel(CscArgs a) {
-    const int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
-    if (k <= 0) return;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.S) return;
-    if (a.chunk_starts) {
-        const int c0 = a.chunk_starts[i], c1 = a.chunk_starts[i + 1];
-        for (int c = c0 + lane; c < c1; c += 64) a.work_latent[c] = i;
-    }
-    const int total = a.counts[i];
-    if (total == 0) return;
-    int out = a.starts[i];
-    const uint32_t* bm = a.bitmap + (size_t)i * a.words;
-    for (int w0 = 0; w0 < a.words; w0 += 64) {
-        uint32_t word = (w0 + lane < a.words) ? bm[w0 + lane] : 0u;
-        const int c = __popc(word);
+    const int groups = a.words >> 3;
+    const uint4* bm = reinterpret_cast<const uint4*>(a.bitmap + (size_t)i * a.words);
+    int base = 0;
+    for (int g0 = 0; g0 < groups; g0 += 64) {
+        const int g = g0 + lane;
+        int c = 0;
+        if (g < groups) {
+            const uint4 lo = bm[2 * g], hi = bm[2 * g + 1];
+            c = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+        }
         int incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            int n = __shfl_up(incl, o, 64);
+            const int n = __shfl_up(incl, o, 64);
             if (lane >= o) incl += n;
         }
-        const int chunk_total = __shfl(incl, 63, 64);
-        if (chunk_total == 0) continue;
-        int pos = out + incl - c;
-        while (word) {
-            const int bit = __ffs(word) - 1;
-            word &= word - 1;
-            const int b = (w0 + lane) * 32 + bit;
-            // binary search for latent i in row b's ascending code list [0, k)
-            const int32_t* r = a.idx + (size_t)b * a.code_stride;
-            int lo = 0, hi = k - 1, j = 0;
-            while (lo <= hi) {
-                const int mid = (lo + hi) >> 1;
-                const int32_t v = r[mid];
-                if (v == i) { j = mid; break; }
-                if (v < i && v >= 0) lo = mid + 1; else hi = mid - 1;
-            }
-            a.pairs[pos] = int2{b, (int)((size_t)b * a.code_stride + j)};
-            ++pos;
+        if (g < groups) a.grp_prefix[(size_t)i * groups + g] = base + incl - c;
+        base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) a.counts[i] = base;
+}
+
+// exclusive scans over the latents, two small coalesced passes (1024 latents per workgroup, then the block offsets):
+//   starts[i]       pair offset            (sum of counts)
+//   chunk_starts[i] work-item offset       (sum of max(1, ceil(count / DW_CHUNK)))
+//   part_starts[i]  partial-sum slot       (sum of chunks of latents with more than one chunk)
+__global__ __launch_bounds__(1024) void csc_scan_block_kernel(CscArgs a) {
+    if (a.k_dev && *a.k_dev <= 0) return;
+    __shared__ int wave_tot[16][3];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = blockIdx.x * 1024 + tid;
+    int v[3] = {0, 0, 0};
+    if (i < a.S) {
+        const int c = a.counts[i];
+        const int nch = (c + DW_CHUNK - 1) / DW_CHUNK;
+        v[0] = c; v[1] = max(1, nch); v[2] = nch > 1 ? nch : 0;
+    }
+    int incl[3] = {v[0], v[1], v[2]};
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int n = __shfl_up(incl[q], o, 64);
+            if (lane >= o) incl[q] += n;
         }
-        out += chunk_total;
+    }
+    if (lane == 63)
+        for (int q = 0; q < 3; ++q) wave_tot[w][q] = incl[q];
+    __syncthreads();
+    int off[3] = {0, 0, 0};
+    for (int j = 0; j < w; ++j)
+        for (int q = 0; q < 3; ++q) off[q] += wave_tot[j][q];
+    if (i < a.S) {
+        a.starts[i] = off[0] + incl[0] - v[0];
+        if (a.chunk_starts) {
+            a.chunk_starts[i] = off[1] + incl[1] - v[1];
+            a.part_starts[i] = off[2] + incl[2] - v[2];
+        }
+    }
+    if (tid == 1023)
+        for (int q = 0; q < 3; ++q) a.scan_totals[blockIdx.x * 3 + q] = off[q] + incl[q];
+}
+__global__ __launch_bounds__(1024) void csc_scan_offset_kernel(CscArgs a) {
+    if (a.k_dev && *a.k_dev <= 0) return;
+    __shared__ int base[3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {  // first wave: sum of the totals of the blocks before this one
+        int s3[3] = {0, 0, 0};
+        for (int b = lane; b < (int)blockIdx.x; b += 64)
+            for (int q = 0; q < 3; ++q) s3[q] += a.scan_totals[b * 3 + q];
+        for (int q = 0; q < 3; ++q) s3[q] = wave_sum_i(s3[q]);
+        if (lane == 0)
+            for (int q = 0; q < 3; ++q) base[q] = s3[q];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + tid;
+    if (i < a.S) {
+        a.starts[i] += base[0];
+        if (a.chunk_starts) { a.chunk_starts[i] += base[1]; a.part_starts[i] += base[2]; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        a.starts[a.S] = base[0] + a.scan_totals[blockIdx.x * 3 + 0];
+        if (a.chunk_starts) a.chunk_starts[a.S] = base[1] + a.scan_totals[blockIdx.x * 3 + 1];
+    }
+}
+
+// one thread per code: its slot inside its latent's list is the number of lower rows that use the same latent
+// (row-ascending order, so the weight-gradient sums are deterministic) = group prefix + popcount of the bits below
+// it inside its 256-row group.  No search, no per-latent serial work: a latent that fires on every row costs the
+// same per code as one that fires once.  The first S threads also label the work items of "their" latent.
+__global__ void csc_place_kernel(CscArgs a) {
+    const int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
+    if (k <= 0) return;
+    const long n = (long)a.n_rows * k;
+    const int groups = a.words >> 3;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < max(n, (long)a.S); p += (long)gridDim.x * blockDim.x) {
+        if (p < a.S && a.chunk_starts) {
+            const int c1 = a.chunk_starts[p + 1];
+            for (int c = a.chunk_starts[p]; c < c1; ++c) a.work_latent[c] = (int)p;
+        }
+        if (p >= n) continue;
+        const int b = (int)(p / k), j = (int)(p % k);
+        const int32_t i = a.idx[(size_t)b * a.code_stride + j];
+        if (i < 0 || i >= a.S) continue;
+        const int g = b >> 8, wi = (b >> 5) & 7;
+        const uint4* grp = reinterpret_cast<const uint4*>(a.bitmap + (size_t)i * a.words + 8 * g);
+        const uint4 lo = grp[0], hi = grp[1];
+        const uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        int rank = a.grp_prefix[(size_t)i * groups + g];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t m = e < wi ? 0xffffffffu : (e == wi ? ((1u << (b & 31)) - 1u) : 0u);
+            rank += __popc(wd[e] & m);
+        }
+        a.pairs[a.starts[i] + rank] = int2{b, (int)((size_t)b * a.code_stride + j)};
     }
 }
 
@@ -572,7 +593,31 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
 #pragma unroll
     for (int n = 0; n < NV; ++n) { accd[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acce[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float dbs = 0.f;
-    for (int c = c0; c < c1; ++c) {
+    int c = c0;
+    // four partial rows per trip: their loads are independent, so a latent with hundreds of chunks is bound by
+    // bandwidth rather than by one load latency per chunk; the summation order is fixed (chunk order inside a trip,
+    // trips in order)
+    for (; c + 4 <= c1; c += 4) {
+        f32x4 td[4][NV], te[4][NV];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4* pd = reinterpret_cast<const f32x4*>(a.partials + (size_t)(c + t) * 2 * D);
+            const f32x4* pe = pd + D4;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                td[t][n] = (q < D4) ? pd[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                te[t][n] = (q < D4) ? pe[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            accd[n] += (td[0][n] + td[1][n]) + (td[2][n] + td[3][n]);
+            acce[n] += (te[0][n] + te[1][n]) + (te[2][n] + te[3][n]);
+        }
+        dbs += (a.db_partials[c] + a.db_partials[c + 1]) + (a.db_partials[c + 2] + a.db_partials[c + 3]);
+    }
+    for (; c < c1; ++c) {
         const f32x4* pd = reinterpret_cast<const f32x4*>(a.partials + (size_t)c * 2 * D);
         const f32x4* pe = pd + D4;
 #pragma unroll
@@ -686,10 +731,13 @@ hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
     const long n = (long)a.n_rows * a.k;
     const int blocks = (int)std::min<long>((n + 255) / 256, 4096);
+    const int place_blocks = (int)std::min<long>((std::max<long>(n, a.S) + 255) / 256, 8192);
     hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
-    hipLaunchKernelGGL(csc_emit_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(csc_count_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(csc_scan_block_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(csc_scan_offset_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(csc_place_kernel, dim3(place_blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream) {

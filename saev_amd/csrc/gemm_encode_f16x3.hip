@@ -108,13 +108,6 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     const int b0 = bb * HTB;
 
     constexpr int NSLOT = NG / 2;
-    float smax[2][NSLOT];
-    if (EPI == EPI_TOPK) {
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int r = 0; r < NSLOT; ++r) smax[jb][r] = NEG_INF;
-    }
 
     const int nks = Dp / (NP == 3 ? 16 : 32);  // k-steps per tile
     // The 8 workgroups of an XCD that stream the same W images (same latent range, different batch block) walk the
@@ -247,6 +240,14 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             }
             __syncthreads();
         } else {
+            // group maxima of THIS tile only; the running maxima over earlier tiles (of this and of every other
+            // workgroup that owns the same rows) live in a.gmax and are merged below, so nothing is carried in
+            // registers across the contraction loop
+            float smax[2][NSLOT];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < NSLOT; ++r) smax[jb][r] = NEG_INF;
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
@@ -284,32 +285,27 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 const int part = __builtin_amdgcn_readfirstlane(tid / HTB);  // wave-uniform: group bases stay in SGPRs  // 512 threads = 2 x HTB rows
                 constexpr int GPT = NG / 2;                     // groups per thread
                 const int b = b0 + row;
-                const bool share = (a.s_splits > 1) && (b < B);
+                const bool share = b < B;
                 const uint32_t boff = (uint32_t)b * 4u;
                 int32_t m = INT32_MAX;
-#pragma unroll 1
-                for (int c0 = 0; c0 < GPT; c0 += 4) {  // four global reads in flight at a time (register pressure)
-                    int32_t v[4], old[4];
+                int32_t old[GPT];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int g = part * GPT + c0 + i;
-                        const int32_t v0 = (NG == 32) ? sm.e32.slots32[0][g][row] : sm.slots64[0][g][row];
-                        const int32_t v1 = (NG == 32) ? sm.e32.slots32[1][g][row] : sm.slots64[1][g][row];
-                        v[i] = max(v0, v1);
-                        old[i] = INT32_MIN;
-                        if (share)
-                            old[i] = __hip_atomic_load(
-                                reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)g * a.gmax_stride) + boff),
-                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                for (int i = 0; i < GPT; ++i) {  // all global reads of this thread in flight together
+                    old[i] = INT32_MIN;
+                    if (share)
+                        old[i] = __hip_atomic_load(
+                            reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)(part * GPT + i) * a.gmax_stride) + boff),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (share && v[i] > old[i])
-                            atomicMax(reinterpret_cast<int32_t*>(
-                                          reinterpret_cast<char*>(a.gmax + (size_t)(part * GPT + c0 + i) * a.gmax_stride) + boff),
-                                      v[i]);
-                        m = min(m, max(v[i], old[i]));
-                    }
+                for (int i = 0; i < GPT; ++i) {
+                    const int g = part * GPT + i;
+                    const int32_t v0 = (NG == 32) ? sm.e32.slots32[0][g][row] : sm.slots64[0][g][row];
+                    const int32_t v1 = (NG == 32) ? sm.e32.slots32[1][g][row] : sm.slots64[1][g][row];
+                    const int32_t v = max(v0, v1);
+                    if (share && v > old[i])
+                        atomicMax(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)g * a.gmax_stride) + boff), v);
+                    m = min(m, max(v, old[i]));
                 }
                 atomicMin(&sm.tau_key[row], m);
             }

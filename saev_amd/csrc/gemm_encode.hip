@@ -256,12 +256,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void encode_gemm_kernel(EncodeArgs a) 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int sl = ws * 64 + sb * 32 + 8 * q + 4 * half;
-                    const bool ok = (s0 + sl) < S;
+                    const bool ok = (s0 + sl) < S;  // d_sae % 4 == 0: a float4 of latents is all in or all out
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(&sm.bias[sl]);  // one unconditional 16-byte LDS read
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = ok ? acc[sb][jb][4 * q + e] + sm.bias[sl + e] : NEG_INF;
+                            const float hv = acc[sb][jb][4 * q + e] + bq[e];
+                            const float v = ok ? hv : NEG_INF;
                             acc[sb][jb][4 * q + e] = v;
                             const int slot = (NG == 32) ? (4 * q + e) : (16 * sb + 4 * q + e);
                             smax[jb][slot] = fmaxf(smax[jb][slot], v);
@@ -337,6 +339,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void encode_gemm_kernel(EncodeArgs a) 
                 pos[jb] = 0;
                 if (npass[jb] > 0) pos[jb] = atomicAdd(&a.cand_cnt[b0 + wb * 64 + jb * 32 + l31], npass[jb]);
             }
+            // wait for the two counters once, here: otherwise every conditionally executed store block below gets its own
+            // s_waitcnt vmcnt(0) (the block before it may have been skipped), which also serialises the stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(pos[0]), "+v"(pos[1]));
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
                 if (npass[jb] > 0) {

@@ -315,14 +315,18 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             }
             __syncthreads();
             int npass[2], pos[2];
+            float tau2[2];
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
-                const float tau = key2f(sm.tau_key[wb * 64 + jb * 32 + l31]);
+                // a finite bound: padded latents carry -inf and must never pass (a row whose bound is still -inf has seen
+                // fewer than k groups with a real value; everything real passes then)
+                const float tau = fmaxf(key2f(sm.tau_key[wb * 64 + jb * 32 + l31]), -3.0e38f);
+                tau2[jb] = tau;
                 int n = 0;
 #pragma unroll
                 for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) n += (acc[sb][jb][r] >= tau && acc[sb][jb][r] > NEG_INF) ? 1 : 0;
+                    for (int r = 0; r < 16; ++r) n += (acc[sb][jb][r] >= tau) ? 1 : 0;
                 npass[jb] = (b0 + wb * 64 + jb * 32 + l31 < B) ? n : 0;
             }
 #pragma unroll
@@ -336,23 +340,23 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             asm volatile("" : "+v"(pos[0]), "+v"(pos[1]));
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
-                if (npass[jb] > 0) {
+                // a row whose list would overflow is not written at all: its counter already says so, and the step then
+                // re-runs on the exact dense route (overflow_check).  Offsets are 32-bit from the uniform buffer bases
+                // (n_rows * cand_cap * 4 < 2^32), so a kept value costs one address add and two stores.
+                if (npass[jb] > 0 && pos[jb] + npass[jb] <= a.cand_cap) {
                     const int bl_ = wb * 64 + jb * 32 + l31;
-                    const float tau = key2f(sm.tau_key[bl_]);
-                    float* cv = a.cand_val + (size_t)(b0 + bl_) * a.cand_cap;
-                    int32_t* ci = a.cand_idx + (size_t)(b0 + bl_) * a.cand_cap;
-                    int p = pos[jb];
+                    const float tau = tau2[jb];
+                    uint32_t off = ((uint32_t)(b0 + bl_) * (uint32_t)a.cand_cap + (uint32_t)pos[jb]) * 4u;
 #pragma unroll
                     for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[sb][jb][r];
-                            if (v >= tau && v > NEG_INF) {
-                                if (p < a.cand_cap) {
-                                    cv[p] = v;
-                                    ci[p] = s0 + ws * 128 + sb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                                }
-                                ++p;
+                            if (v >= tau) {
+                                *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;
+                                *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) =
+                                    s0 + ws * 128 + sb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                                off += 4u;
                             }
                         }
                 }

@@ -1,0 +1,61 @@
+"""Build ablated variants of the f16x3 encoder (timing experiments only; results are wrong by construction).
+
+    python tools/ablate_encoder.py            # writes build/abl/lib_<VARIANT>.so
+    SAEV_AMD_LIB=build/abl/lib_NOEPI.so python tools/time_encoder.py
+
+Variants: NOEPI (no TopK epilogue), NOSTAGE (no in-loop operand staging), NOCAND (no candidate count/reserve/store),
+and combinations.  The patches are textual and applied to a temporary copy of the kernel source.
+"""
+import pathlib
+import subprocess
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+SRC = ROOT / "saev_amd" / "csrc" / "gemm_encode_f16x3.hip"
+OUT = ROOT / "build" / "abl"
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def patched(text: str) -> str:
+    def sub(old, new):
+        nonlocal text
+        assert old in text, old[:60]
+        text = text.replace(old, new, 1)
+
+    sub("            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));",
+        "#ifndef ABL_NOSTAGE\n            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));\n#endif")
+    sub("        const float unscale = 1.0f / a.w_scale;\n",
+        "        const float unscale = 1.0f / a.w_scale;\n        bool skip_epi = false;\n")
+    sub("        } else {\n            // group maxima of THIS tile only;",
+        "        } else {\n#ifdef ABL_NOEPI\n            { float chk = 0.f;\n"
+        "              for (int sb = 0; sb < 4; ++sb) for (int jb = 0; jb < 2; ++jb) for (int r = 0; r < 16; ++r) chk += acc[sb][jb][r];\n"
+        "              if (chk == 12345.f) a.cand_cnt[0] = 1; }\n            __syncthreads();\n            skip_epi = true;\n#endif\n"
+        "            if (!skip_epi) {\n            // group maxima of THIS tile only;")
+    sub("            int npass[2], pos[2];\n",
+        "#ifdef ABL_NOCAND\n            if (sm.tau_key[0] == 12345) a.cand_cnt[0] = (int)acc[0][0][0] + (int)acc[1][1][1] + (int)acc[2][0][2] + (int)acc[3][1][3];\n"
+        "            if (sm.tau_key[1] != 777777) goto tile_done;\n#endif\n            int npass[2], pos[2];\n")
+    sub("        if (!prefetched && st + 1 < st_end) {",
+        "            }\n#ifdef ABL_NOCAND\n        tile_done:;\n#endif\n        if (!prefetched && st + 1 < st_end) {")
+    # the extra '}' above closes `if (!skip_epi) {`; it must sit inside the else-branch: move the else's own brace
+    sub("            }\n        }\n            }\n#ifdef ABL_NOCAND", "            }\n            }\n        }\n#ifdef ABL_NOCAND")
+    return text
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    tmp = OUT / "gemm_encode_f16x3_abl.hip"
+    tmp.write_text(patched(SRC.read_text()))
+    variants = sys.argv[1:] or ["NOEPI", "NOSTAGE", "NOCAND", "NOSTAGE+NOEPI"]
+    objs = [str(ROOT / "build" / f"{n}.o") for n in ("ctx", "gemm_encode", "split", "select", "sparse", "tail", "auxk")]
+    for v in variants:
+        defs = [f"-DABL_{x}" for x in v.split("+")]
+        obj = OUT / f"f16_{v}.o"
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-unused-value",
+                               f"-I{ROOT / 'include'}", f"-I{ROOT / 'saev_amd' / 'csrc'}", *defs, "-c", str(tmp), "-o", str(obj)])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, str(obj), "-L/opt/rocm/lib", "-lrocblas",
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", str(OUT / f"lib_{v}.so")])
+        print("built", OUT / f"lib_{v}.so")
+
+
+if __name__ == "__main__":
+    main()

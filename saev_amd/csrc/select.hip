@@ -177,17 +177,15 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
     uint32_t T = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t trial = T | (1u << bit);
+        // wave-wide count through ballots: scalar popcounts, no cross-lane shuffle chain per bit
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) c += (key[e] >= trial);
-        c = wave_sum_i(c);
+        for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(key[e] >= trial));
         if (c >= k) T = trial;
     }
     int cgt = 0, ceq = 0;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) { cgt += (key[e] > T); ceq += (key[e] == T); }
-    cgt = wave_sum_i(cgt);
-    ceq = wave_sum_i(ceq);
+    for (int e = 0; e < EPL; ++e) { cgt += __popcll(__ballot(key[e] > T)); ceq += __popcll(__ballot(key[e] == T)); }
     const int need = k - cgt;  // ties to keep (>= 1 when k > 0)
     int32_t idx_cut = 0x7fffffff;  // keep ties with idx <= idx_cut
     if (ceq > need) {
@@ -198,8 +196,7 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
             const int32_t trial = X | (1 << bit);
             int c = 0;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) c += (key[e] == T && idx[e] < trial);
-            c = wave_sum_i(c);
+            for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(key[e] == T && idx[e] < trial));
             if (c < need) X = trial;
         }
         idx_cut = X;

@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--encoder", choices=["f32", "f16x3", "bf16"], default=None, help="encoder arithmetic (default: engine default)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the data-parallel code path (RCCL init + per-step collectives) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,8 +83,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_PORT", "29531")
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -110,7 +114,7 @@ def main():
     pool = torch.randn(POOL_BATCHES * B, D_MODEL, device=dev, generator=g) + mu
     perm = torch.randperm(pool.shape[0], device=dev, generator=g)
     x = torch.empty(B, D_MODEL, device=dev)
-    stepper = DataParallelStepper(eng, dist, world)
+    stepper = DataParallelStepper(eng, dist, world, force=args.force_dist)
     lr_sched = lambda i: 4e-4 * min(1.0, i / 500)  # noqa: E731  warm-up region of the reference schedule
 
     def one_step(i):
@@ -182,9 +186,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # before the result line: RCCL may print its own banner lines on stdout
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -17,9 +17,10 @@ import torch
 
 
 class DataParallelStepper:
-    def __init__(self, engine, dist=None, world_size: int = 1):
+    def __init__(self, engine, dist=None, world_size: int = 1, force: bool = False):
+        """``force`` keeps the collective path even for one rank (exercises RCCL on a single-GPU box)."""
         self.engine = engine
-        self.dist = dist if world_size > 1 else None
+        self.dist = dist if (world_size > 1 or force) else None
         self.world = world_size
 
     def train_step(self, x_local: torch.Tensor, lr: float, max_norm: float = 1.0) -> None:

@@ -18,6 +18,8 @@ Fixture index:
   G7  clip             clip_grad_norm_ (coef < 1 and coef = 1)
   G8  adam             5 fused-Adam steps incl. the lr=0 first step
   G9  train_a/train_b  20ish-step train() trajectories + evaluate() metrics
+  G10 make_saes        datapoint initialisation (reinit_blend 0.8 and 1.0, two SAEs sharing one stream) from fixed
+                       batches under torch.manual_seed: W_enc / W_dec of the reference's make_saes
   G11 schedule         WarmupCosine lr lists and BatchLimiter step counts
   G12 checkpoint       header bytes/JSON written by the reference's nn.dump
   G13 matryoshka       objective fwd/bwd with 4 fixed prefixes (with and without dead latents)
@@ -340,6 +342,21 @@ def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm):
           f"eval nmse {ev.normalized_mse:.6f}")
 
 
+def g10_make_saes(ref):
+    d, s, bsz = 24, 96, 64
+    acts = lowrank_data(320, d, seed=100)
+    cfgs = [(ref.modeling.SparseAutoencoderConfig(d_model=d, d_sae=s, reinit_blend=blend,
+                                                  activation=ref.modeling.TopK(top_k=4)),
+             ref.objectives.Matryoshka(n_prefixes=1)) for blend in (0.8, 1.0)]
+    torch.manual_seed(1234)
+    saes, _, groups = ref.train.make_saes(cfgs, MemLoader(acts, bsz))
+    assert len(groups) == 2 and groups[0]["lr"] == 0.0
+    npz("g10_make_saes", acts=acts, bsz=bsz, seed=1234, blends=np.array([0.8, 1.0]),
+        **{f"W_enc_{i}": sae.W_enc.detach() for i, sae in enumerate(saes)},
+        **{f"W_dec_{i}": sae.W_dec.detach() for i, sae in enumerate(saes)},
+        **{f"b_enc_{i}": sae.b_enc.detach() for i, sae in enumerate(saes)})
+
+
 def g11_schedule(ref):
     S = ref.scheduling
     out = {}
@@ -447,6 +464,9 @@ def ref_disk_new(tmp, shards_dir):
 
 def main():
     ref = _refshim.install()
+    if "--only-g10" in sys.argv:
+        g10_make_saes(ref)
+        return
     if "--only-g14" in sys.argv:
         g14_inference(ref, "plain", False)
         g14_inference(ref, "labels", True)
@@ -458,6 +478,7 @@ def main():
     g6_g7_g8(ref)
     g9_train(ref, "a", d=64, s=512, k=8, bsz=128, n_rows=1024, n_train=2048, thr=10_000_000, k_aux=512, lr=4e-4, n_warm=5)
     g9_train(ref, "b", d=128, s=1024, k=16, bsz=256, n_rows=2048, n_train=6144, thr=512, k_aux=32, lr=2e-3, n_warm=4)
+    g10_make_saes(ref)
     g11_schedule(ref)
     g12_checkpoint(ref)
     g13_matryoshka(ref)

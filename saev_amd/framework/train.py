@@ -141,15 +141,19 @@ def make_saes(
             if n_seen >= n_samples:
                 break
         assert n_seen >= n_samples, f"Datapoint init requested {n_samples} samples but saw {n_seen}."
+        # Random draws come from torch's global CPU generator in the reference's call order (one permutation of the
+        # samples, one Kaiming matrix, one permutation per SAE), so the same seed and the same batches give the same
+        # initial weights as the reference (fixture G10); the arithmetic runs wherever the activations live.
         acts = torch.cat(got, dim=0)
-        acts = acts[torch.randperm(n_samples, device=acts.device)]
+        acts = acts[torch.randperm(n_samples).to(acts.device)]
         centred = acts[:d_sae] - acts.mean(dim=0, keepdim=True)
-        kaiming = torch.nn.init.kaiming_uniform_(torch.empty_like(centred))
+        kaiming = torch.nn.init.kaiming_uniform_(torch.empty(centred.shape, dtype=centred.dtype)).to(acts.device)
         for sae in saes:
             p = sae.cfg.reinit_blend
             assert 0.0 <= p <= 1.0, f"reinit_blend must be in [0, 1], got {p}."
-            order = torch.randperm(d_sae, device=acts.device)
+            order = torch.randperm(d_sae).to(acts.device)
             rows = (p * centred[order] + (1 - p) * kaiming[order]).to("cpu")
+            assert rows.shape == (sae.cfg.d_sae, sae.cfg.d_model), f"enc_rows has shape {tuple(rows.shape)}"
             sae.W_enc.data.copy_(rows.T)
             if sae.cfg.reinit_enc_dec_tranpose:
                 sae.W_dec.data.copy_(sae.W_enc.data.T)

@@ -332,3 +332,39 @@ def test_sample_prefixes_contract():
     torch.manual_seed(0)
     assert torch.equal(p, R.sample_prefixes(512, 10)), "same draw as the oracle restatement under the same seed"
     assert O.Matryoshka() == O.Matryoshka(n_prefixes=10, dead_threshold_tokens=10_000_000)
+
+
+def test_make_saes_datapoint_init_matches_reference(golden):
+    """The reference's default (reinit_blend = 0.8) initialises encoder columns from mean-centred activations
+    (train.py:108-189).  Same seed + same batches -> same weights as the reference produced (fixture G10)."""
+    from saev_amd import data
+    from saev_amd.framework import train as T
+    from saev_amd.nn import modeling as M, objectives as O
+
+    g = golden("g10_make_saes")
+    acts, bsz = g["acts"], int(g["bsz"])
+
+    class Loader:  # the reference's loader contract, in memory and in order
+        n_samples = acts.shape[0]
+
+        def __iter__(self):
+            for lo in range(0, acts.shape[0], bsz):
+                yield {"act": acts[lo : lo + bsz]}
+
+    d, s = acts.shape[1], g["W_dec_0"].shape[0]
+    cfgs = [(M.SparseAutoencoderConfig(d_model=d, d_sae=s, reinit_blend=float(b), activation=M.TopK(top_k=4)),
+             O.Matryoshka(n_prefixes=1)) for b in g["blends"].tolist()]
+    torch.manual_seed(int(g["seed"]))
+    saes, objs, groups = T.make_saes(cfgs, Loader(), device="cpu")
+    assert len(saes) == len(objs) == 2 and all(grp["lr"] == 0.0 for grp in groups)
+    for i, sae in enumerate(saes):
+        torch.testing.assert_close(sae.W_enc.detach(), g[f"W_enc_{i}"], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(sae.W_dec.detach(), g[f"W_dec_{i}"], rtol=1e-6, atol=1e-7)
+        assert torch.equal(sae.b_enc.detach(), g[f"b_enc_{i}"])
+        torch.testing.assert_close(sae.W_dec.detach().norm(dim=1), torch.ones(s), rtol=1e-5, atol=1e-6)
+        assert torch.equal(sae.W_enc.detach(), sae.W_dec.detach().T)
+        assert sae.W_enc.data_ptr() != sae.W_dec.data_ptr()
+    # too few samples for the dictionary is an error, as in the reference
+    small = type("L", (), {"n_samples": s - 1, "__iter__": lambda self: iter(())})()
+    with pytest.raises(AssertionError, match="samples for datapoint init"):
+        T.make_saes(cfgs, small, device="cpu")

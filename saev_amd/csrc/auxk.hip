@@ -79,6 +79,12 @@ __global__ __launch_bounds__(256) void dead_bias_kernel(float* H, long n_rows, i
     }
 }
 
+// compact bias of the dead set for the fused dense contraction: out[j] = b_enc[dl[j]], -inf on the padding columns
+__global__ void dead_bias_vec_kernel(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < ndp) out[j] = (j < nd) ? b_enc[dl[j]] : NEG_INF;
+}
+
 // A[b][idx] = val, mask[b][idx] = 1 for the selected codes (A and mask are zeroed by the caller)
 __global__ __launch_bounds__(256) void aux_scatter_kernel(const int32_t* idx, const float* val, long n_rows, int k,
                                                           int stride, int ndp, float* A, uint8_t* mask) {
@@ -183,6 +189,10 @@ hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int3
 hipError_t launch_dead_bias(float* H, int n_rows, int nd, int ndp, const float* b_enc, const int32_t* dl, hipStream_t s) {
     hipLaunchKernelGGL(dead_bias_kernel, dim3(grid_for((long)n_rows * ndp)), dim3(256), 0, s, H, (long)n_rows, nd, ndp,
                        b_enc, dl);
+    return hipGetLastError();
+}
+hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(dead_bias_vec_kernel, dim3((ndp + 255) / 256), dim3(256), 0, s, b_enc, dl, nd, ndp, out);
     return hipGetLastError();
 }
 hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, int k, int stride, int ndp, float* A,

@@ -69,6 +69,10 @@ struct saev_ctx {
     float *Wenc_dead = nullptr, *Wdec_dead = nullptr, *H_dead = nullptr, *A_dead = nullptr, *dWd = nullptr, *dWe = nullptr,
           *dbe = nullptr, *aux_partials = nullptr;
     uint8_t* A_mask = nullptr;
+    // AuxK contractions on the f16x3 encoder kernel (F16X3 mode): operand images and compact vectors
+    _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr;
+    float *bias_dead = nullptr, *zero_bias = nullptr;
+    int aux_Dp2 = 0;
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -198,6 +202,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         c->MB_pad = (int)((MB + 255) / 256 * 256);
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
+        A(zero_bias, std::max(S, D));
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
 #undef A
@@ -214,6 +219,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
     hipMemset(c->rowstats, 0, MB * sizeof(RowStats));
     if (c->xs) hipMemset(c->xs, 0, (size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
+    if (c->zero_bias) hipMemset(c->zero_bias, 0, std::max(S, D) * sizeof(float));
     hipDeviceSynchronize();
     *out = c;
     return SAEV_OK;
@@ -645,13 +651,40 @@ int ensure_aux_capacity(saev_ctx* c, int ndp) {
     c->dWe = (float*)grab((size_t)cap * D * 4);
     c->dbe = (float*)grab((size_t)cap * 4);
     c->aux_partials = (float*)grab(((MB + 63) / 64) * (size_t)cap * 4);
-    if (!c->Wenc_dead || !c->Wdec_dead || !c->H_dead || !c->A_dead || !c->A_mask || !c->dWd || !c->dWe || !c->dbe ||
+    bool fast_ok = true;
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+        const size_t cap256 = ((size_t)cap + 255) / 256 * 256, D256 = (D + 255) / 256 * 256;
+        c->aux_Dp2 = (int)(((size_t)cap + 31) / 32 * 32);
+        c->aux_ws1 = (_Float16*)grab(cap256 * 2 * c->Dp * sizeof(_Float16));          // W_enc[:, dl]^T, later W_dec[dl]
+        c->aux_ws2 = (_Float16*)grab(D256 * 2 * c->aux_Dp2 * sizeof(_Float16));        // W_dec[dl] as a (n_dead x D) "encoder"
+        c->aux_xsA = (_Float16*)grab((size_t)c->MB_pad * 2 * c->aux_Dp2 * sizeof(_Float16));
+        c->aux_xsg = (_Float16*)grab((size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
+        c->bias_dead = (float*)grab(cap256 * sizeof(float));
+        fast_ok = c->aux_ws1 && c->aux_ws2 && c->aux_xsA && c->aux_xsg && c->bias_dead;
+    }
+    if (!fast_ok || !c->Wenc_dead || !c->Wdec_dead || !c->H_dead || !c->A_dead || !c->A_mask || !c->dWd || !c->dWe || !c->dbe ||
         !c->aux_partials) {
         c->err = "AuxK: out of device memory for the dead-set buffers";
         c->nd_cap = 0;
         return SAEV_HIP_ERROR;
     }
     c->nd_cap = cap;
+    return SAEV_OK;
+}
+
+// out (n_rows x S_out, row-major) = rows-operand x cols-operand + bias on the f16x3 encoder kernel (dense epilogue):
+// the three AuxK contractions whose long axis is the batch are exactly the encoder's shape.  `scale` is the product
+// of the power-of-two scales applied to the two operands when they were split.
+int dense_f16x3(saev_ctx* c, const _Float16* xs, const _Float16* ws, const float* bias, int n_rows, int Dp, int S_out,
+                float scale, float* out, hipStream_t s) {
+    EncodeF16Args a{};
+    a.xs = xs; a.ws = ws; a.b_enc = bias;
+    a.n_rows = n_rows; a.Dp = Dp; a.S = S_out; a.w_scale = scale; a.nprod = 3;
+    a.s_splits = encoder_splits(n_rows, S_out, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
+    a.h_out = out;
+    a.ngroups = 32;
+    a.enable_flag = nullptr; a.enable_when = 0;
+    HIPCHK(c, launch_encode_f16x3(a, EPI_DENSE, s));
     return SAEV_OK;
 }
 
@@ -662,13 +695,23 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     const int ndp = (nd + 3) / 4 * 4;
     int rc = ensure_aux_capacity(c, ndp);
     if (rc != SAEV_OK) return rc;
+    const bool fast = c->cfg.encoder_mode == SAEV_ENCODER_F16X3;
+    const int ndp256 = (ndp + 255) / 256 * 256, Dp2 = (ndp + 31) / 32 * 32;
     BLASCHK(c, rocblas_set_stream(c->blas, s));
     HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
     HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
                                  c->Wenc_dead, c->Wdec_dead, s));
-    rc = gemm_nn(c, n, ndp, D, c->x_last, c->Wenc_dead, c->H_dead);  // H = x W_enc[:, dl]
-    if (rc != SAEV_OK) return rc;
-    HIPCHK(c, launch_dead_bias(c->H_dead, n, nd, ndp, c->params + c->off_b_enc, c->dead_list, s));
+    if (fast) {
+        // H = x W_enc[:, dl] + b_enc[dl]: the x images of this step are already there (prepare_encoder)
+        HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, false, s));
+        HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s));
+        rc = dense_f16x3(c, c->xs, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->H_dead, s);
+        if (rc != SAEV_OK) return rc;
+    } else {
+        rc = gemm_nn(c, n, ndp, D, c->x_last, c->Wenc_dead, c->H_dead);  // H = x W_enc[:, dl]
+        if (rc != SAEV_OK) return rc;
+        HIPCHK(c, launch_dead_bias(c->H_dead, n, nd, ndp, c->params + c->off_b_enc, c->dead_list, s));
+    }
     SelectDenseArgs sd{};
     sd.h = c->H_dead; sd.n_rows = n; sd.S = ndp; sd.k = ku;
     sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
@@ -676,7 +719,14 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     HIPCHK(c, hipMemsetAsync(c->A_dead, 0, (size_t)n * ndp * sizeof(float), s));
     HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
     HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
-    rc = gemm_nn(c, n, D, ndp, c->A_dead, c->Wdec_dead, c->g_aux);  // E = A W_dec[dl]
+    if (fast) {
+        // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
+        HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, false, s));
+        HIPCHK(c, launch_split_wT(c->Wdec_dead, ndp, D, (D + 255) / 256 * 256, Dp2, 256.0f, c->aux_ws2, false, s));
+        rc = dense_f16x3(c, c->aux_xsA, c->aux_ws2, c->zero_bias, n, Dp2, D, 256.0f, c->g_aux, s);
+    } else {
+        rc = gemm_nn(c, n, D, ndp, c->A_dead, c->Wdec_dead, c->g_aux);  // E = A W_dec[dl]
+    }
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
                                c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s));
@@ -691,7 +741,18 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     const int ndp = (nd + 3) / 4 * 4;
     BLASCHK(c, rocblas_set_stream(c->blas, s));
     float* dA = c->H_dead;  // H is dead after the select
-    int rc = gemm_nt(c, n, ndp, D, c->g_aux, c->Wdec_dead, dA);  // dA = g_aux W_dec[dl]^T
+    int rc;
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+        // dA = g_aux W_dec[dl]^T.  g_aux carries the factor alpha * 2 / (n D) (~1e-10): bring it to O(residual) with an
+        // exact power of two before the fp16 split; W_dec[dl] rows are already "latent-major", so they split like x.
+        const float gscale = c->cfg.alpha * 2.0f / ((float)n * (float)D);
+        const float sg = std::exp2(-std::floor(std::log2(gscale)));
+        HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, false, s, sg));
+        HIPCHK(c, launch_split_rows(c->Wdec_dead, ndp, D, c->Dp, c->aux_ws1, false, s, 256.0f));
+        rc = dense_f16x3(c, c->aux_xsg, c->aux_ws1, c->zero_bias, n, c->Dp, ndp, sg * 256.0f, dA, s);
+    } else {
+        rc = gemm_nt(c, n, ndp, D, c->g_aux, c->Wdec_dead, dA);  // dA = g_aux W_dec[dl]^T
+    }
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_mask_apply(dA, c->A_mask, (long)n * ndp, s));
     rc = gemm_tn(c, ndp, D, n, c->A_dead, c->g_aux, c->dWd);  // dW_dec[dl] = A^T g_aux

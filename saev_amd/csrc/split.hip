@@ -7,7 +7,7 @@
 //               (part 0 = hi, 1 = lo; h = which half of the k-step: k%16 < 8 or >= 8)
 //               is stored at position c ^ ((rl >> 2) & 3)   <- the bank-conflict swizzle of the fragment reads
 //
-//   split_rows_kernel : x (n, D) fp32            -> xs images (rows padded to 256)
+//   split_rows_kernel : x (n, D) fp32 (* scale)  -> xs images (rows padded to 256)
 //   split_wT_kernel   : W_enc (D, S) fp32, i.e. k-major -> ws images of W_enc^T * scale (rows = latents)
 // hi = fp16(a*scale) (round to nearest even), lo = fp16(a*scale - hi): together 22 significand bits.
 // Rows beyond n / S and k beyond D are written as zeros where the kernels cover them; x padding rows are
@@ -43,7 +43,7 @@ __device__ __forceinline__ half8 round8_bf16(const float (&v)[8]) {
 
 // one thread = one 16-byte chunk of the image; grid.x = ceil(n/256) * nks images, 1024 threads each
 template <bool BF16>
-__global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks,
+__global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks, float scale,
                                                           _Float16* __restrict__ xs) {
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
     const int i = threadIdx.x;           // chunk index inside the image
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (r < n && k < D) {  // D % 4 == 0: load in two float4s, the second may fall off the end
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k);
-        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[0] = a[0] * scale; v[1] = a[1] * scale; v[2] = a[2] * scale; v[3] = a[3] * scale;
         if (k + 4 < D) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k + 4);
-            v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+            v[4] = b[0] * scale; v[5] = b[1] * scale; v[6] = b[2] * scale; v[7] = b[3] * scale;
         }
     }
     reinterpret_cast<half8*>(xs + (size_t)blockIdx.x * 256 * 32)[i] = BF16 ? round8_bf16(v) : split8(v, part);
@@ -90,14 +90,14 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
 
 }  // namespace
 
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, bool bf16, hipStream_t stream) {
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, bool bf16, hipStream_t stream, float scale) {
     const int nks = Dp / (bf16 ? 32 : 16), nblk = (n + 255) / 256;
     if (nblk <= 0) return hipSuccess;
     if (bf16)
-        hipLaunchKernelGGL(split_rows_kernel<true>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks,
+        hipLaunchKernelGGL(split_rows_kernel<true>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale,
                            reinterpret_cast<_Float16*>(xs));
     else
-        hipLaunchKernelGGL(split_rows_kernel<false>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks,
+        hipLaunchKernelGGL(split_rows_kernel<false>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale,
                            reinterpret_cast<_Float16*>(xs));
     return hipGetLastError();
 }

@@ -169,6 +169,8 @@ hipError_t dispatch_nv(int D, F&& f) {
         case 5: f(std::integral_constant<int, 5>()); break;
         case 6: f(std::integral_constant<int, 6>()); break;
         case 7: case 8: f(std::integral_constant<int, 8>()); break;
+        case 9: case 10: case 11: case 12: f(std::integral_constant<int, 12>()); break;  // d_model <= 3072
+        case 13: case 14: case 15: case 16: f(std::integral_constant<int, 16>()); break;  // d_model <= 4096
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -155,7 +155,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     if (!cfg || !out) return SAEV_INVALID_ARG;
     *out = nullptr;
     if (cfg->d_model <= 0 || cfg->d_sae <= 0 || cfg->top_k <= 0 || cfg->max_batch <= 0) return SAEV_INVALID_ARG;
-    if (cfg->d_model % 4 != 0 || cfg->d_sae % 4 != 0 || cfg->d_model > 2048) return SAEV_UNSUPPORTED;
+    if (cfg->d_model % 4 != 0 || cfg->d_sae % 4 != 0 || cfg->d_model > 4096) return SAEV_UNSUPPORTED;
     if (cfg->k_aux < 0 || cfg->k_aux > 1024) return SAEV_UNSUPPORTED;
     if (cfg->encoder_mode != SAEV_ENCODER_F32 && cfg->encoder_mode != SAEV_ENCODER_F16X3 && cfg->encoder_mode != SAEV_ENCODER_BF16)
         return SAEV_INVALID_ARG;

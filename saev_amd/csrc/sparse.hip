@@ -597,6 +597,7 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
     // four partial rows per trip: their loads are independent, so a latent with hundreds of chunks is bound by
     // bandwidth rather than by one load latency per chunk; the summation order is fixed (chunk order inside a trip,
     // trips in order)
+    if constexpr (NV <= 8)  // (wider rows keep to one partial row per trip: 8 * NV float4 temporaries would spill)
     for (; c + 4 <= c1; c += 4) {
         f32x4 td[4][NV], te[4][NV];
 #pragma unroll
@@ -708,6 +709,8 @@ hipError_t dispatch_nv(int D, F&& f) {
         case 5: f(std::integral_constant<int, 5>()); break;
         case 6: f(std::integral_constant<int, 6>()); break;
         case 7: case 8: f(std::integral_constant<int, 8>()); break;
+        case 9: case 10: case 11: case 12: f(std::integral_constant<int, 12>()); break;  // d_model <= 3072
+        case 13: case 14: case 15: case 16: f(std::integral_constant<int, 16>()); break;  // d_model <= 4096
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

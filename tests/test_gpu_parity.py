@@ -302,3 +302,31 @@ def test_ragged_batches_through_the_full_step(n):
     assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-3)
     for key in R.PARAM_ORDER:
         torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("d", [2304, 4096])
+def test_wide_d_model_step_matches_oracle(d):
+    """d_model above 2048 (ViT-g / 7B-class backbones) takes the wide instantiations of the row kernels."""
+    s, k, n = 512, 8, 96
+    p = rand_params(d, s, seed=d)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(d + 1))
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=16, dead_threshold_tokens=50)
+    toks = torch.zeros(s, dtype=torch.int64)
+    toks[::7] = 50  # some latents are dead so that the AuxK branch runs too
+    eng = make_engine(d, s, k, k_aux=16, thr=50, max_batch=n)
+    eng.load_params(p)
+    eng.set_tracker(toks)
+    state = R.TrainState.create({k_: v.clone() for k_, v in p.items()})
+    state.toks_since_active.copy_(toks)
+    state.lr = 1e-3
+    ref = R.train_step(state, x, cfg)
+    eng.train_step(x.cuda(), 1e-3, 1.0)
+    st = eng.read_stats()
+    assert math.isclose(st.mse, ref["mse"], rel_tol=1e-4) and math.isclose(st.aux, ref["aux"], rel_tol=1e-3, abs_tol=1e-9)
+    assert st.n_dead == ref["n_dead"] and math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-3)
+    for key in R.PARAM_ORDER:
+        # the first Adam step moves every element by ~lr * g / (|g| + eps): where g is tiny, rounding-level differences
+        # in g show up as a visible fraction of lr, so a handful of elements may sit outside the tight band
+        bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-3, atol=2e-6)
+        assert bad.float().mean() < 1e-5, f"{key}: {int(bad.sum())} of {bad.numel()} elements off"
+        torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-2, atol=2e-5, msg=lambda m: f"{key}: {m}")

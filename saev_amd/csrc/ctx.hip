@@ -449,8 +449,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     }
     timing_begin(c, s);
     if (fused_supported(c->cfg)) {
-        HIPCHK(c, hipMemsetAsync(c->cand_cnt, 0, (size_t)n * sizeof(int32_t), s));
-        HIPCHK(c, launch_init_i32(c->gmax, INT32_MIN, (c->cfg.top_k <= 32 ? 32 : 64) * c->gmax_stride, s));
+        HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, (c->cfg.top_k <= 32 ? 32 : 64) * c->gmax_stride, s));
         int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
         if (rc != SAEV_OK) return rc;
         HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
@@ -564,10 +563,8 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
         int rc = saev_normalize_w_dec(c, stream);
         if (rc != SAEV_OK) return rc;
     }
-    HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(saev_step_stats), s));
-    HIPCHK(c, hipMemsetAsync(c->upper, 0, sizeof(float), s));
+    HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));  // flags[0]: force-dense flag, unused by the step
     HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
-    HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int32_t), s));  // [0]: force-dense flag, unused by the step
     (void)n_rows_global;
     int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s);
     if (rc != SAEV_OK) return rc;

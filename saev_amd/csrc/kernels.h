@@ -61,6 +61,8 @@ struct SelectCandArgs {
 };
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
+hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream);
+hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                  int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);
 

@@ -254,6 +254,21 @@ __global__ void init_i32_kernel(int32_t* p, int32_t v, int n) {
     if (i < n) p[i] = v;
 }
 
+// per-launch state of the fused encoder in one pass: candidate counters to 0, shared group maxima to "-inf"
+__global__ void encoder_init_kernel(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) cand_cnt[i] = 0;
+    if (i < n_gmax) gmax[i] = INT32_MIN;
+}
+// per-step scalars in one pass: the stats block, max|x| and the force-dense flag
+__global__ void step_zero_kernel(saev_step_stats* stats, float* upper, int32_t* flag0) {
+    if (threadIdx.x == 0) {
+        *stats = saev_step_stats{};
+        *upper = 0.f;
+        *flag0 = 0;
+    }
+}
+
 // need_dense = pre_flag || any(cand_cnt > cap); also counts overflowing rows
 __global__ void overflow_check_kernel(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                       int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max) {
@@ -292,6 +307,17 @@ hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream) {
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(init_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream) {
+    const int n = n_rows > n_gmax ? n_rows : n_gmax;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encoder_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cand_cnt, n_rows, gmax, n_gmax);
+    return hipGetLastError();
+}
+hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream) {
+    hipLaunchKernelGGL(step_zero_kernel, dim3(1), dim3(64), 0, stream, stats, upper, flag0);
     return hipGetLastError();
 }
 

@@ -206,6 +206,17 @@ class DataLoader:
         n = self.n_local
         return n // self.local_batch if self.drop_last else math.ceil(n / self.local_batch)
 
+    def shutdown(self):
+        """Stop the reader threads of the streaming mode (no-op in resident mode); reference shuffled.py shutdown()."""
+        if self.reservoir is not None:
+            self.reservoir.stop()
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
     def _iter_streaming(self):
         res = self.reservoir
         self._epoch += 1

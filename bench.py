@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--encoder", choices=["f32", "f16x3", "bf16"], default=None, help="encoder arithmetic (default: engine default)")
+    ap.add_argument("--encoder", choices=["f32", "f16x3", "bf16", "f16r"], default=None, help="encoder arithmetic (default: engine default)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL init + per-step collectives) even with one rank")
     args = ap.parse_args()
@@ -149,9 +149,11 @@ def main():
         peak = F32_MFMA_PEAK_TFLOPS if eng.cfg.encoder == "f32" else F16_MFMA_PEAK_TFLOPS
         kernel_name = {"f16x3": "encode_f16x3_kernel<EPI_TOPK,32,3> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)",
                        "bf16": "encode_f16x3_kernel<EPI_TOPK,32,1> (v_mfma_f32_32x32x16_bf16)",
+                       "f16r": "encode_f16x3_kernel<EPI_TOPK,32,2> (v_mfma_f32_32x32x16_f16 first pass; exact fp32 refinement in select)",
                        "f32": "encode_gemm_kernel<EPI_TOPK> (v_mfma_f32_32x32x2_f32)"}[eng.cfg.encoder]
         dtype_name = {"f16x3": "f32 (encoder products as 3 x f16 MFMA on fp16 hi/lo splits, fp32 accumulate; all else fp32)",
                       "bf16": "bf16 encoder operands, fp32 accumulate; all else fp32 (NOT the headline precision)",
+                      "f16r": "f32 (encoder: fp16 MFMA first pass with a rigorous error margin, survivors recomputed exactly in fp32; all else fp32)",
                       "f32": "f32"}[eng.cfg.encoder]
         roof = {"bound": "mfma",
                 "kernel": kernel_name,

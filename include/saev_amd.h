@@ -49,10 +49,10 @@ typedef struct {
     int32_t normalize_w_dec;       /* modeling.py:283                                       */
     int32_t remove_parallel_grads; /* modeling.py:281                                       */
     int32_t max_batch;             /* scratch is sized for this many activation rows        */
-    int32_t encoder_mode;          /* SAEV_ENCODER_F32, _F16X3 or _BF16                     */
+    int32_t encoder_mode;          /* SAEV_ENCODER_F32, _F16X3, _BF16 or _F16R              */
 } saev_cfg;
 
-/* Encoder arithmetic.  F32 and F16X3 are fp32-accurate (error vs fp64 at the level of a native fp32 GEMM):
+/* Encoder arithmetic.  F32, F16X3 and F16R are fp32-accurate (error vs fp64 at the level of a native fp32 GEMM):
  *   F32   : v_mfma_f32_32x32x2_f32, exact fp32 products;
  *   F16X3 : operands split into fp16 hi+lo (22 significand bits), three v_mfma_f32_32x32x16_f16 per
  *           product pair, fp32 accumulate -- 16/3 of the F32 matrix rate;
@@ -62,6 +62,12 @@ typedef struct {
 #define SAEV_ENCODER_F32 0
 #define SAEV_ENCODER_F16X3 1
 #define SAEV_ENCODER_BF16 2
+/*   F16R  : one v_mfma_f32_32x32x16_f16 per product on fp16-rounded operands as a FIRST PASS whose error is bounded per
+ *           row (|error| <= 1.2 * 2^-10 * ||x_row|| * max ||W_enc column||); candidates are kept down to the running
+ *           bound minus twice that, and the select stage recomputes every survivor exactly in fp32 (dot product with
+ *           the fp32 encoder column + bias) before the final cut.  Codes and values are those of exact fp32 arithmetic;
+ *           a dense h (saev_encode_dense, overflow route) always comes from the exact fp32 kernel. */
+#define SAEV_ENCODER_F16R 3
 
 /* Scalars of one step (nn/objectives.py:57-89 MatryoshkaLoss + train.py:356-362 grad norm). */
 typedef struct {

@@ -73,6 +73,9 @@ struct saev_ctx {
     _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr;
     float *bias_dead = nullptr, *zero_bias = nullptr;
     int aux_Dp2 = 0;
+    // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
+    float *row_margin = nullptr, *wmax = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
+    int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -157,7 +160,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     if (cfg->d_model <= 0 || cfg->d_sae <= 0 || cfg->top_k <= 0 || cfg->max_batch <= 0) return SAEV_INVALID_ARG;
     if (cfg->d_model % 4 != 0 || cfg->d_sae % 4 != 0 || cfg->d_model > 4096) return SAEV_UNSUPPORTED;
     if (cfg->k_aux < 0 || cfg->k_aux > 1024) return SAEV_UNSUPPORTED;
-    if (cfg->encoder_mode != SAEV_ENCODER_F32 && cfg->encoder_mode != SAEV_ENCODER_F16X3 && cfg->encoder_mode != SAEV_ENCODER_BF16)
+    if (cfg->encoder_mode != SAEV_ENCODER_F32 && cfg->encoder_mode != SAEV_ENCODER_F16X3 && cfg->encoder_mode != SAEV_ENCODER_BF16 &&
+        cfg->encoder_mode != SAEV_ENCODER_F16R)
         return SAEV_INVALID_ARG;
     saev_ctx* c = new saev_ctx();
     c->cfg = *cfg;
@@ -203,6 +207,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
         A(zero_bias, std::max(S, D));
+        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4);
+        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
 #undef A
@@ -369,21 +375,32 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
 static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s) {
     if (c->cfg.encoder_mode == SAEV_ENCODER_F32) return SAEV_OK;
     const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
-    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xs, bf, s));
+    const int mode = bf ? 1 : (c->cfg.encoder_mode == SAEV_ENCODER_F16R ? 2 : 0);
+    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xs, mode, s));
     HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, c->cfg.d_model, c->cfg.d_sae, c->S_pad, c->Dp, bf ? 1.0f : 256.0f,
-                              c->ws, bf, s));
+                              c->ws, mode, s));
+    if (mode == 2) {
+        // the exact refinement reads encoder columns as rows: W_enc^T in fp32 (the gradient scratch dW_encT is free
+        // until the backward), and the margins that make the approximate cut safe
+        HIPCHK(c, launch_transpose(c->params + c->off_W_enc, c->dW_encT, c->cfg.d_model, c->cfg.d_sae, s));
+        HIPCHK(c, launch_row_margins(x, n, c->cfg.d_model, c->dW_encT, c->cfg.d_sae, c->wnorm_scratch, c->wmax,
+                                     c->row_margin, s));
+    }
     return SAEV_OK;
 }
 
 static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out, const int32_t* flag, int when,
                        hipStream_t s) {
-    if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
+    // F16R: only the TopK pass is approximate-then-refined; a dense h must be exact, so it comes from the fp32 kernel
+    const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
+    if (c->cfg.encoder_mode != SAEV_ENCODER_F32 && !(f16r && epi == EPI_DENSE)) {
         const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
         EncodeF16Args a{};
         a.xs = c->xs; a.ws = c->ws;
         a.b_enc = c->params + c->off_b_enc;
         a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = bf ? 1.0f : 256.0f;
-        a.nprod = bf ? 1 : 3;
+        a.arith = bf ? 1 : (f16r ? 2 : 0);
+        a.row_margin = f16r ? c->row_margin : nullptr;
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
         a.h_out = h_out;
         a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
@@ -453,21 +470,32 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
         if (rc != SAEV_OK) return rc;
         HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
-    } else {
-        HIPCHK(c, launch_init_i32(need_dense, 1, 1, s));
-        HIPCHK(c, hipMemsetAsync(c->flags + 2, 0, 2 * sizeof(int32_t), s));
-    }
-    int rc = run_encoder(c, x, n, EPI_DENSE, c->h_dense, need_dense, 1, s);
-    if (rc != SAEV_OK) return rc;
-    timing_end(c, s);
-    if (fused_supported(c->cfg)) {
+        timing_end(c, s);
         SelectCandArgs sc{};
         sc.cand_cnt = c->cand_cnt; sc.cand_val = c->cand_val; sc.cand_idx = c->cand_idx;
         sc.cand_cap = CAND_CAP; sc.n_rows = n; sc.k = K;
         sc.idx_out = idx_out; sc.val_out = val_out; sc.out_stride = K;
         sc.enable_flag = need_dense; sc.enable_when = 0;
+        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
+            // approximate values: (1) survivors of the cut lowered by the row margin, (2) their exact fp32 values,
+            // (3) the final cut on exact values.  A row with more than REFINE_CAP survivors raises need_dense.
+            sc.row_margin = c->row_margin; sc.x = x; sc.W_encT = c->dW_encT; sc.b_enc = c->params + c->off_b_enc;
+            sc.D = c->cfg.d_model; sc.refine_overflow = need_dense;
+            sc.surv_idx = c->surv_idx; sc.surv_val = c->surv_val; sc.surv_cnt = c->surv_cnt;
+            HIPCHK(c, launch_select_cand(sc, s));
+            HIPCHK(c, launch_refine_exact(sc, s));
+            sc.row_margin = nullptr;
+            sc.cand_cnt = c->surv_cnt; sc.cand_val = c->surv_val; sc.cand_idx = c->surv_idx; sc.cand_cap = REFINE_CAP;
+        }
         HIPCHK(c, launch_select_cand(sc, s));
+    } else {
+        HIPCHK(c, launch_init_i32(need_dense, 1, 1, s));
+        HIPCHK(c, hipMemsetAsync(c->flags + 2, 0, 2 * sizeof(int32_t), s));
+        timing_end(c, s);
     }
+    // exact dense route, predicated on the device flag (list overflow, refinement overflow, or k > 64)
+    int rc = run_encoder(c, x, n, EPI_DENSE, c->h_dense, need_dense, 1, s);
+    if (rc != SAEV_OK) return rc;
     SelectDenseArgs sd{};
     sd.h = c->h_dense; sd.n_rows = n; sd.S = c->cfg.d_sae; sd.k = K;
     sd.idx_out = idx_out; sd.val_out = val_out; sd.out_stride = K;
@@ -649,7 +677,7 @@ int ensure_aux_capacity(saev_ctx* c, int ndp) {
     c->dbe = (float*)grab((size_t)cap * 4);
     c->aux_partials = (float*)grab(((MB + 63) / 64) * (size_t)cap * 4);
     bool fast_ok = true;
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
         const size_t cap256 = ((size_t)cap + 255) / 256 * 256, D256 = (D + 255) / 256 * 256;
         c->aux_Dp2 = (int)(((size_t)cap + 31) / 32 * 32);
         c->aux_ws1 = (_Float16*)grab(cap256 * 2 * c->Dp * sizeof(_Float16));          // W_enc[:, dl]^T, later W_dec[dl]
@@ -676,7 +704,7 @@ int dense_f16x3(saev_ctx* c, const _Float16* xs, const _Float16* ws, const float
                 float scale, float* out, hipStream_t s) {
     EncodeF16Args a{};
     a.xs = xs; a.ws = ws; a.b_enc = bias;
-    a.n_rows = n_rows; a.Dp = Dp; a.S = S_out; a.w_scale = scale; a.nprod = 3;
+    a.n_rows = n_rows; a.Dp = Dp; a.S = S_out; a.w_scale = scale; a.arith = 0;
     a.s_splits = encoder_splits(n_rows, S_out, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
     a.h_out = out;
     a.ngroups = 32;
@@ -692,7 +720,8 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     const int ndp = (nd + 3) / 4 * 4;
     int rc = ensure_aux_capacity(c, ndp);
     if (rc != SAEV_OK) return rc;
-    const bool fast = c->cfg.encoder_mode == SAEV_ENCODER_F16X3;
+    const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
+    const bool fast = c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || f16r;
     const int ndp256 = (ndp + 255) / 256 * 256, Dp2 = (ndp + 31) / 32 * 32;
     BLASCHK(c, rocblas_set_stream(c->blas, s));
     HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
@@ -700,9 +729,14 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
                                  c->Wenc_dead, c->Wdec_dead, s));
     if (fast) {
         // H = x W_enc[:, dl] + b_enc[dl]: the x images of this step are already there (prepare_encoder)
-        HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, false, s));
+        HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, 0, s));
         HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s));
-        rc = dense_f16x3(c, c->xs, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->H_dead, s);
+        const _Float16* xs_hl = c->xs;
+        if (f16r) {  // the step's x images are single fp16 here: make the hi/lo ones (the buffer is free until the backward)
+            HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s));
+            xs_hl = c->aux_xsg;
+        }
+        rc = dense_f16x3(c, xs_hl, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->H_dead, s);
         if (rc != SAEV_OK) return rc;
     } else {
         rc = gemm_nn(c, n, ndp, D, c->x_last, c->Wenc_dead, c->H_dead);  // H = x W_enc[:, dl]
@@ -718,8 +752,8 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
     if (fast) {
         // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
-        HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, false, s));
-        HIPCHK(c, launch_split_wT(c->Wdec_dead, ndp, D, (D + 255) / 256 * 256, Dp2, 256.0f, c->aux_ws2, false, s));
+        HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, 0, s));
+        HIPCHK(c, launch_split_wT(c->Wdec_dead, ndp, D, (D + 255) / 256 * 256, Dp2, 256.0f, c->aux_ws2, 0, s));
         rc = dense_f16x3(c, c->aux_xsA, c->aux_ws2, c->zero_bias, n, Dp2, D, 256.0f, c->g_aux, s);
     } else {
         rc = gemm_nn(c, n, D, ndp, c->A_dead, c->Wdec_dead, c->g_aux);  // E = A W_dec[dl]
@@ -739,13 +773,13 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     BLASCHK(c, rocblas_set_stream(c->blas, s));
     float* dA = c->H_dead;  // H is dead after the select
     int rc;
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) {
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
         // dA = g_aux W_dec[dl]^T.  g_aux carries the factor alpha * 2 / (n D) (~1e-10): bring it to O(residual) with an
         // exact power of two before the fp16 split; W_dec[dl] rows are already "latent-major", so they split like x.
         const float gscale = c->cfg.alpha * 2.0f / ((float)n * (float)D);
         const float sg = std::exp2(-std::floor(std::log2(gscale)));
-        HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, false, s, sg));
-        HIPCHK(c, launch_split_rows(c->Wdec_dead, ndp, D, c->Dp, c->aux_ws1, false, s, 256.0f));
+        HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, 0, s, sg));
+        HIPCHK(c, launch_split_rows(c->Wdec_dead, ndp, D, c->Dp, c->aux_ws1, 0, s, 256.0f));
         rc = dense_f16x3(c, c->aux_xsg, c->aux_ws1, c->zero_bias, n, c->Dp, ndp, sg * 256.0f, dA, s);
     } else {
         rc = gemm_nt(c, n, ndp, D, c->g_aux, c->Wdec_dead, dA);  // dA = g_aux W_dec[dl]^T

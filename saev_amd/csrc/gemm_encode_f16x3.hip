@@ -63,15 +63,23 @@ __device__ __forceinline__ f32x16 mfma_bf16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+template <int AR>
+__device__ __forceinline__ f32x16 mfma1(half8 a, half8 b, f32x16 c) {
+    if constexpr (AR == 1) return mfma_bf16(a, b, c);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ void glds16h(const char* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// NP = 3: the split-fp16 scheme above.  NP = 1: single-product bf16 (SAEV_ENCODER_BF16): the same 16 KB images hold 32
-// consecutive k of bf16(x) / bf16(W^T) per row, chunk pairs (0,1) and (2,3) feed two v_mfma_f32_32x32x16_bf16 per
-// block, fp32 accumulate; everything after the contraction is identical.
-template <int EPI, int NG, int NP>
+// AR = 0: the split-fp16 scheme above (three products).  AR = 1 / 2: single product on bf16 / fp16 operands: the same
+// 16 KB images hold 32 consecutive k of the rounded x / W^T per row, chunk pairs (0,1) and (2,3) feed two
+// v_mfma_f32_32x32x16_{bf16,f16} per block, fp32 accumulate; everything after the contraction is identical.  AR = 2
+// is the first pass of SAEV_ENCODER_F16R: its pre-activations carry a bounded rounding error, the candidate cut is
+// lowered by a per-row margin (a.row_margin) and select.hip recomputes the survivors exactly in fp32.
+template <int EPI, int NG, int AR>
 __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     HSmem& sm = *reinterpret_cast<HSmem*>(smem_raw);
@@ -109,6 +117,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
 
     constexpr int NSLOT = NG / 2;
 
+    constexpr int NP = AR == 0 ? 3 : 1;
     const int nks = Dp / (NP == 3 ? 16 : 32);  // k-steps per tile
     // The 8 workgroups of an XCD that stream the same W images (same latent range, different batch block) walk the
     // k-steps in an order rotated by one step each, so they do not hit the same 16 KB at the same moment but stay
@@ -190,13 +199,13 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                     acc[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[0][0], acc[sb][0], 0, 0, 0);
                     acc[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[as][1], fb[1][0], acc[sb][1], 0, 0, 0);
                 } else {
-                    acc[sb][0] = mfma_bf16(fa[as][0], fb[0][0], acc[sb][0]);
+                    acc[sb][0] = mfma1<AR>(fa[as][0], fb[0][0], acc[sb][0]);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (sb + 2 < 4) load_a((sb + 2) % 3, sb + 2);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[sb][1] = mfma_bf16(fa[as][0], fb[1][0], acc[sb][1]);
-                    acc[sb][0] = mfma_bf16(fa[as][1], fb[0][1], acc[sb][0]);
-                    acc[sb][1] = mfma_bf16(fa[as][1], fb[1][1], acc[sb][1]);
+                    acc[sb][1] = mfma1<AR>(fa[as][0], fb[1][0], acc[sb][1]);
+                    acc[sb][0] = mfma1<AR>(fa[as][1], fb[0][1], acc[sb][0]);
+                    acc[sb][1] = mfma1<AR>(fa[as][1], fb[1][1], acc[sb][1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -320,7 +329,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             for (int jb = 0; jb < 2; ++jb) {
                 // a finite bound: padded latents carry -inf and must never pass (a row whose bound is still -inf has seen
                 // fewer than k groups with a real value; everything real passes then)
-                const float tau = fmaxf(key2f(sm.tau_key[wb * 64 + jb * 32 + l31]), -3.0e38f);
+                float tau = fmaxf(key2f(sm.tau_key[wb * 64 + jb * 32 + l31]), -3.0e38f);
+                if (a.row_margin != nullptr) {  // approximate first pass: keep everything that could still be in the exact top-k
+                    const int b = b0 + wb * 64 + jb * 32 + l31;
+                    tau -= (b < B) ? a.row_margin[b] : 0.f;
+                }
                 tau2[jb] = tau;
                 int n = 0;
 #pragma unroll
@@ -378,12 +391,15 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
     const size_t smem = sizeof(HSmem);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[6] = {reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 3>),
-                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 3>),
-                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 3>),
+        const void* fns[9] = {reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 0>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 0>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 0>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 1>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 1>),
-                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 1>)};
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 1>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 2>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 2>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 2>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
@@ -391,14 +407,16 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
         attr_set = true;
     }
 #define LAUNCH_ENC(E, G, N) hipLaunchKernelGGL((encode_f16x3_kernel<E, G, N>), grid, block, smem, stream, a)
-    const bool one = a.nprod == 1;
-    if (epi == EPI_DENSE) {
-        if (one) LAUNCH_ENC(EPI_DENSE, 32, 1); else LAUNCH_ENC(EPI_DENSE, 32, 3);
-    } else if (a.ngroups <= 32) {
-        if (one) LAUNCH_ENC(EPI_TOPK, 32, 1); else LAUNCH_ENC(EPI_TOPK, 32, 3);
-    } else {
-        if (one) LAUNCH_ENC(EPI_TOPK, 64, 1); else LAUNCH_ENC(EPI_TOPK, 64, 3);
-    }
+#define LAUNCH_AR(E, G)                                   \
+    do {                                                  \
+        if (a.arith == 1) LAUNCH_ENC(E, G, 1);            \
+        else if (a.arith == 2) LAUNCH_ENC(E, G, 2);       \
+        else LAUNCH_ENC(E, G, 0);                         \
+    } while (0)
+    if (epi == EPI_DENSE) LAUNCH_AR(EPI_DENSE, 32);
+    else if (a.ngroups <= 32) LAUNCH_AR(EPI_TOPK, 32);
+    else LAUNCH_AR(EPI_TOPK, 64);
+#undef LAUNCH_AR
 #undef LAUNCH_ENC
     return hipGetLastError();
 }

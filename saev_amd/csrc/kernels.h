@@ -58,11 +58,26 @@ struct SelectCandArgs {
     int out_stride;
     const int32_t* enable_flag;
     int enable_when;
+    // exact refinement (SAEV_ENCODER_F16R): candidate values are approximate (|error| <= row_margin / 2); the entries
+    // within row_margin of the k-th largest are recomputed in fp32 from x and W_enc^T before the final cut
+    const float* row_margin;  // (n_rows) or NULL = values are exact already
+    const float* x;           // (n_rows, D)
+    const float* W_encT;      // (S, D)
+    const float* b_enc;       // (S)
+    int D;
+    int32_t* surv_idx;        // (n_rows, REFINE_CAP) survivors of the approximate cut
+    float* surv_val;          // (n_rows, REFINE_CAP) their exact pre-activations (refine_exact_kernel)
+    int32_t* surv_cnt;        // (n_rows)
+    int32_t* refine_overflow; // set to 1 when a row has more than REFINE_CAP survivors (caller re-runs it densely)
 };
+hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream);
+constexpr int REFINE_CAP = 512;
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream);
 hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream);
+hipError_t launch_row_margins(const float* x, int n, int D, const float* W_encT, int S, float* wg_scratch, float* wmax,
+                              float* margin, hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                  int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);
 
@@ -198,7 +213,9 @@ struct EncodeF16Args {
     const float* b_enc;       // (S)
     int n_rows, Dp, S;
     float w_scale;
-    int nprod;                // 3: fp16 hi/lo split, three products (fp32-accurate); 1: bf16 operands, one product
+    int arith;                // image mode of the operands: 0 fp16 hi/lo, three products (fp32-accurate); 1 bf16, 2 fp16:
+                              // one product
+    const float* row_margin;  // (n_rows) or NULL: candidates are kept down to bound - row_margin[row] (EPI_TOPK)
     int s_splits;
     float* h_out;             // EPI_DENSE
     int ngroups;              // EPI_TOPK
@@ -214,8 +231,9 @@ struct EncodeF16Args {
 hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream);
 int encode_f16x3_tile_rows();
 int encode_f16x3_tile_latents();
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, bool bf16, hipStream_t stream, float scale = 1.0f);
-hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, bool bf16,
+// image mode: 0 = fp16 hi/lo (16 k per image), 1 = bf16 single, 2 = fp16 single (32 k per image)
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale = 1.0f);
+hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
                            hipStream_t stream);
 
 // ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------

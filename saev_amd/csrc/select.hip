@@ -156,6 +156,24 @@ __global__ __launch_bounds__(SD_THREADS) void select_dense_kernel(SelectDenseArg
 
 // ---------------------------------------------------------------------------------------------
 
+// lane l ends up with the wave-wide sum of p[(l >> 3) & 7] (see sparse.hip wave_reduce_scatter)
+__device__ __forceinline__ float wave_reduce_scatter8(float (&p)[8], int lane) {
+    int bit = 32;
+#pragma unroll
+    for (int h = 4; h >= 1; h >>= 1, bit >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const float keep = up ? p[i + h] : p[i];
+            const float send = up ? p[i] : p[i + h];
+            p[i] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    float r = p[0];
+    for (; bit >= 1; bit >>= 1) r += __shfl_xor(r, bit, 64);
+    return r;
+}
+
 template <int EPL>  // elements per lane: handles lists of up to 64*EPL candidates
 __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row, int n, int32_t (&s_idx)[4][64],
                                                 float (&s_val)[4][64]) {
@@ -174,14 +192,39 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
         else { key[e] = 0u; idx[e] = 0x7fffffff; }  // key 0 sorts below every real float key
     }
     // largest T with count(key >= T) >= k
-    uint32_t T = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t trial = T | (1u << bit);
-        // wave-wide count through ballots: scalar popcounts, no cross-lane shuffle chain per bit
-        int c = 0;
+    auto kth_largest = [&]() {
+        uint32_t t = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = t | (1u << bit);
+            // wave-wide count through ballots: scalar popcounts, no cross-lane shuffle chain per bit
+            int c = 0;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(key[e] >= trial));
-        if (c >= k) T = trial;
+            for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(key[e] >= trial));
+            if (c >= k) t = trial;
+        }
+        return t;
+    };
+    uint32_t T = kth_largest();
+    if (a.row_margin != nullptr) {
+        // The values are approximate (first pass of SAEV_ENCODER_F16R).  Every member of the exact top-k has an
+        // approximate value >= (k-th largest approximate value) - row_margin: emit those survivors; refine_exact_kernel
+        // recomputes them in fp32 and a second run of this kernel (exact values, no margin) makes the final cut.
+        const uint32_t key_lo = f2ukey(ukey2f(T) - a.row_margin[row]);
+        int32_t* so = a.surv_idx + (size_t)row * REFINE_CAP;
+        int base = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const bool sv = key[e] >= key_lo && idx[e] != 0x7fffffff;
+            const unsigned long long m = __ballot(sv);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (sv && pos < REFINE_CAP) so[pos] = idx[e];
+            base += __popcll(m);
+        }
+        if (lane == 0) {
+            a.surv_cnt[row] = min(base, REFINE_CAP);
+            if (base > REFINE_CAP) *a.refine_overflow = 1;  // the caller's dense route redoes the launch exactly
+        }
+        return;
     }
     int cgt = 0, ceq = 0;
 #pragma unroll
@@ -269,6 +312,95 @@ __global__ void step_zero_kernel(saev_step_stats* stats, float* upper, int32_t* 
     }
 }
 
+// exact pre-activations of the survivors: h = <x_row, W_enc^T[idx]> + b_enc[idx] in fp32, one wave per row, eight
+// survivors at a time with all their row loads in flight; the x row stays in registers.
+template <int NV>
+__global__ __launch_bounds__(256) void refine_exact_kernel(SelectCandArgs a) {
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int ns = a.surv_cnt[row];
+    const int D4 = a.D >> 2;
+    f32x4 xv[NV];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(a.x + (size_t)row * a.D);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) xv[n] = (lane + 64 * n < D4) ? xr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int32_t* si = a.surv_idx + (size_t)row * REFINE_CAP;
+    float* sv = a.surv_val + (size_t)row * REFINE_CAP;
+    for (int j0 = 0; j0 < ns; j0 += 8) {
+        const int32_t my = si[min(j0 + (lane & 7), ns - 1)];
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int32_t li = __shfl(my, t, 64);
+            const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_encT + (size_t)li * a.D);
+            float acc = 0.f;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                if (lane + 64 * n < D4) {
+                    const f32x4 wv = wr[lane + 64 * n];
+                    acc += xv[n][0] * wv[0] + xv[n][1] * wv[1] + xv[n][2] * wv[2] + xv[n][3] * wv[3];
+                }
+            }
+            p[t] = acc;
+        }
+        const float r = wave_reduce_scatter8(p, lane);  // lane l holds the sum of slot (l >> 3) & 7
+        if ((lane & 7) == 0) {
+            const int t = lane >> 3;
+            if (j0 + t < ns) sv[j0 + t] = r + a.b_enc[si[j0 + t]];
+        }
+    }
+}
+
+// max over rows of the L2 norm of an (R x D) matrix: one wave per row, per-workgroup maxima, then one small pass
+__global__ __launch_bounds__(256) void rownorm_wgmax_kernel(const float* m, int R, int D, float* wg_max) {
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    float s = 0.f;
+    if (r < R) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(m + (size_t)r * D);
+        for (int q = lane; q < (D >> 2); q += 64) {
+            const f32x4 v = p[q];
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        s = wave_sum(s);
+    }
+    if (lane == 0) sh[w] = sqrtf(s);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n, float* out) {
+    __shared__ float sh[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, v[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t = fmaxf(t, sh[i]);
+        *out = t;
+    }
+}
+// margin[b] = 2 E_b with E_b = 1.2 * 2^-10 * (||x_b|| + 1e-3) * max_s ||W_enc[:, s]||: an upper bound of the error of a
+// pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products, fp32 accumulation), by
+// Cauchy-Schwarz; see DESIGN.md 3.1 (F16R).
+__global__ __launch_bounds__(256) void row_margin_kernel(const float* x, int n, int D, const float* wmax, float* margin) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + (size_t)r * D);
+    float s = 0.f;
+    for (int q = lane; q < (D >> 2); q += 64) {
+        const f32x4 v = p[q];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) margin[r] = 2.0f * 1.2f * 0.0009765625f * (sqrtf(s) + 1e-3f) * (*wmax);
+}
+
 // need_dense = pre_flag || any(cand_cnt > cap); also counts overflowing rows
 __global__ void overflow_check_kernel(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                       int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max) {
@@ -318,6 +450,27 @@ hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int
 }
 hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream) {
     hipLaunchKernelGGL(step_zero_kernel, dim3(1), dim3(64), 0, stream, stats, upper, flag0);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_margins(const float* x, int n, int D, const float* W_encT, int S, float* wg_scratch, float* wmax,
+                              float* margin, hipStream_t stream) {
+    const int nwg = (S + 3) / 4;
+    hipLaunchKernelGGL(rownorm_wgmax_kernel, dim3(nwg), dim3(256), 0, stream, W_encT, S, D, wg_scratch);
+    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, wg_scratch, nwg, wmax);
+    hipLaunchKernelGGL(row_margin_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, D, wmax, margin);
+    return hipGetLastError();
+}
+
+hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    const dim3 grid((a.n_rows + 3) / 4), block(256);
+    const int nv = (a.D / 4 + 63) / 64;
+#define RF(N) hipLaunchKernelGGL(refine_exact_kernel<N>, grid, block, 0, stream, a)
+    if (nv <= 1) RF(1); else if (nv <= 2) RF(2); else if (nv <= 3) RF(3); else if (nv <= 4) RF(4);
+    else if (nv <= 6) RF(6); else if (nv <= 8) RF(8); else if (nv <= 12) RF(12); else if (nv <= 16) RF(16);
+    else return hipErrorInvalidValue;
+#undef RF
     return hipGetLastError();
 }
 

@@ -13,8 +13,8 @@
 // Rows beyond n / S and k beyond D are written as zeros where the kernels cover them; x padding rows are
 // zeroed once at context creation.
 //
-// BF16 = true (the single-product bf16 encoder): same images, but a row's 4 chunks are 32 consecutive k of one
-// bf16 value each (chunk c = k 8c..8c+7 of a 32-wide k-step, nks = Dp / 32), no scaling, round to nearest even.
+// MODE 1 / 2 (the single-product encoders, bf16 / fp16): same images, but a row's 4 chunks are 32 consecutive k of
+// one rounded value each (chunk c = k 8c..8c+7 of a 32-wide k-step, nks = Dp / 32), round to nearest even.
 #include "common.h"
 #include "kernels.h"
 
@@ -40,9 +40,15 @@ __device__ __forceinline__ half8 round8_bf16(const float (&v)[8]) {
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
     return __builtin_bit_cast(half8, o);
 }
+template <int MODE>
+__device__ __forceinline__ half8 pack8(const float (&v)[8], int part) {
+    if constexpr (MODE == 0) return split8(v, part);
+    else if constexpr (MODE == 1) return round8_bf16(v);
+    else return split8(v, 0);  // fp16(v), single
+}
 
 // one thread = one 16-byte chunk of the image; grid.x = ceil(n/256) * nks images, 1024 threads each
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks, float scale,
                                                           _Float16* __restrict__ xs) {
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
     const int rl = i >> 2, p = i & 3;
     const int c = p ^ ((rl >> 2) & 3);
     const int part = c >> 1, h = c & 1;
-    const int r = blk * 256 + rl, k = BF16 ? ks * 32 + c * 8 : ks * 16 + h * 8;
+    const int r = blk * 256 + rl, k = MODE != 0 ? ks * 32 + c * 8 : ks * 16 + h * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (r < n && k < D) {  // D % 4 == 0: load in two float4s, the second may fall off the end
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k);
@@ -60,15 +66,15 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
             v[4] = b[0] * scale; v[5] = b[1] * scale; v[6] = b[2] * scale; v[7] = b[3] * scale;
         }
     }
-    reinterpret_cast<half8*>(xs + (size_t)blockIdx.x * 256 * 32)[i] = BF16 ? round8_bf16(v) : split8(v, part);
+    reinterpret_cast<half8*>(xs + (size_t)blockIdx.x * 256 * 32)[i] = pack8<MODE>(v, part);
 }
 
 // one workgroup = one image of W_enc^T: 256 latents x 16 k (32 k for bf16).  The k-rows of W_enc (1 KB each) are
 // read coalesced into LDS, then every thread assembles its chunk from a column.
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict__ W, int D, int S, int nks, float scale,
                                                         _Float16* __restrict__ ws) {
-    constexpr int KS = BF16 ? 32 : 16;
+    constexpr int KS = MODE != 0 ? 32 : 16;
     __shared__ float tile[KS][257];
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
     const int s0 = blk * 256, k0 = ks * KS;
@@ -84,32 +90,29 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
     const int part = c >> 1, h = c & 1;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = tile[(BF16 ? c : h) * 8 + e][rl];
-    reinterpret_cast<half8*>(ws + (size_t)blockIdx.x * 256 * 32)[i] = BF16 ? round8_bf16(v) : split8(v, part);
+    for (int e = 0; e < 8; ++e) v[e] = tile[(MODE != 0 ? c : h) * 8 + e][rl];
+    reinterpret_cast<half8*>(ws + (size_t)blockIdx.x * 256 * 32)[i] = pack8<MODE>(v, part);
 }
 
 }  // namespace
 
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, bool bf16, hipStream_t stream, float scale) {
-    const int nks = Dp / (bf16 ? 32 : 16), nblk = (n + 255) / 256;
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale) {
+    const int nks = Dp / (mode != 0 ? 32 : 16), nblk = (n + 255) / 256;
     if (nblk <= 0) return hipSuccess;
-    if (bf16)
-        hipLaunchKernelGGL(split_rows_kernel<true>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale,
-                           reinterpret_cast<_Float16*>(xs));
-    else
-        hipLaunchKernelGGL(split_rows_kernel<false>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale,
-                           reinterpret_cast<_Float16*>(xs));
+    _Float16* o = reinterpret_cast<_Float16*>(xs);
+    if (mode == 1) hipLaunchKernelGGL(split_rows_kernel<1>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, o);
+    else if (mode == 2) hipLaunchKernelGGL(split_rows_kernel<2>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, o);
+    else hipLaunchKernelGGL(split_rows_kernel<0>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, o);
     return hipGetLastError();
 }
 
-hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, bool bf16,
+hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
                            hipStream_t stream) {
-    const int nks = Dp / (bf16 ? 32 : 16);
-    if (bf16)
-        hipLaunchKernelGGL(split_wT_kernel<true>, dim3((S_pad / 256) * nks), dim3(1024), 0, stream, W, D, S, nks, scale,
-                           reinterpret_cast<_Float16*>(ws));
-    else
-        hipLaunchKernelGGL(split_wT_kernel<false>, dim3((S_pad / 256) * nks), dim3(1024), 0, stream, W, D, S, nks, scale,
-                           reinterpret_cast<_Float16*>(ws));
+    const int nks = Dp / (mode != 0 ? 32 : 16);
+    const dim3 grid((S_pad / 256) * nks);
+    _Float16* o = reinterpret_cast<_Float16*>(ws);
+    if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, o);
+    else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, o);
+    else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, o);
     return hipGetLastError();
 }

@@ -33,7 +33,8 @@ class EngineConfig:
     remove_parallel_grads: bool = True
     max_batch: int = 16384
     # "f32": exact fp32 MFMA; "f16x3": split-fp16 MFMA at fp32 accuracy (16/3 of the f32 matrix rate);
-    # "bf16": bf16-rounded encoder operands, one MFMA product, fp32 accumulate (everything else stays fp32).
+    # "bf16": bf16-rounded encoder operands, one MFMA product, fp32 accumulate (everything else stays fp32);
+    # "f16r": one fp16 MFMA product as a bounded-error first pass + exact fp32 recomputation of the surviving candidates.
     # The default can be overridden with the SAEV_AMD_ENCODER environment variable.
     encoder: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_ENCODER", DEFAULT_ENCODER))
 
@@ -90,7 +91,7 @@ class SaeEngine:
                 d_model=D, d_sae=S, top_k=cfg.top_k, k_aux=cfg.k_aux, alpha=cfg.alpha,
                 dead_threshold_tokens=cfg.dead_threshold_tokens,
                 normalize_w_dec=int(cfg.normalize_w_dec), remove_parallel_grads=int(cfg.remove_parallel_grads),
-                max_batch=cfg.max_batch, encoder_mode={"f32": 0, "f16x3": 1, "bf16": 2}[cfg.encoder],
+                max_batch=cfg.max_batch, encoder_mode={"f32": 0, "f16x3": 1, "bf16": 2, "f16r": 3}[cfg.encoder],
             )
             ctx = C.c_void_p()
             rc = self.lib.saev_create(C.byref(ccfg), self.device.index, C.byref(ctx))

@@ -42,7 +42,7 @@ def golden():
     return load_golden
 
 
-@pytest.fixture(params=["f32", "f16x3"], autouse=True)
+@pytest.fixture(params=["f32", "f16x3", "f16r"], autouse=True)
 def encoder_mode(request, monkeypatch):
     """GPU tests run once per encoder arithmetic (both are fp32-accurate); CPU tests ignore it."""
     if "gpu" not in request.keywords:

@@ -160,17 +160,22 @@ def main():
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                 "kernel_ms": enc_ms, "traffic": None}
         # HBM/fabric bytes per launch of that kernel come from rocprofv3 PMC passes (they cannot be collected inside the
-        # timed run); the committed summary is the source, and it only applies to the shape/encoder it was taken on
-        tfile = ROOT / "profiles" / "r01_d_encoder_traffic.json"
-        if f16x3 and B == BATCH and tfile.exists():
+        # timed run); the committed summaries are the source, and they only apply to the shape/encoder they were taken on
+        tfile = {"f16x3": ROOT / "profiles" / "r01_d_encoder_traffic.json",
+                 "f16r": ROOT / "profiles" / "r01_e_encoder_traffic.json"}.get(eng.cfg.encoder)
+        if tfile is not None and B == BATCH and tfile.exists():
             tj = json.loads(tfile.read_text())
             roof["traffic"] = tj["traffic_bytes_per_launch"]
             roof["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
             roof["traffic_source"] = tj["source"]
-            roof["algorithmic_bytes"] = 4.0 * (B * D_MODEL + D_MODEL * D_SAE) + 8.0 * B * 1000  # operands once + ~1k candidates/row
+            op_bytes = 4.0 if f16x3 else 2.0  # bytes per operand element in the staged images (hi+lo fp16 / single fp16)
+            roof["algorithmic_bytes"] = op_bytes * (B * D_MODEL + D_MODEL * D_SAE) + 8.0 * B * 1000  # operands once + ~1k candidates/row
         if f16x3 and achieved:
             roof["executed_tflops"] = 3 * achieved
             roof["executed_frac"] = 3 * achieved / peak
+        if eng.cfg.encoder == "f16r":
+            roof["note"] = ("first pass only (one fp16 MFMA per product, flops = 2*B*D*S); the exact fp32 refinement of the "
+                            "~45 survivors per row (refine_exact_kernel, 0.24 ms) and the selects are separate kernels inside ms_per_step")
         out = {
             "metric": "activations/sec (train step), d_in=1024 x32 k=32",
             "value": B * world * args.steps / dt,

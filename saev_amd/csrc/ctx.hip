@@ -76,6 +76,7 @@ struct saev_ctx {
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
     float *row_margin = nullptr, *wmax = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
     int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
+    float *f16r_scales = nullptr, *xabs = nullptr;
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -207,7 +208,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
         A(zero_bias, std::max(S, D));
-        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4);
+        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 2); A(xabs, 1);
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
@@ -371,21 +372,31 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
     return SAEV_OK;
 }
 
-// operand preparation for the f16x3 encoder: split x and W_enc^T into fp16 hi/lo (no-op for the f32 encoder)
-static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s) {
+// operand preparation for the f16 encoders: x and W_enc^T rewritten as fp16 / bf16 images (no-op for the f32 encoder).
+// `xmax_dev` = device scalar max|x| when the caller has it already (the step computes it for the MSE), else NULL.
+static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s, const float* xmax_dev = nullptr) {
     if (c->cfg.encoder_mode == SAEV_ENCODER_F32) return SAEV_OK;
+    const int D = c->cfg.d_model, S = c->cfg.d_sae;
     const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
-    const int mode = bf ? 1 : (c->cfg.encoder_mode == SAEV_ENCODER_F16R ? 2 : 0);
-    HIPCHK(c, launch_split_rows(x, n, c->cfg.d_model, c->Dp, c->xs, mode, s));
-    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, c->cfg.d_model, c->cfg.d_sae, c->S_pad, c->Dp, bf ? 1.0f : 256.0f,
-                              c->ws, mode, s));
-    if (mode == 2) {
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
         // the exact refinement reads encoder columns as rows: W_enc^T in fp32 (the gradient scratch dW_encT is free
-        // until the backward), and the margins that make the approximate cut safe
-        HIPCHK(c, launch_transpose(c->params + c->off_W_enc, c->dW_encT, c->cfg.d_model, c->cfg.d_sae, s));
-        HIPCHK(c, launch_row_margins(x, n, c->cfg.d_model, c->dW_encT, c->cfg.d_sae, c->wnorm_scratch, c->wmax,
-                                     c->row_margin, s));
+        // until the backward); its largest row norm and max|x| give the power-of-two operand scales and the margins
+        // that make the approximate cut safe
+        HIPCHK(c, launch_transpose(c->params + c->off_W_enc, c->dW_encT, D, S, s));
+        HIPCHK(c, launch_wnorm_max(c->dW_encT, S, D, c->wnorm_scratch, c->wmax, s));
+        if (xmax_dev == nullptr) {
+            HIPCHK(c, hipMemsetAsync(c->xabs, 0, sizeof(float), s));
+            HIPCHK(c, launch_absmax(x, (long)n * D, c->xabs, s));
+            xmax_dev = c->xabs;
+        }
+        HIPCHK(c, launch_f16r_scales(xmax_dev, c->wmax, c->f16r_scales, s));
+        HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales));
+        HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1));
+        HIPCHK(c, launch_row_margins(x, n, D, c->wmax, c->row_margin, s));
+        return SAEV_OK;
     }
+    HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
+    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, bf ? 1.0f : 256.0f, c->ws, bf ? 1 : 0, s));
     return SAEV_OK;
 }
 
@@ -398,7 +409,8 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         EncodeF16Args a{};
         a.xs = c->xs; a.ws = c->ws;
         a.b_enc = c->params + c->off_b_enc;
-        a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = bf ? 1.0f : 256.0f;
+        a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = (bf || f16r) ? 1.0f : 256.0f;
+        a.scale_dev = f16r ? c->f16r_scales : nullptr;
         a.arith = bf ? 1 : (f16r ? 2 : 0);
         a.row_margin = f16r ? c->row_margin : nullptr;
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
@@ -457,11 +469,11 @@ int saev_topk_dense(saev_ctx* c, const float* h, int32_t n, int32_t k, const int
 
 // encode + top-k into (idx_out, val_out); fused path with exact dense fallback on overflow
 static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out, float* val_out,
-                            const int32_t* pre_flag, hipStream_t s) {
+                            const int32_t* pre_flag, hipStream_t s, const float* xmax_dev = nullptr) {
     const int K = c->cfg.top_k;
     int32_t* need_dense = c->flags + 1;
     {
-        int rc0 = prepare_encoder(c, x, n, s);
+        int rc0 = prepare_encoder(c, x, n, s, xmax_dev);
         if (rc0 != SAEV_OK) return rc0;
     }
     timing_begin(c, s);
@@ -594,7 +606,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));  // flags[0]: force-dense flag, unused by the step
     HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
     (void)n_rows_global;
-    int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s);
+    int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s, c->upper);
     if (rc != SAEV_OK) return rc;
 
     DecodeArgs a{};

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
         // ---------------- epilogue ----------------
         // lane owns batch rows bl(jb) = wb*64 + jb*32 + l31; latent of acc[sb][jb][r]:
         //   sl = ws*128 + sb*32 + 8*(r>>2) + 4*half + (r&3);   acc holds 2^8 * (x . w)
-        const float unscale = 1.0f / a.w_scale;
+        const float unscale = a.scale_dev != nullptr ? 1.0f / (a.w_scale * a.scale_dev[0] * a.scale_dev[1]) : 1.0f / a.w_scale;
         if (EPI == EPI_DENSE) {
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {

@@ -76,8 +76,9 @@ hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream);
 hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream);
-hipError_t launch_row_margins(const float* x, int n, int D, const float* W_encT, int S, float* wg_scratch, float* wmax,
-                              float* margin, hipStream_t stream);
+hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream);
+hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream);
+hipError_t launch_row_margins(const float* x, int n, int D, const float* wmax, float* margin, hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                  int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);
 
@@ -216,6 +217,7 @@ struct EncodeF16Args {
     int arith;                // image mode of the operands: 0 fp16 hi/lo, three products (fp32-accurate); 1 bf16, 2 fp16:
                               // one product
     const float* row_margin;  // (n_rows) or NULL: candidates are kept down to bound - row_margin[row] (EPI_TOPK)
+    const float* scale_dev;   // NULL or two device floats: extra power-of-two scales of the x and W images
     int s_splits;
     float* h_out;             // EPI_DENSE
     int ngroups;              // EPI_TOPK
@@ -232,9 +234,10 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
 int encode_f16x3_tile_rows();
 int encode_f16x3_tile_latents();
 // image mode: 0 = fp16 hi/lo (16 k per image), 1 = bf16 single, 2 = fp16 single (32 k per image)
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale = 1.0f);
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale = 1.0f,
+                             const float* scale_dev = nullptr);  // effective scale = scale * *scale_dev
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
-                           hipStream_t stream);
+                           hipStream_t stream, const float* scale_dev = nullptr);
 
 // ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------
 hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s);

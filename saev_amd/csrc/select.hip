@@ -384,9 +384,11 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n,
         *out = t;
     }
 }
-// margin[b] = 2 E_b with E_b = 1.2 * 2^-10 * (||x_b|| + 1e-3) * max_s ||W_enc[:, s]||: an upper bound of the error of a
-// pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products, fp32 accumulation), by
-// Cauchy-Schwarz; see DESIGN.md 3.1 (F16R).
+// margin[b] = 2 E_b, E_b = 1.05 * (2^-10 + D * 2^-22) * ||x_b|| * max_s ||W_enc[:, s]||: an upper bound of the error of a
+// pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products; 2^-10 by Cauchy-Schwarz) plus
+// the fp32 accumulation of D terms (counted at 2^-22 per add so that a truncating adder is covered).  The operands are
+// pre-scaled so that their largest element sits in [2^13, 2^14): whatever the matrix cores do with fp16 subnormals
+// (flush or keep) then changes a pre-activation by less than 3e-7 of the same product of norms.  DESIGN.md 3.1.
 __global__ __launch_bounds__(256) void row_margin_kernel(const float* x, int n, int D, const float* wmax, float* margin) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -398,7 +400,16 @@ __global__ __launch_bounds__(256) void row_margin_kernel(const float* x, int n, 
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     s = wave_sum(s);
-    if (lane == 0) margin[r] = 2.0f * 1.2f * 0.0009765625f * (sqrtf(s) + 1e-3f) * (*wmax);
+    const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
+    if (lane == 0) margin[r] = coef * sqrtf(s) * (*wmax);
+}
+// power-of-two scales that put the largest |x| and the largest encoder column norm (>= largest |w|) into [2^13, 2^14)
+__global__ void f16r_scales_kernel(const float* xmax, const float* wmax, float* scales) {
+    if (threadIdx.x == 0) {
+        const float xm = *xmax, wm = *wmax;
+        scales[0] = (xm > 0.f && xm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(xm))) : 1.0f;
+        scales[1] = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
+    }
 }
 
 // need_dense = pre_flag || any(cand_cnt > cap); also counts overflowing rows
@@ -453,11 +464,17 @@ hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0
     return hipGetLastError();
 }
 
-hipError_t launch_row_margins(const float* x, int n, int D, const float* W_encT, int S, float* wg_scratch, float* wmax,
-                              float* margin, hipStream_t stream) {
+hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream) {
     const int nwg = (S + 3) / 4;
     hipLaunchKernelGGL(rownorm_wgmax_kernel, dim3(nwg), dim3(256), 0, stream, W_encT, S, D, wg_scratch);
     hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, wg_scratch, nwg, wmax);
+    return hipGetLastError();
+}
+hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream) {
+    hipLaunchKernelGGL(f16r_scales_kernel, dim3(1), dim3(64), 0, stream, xmax, wmax, scales);
+    return hipGetLastError();
+}
+hipError_t launch_row_margins(const float* x, int n, int D, const float* wmax, float* margin, hipStream_t stream) {
     hipLaunchKernelGGL(row_margin_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, D, wmax, margin);
     return hipGetLastError();
 }

@@ -50,7 +50,8 @@ __device__ __forceinline__ half8 pack8(const float (&v)[8], int part) {
 // one thread = one 16-byte chunk of the image; grid.x = ceil(n/256) * nks images, 1024 threads each
 template <int MODE>
 __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks, float scale,
-                                                          _Float16* __restrict__ xs) {
+                                                          const float* __restrict__ scale_dev, _Float16* __restrict__ xs) {
+    if (scale_dev != nullptr) scale *= *scale_dev;
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
     const int i = threadIdx.x;           // chunk index inside the image
     const int rl = i >> 2, p = i & 3;
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
 // read coalesced into LDS, then every thread assembles its chunk from a column.
 template <int MODE>
 __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict__ W, int D, int S, int nks, float scale,
-                                                        _Float16* __restrict__ ws) {
+                                                        const float* __restrict__ scale_dev, _Float16* __restrict__ ws) {
+    if (scale_dev != nullptr) scale *= *scale_dev;
     constexpr int KS = MODE != 0 ? 32 : 16;
     __shared__ float tile[KS][257];
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
@@ -96,23 +98,24 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
 
 }  // namespace
 
-hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale) {
+hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale,
+                             const float* scale_dev) {
     const int nks = Dp / (mode != 0 ? 32 : 16), nblk = (n + 255) / 256;
     if (nblk <= 0) return hipSuccess;
     _Float16* o = reinterpret_cast<_Float16*>(xs);
-    if (mode == 1) hipLaunchKernelGGL(split_rows_kernel<1>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, o);
-    else if (mode == 2) hipLaunchKernelGGL(split_rows_kernel<2>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, o);
-    else hipLaunchKernelGGL(split_rows_kernel<0>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, o);
+    if (mode == 1) hipLaunchKernelGGL(split_rows_kernel<1>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, o);
+    else if (mode == 2) hipLaunchKernelGGL(split_rows_kernel<2>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, o);
+    else hipLaunchKernelGGL(split_rows_kernel<0>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, o);
     return hipGetLastError();
 }
 
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
-                           hipStream_t stream) {
+                           hipStream_t stream, const float* scale_dev) {
     const int nks = Dp / (mode != 0 ? 32 : 16);
     const dim3 grid((S_pad / 256) * nks);
     _Float16* o = reinterpret_cast<_Float16*>(ws);
-    if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, o);
-    else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, o);
-    else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, o);
+    if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o);
+    else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o);
+    else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o);
     return hipGetLastError();
 }

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 
 
-DEFAULT_ENCODER = "f16x3"
+DEFAULT_ENCODER = "f16r"
 
 
 @dataclasses.dataclass(frozen=True)

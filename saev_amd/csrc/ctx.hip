@@ -71,7 +71,7 @@ struct saev_ctx {
     uint8_t* A_mask = nullptr;
     // AuxK contractions on the f16x3 encoder kernel (F16X3 mode): operand images and compact vectors
     _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr;
-    float *bias_dead = nullptr, *zero_bias = nullptr;
+    float *bias_dead = nullptr, *zero_bias = nullptr, *aux_scales = nullptr;  // aux_scales: {absmax, -, sA, 1, sg, 1}
     int aux_Dp2 = 0;
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
     float *row_margin = nullptr, *wmax = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
@@ -207,8 +207,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         c->MB_pad = (int)((MB + 255) / 256 * 256);
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
-        A(zero_bias, std::max(S, D));
-        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 2); A(xabs, 1);
+        A(zero_bias, std::max(S, D)); A(aux_scales, 8);
+        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(xabs, 1);
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
@@ -714,8 +714,9 @@ int ensure_aux_capacity(saev_ctx* c, int ndp) {
 // the three AuxK contractions whose long axis is the batch are exactly the encoder's shape.  `scale` is the product
 // of the power-of-two scales applied to the two operands when they were split.
 int dense_f16x3(saev_ctx* c, const _Float16* xs, const _Float16* ws, const float* bias, int n_rows, int Dp, int S_out,
-                float scale, float* out, hipStream_t s) {
+                float scale, float* out, hipStream_t s, const float* scale_dev = nullptr) {
     EncodeF16Args a{};
+    a.scale_dev = scale_dev;
     a.xs = xs; a.ws = ws; a.b_enc = bias;
     a.n_rows = n_rows; a.Dp = Dp; a.S = S_out; a.w_scale = scale; a.arith = 0;
     a.s_splits = encoder_splits(n_rows, S_out, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
@@ -746,10 +747,12 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s));
         const _Float16* xs_hl = c->xs;
         if (f16r) {  // the step's x images are single fp16 here: make the hi/lo ones (the buffer is free until the backward)
-            HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s));
+            // (with the step's power-of-two x scale, so that no activation magnitude can overflow fp16)
+            HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->f16r_scales));
             xs_hl = c->aux_xsg;
         }
-        rc = dense_f16x3(c, xs_hl, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->H_dead, s);
+        rc = dense_f16x3(c, xs_hl, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->H_dead, s,
+                         f16r ? c->f16r_scales + 2 : nullptr);
         if (rc != SAEV_OK) return rc;
     } else {
         rc = gemm_nn(c, n, ndp, D, c->x_last, c->Wenc_dead, c->H_dead);  // H = x W_enc[:, dl]
@@ -765,9 +768,13 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
     if (fast) {
         // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
-        HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, 0, s));
+        // (the codes are pre-activations of unknown magnitude: power-of-two scale from their device-side max)
+        HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
+        HIPCHK(c, launch_absmax(c->A_dead, (long)n * ndp, c->aux_scales, s));
+        HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 2, s));
+        HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, 0, s, 1.0f, c->aux_scales + 2));
         HIPCHK(c, launch_split_wT(c->Wdec_dead, ndp, D, (D + 255) / 256 * 256, Dp2, 256.0f, c->aux_ws2, 0, s));
-        rc = dense_f16x3(c, c->aux_xsA, c->aux_ws2, c->zero_bias, n, Dp2, D, 256.0f, c->g_aux, s);
+        rc = dense_f16x3(c, c->aux_xsA, c->aux_ws2, c->zero_bias, n, Dp2, D, 256.0f, c->g_aux, s, c->aux_scales + 2);
     } else {
         rc = gemm_nn(c, n, D, ndp, c->A_dead, c->Wdec_dead, c->g_aux);  // E = A W_dec[dl]
     }
@@ -787,13 +794,15 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     float* dA = c->H_dead;  // H is dead after the select
     int rc;
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
-        // dA = g_aux W_dec[dl]^T.  g_aux carries the factor alpha * 2 / (n D) (~1e-10): bring it to O(residual) with an
-        // exact power of two before the fp16 split; W_dec[dl] rows are already "latent-major", so they split like x.
-        const float gscale = c->cfg.alpha * 2.0f / ((float)n * (float)D);
-        const float sg = std::exp2(-std::floor(std::log2(gscale)));
-        HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, 0, s, sg));
+        // dA = g_aux W_dec[dl]^T.  g_aux carries the factor alpha * 2 / (n D) (~1e-10) times a residual of unknown
+        // magnitude: bring it to [2^13, 2^14) with an exact power of two from its device-side max before the fp16 split;
+        // W_dec[dl] rows are already "latent-major", so they split like x.
+        HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
+        HIPCHK(c, launch_absmax(c->g_aux, (long)n * D, c->aux_scales, s));
+        HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 4, s));
+        HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 4));
         HIPCHK(c, launch_split_rows(c->Wdec_dead, ndp, D, c->Dp, c->aux_ws1, 0, s, 256.0f));
-        rc = dense_f16x3(c, c->aux_xsg, c->aux_ws1, c->zero_bias, n, c->Dp, ndp, sg * 256.0f, dA, s);
+        rc = dense_f16x3(c, c->aux_xsg, c->aux_ws1, c->zero_bias, n, c->Dp, ndp, 256.0f, dA, s, c->aux_scales + 4);
     } else {
         rc = gemm_nt(c, n, ndp, D, c->g_aux, c->Wdec_dead, dA);  // dA = g_aux W_dec[dl]^T
     }

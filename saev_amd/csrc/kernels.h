@@ -78,6 +78,7 @@ hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int
 hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream);
 hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream);
 hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream);
+hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream);
 hipError_t launch_row_margins(const float* x, int n, int D, const float* wmax, float* margin, hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                  int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);

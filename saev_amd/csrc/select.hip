@@ -403,12 +403,23 @@ __global__ __launch_bounds__(256) void row_margin_kernel(const float* x, int n, 
     const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
     if (lane == 0) margin[r] = coef * sqrtf(s) * (*wmax);
 }
+// {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
+// on the device (AuxK codes and gradients)
+__global__ void pow2_scale_kernel(const float* absmax, float* pair) {
+    if (threadIdx.x == 0) {
+        const float m = *absmax;
+        pair[0] = (m > 0.f && m < 3.0e38f) ? exp2f(13.0f - floorf(log2f(m))) : 1.0f;
+        pair[1] = 1.0f;
+    }
+}
 // power-of-two scales that put the largest |x| and the largest encoder column norm (>= largest |w|) into [2^13, 2^14)
 __global__ void f16r_scales_kernel(const float* xmax, const float* wmax, float* scales) {
     if (threadIdx.x == 0) {
         const float xm = *xmax, wm = *wmax;
         scales[0] = (xm > 0.f && xm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(xm))) : 1.0f;
         scales[1] = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
+        scales[2] = scales[0];  // {x scale, 1}: for contractions whose second operand carries a fixed scale (AuxK)
+        scales[3] = 1.0f;
     }
 }
 
@@ -472,6 +483,10 @@ hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch
 }
 hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream) {
     hipLaunchKernelGGL(f16r_scales_kernel, dim3(1), dim3(64), 0, stream, xmax, wmax, scales);
+    return hipGetLastError();
+}
+hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream) {
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, stream, absmax, pair);
     return hipGetLastError();
 }
 hipError_t launch_row_margins(const float* x, int n, int D, const float* wmax, float* margin, hipStream_t stream) {

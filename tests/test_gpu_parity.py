@@ -372,3 +372,35 @@ def test_f16r_refinement_resolves_near_ties_exactly(encoder_mode):
     approx_sets = torch.topk(hh, k, dim=-1).indices.sort(dim=1).values
     exact_sets = exact.indices.sort(dim=1).values
     assert (approx_sets != exact_sets).any(dim=1).float().mean() > 0.05
+
+
+@pytest.mark.parametrize("scale", [3.0e5, 1.0e-6])
+def test_f16r_handles_any_activation_scale(encoder_mode, scale):
+    """fp16 tops out at 65504 and flushes below 6e-8; the f16r images are pre-scaled by a power of two taken from
+    max|x| on the device, so the codes of scaled activations are the codes of the unscaled ones (AuxK included)."""
+    if encoder_mode != "f32":
+        pytest.skip("picks its own encoder mode; run once")
+    d, s, k, n = 64, 1024, 16, 200
+    p = rand_params(d, s, seed=21)
+    p["b_enc"] = torch.zeros(s)  # no biases: a pure scaling of x then scales pre-activations, reconstruction and losses
+    p["b_dec"] = torch.zeros(d)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(22))
+    toks = torch.zeros(s, dtype=torch.int64)
+    toks[::5] = 100
+    out = []
+    for sc in (1.0, scale):
+        eng = make_engine(d, s, k, k_aux=32, thr=100, max_batch=n, encoder="f16r")
+        eng.load_params(p)
+        eng.set_tracker(toks)
+        xs = (x * sc).cuda()
+        eng.step_forward(xs, training=True)
+        eng.step_dead(n)
+        idx, val, _ = eng.last_codes(n)
+        st = eng.read_stats()
+        out.append((idx.cpu(), val.cpu() / sc, st.mse / sc**2, st.aux / sc**2, st.n_dead))
+    assert torch.isfinite(out[1][1]).all()
+    same = (out[0][0] == out[1][0]).all(dim=1).float().mean()
+    assert same > 0.98, same  # a scaled row can only differ where fp32 rounding moves a near-tie
+    torch.testing.assert_close(out[0][1][(out[0][0] == out[1][0])], out[1][1][(out[0][0] == out[1][0])], rtol=2e-5, atol=1e-6)
+    assert math.isclose(out[0][2], out[1][2], rel_tol=1e-3) and math.isclose(out[0][3], out[1][3], rel_tol=1e-2)
+    assert out[0][4] == out[1][4] > 0

@@ -404,3 +404,25 @@ def test_f16r_handles_any_activation_scale(encoder_mode, scale):
     torch.testing.assert_close(out[0][1][(out[0][0] == out[1][0])], out[1][1][(out[0][0] == out[1][0])], rtol=2e-5, atol=1e-6)
     assert math.isclose(out[0][2], out[1][2], rel_tol=1e-3) and math.isclose(out[0][3], out[1][3], rel_tol=1e-2)
     assert out[0][4] == out[1][4] > 0
+
+
+def test_f16r_refinement_overflow_takes_the_exact_dense_route(encoder_mode):
+    """More than 512 latents within the error margin of the cut (here: 700 identical encoder columns that lead every row)
+    cannot be refined in place; the device flag must send the launch down the exact dense route."""
+    if encoder_mode != "f32":
+        pytest.skip("picks its own encoder mode; run once")
+    d, s, k, n = 64, 2048, 16, 96
+    p = rand_params(d, s, seed=31)
+    g = torch.Generator().manual_seed(32)
+    lead = torch.randn(d, 1, generator=g)
+    p["W_enc"][:, :700] = lead  # 700 exact ties per row ...
+    p["b_enc"][:700] = 50.0     # ... far above everything else
+    x = torch.randn(n, d, generator=g)
+    eng = make_engine(d, s, k, k_aux=0, max_batch=n, encoder="f16r")
+    eng.load_params(p)
+    idx, val = eng.encode_topk(x.cuda())
+    h = R.encode_pre(x, p["W_enc"], p["b_enc"])
+    want = torch.topk(h, k, dim=-1).values
+    torch.testing.assert_close(val.cpu().sort(dim=-1, descending=True).values, want, rtol=1e-5, atol=1e-5)
+    assert (idx.cpu() < 700).all(), "all winners come from the tied block"
+    torch.testing.assert_close(h.gather(1, idx.cpu().long()), val.cpu(), rtol=1e-5, atol=1e-5)

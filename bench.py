@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--encoder", choices=["f32", "f16x3", "bf16", "f16r"], default=None, help="encoder arithmetic (default: engine default)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="bucketed gradient all-reduce overlapped with the backward instead of one flat all-reduce after it")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL init + per-step collectives) even with one rank")
     args = ap.parse_args()
@@ -114,7 +116,7 @@ def main():
     pool = torch.randn(POOL_BATCHES * B, D_MODEL, device=dev, generator=g) + mu
     perm = torch.randperm(pool.shape[0], device=dev, generator=g)
     x = torch.empty(B, D_MODEL, device=dev)
-    stepper = DataParallelStepper(eng, dist, world, force=args.force_dist)
+    stepper = DataParallelStepper(eng, dist, world, force=args.force_dist, overlap=args.overlap)
     lr_sched = lambda i: 4e-4 * min(1.0, i / 500)  # noqa: E731  warm-up region of the reference schedule
 
     def one_step(i):
@@ -187,17 +189,25 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[1]: d_in={D_MODEL}, d_sae={D_SAE} (32x), k={TOP_K}, batch={B}/GPU, "
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder,
+                       "grad_exchange": ("none" if stepper.dist is None else
+                                         ("bucketed all-reduce overlapped with the backward" if stepper.overlap else "one flat all-reduce"))},
             "mse_last": stats.mse, "n_overflow_rows": stats.n_overflow_rows, "cand_max": stats.cand_max,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if dist is not None:
-        dist.destroy_process_group()  # before the result line: RCCL may print its own banner lines on stdout
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    sys.stderr.flush()
     if rank == 0:
-        sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        # RCCL prints a version banner on stdout when the process exits normally; leave without running exit handlers so
+        # that the result line stays the last thing on stdout (everything is flushed, the process group is gone)
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -162,6 +162,20 @@ int saev_step_dead(saev_ctx* ctx, int64_t n_rows_global, void* stream);
 /* Phase 3: all four parameter gradients into the bound grad buffer (replaces autograd,
  * train.py:347-348), un-projected and un-clipped. */
 int saev_step_backward(saev_ctx* ctx, void* stream);
+/* Phase 3 in pieces, for data-parallel runs that overlap the gradient exchange with the backward:
+ *   saev_backward_begin   latent-major ordering of the codes, db_dec, the AuxK contractions;
+ *   saev_backward_rows    rows [lat_lo, lat_hi) of dW_dec (in the bound gradient buffer), of the TRANSPOSED W_enc
+ *                         gradient (saev_grad_w_enc_t: (d_sae, d_model) row-major) and entries [lat_lo, lat_hi) of db_enc
+ *                         are final when it returns (in stream order) -- the host may start reducing them;
+ *   saev_backward_end     transposes saev_grad_w_enc_t (after the host has reduced it) into the W_enc segment.
+ * saev_step_backward == begin + rows(0, d_sae) + end.  saev_bind_w_enc_t lets the host own the transposed-gradient
+ * scratch ((d_sae * d_model) floats) so that a torch tensor can alias it for the collectives; the f16r encoder also
+ * uses it as W_enc^T scratch during the forward. */
+int saev_backward_begin(saev_ctx* ctx, void* stream);
+int saev_backward_rows(saev_ctx* ctx, int32_t lat_lo, int32_t lat_hi, void* stream);
+int saev_backward_end(saev_ctx* ctx, void* stream);
+float* saev_grad_w_enc_t(saev_ctx* ctx);
+int saev_bind_w_enc_t(saev_ctx* ctx, float* scratch);
 /* Phase 4: grads *= grad_scale (1/world_size after a sum all-reduce), remove_parallel_grads
  * (train.py:351-352), global-norm clip (train.py:356-362, max_norm <= 0 disables), Adam with torch
  * defaults (train.py:294,444-446). `adam_step` is the 1-based step count. */

@@ -62,6 +62,11 @@ _SIGNATURES = {
     "saev_step_forward": (C.c_int, [P, P, C.c_int32, C.c_int64, C.c_int32, P]),
     "saev_step_dead": (C.c_int, [P, C.c_int64, P]),
     "saev_step_backward": (C.c_int, [P, P]),
+    "saev_backward_begin": (C.c_int, [P, P]),
+    "saev_backward_rows": (C.c_int, [P, C.c_int32, C.c_int32, P]),
+    "saev_backward_end": (C.c_int, [P, P]),
+    "saev_grad_w_enc_t": (P, [P]),
+    "saev_bind_w_enc_t": (C.c_int, [P, P]),
     "saev_step_tail": (C.c_int, [P, C.c_float, C.c_float, C.c_float, C.c_int64, P]),
     "saev_train_step": (C.c_int, [P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
     "saev_last_idx": (P, [P]),

@@ -140,11 +140,12 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(float* dA, const uint8_
 // gW_dec[dl[j], :] += dWd[j, :]; gW_encT[dl[j], :] += dWe[j, :]; gb_enc[dl[j]] += dbe[j]   (one wave per dead latent)
 __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl, int nd, int D, const float* dWd,
                                                                const float* dWe, const float* dbe, float* gW_dec,
-                                                               float* gW_encT, float* gb_enc) {
+                                                               float* gW_encT, float* gb_enc, int lat_lo, int lat_hi) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= nd) return;
     const int i = dl[j];
+    if (i < lat_lo || i >= lat_hi) return;
     const f32x4* a = reinterpret_cast<const f32x4*>(dWd + (size_t)j * D);
     const f32x4* e = reinterpret_cast<const f32x4*>(dWe + (size_t)j * D);
     f32x4* oa = reinterpret_cast<f32x4*>(gW_dec + (size_t)i * D);
@@ -215,9 +216,9 @@ hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t
     return hipGetLastError();
 }
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
-                                   float* gW_dec, float* gW_encT, float* gb_enc, hipStream_t s) {
+                                   float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s) {
     if (nd <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_add_dead_kernel, dim3((nd + 3) / 4), dim3(256), 0, s, dl, nd, D, dWd, dWe, dbe, gW_dec,
-                       gW_encT, gb_enc);
+                       gW_encT, gb_enc, lat_lo, lat_hi);
     return hipGetLastError();
 }

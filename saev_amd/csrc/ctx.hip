@@ -814,8 +814,7 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));
     HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
-    HIPCHK(c, launch_scatter_add_dead(c->dead_list, nd, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec, c->dW_encT,
-                                      c->grads + c->off_b_enc, s));
+    // the compact rows dWd / dWe / dbe are added into the gradient rows of the dead latents by saev_backward_rows
     return SAEV_OK;
 }
 
@@ -848,50 +847,78 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     return SAEV_OK;
 }
 
-int saev_step_backward(saev_ctx* c, void* stream) {
+// ---- backward in three pieces (saev_step_backward = all of them over the full latent range) -------------------------
+
+int saev_backward_begin(saev_ctx* c, void* stream) {
     if (!c) return SAEV_INVALID_ARG;
-    REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_step_backward: no training forward in flight");
+    REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_backward_begin: no training forward in flight");
     REQUIRE(c, c->grads, SAEV_NOT_BOUND, "gradient buffer not bound");
     hipStream_t s = (hipStream_t)stream;
     const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
     const int words = ((n + 31) / 32 + 7) / 8 * 8;
-
-    auto build = [&](const int32_t* idx, int stride, int k, const int32_t* k_dev) -> int {
-        CscArgs a{};
-        a.idx = idx; a.code_stride = stride; a.k = k; a.k_dev = k_dev; a.n_rows = n; a.S = S;
-        a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals; a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
-        a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
-        HIPCHK(c, launch_csc_build(a, s));
-        return SAEV_OK;
-    };
-    auto rows = [&](const float* val, const float* dval, const float* g, int k, const int32_t* k_dev,
-                    int accumulate) -> int {
-        DwRowsArgs a{};
-        a.starts = c->starts; a.chunk_starts = c->chunk_starts; a.work_latent = c->work_latent;
-        a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = val; a.dval = dval; a.g = g; a.x = c->x_last;
-        a.D = D; a.S = S; a.k_dev = k_dev; a.accumulate = accumulate;
-        a.P = c->P_last;
-        for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts[p];
-        a.dW_dec = c->grads + c->off_W_dec; a.dW_encT = c->dW_encT; a.db_enc = c->grads + c->off_b_enc;
-        a.partials = c->partials; a.db_partials = c->db_partials;
-        const int max_work = S + (int)(((long)n * k + DW_CHUNK - 1) / DW_CHUNK);
-        HIPCHK(c, launch_dw_rows(a, max_work, s));
-        return SAEV_OK;
-    };
-    int rc = build(c->idx, K, K, nullptr);
-    if (rc != SAEV_OK) return rc;
-    // Matryoshka: rows receive the suffix-summed gradients C_p (c->G); db_dec = column sums of C_0
+    CscArgs a{};
+    a.idx = c->idx; a.code_stride = K; a.k = K; a.k_dev = nullptr; a.n_rows = n; a.S = S;
+    a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals;
+    a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
+    a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
+    HIPCHK(c, launch_csc_build(a, s));
+    // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0); the AuxK contractions add theirs
     const float* gmat = c->P_last > 1 ? c->G : c->g;
-    rc = rows(c->val, c->dval, gmat, K, nullptr, 0);
-    if (rc != SAEV_OK) return rc;
-    HIPCHK(c, launch_colsum(gmat, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s,
-                            (long)c->P_last * D));
+    HIPCHK(c, launch_colsum(gmat, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s, (long)c->P_last * D));
     if (c->n_dead_host > 0) {
-        rc = auxk_backward(c, s);
+        int rc = auxk_backward(c, s);
         if (rc != SAEV_OK) return rc;
     }
-    HIPCHK(c, launch_transpose(c->dW_encT, c->grads + c->off_W_enc, S, D, s));
     return SAEV_OK;
+}
+
+int saev_backward_rows(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->x_last && c->training_last && c->grads, SAEV_INVALID_ARG, "saev_backward_rows: call saev_backward_begin first");
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
+    REQUIRE(c, 0 <= lat_lo && lat_lo < lat_hi && lat_hi <= S, SAEV_INVALID_ARG, "saev_backward_rows: bad latent range");
+    hipStream_t s = (hipStream_t)stream;
+    DwRowsArgs a{};
+    a.starts = c->starts; a.chunk_starts = c->chunk_starts; a.work_latent = c->work_latent;
+    a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = c->val; a.dval = c->dval;
+    a.g = c->P_last > 1 ? c->G : c->g;  // Matryoshka: rows receive the suffix-summed gradients C_p
+    a.x = c->x_last;
+    a.D = D; a.S = S; a.k_dev = nullptr; a.accumulate = 0;
+    a.P = c->P_last;
+    for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts[p];
+    a.dW_dec = c->grads + c->off_W_dec; a.dW_encT = c->dW_encT; a.db_enc = c->grads + c->off_b_enc;
+    a.partials = c->partials; a.db_partials = c->db_partials;
+    a.lat_lo = lat_lo; a.lat_hi = lat_hi;
+    // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
+    const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
+    HIPCHK(c, launch_dw_rows(a, max_work, s));
+    if (c->n_dead_host > 0)
+        HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
+                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s));
+    return SAEV_OK;
+}
+
+float* saev_grad_w_enc_t(saev_ctx* c) { return c ? c->dW_encT : nullptr; }
+
+int saev_bind_w_enc_t(saev_ctx* c, float* scratch) {
+    if (!c || !scratch) return SAEV_INVALID_ARG;
+    c->dW_encT = scratch;
+    return SAEV_OK;
+}
+
+int saev_backward_end(saev_ctx* c, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->grads, SAEV_NOT_BOUND, "gradient buffer not bound");
+    HIPCHK(c, launch_transpose(c->dW_encT, c->grads + c->off_W_enc, c->cfg.d_sae, c->cfg.d_model, (hipStream_t)stream));
+    return SAEV_OK;
+}
+
+int saev_step_backward(saev_ctx* c, void* stream) {
+    int rc = saev_backward_begin(c, stream);
+    if (rc != SAEV_OK) return rc;
+    rc = saev_backward_rows(c, 0, c->cfg.d_sae, stream);
+    if (rc != SAEV_OK) return rc;
+    return saev_backward_end(c, stream);
 }
 
 int saev_step_tail(saev_ctx* c, float lr, float max_norm, float grad_scale, int64_t adam_step, void* stream) {

@@ -164,6 +164,8 @@ struct DwRowsArgs {
     float* db_enc;                // (S)
     float* partials;              // (max_part, 2, D)
     float* db_partials;           // (max_part)
+    int lat_lo, lat_hi;           // only latents in [lat_lo, lat_hi) are processed (data-parallel overlap: rows become
+                                  // final range by range)
 };
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream);
@@ -252,4 +254,4 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
                             float gscale, RowStats* rowstats, hipStream_t s);
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
-                                   float* gW_dec, float* gW_encT, float* gb_enc, hipStream_t s);
+                                   float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s);

@@ -486,8 +486,9 @@ template <int NV>
 __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
     const int lane = threadIdx.x & 63;
-    const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_work = a.chunk_starts[a.S];
+    // work items are latent-major: those of latents [lat_lo, lat_hi) are the contiguous range below
+    const int wi = a.chunk_starts[a.lat_lo] + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_work = a.chunk_starts[a.lat_hi];
     if (wi >= n_work) return;
     const int i = a.work_latent[wi];
     const int c = wi - a.chunk_starts[i];
@@ -583,8 +584,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= a.S) return;
+    const int i = a.lat_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.lat_hi) return;
     const int nch = a.chunk_starts[i + 1] - a.chunk_starts[i];
     if (nch <= 1) return;
     const int c0 = a.part_starts[i], c1 = c0 + nch;
@@ -746,7 +747,7 @@ hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream) {
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream) {
     return dispatch_nv(a.D, [&](auto nv) {
         hipLaunchKernelGGL(dw_rows_kernel<decltype(nv)::value>, dim3((max_work + 3) / 4), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.lat_hi - a.lat_lo + 3) / 4), dim3(256), 0, stream, a);
     });
 }
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream) {

@@ -102,6 +102,7 @@ class SaeEngine:
             self._chk(self.lib.saev_bind_tracker(ctx, _ptr(self.toks_since_active), _ptr(self.fired)), "saev_bind_tracker")
         self.adam_steps = 0
         self._x_keepalive = None
+        self._w_enc_t = None
 
     # ---- plumbing -------------------------------------------------------------------------
     def _chk(self, rc, what):
@@ -224,6 +225,24 @@ class SaeEngine:
 
     def step_backward(self):
         self._chk(self.lib.saev_step_backward(self.ctx, _stream()), "saev_step_backward")
+
+    # backward in pieces (data-parallel overlap, see framework/ddp.py)
+    def grad_w_enc_t(self) -> torch.Tensor:
+        """(d_sae, d_model) transposed W_enc gradient the ranged backward writes; allocated on first use and handed to
+        the context so that collectives can run on it."""
+        if self._w_enc_t is None:
+            self._w_enc_t = torch.zeros(self.cfg.d_sae, self.cfg.d_model, device=self.device, dtype=torch.float32)
+            self._chk(self.lib.saev_bind_w_enc_t(self.ctx, _ptr(self._w_enc_t)), "saev_bind_w_enc_t")
+        return self._w_enc_t
+
+    def backward_begin(self):
+        self._chk(self.lib.saev_backward_begin(self.ctx, _stream()), "saev_backward_begin")
+
+    def backward_rows(self, lo: int, hi: int):
+        self._chk(self.lib.saev_backward_rows(self.ctx, lo, hi, _stream()), "saev_backward_rows")
+
+    def backward_end(self):
+        self._chk(self.lib.saev_backward_end(self.ctx, _stream()), "saev_backward_end")
 
     def step_tail(self, lr: float, max_norm: float = 1.0, grad_scale: float = 1.0):
         self.adam_steps += 1

@@ -65,6 +65,42 @@ class OracleEngine:
             self.grads[off : off + g.numel()] = g.reshape(-1)
             off += g.numel()
 
+    # ---- backward in latent ranges (what the overlapped exchange drives) ----
+    @property
+    def offsets(self):
+        off, out = 0, {}
+        for k in R.PARAM_ORDER:
+            out[k] = off
+            off += self.state.params[k].numel()
+        return out
+
+    def view(self, name, flat=None):
+        flat = self.grads if flat is None else flat
+        p = self.state.params[name]
+        return flat[self.offsets[name] : self.offsets[name] + p.numel()].view(p.shape)
+
+    def grad_w_enc_t(self):
+        if not hasattr(self, "_w_enc_t"):
+            self._w_enc_t = torch.zeros(self.cfg.d_sae, self.cfg.d_model)
+        return self._w_enc_t
+
+    def backward_begin(self):
+        self.calls.append("backward_begin")
+        self.loss.backward()
+        self._g = {k: (torch.zeros_like(self.leaves[k]) if self.leaves[k].grad is None else self.leaves[k].grad)
+                   for k in R.PARAM_ORDER}
+        self.view("b_dec").copy_(self._g["b_dec"])
+
+    def backward_rows(self, lo, hi):
+        self.calls.append(f"rows[{lo}:{hi}]")
+        self.view("W_dec")[lo:hi] = self._g["W_dec"][lo:hi]
+        self.grad_w_enc_t()[lo:hi] = self._g["W_enc"].T[lo:hi]
+        self.view("b_enc")[lo:hi] = self._g["b_enc"][lo:hi]
+
+    def backward_end(self):
+        self.calls.append("backward_end")
+        self.view("W_enc").copy_(self.grad_w_enc_t().T)
+
     def step_tail(self, lr, max_norm=1.0, grad_scale=1.0):
         self.calls.append("tail")
         P = self.state.params
@@ -102,13 +138,13 @@ def _problem():
     return cfg, params, batches
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     cfg, params, batches = _problem()
     eng = OracleEngine(params, cfg)
-    stepper = DataParallelStepper(eng, dist, world)
+    stepper = DataParallelStepper(eng, dist, world, overlap=overlap, n_buckets=3)
     sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, len(batches), 0.0)
     lr, dead_counts = 0.0, []
     for x in batches:
@@ -117,7 +153,11 @@ def _worker(rank, world, port, out):
         dead_counts.append(eng.n_dead)
         lr = sched.step()
     if rank == 0:
-        assert eng.calls[:4] == ["forward", "dead", "backward", "tail"]
+        if overlap:
+            assert eng.calls[:7] == ["forward", "dead", "backward_begin", "rows[0:85]", "rows[85:170]", "rows[170:256]",
+                                     "backward_end"] and eng.calls[7] == "tail"
+        else:
+            assert eng.calls[:4] == ["forward", "dead", "backward", "tail"]
     torch.save({"params": eng.state.params, "toks": eng.state.toks_since_active, "n_dead": dead_counts}, out.format(rank=rank))
     dist.destroy_process_group()
 
@@ -129,10 +169,11 @@ def _free_port():
 
 
 @pytest.mark.timeout(180)
-def test_two_ranks_reproduce_single_process_step(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_reproduce_single_process_step(tmp_path, overlap):
     world = 2
     out = str(tmp_path / "rank{rank}.pt")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, overlap), nprocs=world, join=True)
     r0, r1 = (torch.load(out.format(rank=r)) for r in range(world))
     # replicas stay bit-identical
     for k in R.PARAM_ORDER:

@@ -80,7 +80,8 @@ typedef struct {
     int32_t n_dead;
     int32_t n_overflow_rows; /* rows whose candidate list overflowed (step re-ran on the exact dense route) */
     int32_t cand_max;        /* longest per-row candidate list the fused encoder produced              */
-    int32_t reserved;
+    int32_t dense_route;     /* 1 when the step's codes came from the exact dense route (candidate-list or refinement
+                                overflow, or k > 64), 0 when the fused route held                       */
     double sse;      /* sum (x - x_hat)^2 accumulated in fp64 (train.py:398-401, :561-562)  */
     double sum_sq;   /* sum x^2 in fp64 (train.py:383, :554)                                */
 } saev_step_stats;

@@ -29,7 +29,7 @@ class SaevStepStats(C.Structure):
     _fields_ = [
         ("mse", C.c_float), ("aux", C.c_float), ("l0", C.c_float), ("l1", C.c_float),
         ("grad_norm", C.c_float), ("upper", C.c_float), ("n_dead", C.c_int32),
-        ("n_overflow_rows", C.c_int32), ("cand_max", C.c_int32), ("reserved", C.c_int32), ("sse", C.c_double), ("sum_sq", C.c_double),
+        ("n_overflow_rows", C.c_int32), ("cand_max", C.c_int32), ("dense_route", C.c_int32), ("sse", C.c_double), ("sum_sq", C.c_double),
     ]
 
 

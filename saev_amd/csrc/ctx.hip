@@ -76,7 +76,7 @@ struct saev_ctx {
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
     float *row_margin = nullptr, *wmax = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
     int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
-    float *f16r_scales = nullptr, *xabs = nullptr;
+    float *f16r_scales = nullptr, *xabs = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *bmax = nullptr;
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -208,7 +208,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
         A(zero_bias, std::max(S, D)); A(aux_scales, 8);
-        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(xabs, 1);
+        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(xabs, 1); A(mu, D); A(xnorm, MB); A(b_shift, S); A(bmax, 1);
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
@@ -384,15 +384,19 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s, co
         // that make the approximate cut safe
         HIPCHK(c, launch_transpose(c->params + c->off_W_enc, c->dW_encT, D, S, s));
         HIPCHK(c, launch_wnorm_max(c->dW_encT, S, D, c->wnorm_scratch, c->wmax, s));
-        if (xmax_dev == nullptr) {
-            HIPCHK(c, hipMemsetAsync(c->xabs, 0, sizeof(float), s));
-            HIPCHK(c, launch_absmax(x, (long)n * D, c->xabs, s));
-            xmax_dev = c->xabs;
-        }
-        HIPCHK(c, launch_f16r_scales(xmax_dev, c->wmax, c->f16r_scales, s));
-        HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales));
+        // centre the first pass on the batch's column mean: h = (x - mu) W + (mu W + b)
+        (void)xmax_dev;
+        const float inv_n = 1.0f / (float)n;
+        HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0));
+        HIPCHK(c, launch_scale_vec(c->mu, D, inv_n, s));  // mu, materialised once so every consumer sees the same fp32 values
+        HIPCHK(c, hipMemsetAsync(c->xabs, 0, sizeof(float), s));
+        HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs, s));
+        HIPCHK(c, launch_bias_shift(c->params + c->off_W_enc, c->mu, c->params + c->off_b_enc, D, S, c->b_shift,
+                                    c->wnorm_scratch, c->bmax, s));
+        HIPCHK(c, launch_f16r_scales(c->xabs, c->wmax, c->f16r_scales, s));
+        HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
         HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1));
-        HIPCHK(c, launch_row_margins(x, n, D, c->wmax, c->row_margin, s));
+        HIPCHK(c, launch_row_margins(c->xnorm, n, D, c->wmax, c->bmax, c->row_margin, s));
         return SAEV_OK;
     }
     HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
@@ -408,7 +412,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
         EncodeF16Args a{};
         a.xs = c->xs; a.ws = c->ws;
-        a.b_enc = c->params + c->off_b_enc;
+        a.b_enc = f16r ? c->b_shift : c->params + c->off_b_enc;  // f16r: images are centred, the bias carries mu W
         a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = (bf || f16r) ? 1.0f : 256.0f;
         a.scale_dev = f16r ? c->f16r_scales : nullptr;
         a.arith = bf ? 1 : (f16r ? 2 : 0);
@@ -748,11 +752,12 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         const _Float16* xs_hl = c->xs;
         if (f16r) {  // the step's x images are single fp16 here: make the hi/lo ones (the buffer is free until the backward)
             // (with the step's power-of-two x scale, so that no activation magnitude can overflow fp16)
-            HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->f16r_scales));
+            HIPCHK(c, launch_pow2_scale(c->upper, c->aux_scales + 6, s));  // from max|x| of the step (uncentred here)
+            HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 6));
             xs_hl = c->aux_xsg;
         }
         rc = dense_f16x3(c, xs_hl, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->H_dead, s,
-                         f16r ? c->f16r_scales + 2 : nullptr);
+                         f16r ? c->aux_scales + 6 : nullptr);
         if (rc != SAEV_OK) return rc;
     } else {
         rc = gemm_nn(c, n, ndp, D, c->x_last, c->Wenc_dead, c->H_dead);  // H = x W_enc[:, dl]

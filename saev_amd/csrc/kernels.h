@@ -79,7 +79,13 @@ hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0
 hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream);
 hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream);
 hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream);
-hipError_t launch_row_margins(const float* x, int n, int D, const float* wmax, float* margin, hipStream_t stream);
+hipError_t launch_scale_vec(float* v, int n, float scale, hipStream_t stream);
+hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm,
+                               float* xabs_zeroed, hipStream_t stream);
+hipError_t launch_bias_shift(const float* W_enc, const float* mu, const float* b_enc, int D, int S,
+                             float* b_shift, float* wg_scratch, float* bmax, hipStream_t stream);
+hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin,
+                              hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                  int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);
 
@@ -238,7 +244,8 @@ int encode_f16x3_tile_rows();
 int encode_f16x3_tile_latents();
 // image mode: 0 = fp16 hi/lo (16 k per image), 1 = bf16 single, 2 = fp16 single (32 k per image)
 hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale = 1.0f,
-                             const float* scale_dev = nullptr);  // effective scale = scale * *scale_dev
+                             const float* scale_dev = nullptr,  // effective scale = scale * *scale_dev
+                             const float* mu = nullptr);  // rows are x - mu
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
                            hipStream_t stream, const float* scale_dev = nullptr);
 

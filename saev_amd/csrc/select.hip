@@ -384,24 +384,71 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n,
         *out = t;
     }
 }
-// margin[b] = 2 E_b, E_b = 1.05 * (2^-10 + D * 2^-22) * ||x_b|| * max_s ||W_enc[:, s]||: an upper bound of the error of a
-// pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products; 2^-10 by Cauchy-Schwarz) plus
-// the fp32 accumulation of D terms (counted at 2^-22 per add so that a truncating adder is covered).  The operands are
-// pre-scaled so that their largest element sits in [2^13, 2^14): whatever the matrix cores do with fp16 subnormals
-// (flush or keep) then changes a pre-activation by less than 3e-7 of the same product of norms.  DESIGN.md 3.1.
-__global__ __launch_bounds__(256) void row_margin_kernel(const float* x, int n, int D, const float* wmax, float* margin) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n) return;
-    const f32x4* p = reinterpret_cast<const f32x4*>(x + (size_t)r * D);
-    float s = 0.f;
-    for (int q = lane; q < (D >> 2); q += 64) {
-        const f32x4 v = p[q];
-        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+// The first pass of the f16r encoder works on CENTRED activations: h = (x - mu) W + (mu W + b) for any vector mu, and
+// with mu = the batch's column mean the fp16 rounding error scales with ||x - mu|| instead of ||x|| -- ViT residual
+// streams carry a large common offset (and "massive activation" channels), which would otherwise inflate the margin
+// until every latent survives.  The exact refinement keeps using x and b_enc themselves.
+//
+__global__ void scale_vec_kernel(float* v, int n, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= scale;
+}
+// per row: ||x_b - mu|| and (via one atomic per workgroup) max |x - mu|
+__global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const float* mu, int n, int D,
+                                                           float* xnorm, float* xabs) {
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    float s = 0.f, m = 0.f;
+    if (r < n) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(x + (size_t)r * D);
+        const f32x4* mu4 = reinterpret_cast<const f32x4*>(mu);
+        for (int q = lane; q < (D >> 2); q += 64) {
+            const f32x4 v = p[q] - mu4[q];
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        s = wave_sum(s);
+        if (lane == 0) xnorm[r] = sqrtf(s);
     }
-    s = wave_sum(s);
+    m = wave_max(m);
+    if (lane == 0) sh[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(xabs), __float_as_uint(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]))));
+}
+// b_shift[s] = b_enc[s] + <mu, W_enc[:, s]>, the dot product accumulated in fp64 so that the only error left is the
+// final rounding to fp32 (<= 2^-24 |b_shift|, folded into the margin through max |b_shift|)
+__global__ __launch_bounds__(256) void bias_shift_kernel(const float* W_enc, const float* mu,
+                                                         const float* b_enc, int D, int S, float* b_shift, float* wg_max) {
+    extern __shared__ float mu_s[];
+    __shared__ float sh[4];
+    for (int d = threadIdx.x; d < D; d += 256) mu_s[d] = mu[d];
+    __syncthreads();
+    const int sidx = blockIdx.x * 256 + threadIdx.x;
+    float out = 0.f;
+    if (sidx < S) {
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) acc += (double)mu_s[d] * (double)W_enc[(size_t)d * S + sidx];
+        out = (float)(acc + (double)b_enc[sidx]);
+        b_shift[sidx] = out;
+    }
+    float m = wave_max(fabsf(out));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) wg_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+// margin[b] = 2 E_b, E_b = 1.05 * (2^-10 + D * 2^-22) * ||x_b - mu|| * max_s ||W_enc[:, s]|| + 2^-23 max |b_shift|: an
+// upper bound of the error of a pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products;
+// 2^-10 by Cauchy-Schwarz) plus the fp32 accumulation of D terms (counted at 2^-22 per add so that a truncating adder
+// is covered) plus the rounding of the shifted bias.  The operands are pre-scaled so that their largest element sits in
+// [2^13, 2^14): whatever the matrix cores do with fp16 subnormals (flush or keep) then changes a pre-activation by less
+// than 3e-7 of the same product of norms.  DESIGN.md 3.1.
+__global__ void row_margin_kernel(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
     const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
-    if (lane == 0) margin[r] = coef * sqrtf(s) * (*wmax);
+    margin[r] = coef * xnorm[r] * (*wmax) + 2.0f * 1.1920929e-07f * (*bmax);
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)
@@ -489,8 +536,27 @@ hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t strea
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, stream, absmax, pair);
     return hipGetLastError();
 }
-hipError_t launch_row_margins(const float* x, int n, int D, const float* wmax, float* margin, hipStream_t stream) {
-    hipLaunchKernelGGL(row_margin_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, D, wmax, margin);
+hipError_t launch_scale_vec(float* v, int n, float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, n, scale);
+    return hipGetLastError();
+}
+hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm,
+                               float* xabs_zeroed, hipStream_t stream) {
+    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm,
+                       xabs_zeroed);
+    return hipGetLastError();
+}
+hipError_t launch_bias_shift(const float* W_enc, const float* mu, const float* b_enc, int D, int S,
+                             float* b_shift, float* wg_scratch, float* bmax, hipStream_t stream) {
+    const int nwg = (S + 255) / 256;
+    hipLaunchKernelGGL(bias_shift_kernel, dim3(nwg), dim3(256), (size_t)D * sizeof(float), stream, W_enc, mu,
+                       b_enc, D, S, b_shift, wg_scratch);
+    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, wg_scratch, nwg, bmax);
+    return hipGetLastError();
+}
+hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(row_margin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xnorm, n, D, wmax, bmax, margin);
     return hipGetLastError();
 }
 

@@ -50,7 +50,8 @@ __device__ __forceinline__ half8 pack8(const float (&v)[8], int part) {
 // one thread = one 16-byte chunk of the image; grid.x = ceil(n/256) * nks images, 1024 threads each
 template <int MODE>
 __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks, float scale,
-                                                          const float* __restrict__ scale_dev, _Float16* __restrict__ xs) {
+                                                          const float* __restrict__ scale_dev, const float* __restrict__ mu,
+                                                          _Float16* __restrict__ xs) {
     if (scale_dev != nullptr) scale *= *scale_dev;
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
     const int i = threadIdx.x;           // chunk index inside the image
@@ -60,10 +61,12 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
     const int r = blk * 256 + rl, k = MODE != 0 ? ks * 32 + c * 8 : ks * 16 + h * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (r < n && k < D) {  // D % 4 == 0: load in two float4s, the second may fall off the end
-        const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k);
+        f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k);
+        if (mu != nullptr) a -= *reinterpret_cast<const f32x4*>(mu + k);  // centred images (f16r)
         v[0] = a[0] * scale; v[1] = a[1] * scale; v[2] = a[2] * scale; v[3] = a[3] * scale;
         if (k + 4 < D) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k + 4);
+            f32x4 b = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k + 4);
+            if (mu != nullptr) b -= *reinterpret_cast<const f32x4*>(mu + k + 4);
             v[4] = b[0] * scale; v[5] = b[1] * scale; v[6] = b[2] * scale; v[7] = b[3] * scale;
         }
     }
@@ -99,13 +102,13 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
 }  // namespace
 
 hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale,
-                             const float* scale_dev) {
+                             const float* scale_dev, const float* mu) {
     const int nks = Dp / (mode != 0 ? 32 : 16), nblk = (n + 255) / 256;
     if (nblk <= 0) return hipSuccess;
     _Float16* o = reinterpret_cast<_Float16*>(xs);
-    if (mode == 1) hipLaunchKernelGGL(split_rows_kernel<1>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, o);
-    else if (mode == 2) hipLaunchKernelGGL(split_rows_kernel<2>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, o);
-    else hipLaunchKernelGGL(split_rows_kernel<0>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, o);
+    if (mode == 1) hipLaunchKernelGGL(split_rows_kernel<1>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o);
+    else if (mode == 2) hipLaunchKernelGGL(split_rows_kernel<2>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o);
+    else hipLaunchKernelGGL(split_rows_kernel<0>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o);
     return hipGetLastError();
 }
 

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
         stats->sse = t[4];
         stats->sum_sq = t[5];
         if (upper) stats->upper = *upper;
-        if (n_overflow) { stats->n_overflow_rows = n_overflow[0]; stats->cand_max = n_overflow[1]; }
+        if (n_overflow) { stats->n_overflow_rows = n_overflow[0]; stats->cand_max = n_overflow[1]; stats->dense_route = n_overflow[-1]; }  // ctx flags: [1] need_dense [2] n_overflow [3] cand_max
     }
 }
 

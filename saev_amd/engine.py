@@ -50,7 +50,7 @@ class StepStats:
     n_dead: int
     n_overflow_rows: int
     cand_max: int
-    reserved: int
+    dense_route: int
     sse: float
     sum_sq: float
 

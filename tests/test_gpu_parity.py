@@ -426,3 +426,42 @@ def test_f16r_refinement_overflow_takes_the_exact_dense_route(encoder_mode):
     torch.testing.assert_close(val.cpu().sort(dim=-1, descending=True).values, want, rtol=1e-5, atol=1e-5)
     assert (idx.cpu() < 700).all(), "all winners come from the tied block"
     torch.testing.assert_close(h.gather(1, idx.cpu().long()), val.cpu(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("offset", [30.0, 300.0])
+def test_f16r_first_pass_is_centred_on_the_batch_mean(encoder_mode, offset):
+    """ViT residual streams carry a large common offset and a few "massive" channels.  The f16r first pass runs on
+    x - mean(x) with the bias shifted by mean(x) W_enc, so its error margin follows the spread of the batch, not the
+    offset: the fused route must hold (no dense fallback) and the codes must be the exact-fp32 encoder's."""
+    if encoder_mode != "f32":
+        pytest.skip("picks its own encoder modes; run once")
+    d, s, k, n = 256, 8192, 32, 1024
+    g = torch.Generator().manual_seed(41)
+    p = rand_params(d, s, seed=42)
+    mu = torch.randn(d, generator=g)
+    mu[7] = 40.0   # massive-activation channels
+    mu[100] = -25.0
+    x = torch.randn(n, d, generator=g) + offset * mu / mu.norm() * d**0.5  # |offset| = `offset` x the per-row spread
+    out = {}
+    for mode in ("f32", "f16r"):
+        eng = make_engine(d, s, k, k_aux=0, max_batch=n, encoder=mode)
+        eng.load_params(p)
+        eng.step_forward(x.cuda(), training=True)
+        idx, val, _ = eng.last_codes(n)
+        out[mode] = (idx.cpu(), val.cpu(), eng.read_stats())
+    assert out["f16r"][2].dense_route == 0 and out["f16r"][2].n_overflow_rows == 0
+    h = x.double() @ p["W_enc"].double() + p["b_enc"].double()
+    # values are the fp32 pre-activations of the chosen latents
+    got = out["f16r"][1]
+    want = h.gather(1, out["f16r"][0].long()).float()
+    scale = h.abs().max().item()
+    torch.testing.assert_close(got, want, rtol=2e-6, atol=1e-6 * scale)
+    same = (out["f32"][0] == out["f16r"][0]).all(dim=1)
+    kth = torch.topk(h, k, dim=-1).values[:, -1]
+    for r in torch.nonzero(~same).flatten().tolist():  # only where fp32 itself cannot separate the cut
+        a, b = set(out["f32"][0][r].tolist()), set(out["f16r"][0][r].tolist())
+        for i in a ^ b:
+            assert abs(h[r, i].item() - kth[r].item()) <= 1e-6 * scale, (r, i)
+    if offset <= 30.0:  # (fp32 on the uncentred x resolves ~1e-7 of the offset; the larger one blurs more cuts)
+        assert same.float().mean() > 0.9
+    assert math.isclose(out["f32"][2].mse, out["f16r"][2].mse, rel_tol=2e-4)  # the swapped near-ties move it a little

@@ -76,7 +76,8 @@ struct saev_ctx {
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
     float *row_margin = nullptr, *wmax = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
     int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
-    float *f16r_scales = nullptr, *xabs = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *bmax = nullptr;
+    float *f16r_scales = nullptr, *xabs = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *bmax = nullptr, *dot_part = nullptr, *xabs_part = nullptr, *sq_part = nullptr, *wmax_prev = nullptr;
+    bool wmax_known = false;
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -208,7 +209,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
         A(zero_bias, std::max(S, D)); A(aux_scales, 8);
-        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(xabs, 1); A(mu, D); A(xnorm, MB); A(b_shift, S); A(bmax, 1);
+        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(xabs, 1); A(mu, D); A(xnorm, MB); A(b_shift, S); A(bmax, 1); A(xabs_part, (MB + 3) / 4);
+        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)(c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
@@ -374,28 +376,34 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
 
 // operand preparation for the f16 encoders: x and W_enc^T rewritten as fp16 / bf16 images (no-op for the f32 encoder).
 // `xmax_dev` = device scalar max|x| when the caller has it already (the step computes it for the MSE), else NULL.
-static int prepare_encoder(saev_ctx* c, const float* x, int n, hipStream_t s, const float* xmax_dev = nullptr) {
+static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag, hipStream_t s,
+                           const float* xmax_dev = nullptr) {
     if (c->cfg.encoder_mode == SAEV_ENCODER_F32) return SAEV_OK;
     const int D = c->cfg.d_model, S = c->cfg.d_sae;
     const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
-        // the exact refinement reads encoder columns as rows: W_enc^T in fp32 (the gradient scratch dW_encT is free
-        // until the backward); its largest row norm and max|x| give the power-of-two operand scales and the margins
-        // that make the approximate cut safe
-        HIPCHK(c, launch_transpose(c->params + c->off_W_enc, c->dW_encT, D, S, s));
-        HIPCHK(c, launch_wnorm_max(c->dW_encT, S, D, c->wnorm_scratch, c->wmax, s));
+        // One pass over W_enc (split_wT) yields the fp16 images, W_enc^T in fp32 for the exact refinement (in the
+        // gradient scratch dW_encT, free until the backward), mu W_enc and the column norms.  Its power-of-two scale
+        // comes from the previous step's largest column norm; f16r_check sends the step down the dense route if the
+        // current parameters do not fit that scale.  Only the first use needs a pass of its own for the norm.
+        if (!c->wmax_known) {
+            HIPCHK(c, launch_transpose(c->params + c->off_W_enc, c->dW_encT, D, S, s));
+            HIPCHK(c, launch_wnorm_max(c->dW_encT, S, D, c->wnorm_scratch, c->wmax_prev, s));
+            c->wmax_known = true;
+        }
         // centre the first pass on the batch's column mean: h = (x - mu) W + (mu W + b)
         (void)xmax_dev;
         const float inv_n = 1.0f / (float)n;
         HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0));
         HIPCHK(c, launch_scale_vec(c->mu, D, inv_n, s));  // mu, materialised once so every consumer sees the same fp32 values
-        HIPCHK(c, hipMemsetAsync(c->xabs, 0, sizeof(float), s));
-        HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs, s));
-        HIPCHK(c, launch_bias_shift(c->params + c->off_W_enc, c->mu, c->params + c->off_b_enc, D, S, c->b_shift,
-                                    c->wnorm_scratch, c->bmax, s));
-        HIPCHK(c, launch_f16r_scales(c->xabs, c->wmax, c->f16r_scales, s));
+        HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, c->xabs, s));
+        HIPCHK(c, launch_f16r_scales(c->xabs, c->wmax_prev, c->f16r_scales, s));
         HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
-        HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1));
+        HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
+                                  c->mu, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
+        HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
+                                     c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, c->bmax,
+                                     c->wmax, pre_flag, c->wmax_prev, s));
         HIPCHK(c, launch_row_margins(c->xnorm, n, D, c->wmax, c->bmax, c->row_margin, s));
         return SAEV_OK;
     }
@@ -454,8 +462,10 @@ int saev_encode_dense(saev_ctx* c, const float* x, int32_t n, float* h_out, void
     REQUIRE(c, x && h_out && n > 0, SAEV_INVALID_ARG, "saev_encode_dense: bad arguments");
     REQUIRE(c, n <= c->cfg.max_batch || c->cfg.encoder_mode == SAEV_ENCODER_F32, SAEV_INVALID_ARG,
             "saev_encode_dense: n_rows > max_batch");
-    int rc = prepare_encoder(c, x, n, (hipStream_t)stream);
-    if (rc != SAEV_OK) return rc;
+    if (c->cfg.encoder_mode != SAEV_ENCODER_F16R) {  // (f16r: a dense h comes from the fp32 kernel, no images needed)
+        int rc = prepare_encoder(c, x, n, nullptr, (hipStream_t)stream);
+        if (rc != SAEV_OK) return rc;
+    }
     return run_encoder(c, x, n, EPI_DENSE, h_out, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -477,7 +487,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     const int K = c->cfg.top_k;
     int32_t* need_dense = c->flags + 1;
     {
-        int rc0 = prepare_encoder(c, x, n, s, xmax_dev);
+        int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev);
         if (rc0 != SAEV_OK) return rc0;
     }
     if (fused_supported(c->cfg)) {

@@ -80,10 +80,8 @@ hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch
 hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream);
 hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream);
 hipError_t launch_scale_vec(float* v, int n, float scale, hipStream_t stream);
-hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm,
-                               float* xabs_zeroed, hipStream_t stream);
-hipError_t launch_bias_shift(const float* W_enc, const float* mu, const float* b_enc, int D, int S,
-                             float* b_shift, float* wg_scratch, float* bmax, hipStream_t stream);
+hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_scratch,
+                               float* xabs, hipStream_t stream);
 hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin,
                               hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
@@ -247,7 +245,17 @@ hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int
                              const float* scale_dev = nullptr,  // effective scale = scale * *scale_dev
                              const float* mu = nullptr);  // rows are x - mu
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
-                           hipStream_t stream, const float* scale_dev = nullptr);
+                           hipStream_t stream, const float* scale_dev = nullptr,
+                           // mode 2 with mu (f16r): also dot_part[ks][s] = shares of <mu, W*scale>, sq_part = shares of
+                           // ||W*scale||^2 per column, W_T = fp32 transpose of W
+                           const float* mu = nullptr, double* dot_part = nullptr, float* sq_part = nullptr,
+                           float* W_T = nullptr);
+// f16r: b_shift = float(sum_ks dot_part / *w_scale + b_enc), bmax = max |b_shift|, wmax = largest column norm of W_enc;
+// raises *pre_flag when wmax * *w_scale is outside the safe fp16 window, then wmax_prev = wmax.  wg_scratch: 2*ceil(S/256)
+hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int Dp, int S, int S_pad, const float* w_scale,
+                              const float* b_enc, float* b_shift, float* wg_scratch, float* bmax, float* wmax,
+                              int32_t* pre_flag, float* wmax_prev, hipStream_t stream);
+hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream);
 
 // ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------
 hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s);

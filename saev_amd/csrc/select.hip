@@ -393,9 +393,9 @@ __global__ void scale_vec_kernel(float* v, int n, float scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] *= scale;
 }
-// per row: ||x_b - mu|| and (via one atomic per workgroup) max |x - mu|
+// per row: ||x_b - mu||; per workgroup: max |x - mu| (thousands of same-address atomics would serialise: two stages)
 __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const float* mu, int n, int D,
-                                                           float* xnorm, float* xabs) {
+                                                           float* xnorm, float* wg_max) {
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
@@ -403,38 +403,25 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
     if (r < n) {
         const f32x4* p = reinterpret_cast<const f32x4*>(x + (size_t)r * D);
         const f32x4* mu4 = reinterpret_cast<const f32x4*>(mu);
-        for (int q = lane; q < (D >> 2); q += 64) {
-            const f32x4 v = p[q] - mu4[q];
-            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-            m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        const int nq = D >> 2;
+        for (int q0 = lane; q0 < nq; q0 += 256) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + 64 * u;
+                v[u] = q < nq ? p[q] - mu4[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+                m = fmaxf(fmaxf(fmaxf(m, fabsf(v[u][0])), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+            }
         }
         s = wave_sum(s);
         if (lane == 0) xnorm[r] = sqrtf(s);
     }
     m = wave_max(m);
     if (lane == 0) sh[w] = m;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned int*>(xabs), __float_as_uint(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]))));
-}
-// b_shift[s] = b_enc[s] + <mu, W_enc[:, s]>, the dot product accumulated in fp64 so that the only error left is the
-// final rounding to fp32 (<= 2^-24 |b_shift|, folded into the margin through max |b_shift|)
-__global__ __launch_bounds__(256) void bias_shift_kernel(const float* W_enc, const float* mu,
-                                                         const float* b_enc, int D, int S, float* b_shift, float* wg_max) {
-    extern __shared__ float mu_s[];
-    __shared__ float sh[4];
-    for (int d = threadIdx.x; d < D; d += 256) mu_s[d] = mu[d];
-    __syncthreads();
-    const int sidx = blockIdx.x * 256 + threadIdx.x;
-    float out = 0.f;
-    if (sidx < S) {
-        double acc = 0.0;
-        for (int d = 0; d < D; ++d) acc += (double)mu_s[d] * (double)W_enc[(size_t)d * S + sidx];
-        out = (float)(acc + (double)b_enc[sidx]);
-        b_shift[sidx] = out;
-    }
-    float m = wave_max(fabsf(out));
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) wg_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
@@ -540,18 +527,15 @@ hipError_t launch_scale_vec(float* v, int n, float scale, hipStream_t stream) {
     hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, n, scale);
     return hipGetLastError();
 }
-hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm,
-                               float* xabs_zeroed, hipStream_t stream) {
-    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm,
-                       xabs_zeroed);
+hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_scratch,
+                               float* xabs, hipStream_t stream) {
+    const int nwg = (n + 3) / 4;
+    hipLaunchKernelGGL(center_stats_kernel, dim3(nwg), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_scratch);
+    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, wg_scratch, nwg, xabs);
     return hipGetLastError();
 }
-hipError_t launch_bias_shift(const float* W_enc, const float* mu, const float* b_enc, int D, int S,
-                             float* b_shift, float* wg_scratch, float* bmax, hipStream_t stream) {
-    const int nwg = (S + 255) / 256;
-    hipLaunchKernelGGL(bias_shift_kernel, dim3(nwg), dim3(256), (size_t)D * sizeof(float), stream, W_enc, mu,
-                       b_enc, D, S, b_shift, wg_scratch);
-    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, wg_scratch, nwg, bmax);
+hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, v, n, out);
     return hipGetLastError();
 }
 hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin,

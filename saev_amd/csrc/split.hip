@@ -75,14 +75,26 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
 
 // one workgroup = one image of W_enc^T: 256 latents x 16 k (32 k for bf16).  The k-rows of W_enc (1 KB each) are
 // read coalesced into LDS, then every thread assembles its chunk from a column.
+//
+// With `mu` given (the f16r encoder) the same pass over W_enc also produces everything else that mode needs from it --
+// the tile is in LDS anyway:
+//   * this image's share of <mu, W[:, s]> in fp64 -> dot_part[ks][s]   (bias of the centred first pass)
+//   * this image's share of ||W[:, s]||^2         -> sq_part[ks][s]    (largest column norm: error margin, next scale)
+//   * the fp32 transpose W_T[s][k]                                      (rows for the exact refinement)
+// bias_finish_kernel adds the nks shares in a fixed order.  The tile holds W * scale with a power-of-two scale: exact,
+// undone where it matters.
 template <int MODE>
 __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict__ W, int D, int S, int nks, float scale,
-                                                        const float* __restrict__ scale_dev, _Float16* __restrict__ ws) {
+                                                        const float* __restrict__ scale_dev, _Float16* __restrict__ ws,
+                                                        const float* __restrict__ mu, double* __restrict__ dot_part,
+                                                        float* __restrict__ sq_part, float* __restrict__ W_T) {
     if (scale_dev != nullptr) scale *= *scale_dev;
     constexpr int KS = MODE != 0 ? 32 : 16;
     __shared__ float tile[KS][257];
+    __shared__ float mu_s[KS];
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
     const int s0 = blk * 256, k0 = ks * KS;
+    if (MODE == 2 && mu != nullptr && threadIdx.x < KS) mu_s[threadIdx.x] = (k0 + threadIdx.x < D) ? mu[k0 + threadIdx.x] : 0.f;
     for (int q = threadIdx.x; q < KS * 256; q += 1024) {
         const int kk = q >> 8, sl = q & 255;
         const int k = k0 + kk, s = s0 + sl;
@@ -97,6 +109,76 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[(MODE != 0 ? c : h) * 8 + e][rl];
     reinterpret_cast<half8*>(ws + (size_t)blockIdx.x * 256 * 32)[i] = pack8<MODE>(v, part);
+    if constexpr (MODE == 2) {
+        if (mu != nullptr) {  // the four threads of a latent hold its 32 k of this image
+            double acc = 0.0;
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc += (double)mu_s[c * 8 + e] * (double)v[e];
+                sq += v[e] * v[e];
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            if (p == 0) {
+                const size_t o = (size_t)ks * ((size_t)gridDim.x / nks * 256) + s0 + rl;
+                dot_part[o] = acc;
+                sq_part[o] = sq;
+            }
+            const int k = k0 + c * 8;
+            if (s0 + rl < S && k < D) {  // D % 4 == 0
+                const float inv = 1.0f / scale;  // power of two
+                f32x4* o = reinterpret_cast<f32x4*>(W_T + (size_t)(s0 + rl) * D + k);
+                o[0] = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+                if (k + 4 < D) o[1] = f32x4{v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv};
+            }
+        }
+    }
+}
+
+// b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]) and ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale;
+// per workgroup one maximum of |b_shift| (wg_max[0..nwg)) and one of the norms (wg_max[nwg..2 nwg))
+__global__ __launch_bounds__(256) void bias_finish_kernel(const double* __restrict__ dot_part,
+                                                          const float* __restrict__ sq_part, int nks, int S, int S_pad,
+                                                          const float* __restrict__ w_scale, const float* __restrict__ b_enc,
+                                                          float* __restrict__ b_shift, float* __restrict__ wg_max) {
+    __shared__ float sh[2][4];
+    const int sidx = blockIdx.x * 256 + threadIdx.x;
+    float out = 0.f, nrm = 0.f;
+    if (sidx < S) {
+        double acc = 0.0, sq = 0.0;
+        for (int ks = 0; ks < nks; ++ks) {
+            acc += dot_part[(size_t)ks * S_pad + sidx];
+            sq += (double)sq_part[(size_t)ks * S_pad + sidx];
+        }
+        const double sc = (double)(*w_scale);
+        out = (float)(acc / sc + (double)b_enc[sidx]);
+        b_shift[sidx] = out;
+        nrm = (float)(sqrt(sq) / sc) * 1.000001f;  // (rounded up: it bounds an error)
+    }
+    float m = fabsf(out);
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); nrm = fmaxf(nrm, __shfl_xor(nrm, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = m; sh[1][threadIdx.x >> 6] = nrm; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float* q = sh[threadIdx.x];
+        wg_max[threadIdx.x * gridDim.x + blockIdx.x] = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+    }
+}
+
+// The W images of this step were scaled with the power of two derived from the PREVIOUS step's largest column norm
+// (so that one pass over W_enc suffices).  Parameters move a little per step, but they belong to the caller and may
+// have been replaced: if the largest column norm of the current W_enc leaves the window in which the fp16 images are
+// safe (no overflow; no more than two bits below the intended range), raise the dense-route flag -- the step then runs
+// on the exact fp32 kernel -- and in any case remember the current norm for the next step.
+__global__ void f16r_check_kernel(const float* wmax, const float* w_scale, int32_t* pre_flag, float* wmax_prev) {
+    if (threadIdx.x == 0) {
+        const float t = (*wmax) * (*w_scale);
+        if (!(t < 60000.0f && (t >= 2048.0f || *wmax == 0.f))) *pre_flag = 1;  // (an all-zero W_enc has exact images)
+        *wmax_prev = *wmax;
+    }
 }
 
 }  // namespace
@@ -113,12 +195,27 @@ hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int
 }
 
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
-                           hipStream_t stream, const float* scale_dev) {
+                           hipStream_t stream, const float* scale_dev, const float* mu, double* dot_part, float* sq_part,
+                           float* W_T) {
     const int nks = Dp / (mode != 0 ? 32 : 16);
     const dim3 grid((S_pad / 256) * nks);
     _Float16* o = reinterpret_cast<_Float16*>(ws);
-    if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o);
-    else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o);
-    else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o);
+    if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr);
+    else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, mu, dot_part, sq_part, W_T);
+    else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int Dp, int S, int S_pad, const float* w_scale,
+                              const float* b_enc, float* b_shift, float* wg_scratch, float* bmax, float* wmax,
+                              int32_t* pre_flag, float* wmax_prev, hipStream_t stream) {
+    const int nwg = (S + 255) / 256;
+    hipLaunchKernelGGL(bias_finish_kernel, dim3(nwg), dim3(256), 0, stream, dot_part, sq_part, Dp / 32, S, S_pad, w_scale,
+                       b_enc, b_shift, wg_scratch);
+    hipError_t e = launch_max_reduce(wg_scratch, nwg, bmax, stream);
+    if (e != hipSuccess) return e;
+    e = launch_max_reduce(wg_scratch + nwg, nwg, wmax, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(f16r_check_kernel, dim3(1), dim3(64), 0, stream, wmax, w_scale, pre_flag, wmax_prev);
     return hipGetLastError();
 }

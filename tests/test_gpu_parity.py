@@ -465,3 +465,29 @@ def test_f16r_first_pass_is_centred_on_the_batch_mean(encoder_mode, offset):
     if offset <= 30.0:  # (fp32 on the uncentred x resolves ~1e-7 of the offset; the larger one blurs more cuts)
         assert same.float().mean() > 0.9
     assert math.isclose(out["f32"][2].mse, out["f16r"][2].mse, rel_tol=2e-4)  # the swapped near-ties move it a little
+
+
+def test_f16r_survives_replaced_parameters(encoder_mode):
+    """The f16r W images are scaled with the previous call's largest encoder-column norm (one pass over W_enc per step).
+    Parameters belong to the caller: when they are replaced by something of a very different magnitude the device-side
+    check must send that call down the exact dense route, and the next call is back on the fused route."""
+    if encoder_mode != "f32":
+        pytest.skip("picks its own encoder mode; run once")
+    d, s, k, n = 128, 4096, 16, 512
+    p = rand_params(d, s, seed=51)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(52))
+    eng = make_engine(d, s, k, k_aux=0, max_batch=n, encoder="f16r")
+    eng.load_params(p)
+    routes = []
+    for scale in (1.0, 1.0e4, 1.0e4, 1.0e-3, 1.0e-3):
+        q = dict(p)
+        q["W_enc"] = p["W_enc"] * scale
+        eng.load_params(q)
+        eng.step_forward(x.cuda(), training=True)
+        idx, val, _ = eng.last_codes(n)
+        routes.append(eng.read_stats().dense_route)
+        h = x.double() @ q["W_enc"].double() + q["b_enc"].double()
+        want = torch.topk(h, k, dim=-1).values.float()
+        torch.testing.assert_close(val.cpu().sort(dim=-1, descending=True).values, want, rtol=1e-5, atol=1e-5 * scale)
+        torch.testing.assert_close(h.gather(1, idx.cpu().long()).float(), val.cpu(), rtol=1e-5, atol=1e-5 * scale)
+    assert routes == [0, 1, 0, 1, 0], routes

@@ -58,6 +58,10 @@ class StreamingReservoir:
         self._src = None
         self._src_lock = threading.Lock()
         self._stop = False
+        self._staging: dict[int, tuple[list[torch.Tensor], list[torch.Tensor]]] = {}
+        # seconds spent per phase, summed over reader threads / consumer calls (tools/bench_feed.py prints them)
+        self.phase_s = {"alloc": 0.0, "read": 0.0, "wait_free": 0.0, "wait_copy": 0.0, "enqueue": 0.0, "get_wait": 0.0,
+                        "get_draw": 0.0, "get_gather": 0.0}
 
     # ---- reader side -----------------------------------------------------------------------------------------------
     def start_epoch(self):
@@ -70,7 +74,7 @@ class StreamingReservoir:
             self._done, self._err, self._stop = False, None, False
             self._n_running = self.n_threads
         self._src = iter(self.blocks())
-        self._threads = [threading.Thread(target=self._reader, name=f"saev-reservoir-reader-{i}", daemon=True)
+        self._threads = [threading.Thread(target=self._reader, args=(i,), name=f"saev-reservoir-reader-{i}", daemon=True)
                          for i in range(self.n_threads)]
         for t in self._threads:
             t.start()
@@ -110,19 +114,28 @@ class StreamingReservoir:
                     return self._free[self._n_free : self._n_free + n].copy()
                 self._cv.wait(timeout=0.002 if self._pending else 0.05)
 
-    def _reader(self):
+    def _reader(self, tid: int = 0):
         try:
+            ph = self.phase_s
+            t0 = time.perf_counter()
             copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
-            stage = [torch.empty(self.chunk_rows, self.D, dtype=torch.float32, pin_memory=self.on_gpu) for _ in range(2)]
-            stage_meta = [torch.empty(self.chunk_rows, 2, dtype=torch.int32, pin_memory=self.on_gpu) for _ in range(2)]
+            # pinned staging is expensive to allocate (hundreds of ms per reader): kept across epochs
+            if tid not in self._staging:
+                self._staging[tid] = (
+                    [torch.empty(self.chunk_rows, self.D, dtype=torch.float32, pin_memory=self.on_gpu) for _ in range(2)],
+                    [torch.empty(self.chunk_rows, 2, dtype=torch.int32, pin_memory=self.on_gpu) for _ in range(2)])
+            stage, stage_meta = self._staging[tid]
             inflight: list[tuple[object, np.ndarray] | None] = [None, None]
+            ph["alloc"] += time.perf_counter() - t0
 
             def publish(j):
                 if inflight[j] is None:
                     return
                 ev, slots = inflight[j]
                 if ev is not None:
+                    t1 = time.perf_counter()
                     ev.synchronize()  # rows are published only once they are in HBM
+                    ph["wait_copy"] += time.perf_counter() - t1
                 inflight[j] = None
                 with self._cv:
                     n = slots.shape[0]
@@ -139,6 +152,7 @@ class StreamingReservoir:
                 i += 1
                 publish(j)  # the copy that last used this staging buffer has landed
                 # host read (page cache / disk) straight into pinned memory; overlaps the other buffer's copy
+                t1 = time.perf_counter()
                 if callable(item):
                     n, ex, tk = item(stage[j].numpy())
                 else:
@@ -146,14 +160,18 @@ class StreamingReservoir:
                     n = act.shape[0]
                     assert n <= self.chunk_rows
                     stage[j].numpy()[:n] = act
+                ph["read"] += time.perf_counter() - t1
                 if n == 0:
                     continue
                 sm = stage_meta[j].numpy()
                 sm[:n, 0], sm[:n, 1] = ex, tk
                 publish(1 - j)  # never wait for free slots while holding unpublished rows
+                t1 = time.perf_counter()
                 slots = self._take_free(n)
+                ph["wait_free"] += time.perf_counter() - t1
                 if slots is None:
                     return
+                t1 = time.perf_counter()
                 slots_t = torch.from_numpy(slots)
                 ev = None
                 if self.on_gpu:
@@ -167,6 +185,7 @@ class StreamingReservoir:
                     self.rows.index_copy_(0, slots_t, stage[j][:n])
                     self.meta.index_copy_(0, slots_t, stage_meta[j][:n])
                 inflight[j] = (ev, slots)
+                ph["enqueue"] += time.perf_counter() - t1
             publish(0)
             publish(1)
         except BaseException as e:  # surfaced to the consumer
@@ -199,6 +218,8 @@ class StreamingReservoir:
         """Up to ``batch_size`` rows drawn uniformly without replacement from the reservoir; fewer only when the epoch
         is running out; ``None`` when it is exhausted."""
         deadline = time.monotonic() + self.timeout_s
+        ph = self.phase_s
+        t0 = time.perf_counter()
         with self._cv:
             while True:
                 if self._err is not None:
@@ -213,6 +234,8 @@ class StreamingReservoir:
                     return None
                 if not self._cv.wait(timeout=0.5) and time.monotonic() > deadline:
                     raise TimeoutError(f"no batch within {self.timeout_s}s (reservoir fill {self.fill():.3f})")
+            t1 = time.perf_counter()
+            ph["get_wait"] += t1 - t0
             n = self._n_filled
             b = min(batch_size, n)
             pick = self._draw(n, b)
@@ -223,6 +246,8 @@ class StreamingReservoir:
             tail_kept[pick[in_tail] - (n - b)] = False
             self._filled[pick[~in_tail]] = self._filled[n - b : n][tail_kept]
             self._n_filled = n - b
+        t2 = time.perf_counter()
+        ph["get_draw"] += t2 - t1
         slots_t = torch.from_numpy(slots).to(self.device)
         act = self.gather(self.rows, slots_t) if self.gather is not None else self.rows[slots_t]
         meta = self.meta[slots_t]
@@ -233,4 +258,5 @@ class StreamingReservoir:
         with self._cv:
             self._pending.append((ev, slots))
             self._cv.notify_all()
+        ph["get_gather"] += time.perf_counter() - t2
         return act, meta[:, 0].contiguous(), meta[:, 1].contiguous()

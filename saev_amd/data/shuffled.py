@@ -25,7 +25,9 @@ import dataclasses
 import math
 import os
 import pathlib
+import threading
 import typing as tp
+import warnings
 
 import numpy as np
 import torch
@@ -70,6 +72,8 @@ class DataLoader:
         self.manager_pid = -1
         self.engine = engine
         self._epoch = 0
+        self._fds: dict[str, int] = {}
+        self._fd_lock = threading.Lock()
         if pool is not None:  # in-memory pool (tests, synthetic benchmarks)
             assert pool.ndim == 2
             self.metadata = shards_lib.Metadata(
@@ -133,6 +137,7 @@ class DataLoader:
         else:
             self._n_local = int(sum(keep_all[ex_base[si] : ex_base[si] + info.shards[si][1]].sum() for si in mine))
         tok_arr = np.asarray(tok)
+        tok_contiguous = tok == list(range(tok[0], tok[0] + len(tok)))
         tok_out = (tok_arr - first * (cfg.tokens == "content")).astype(np.int32)
 
         def blocks(epoch: int, max_rows: int | None):
@@ -145,24 +150,44 @@ class DataLoader:
                 for li in layer_ids:
                     for lo in range(0, n_ex, step):
                         hi = min(n_ex, lo + step)
-                        def read(out=None, mm=mm, si=si, li=li, lo=lo, hi=hi):
+                        def read(out=None, mm=mm, si=si, li=li, lo=lo, hi=hi, name=name):
                             """Rows of examples [lo, hi) of one shard/layer into out[:n]; returns (n, example_idx, token_idx)
                             (or (rows, example_idx, token_idx) when no output buffer is given)."""
                             ex = np.repeat((np.arange(lo, hi) + ex_base[si]).astype(np.int32), len(tok))
                             tk = np.tile(tok_out, hi - lo)
-                            src = mm[lo:hi, li][:, tok]  # (n_ex, n_tok, D) strided view of the mapped file
+                            def src():  # (n_ex, n_tok, D) of the mapped file: a strided view when the tokens are a range
+                                if tok_contiguous:
+                                    return mm[lo:hi, li, tok[0] : tok[0] + len(tok)]
+                                return mm[lo:hi, li][:, tok]
                             keep = None
                             if labels is not None:
                                 keep = keep_all[ex_base[si] + lo : ex_base[si] + hi].reshape(-1)
                                 ex, tk = ex[keep], tk[keep]
                             n = ex.shape[0]
                             if out is None:
-                                rows = np.ascontiguousarray(src).reshape(-1, md.d_model)
+                                rows = np.ascontiguousarray(src()).reshape(-1, md.d_model)
                                 return (rows if keep is None else rows[keep]), ex, tk
-                            if keep is None:
-                                np.copyto(out[:n].reshape(hi - lo, len(tok), md.d_model), src)
+                            if keep is None and tok_contiguous:
+                                # one positional read per example straight into the (pinned) staging rows: no page
+                                # faults on a shared mapping, the GIL is released for the whole copy, and any number
+                                # of reader threads can share the descriptor
+                                fd = self._shard_fd(d / name)
+                                row_bytes = md.d_model * 4
+                                ex_bytes = len(tok) * row_bytes
+                                flat = memoryview(out[:n].reshape(-1)).cast("B")
+                                for e in range(lo, hi):
+                                    off = ((e * len(md.layers) + li) * md.tokens_per_example + tok[0]) * row_bytes
+                                    pos, end = (e - lo) * ex_bytes, (e - lo + 1) * ex_bytes
+                                    while pos < end:
+                                        got = os.preadv(fd, [flat[pos:end]], off)
+                                        if got <= 0:
+                                            raise IOError(f"short read in shard {name} at byte {off}")
+                                        pos += got
+                                        off += got
+                            elif keep is None:
+                                np.copyto(out[:n].reshape(hi - lo, len(tok), md.d_model), src())
                             elif n:
-                                out[:n] = np.ascontiguousarray(src).reshape(-1, md.d_model)[keep]
+                                out[:n] = np.ascontiguousarray(src()).reshape(-1, md.d_model)[keep]
                             return n, ex, tk
 
                         yield read
@@ -181,7 +206,12 @@ class DataLoader:
             acts, exs, tks = [], [], []
             for read in blocks(0, None):
                 a, ex, tk = read()
-                acts.append(torch.from_numpy(a).to(self.device))
+                if self.device.type == "cuda":  # read once by the H2D copy; a read-only mapped view is fine as a source
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore", UserWarning)
+                        acts.append(torch.from_numpy(a).to(self.device))
+                else:
+                    acts.append(torch.from_numpy(np.array(a, dtype=np.float32)))  # never alias the mapped file
                 exs.append(torch.from_numpy(ex))
                 tks.append(torch.from_numpy(tk))
             self.pool = torch.cat(acts).contiguous()
@@ -206,10 +236,24 @@ class DataLoader:
         n = self.n_local
         return n // self.local_batch if self.drop_last else math.ceil(n / self.local_batch)
 
+    def _shard_fd(self, path) -> int:
+        key = str(path)
+        fd = self._fds.get(key)
+        if fd is None:
+            with self._fd_lock:
+                fd = self._fds.get(key)
+                if fd is None:
+                    fd = self._fds[key] = os.open(key, os.O_RDONLY)
+        return fd
+
     def shutdown(self):
         """Stop the reader threads of the streaming mode (no-op in resident mode); reference shuffled.py shutdown()."""
         if self.reservoir is not None:
             self.reservoir.stop()
+        with self._fd_lock:
+            for fd in self._fds.values():
+                os.close(fd)
+            self._fds.clear()
 
     def __del__(self):
         try:

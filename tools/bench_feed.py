@@ -50,6 +50,8 @@ def main():
             dt = time.perf_counter() - t0
             assert n == n_rows
             print(f"{label}: {n / dt / 1e6:.2f} M rows/s, {n * D * 4 / dt / 1e9:.2f} GB/s ({dt:.2f} s for {n} rows)", flush=True)
+            if getattr(dl, "reservoir", None) is not None:
+                print("    phases [s, summed over threads]: " + ", ".join(f"{k} {v:.2f}" for k, v in dl.reservoir.phase_s.items()), flush=True)
 
         for nt in a.threads:
             dl = data.ShuffledDataLoader(dataclasses.replace(cfg, n_threads=nt), device=dev, resident=False)

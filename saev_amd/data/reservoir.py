@@ -59,6 +59,8 @@ class StreamingReservoir:
         self._src_lock = threading.Lock()
         self._stop = False
         self._staging: dict[int, tuple[list[torch.Tensor], list[torch.Tensor]]] = {}
+        self._slot_ring: list[list] = []
+        self._slot_i = 0
         # seconds spent per phase, summed over reader threads / consumer calls (tools/bench_feed.py prints them)
         self.phase_s = {"alloc": 0.0, "read": 0.0, "wait_free": 0.0, "wait_copy": 0.0, "enqueue": 0.0, "get_wait": 0.0,
                         "get_draw": 0.0, "get_gather": 0.0}
@@ -248,7 +250,24 @@ class StreamingReservoir:
             self._n_filled = n - b
         t2 = time.perf_counter()
         ph["get_draw"] += t2 - t1
-        slots_t = torch.from_numpy(slots).to(self.device)
+        if self.on_gpu:
+            # the slot list goes up through a small ring of pinned buffers with an asynchronous copy: a pageable source
+            # would make the copy synchronous, i.e. stall the host until the stream has drained, once per batch
+            ring = self._slot_ring
+            if not ring:
+                ring.extend([torch.empty(batch_size, dtype=torch.int64, pin_memory=True), None] for _ in range(8))
+            ent = ring[self._slot_i % len(ring)]
+            self._slot_i += 1
+            if ent[0].shape[0] < b:
+                ent[0], ent[1] = torch.empty(b, dtype=torch.int64, pin_memory=True), None
+            if ent[1] is not None:
+                ent[1].synchronize()
+            ent[0][:b].copy_(torch.from_numpy(slots))
+            slots_t = ent[0][:b].to(self.device, non_blocking=True)
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
+        else:
+            slots_t = torch.from_numpy(slots)
         act = self.gather(self.rows, slots_t) if self.gather is not None else self.rows[slots_t]
         meta = self.meta[slots_t]
         ev = None

@@ -15,6 +15,12 @@
 
 namespace {
 constexpr int CAND_CAP = 4096;
+// Entries between the candidate lists of consecutive rows.  Not the capacity: with a 16 KB (power-of-two) row pitch the
+// 32 rows a wave appends to at once fall on few memory channels, and how badly depends on which physical pages the
+// allocation got -- the fused encoder then ran at 1.40 or 1.54 ms from one engine instance to the next
+// (tools/experiments/bimodal_probe.py).  Measured pitches: +128 B 1.50 ms, +256 B / +512 B / +1 KB 1.41-1.42 ms, all
+// stable; 1 KB it is.
+constexpr int CAND_STRIDE = CAND_CAP + 256;
 constexpr int TIMING_RING = 512;
 }
 
@@ -160,6 +166,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     if (!cfg || !out) return SAEV_INVALID_ARG;
     *out = nullptr;
     if (cfg->d_model <= 0 || cfg->d_sae <= 0 || cfg->top_k <= 0 || cfg->max_batch <= 0) return SAEV_INVALID_ARG;
+    // candidate lists are addressed with 32-bit byte offsets (max_batch <= 246 723 rows per call)
+    if ((uint64_t)cfg->max_batch * CAND_STRIDE * 4ull >= (1ull << 32)) return SAEV_INVALID_ARG;
     if (cfg->d_model % 4 != 0 || cfg->d_sae % 4 != 0 || cfg->d_model > 4096) return SAEV_UNSUPPORTED;
     if (cfg->k_aux < 0 || cfg->k_aux > 1024) return SAEV_UNSUPPORTED;
     if (cfg->encoder_mode != SAEV_ENCODER_F32 && cfg->encoder_mode != SAEV_ENCODER_F16X3 && cfg->encoder_mode != SAEV_ENCODER_BF16 &&
@@ -181,8 +189,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     c->n_params = 2 * S * D + S + D;
     int rc = SAEV_OK;
 #define A(p, n) if (rc == SAEV_OK) rc = alloc(c, &c->p, (size_t)(n))
-    c->gmax_stride = (int)((MB + 255) / 256 * 256);
-    A(cand_cnt, MB); A(gmax, (size_t)64 * c->gmax_stride); A(cand_idx, MB * CAND_CAP); A(cand_val, MB * CAND_CAP);
+    c->gmax_stride = (int)((MB + 255) / 256 * 256);  // (padding the group pitch changes nothing: measured)
+    A(cand_cnt, MB); A(gmax, (size_t)64 * c->gmax_stride); A(cand_idx, MB * CAND_STRIDE); A(cand_val, MB * CAND_STRIDE);
     A(h_dense, MB * S);
     A(idx, MB * K); A(val, MB * K); A(dval, MB * K);
     if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(g_aux, MB * D); A(dead_list, S); }
@@ -429,7 +437,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.h_out = h_out;
         a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
         a.gmax = c->gmax; a.gmax_stride = c->gmax_stride; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
-        a.cand_cap = CAND_CAP;
+        a.cand_cap = CAND_CAP; a.cand_stride = CAND_STRIDE;
         a.enable_flag = flag; a.enable_when = when;
         HIPCHK(c, launch_encode_f16x3(a, epi, s));
         return SAEV_OK;
@@ -449,7 +457,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
     a.cand_cnt = c->cand_cnt;
     a.cand_val = c->cand_val;
     a.cand_idx = c->cand_idx;
-    a.cand_cap = CAND_CAP;
+    a.cand_cap = CAND_CAP; a.cand_stride = CAND_STRIDE;
     a.enable_flag = flag;
     a.enable_when = when;
     HIPCHK(c, launch_encode_gemm(a, epi, s));
@@ -499,7 +507,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
         SelectCandArgs sc{};
         sc.cand_cnt = c->cand_cnt; sc.cand_val = c->cand_val; sc.cand_idx = c->cand_idx;
-        sc.cand_cap = CAND_CAP; sc.n_rows = n; sc.k = K;
+        sc.cand_cap = CAND_CAP; sc.cand_stride = CAND_STRIDE; sc.n_rows = n; sc.k = K;
         sc.idx_out = idx_out; sc.val_out = val_out; sc.out_stride = K;
         sc.enable_flag = need_dense; sc.enable_when = 0;
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
@@ -511,7 +519,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
             HIPCHK(c, launch_select_cand(sc, s));
             HIPCHK(c, launch_refine_exact(sc, s));
             sc.row_margin = nullptr;
-            sc.cand_cnt = c->surv_cnt; sc.cand_val = c->surv_val; sc.cand_idx = c->surv_idx; sc.cand_cap = REFINE_CAP;
+            sc.cand_cnt = c->surv_cnt; sc.cand_val = c->surv_val; sc.cand_idx = c->surv_idx; sc.cand_cap = REFINE_CAP; sc.cand_stride = REFINE_CAP;
         }
         HIPCHK(c, launch_select_cand(sc, s));
     } else {

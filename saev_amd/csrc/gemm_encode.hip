@@ -351,11 +351,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void encode_gemm_kernel(EncodeArgs a) 
             for (int jb = 0; jb < 2; ++jb) {
                 // a row whose list would overflow is not written at all: its counter already says so, and the step then
                 // re-runs on the exact dense route (overflow_check).  Offsets are 32-bit from the uniform buffer bases
-                // (n_rows * cand_cap * 4 < 2^32), so a kept value costs one address add and two stores.
+                // (n_rows * cand_stride * 4 < 2^32), so a kept value costs one address add and two stores.
                 if (npass[jb] > 0 && pos[jb] + npass[jb] <= a.cand_cap) {
                     const int bl = wb * 64 + jb * 32 + l31;
                     const float tau = tau2[jb];
-                    uint32_t off = ((uint32_t)(b0 + bl) * (uint32_t)a.cand_cap + (uint32_t)pos[jb]) * 4u;
+                    uint32_t off = ((uint32_t)(b0 + bl) * (uint32_t)a.cand_stride + (uint32_t)pos[jb]) * 4u;
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll

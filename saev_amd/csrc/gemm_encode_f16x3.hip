@@ -185,6 +185,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             }
             load_a(0, 0);
             load_a(1, 1);
+            // the two waves of a SIMD run this loop in step; raising the priority for the MFMA groups lets whichever
+            // gets there first keep the matrix pipe while the other is still waiting on its fragments (-2 %, measured)
+            __builtin_amdgcn_s_setprio(1);
             static_for<4>([&](auto G) {
                 constexpr int sb = decltype(G)::value;
                 constexpr int as = sb % 3;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            __builtin_amdgcn_s_setprio(0);
             // k-step t+1 must have landed (this wave's part) before the barrier publishes it; newer requests
             // (t+2, t+3: 4 loads each) stay in flight.  Raw barrier: __syncthreads() would drain the queue.
             if (t + 3 < nks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -355,11 +359,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             for (int jb = 0; jb < 2; ++jb) {
                 // a row whose list would overflow is not written at all: its counter already says so, and the step then
                 // re-runs on the exact dense route (overflow_check).  Offsets are 32-bit from the uniform buffer bases
-                // (n_rows * cand_cap * 4 < 2^32), so a kept value costs one address add and two stores.
+                // (n_rows * cand_stride * 4 < 2^32), so a kept value costs one address add and two stores.
                 if (npass[jb] > 0 && pos[jb] + npass[jb] <= a.cand_cap) {
                     const int bl_ = wb * 64 + jb * 32 + l31;
                     const float tau = tau2[jb];
-                    uint32_t off = ((uint32_t)(b0 + bl_) * (uint32_t)a.cand_cap + (uint32_t)pos[jb]) * 4u;
+                    uint32_t off = ((uint32_t)(b0 + bl_) * (uint32_t)a.cand_stride + (uint32_t)pos[jb]) * 4u;
 #pragma unroll
                     for (int sb = 0; sb < 4; ++sb)
 #pragma unroll

@@ -21,9 +21,10 @@ struct EncodeArgs {
                           // all latent ranges of the row
     int gmax_stride;
     int32_t* cand_cnt;    // (n_rows) init 0
-    float* cand_val;      // (n_rows, cand_cap)
-    int32_t* cand_idx;    // (n_rows, cand_cap)
-    int cand_cap;
+    float* cand_val;      // (n_rows, cand_stride)
+    int32_t* cand_idx;    // (n_rows, cand_stride)
+    int cand_cap;         // capacity of a row's list
+    int cand_stride;      // entries between rows (>= cand_cap; not a power of two, see ctx.hip CAND_STRIDE)
     // optional device-side predicate: run only when (*enable_flag != 0) == enable_when
     const int32_t* enable_flag;
     int enable_when;
@@ -52,7 +53,7 @@ struct SelectCandArgs {
     const int32_t* cand_cnt;
     const float* cand_val;
     const int32_t* cand_idx;
-    int cand_cap, n_rows, k;
+    int cand_cap, cand_stride, n_rows, k;
     int32_t* idx_out;
     float* val_out;
     int out_stride;
@@ -233,7 +234,7 @@ struct EncodeF16Args {
     int32_t* cand_cnt;
     float* cand_val;
     int32_t* cand_idx;
-    int cand_cap;
+    int cand_cap, cand_stride;
     const int32_t* enable_flag;
     int enable_when;
 };

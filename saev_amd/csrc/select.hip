@@ -180,8 +180,8 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int k = min(a.k, n);
-    const float* cv = a.cand_val + (size_t)row * a.cand_cap;
-    const int32_t* ci = a.cand_idx + (size_t)row * a.cand_cap;
+    const float* cv = a.cand_val + (size_t)row * a.cand_stride;
+    const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
 
     uint32_t key[EPL];
     int32_t idx[EPL];

@@ -17,9 +17,9 @@ eng.view("W_enc").copy_(W.t())
 x = torch.randn(B, D, device="cuda", generator=g) + torch.randn(D, device="cuda", generator=g)
 eng.enable_kernel_timing(True)
 ts = []
-for i in range(12):
+for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     eng.step_forward(x, training=False)
     torch.cuda.synchronize()
     ts.append(eng.encoder_ms())
 ts = ts[4:]
-print("encoder ms:", " ".join(f"{t:.3f}" for t in ts), " median %.3f" % sorted(ts)[len(ts) // 2])
+print("encoder ms:", " ".join(f"{t:.3f}" for t in ts[:8]), " median %.3f min %.3f" % (sorted(ts)[len(ts) // 2], min(ts)))

@@ -137,6 +137,20 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(float* dA, const uint8_
         if (!mask[q]) dA[q] = 0.f;
 }
 
+// out[i] = sum_j parts[j][i] in the order j = 0, 1, ...: the contraction slices of a split product (fixed order, so the
+// result does not depend on scheduling)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* parts, int n_parts, long n4, float* out) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(parts);
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        f32x4 acc = p[q];
+        for (int j = 1; j < n_parts; ++j) acc += p[(long)j * n4 + q];
+        reinterpret_cast<f32x4*>(out)[q] = acc;
+    }
+}
+__global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
+    if (threadIdx.x == 0) { out[0] = *a; out[1] = *b; }
+}
+
 // gW_dec[dl[j], :] += dWd[j, :]; gW_encT[dl[j], :] += dWe[j, :]; gb_enc[dl[j]] += dbe[j]   (one wave per dead latent)
 __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl, int nd, int D, const float* dWd,
                                                                const float* dWe, const float* dbe, float* gW_dec,
@@ -213,6 +227,14 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
 }
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s) {
     hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for(n)), dim3(256), 0, s, dA, mask, n);
+    return hipGetLastError();
+}
+hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, parts, n_parts, n / 4, out);  // n % 4 == 0
+    return hipGetLastError();
+}
+hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(scale_pair_kernel, dim3(1), dim3(64), 0, s, a, b, out);
     return hipGetLastError();
 }
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,

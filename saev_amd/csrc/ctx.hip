@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 namespace {
+constexpr int AUX_KSPLIT_MAX = 16;
 constexpr int CAND_CAP = 4096;
 // Entries between the candidate lists of consecutive rows.  Not the capacity: with a 16 KB (power-of-two) row pitch the
 // 32 rows a wave appends to at once fall on few memory channels, and how badly depends on which physical pages the
@@ -76,7 +77,9 @@ struct saev_ctx {
           *dbe = nullptr, *aux_partials = nullptr;
     uint8_t* A_mask = nullptr;
     // AuxK contractions on the f16x3 encoder kernel (F16X3 mode): operand images and compact vectors
-    _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr;
+    _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr, *aux_kA = nullptr, *aux_kD = nullptr;
+    float* aux_parts = nullptr;
+    int aux_kpad = 0;
     float *bias_dead = nullptr, *zero_bias = nullptr, *aux_scales = nullptr;  // aux_scales: {absmax, -, sA, 1, sg, 1}
     int aux_Dp2 = 0;
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
@@ -216,7 +219,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         c->MB_pad = (int)((MB + 255) / 256 * 256);
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
-        A(zero_bias, std::max(S, D)); A(aux_scales, 8);
+        A(zero_bias, std::max(S, D)); A(aux_scales, 16);
         A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(xabs, 1); A(mu, D); A(xnorm, MB); A(b_shift, S); A(bmax, 1); A(xabs_part, (MB + 3) / 4);
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)(c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
@@ -720,7 +723,12 @@ int ensure_aux_capacity(saev_ctx* c, int ndp) {
         c->aux_xsA = (_Float16*)grab((size_t)c->MB_pad * 2 * c->aux_Dp2 * sizeof(_Float16));
         c->aux_xsg = (_Float16*)grab((size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
         c->bias_dead = (float*)grab(cap256 * sizeof(float));
-        fast_ok = c->aux_ws1 && c->aux_ws2 && c->aux_xsA && c->aux_xsg && c->bias_dead;
+        // weight gradients: contraction over the batch axis, split into AUX_KSPLIT_MAX slices at most
+        c->aux_kpad = (int)((MB + 16 * AUX_KSPLIT_MAX - 1) / (16 * AUX_KSPLIT_MAX) * (16 * AUX_KSPLIT_MAX));
+        c->aux_kA = (_Float16*)grab(cap256 * 2 * (size_t)c->aux_kpad * sizeof(_Float16));   // A^T, later dA^T
+        c->aux_kD = (_Float16*)grab(D256 * 2 * (size_t)c->aux_kpad * sizeof(_Float16));     // g_aux^T, later x^T
+        c->aux_parts = (float*)grab((size_t)AUX_KSPLIT_MAX * cap * D * sizeof(float));
+        fast_ok = c->aux_ws1 && c->aux_ws2 && c->aux_xsA && c->aux_xsg && c->bias_dead && c->aux_kA && c->aux_kD && c->aux_parts;
     }
     if (!fast_ok || !c->Wenc_dead || !c->Wdec_dead || !c->H_dead || !c->A_dead || !c->A_mask || !c->dWd || !c->dWe || !c->dbe ||
         !c->aux_partials) {
@@ -746,6 +754,33 @@ int dense_f16x3(saev_ctx* c, const _Float16* xs, const _Float16* ws, const float
     a.ngroups = 32;
     a.enable_flag = nullptr; a.enable_when = 0;
     HIPCHK(c, launch_encode_f16x3(a, EPI_DENSE, s));
+    return SAEV_OK;
+}
+
+// out (R x C) = sum over the long axis k (length K <= aux_kpad) of P[k][r] * Q[k][c] for two k-major fp32 matrices
+// P (K x R), Q (K x C): the AuxK weight gradients.  Both are split into hi/lo fp16 images of their transposes
+// (split_wT), the contraction is cut into n_split slices that run as one batched launch of the encoder kernel (a single
+// slice would leave most CUs idle: R x C is only a few tiles), and the slices are added in a fixed order.
+int ksplit_f16x3(saev_ctx* c, const float* P, const float* sP, int R, const float* Q, const float* sQ, int C, int K,
+                 float* out, hipStream_t s) {
+    const int R256 = (R + 255) / 256 * 256, C256 = (C + 255) / 256 * 256;
+    const int tiles = (R256 / 256) * (C256 / 256);
+    int n_split = 1;
+    while (n_split < AUX_KSPLIT_MAX && tiles * n_split < 256) n_split *= 2;
+    const int Kp = (K + 16 * n_split - 1) / (16 * n_split) * (16 * n_split);  // <= aux_kpad
+    HIPCHK(c, launch_split_wT(P, K, R, R256, Kp, 1.0f, c->aux_kA, 0, s, sP));
+    HIPCHK(c, launch_split_wT(Q, K, C, C256, Kp, 1.0f, c->aux_kD, 0, s, sQ));
+    HIPCHK(c, launch_scale_pair(sP, sQ, c->aux_scales + 8, s));
+    EncodeF16Args a{};
+    a.scale_dev = c->aux_scales + 8;
+    a.xs = c->aux_kA; a.ws = c->aux_kD; a.b_enc = c->zero_bias;
+    a.n_rows = R; a.Dp = Kp / n_split; a.S = C; a.w_scale = 1.0f; a.arith = 0;
+    a.s_splits = encoder_splits(R, C, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
+    a.ngroups = 32;
+    a.n_batches = n_split; a.blk_imgs = Kp / 16; a.out_bstride = (long)R * C;
+    a.h_out = n_split > 1 ? c->aux_parts : out;
+    HIPCHK(c, launch_encode_f16x3(a, EPI_DENSE, s));
+    if (n_split > 1) HIPCHK(c, launch_sum_parts(c->aux_parts, n_split, (long)R * C, out, s));
     return SAEV_OK;
 }
 
@@ -831,10 +866,22 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     }
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_mask_apply(dA, c->A_mask, (long)n * ndp, s));
-    rc = gemm_tn(c, ndp, D, n, c->A_dead, c->g_aux, c->dWd);  // dW_dec[dl] = A^T g_aux
-    if (rc != SAEV_OK) return rc;
-    rc = gemm_tn(c, ndp, D, n, dA, c->x_last, c->dWe);  // dW_enc^T[dl] = dA^T x
-    if (rc != SAEV_OK) return rc;
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
+        // operand scales: A from the forward (aux_scales + 2), g_aux from above (+ 4), x from max|x| (+ 6), dA fresh
+        rc = ksplit_f16x3(c, c->A_dead, c->aux_scales + 2, ndp, c->g_aux, c->aux_scales + 4, D, n, c->dWd, s);
+        if (rc != SAEV_OK) return rc;
+        HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
+        HIPCHK(c, launch_absmax(dA, (long)n * ndp, c->aux_scales, s));
+        HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 10, s));
+        HIPCHK(c, launch_pow2_scale(c->upper, c->aux_scales + 6, s));
+        rc = ksplit_f16x3(c, dA, c->aux_scales + 10, ndp, c->x_last, c->aux_scales + 6, D, n, c->dWe, s);
+        if (rc != SAEV_OK) return rc;
+    } else {
+        rc = gemm_tn(c, ndp, D, n, c->A_dead, c->g_aux, c->dWd);  // dW_dec[dl] = A^T g_aux
+        if (rc != SAEV_OK) return rc;
+        rc = gemm_tn(c, ndp, D, n, dA, c->x_last, c->dWe);  // dW_enc^T[dl] = dA^T x
+        if (rc != SAEV_OK) return rc;
+    }
     HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));
     HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
     // the compact rows dWd / dWe / dbe are added into the gradient rows of the dead latents by saev_backward_rows

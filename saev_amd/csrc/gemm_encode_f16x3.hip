@@ -129,10 +129,12 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     // a slot image is 16 KB per operand; wave w copies bytes [2 KB * w, +2 KB) of each with two 1 KB calls
     const uint32_t g_off = (uint32_t)(wid * 2048 + lane * 16);
     const size_t img = (size_t)256 * 32;  // halfs per image
-    const _Float16* x_imgs = a.xs + (size_t)bb * nks * img;
+    const int blk_imgs = a.blk_imgs > 0 ? a.blk_imgs : nks;  // images per row block in memory
+    const int k_first = (EPI == EPI_DENSE) ? (int)blockIdx.y * nks : 0;  // contraction slice of this batch
+    const _Float16* x_imgs = a.xs + ((size_t)bb * blk_imgs + k_first) * img;
     auto stage_kstep = [&](int slot, int s0, int ks) {
         KSlot& st = sm.slot[slot];
-        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * nks + ks) * img) + g_off;
+        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * blk_imgs + k_first + ks) * img) + g_off;
         const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + g_off;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                             f32x4 v;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = acc[sb][jb][4 * q + e] * unscale + sm.bias[sl + e];
-                            *reinterpret_cast<f32x4*>(a.h_out + (size_t)b * S + s) = v;
+                            *reinterpret_cast<f32x4*>(a.h_out + (size_t)blockIdx.y * a.out_bstride + (size_t)b * S + s) = v;
                         }
                     }
             }
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
 
 hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream) {
     const int n_bblocks = (a.n_rows + HTB - 1) / HTB;
-    dim3 grid(n_bblocks * a.s_splits), block(HTHREADS);
+    dim3 grid(n_bblocks * a.s_splits, (epi == EPI_DENSE && a.n_batches > 1) ? a.n_batches : 1), block(HTHREADS);
     const size_t smem = sizeof(HSmem);
     static bool attr_set = false;
     if (!attr_set) {

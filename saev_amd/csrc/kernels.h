@@ -237,6 +237,13 @@ struct EncodeF16Args {
     int cand_cap, cand_stride;
     const int32_t* enable_flag;
     int enable_when;
+    // EPI_DENSE only: a batch of independent products (grid.y), used to split a long contraction into slices whose
+    // partial outputs are summed afterwards (AuxK weight gradients contract over the batch axis).  Batch j reads the
+    // k-steps [j*nks, (j+1)*nks) of every row block -- blk_imgs is the number of images a row block has in memory
+    // (0: nks, i.e. no slicing) -- and writes h_out + j*out_bstride.
+    int n_batches;
+    int blk_imgs;
+    long out_bstride;
 };
 hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream);
 int encode_f16x3_tile_rows();
@@ -269,5 +276,7 @@ hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, 
 hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const float* b_dec, int n_rows, int D,
                             float gscale, RowStats* rowstats, hipStream_t s);
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
+hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s);  // out = sum_j parts[j], n % 4 == 0
+hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStream_t s);          // out = {*a, *b}
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s);

@@ -645,17 +645,23 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
 // out (D, S) = in (S, D)^T, 64 x 64 tiles through LDS (padded: conflict-free both ways)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int S,
                                                         int D) {
+    // 64 x 64 tile; both sides move 16 bytes per lane (S % 4 == 0 and D % 4 == 0)
     __shared__ float tile[64][65];
     const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {
-        const int s = s0 + r, d = d0 + tx;
-        tile[r][tx] = (s < S && d < D) ? in[(size_t)s * D + d] : 0.f;
+    const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int r = r0; r < 64; r += 16) {
+        const int s = s0 + r, d = d0 + c4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s < S && d < D) v = *reinterpret_cast<const f32x4*>(in + (size_t)s * D + d);
+        tile[r][c4] = v[0]; tile[r][c4 + 1] = v[1]; tile[r][c4 + 2] = v[2]; tile[r][c4 + 3] = v[3];
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int d = d0 + r, s = s0 + tx;
-        if (d < D && s < S) out[(size_t)d * S + s] = tile[tx][r];
+#pragma unroll
+    for (int r = r0; r < 64; r += 16) {
+        const int d = d0 + r, s = s0 + c4;
+        if (d < D && s < S)
+            *reinterpret_cast<f32x4*>(out + (size_t)d * S + s) = f32x4{tile[c4][r], tile[c4 + 1][r], tile[c4 + 2][r], tile[c4 + 3][r]};
     }
 }
 

@@ -95,10 +95,12 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
     const int s0 = blk * 256, k0 = ks * KS;
     if (MODE == 2 && mu != nullptr && threadIdx.x < KS) mu_s[threadIdx.x] = (k0 + threadIdx.x < D) ? mu[k0 + threadIdx.x] : 0.f;
-    for (int q = threadIdx.x; q < KS * 256; q += 1024) {
-        const int kk = q >> 8, sl = q & 255;
+    for (int q = threadIdx.x; q < KS * 64; q += 1024) {  // 16 bytes per lane (S % 4 == 0)
+        const int kk = q >> 6, sl = (q & 63) * 4;
         const int k = k0 + kk, s = s0 + sl;
-        tile[kk][sl] = (k < D && s < S) ? W[(size_t)k * S + s] * scale : 0.f;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < D && s < S) v = *reinterpret_cast<const f32x4*>(W + (size_t)k * S + s) * scale;
+        tile[kk][sl] = v[0]; tile[kk][sl + 1] = v[1]; tile[kk][sl + 2] = v[2]; tile[kk][sl + 3] = v[3];
     }
     __syncthreads();
     const int i = threadIdx.x;

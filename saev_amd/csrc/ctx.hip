@@ -57,7 +57,7 @@ struct saev_ctx {
     double *sumsq_partials = nullptr, *sumsq_total = nullptr;
     int64_t* toks = nullptr;
     int32_t *fired = nullptr, *dead = nullptr;
-    int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use
+    int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use [6,7] dead_update scratch
     int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
     float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
     // Matryoshka prefixes of the step (P == 1: plain objective)
@@ -898,7 +898,7 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     DeadArgs d{};
     d.toks = c->toks; d.fired = c->fired; d.dead = c->dead; d.S = S;
     d.add_tokens = n_rows_global; d.threshold = c->cfg.dead_threshold_tokens; d.k_aux = c->cfg.k_aux;
-    d.n_dead = c->flags + 4; d.k_use = c->flags + 5; d.stats = c->stats;
+    d.n_dead = c->flags + 4; d.k_use = c->flags + 5; d.stats = c->stats; d.scratch = c->flags + 6;
     HIPCHK(c, launch_dead_update(d, s));
     c->n_dead_host = 0;
     c->k_use_host = 0;

@@ -205,6 +205,7 @@ struct DeadArgs {
     int32_t* n_dead;        // device scalar out
     int32_t* k_use;         // device scalar out: min(k_aux, n_dead)
     saev_step_stats* stats;
+    int32_t* scratch;       // two ints, zero between launches: running count and block ticket
 };
 hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream);
 hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream);

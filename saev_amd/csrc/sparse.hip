@@ -674,7 +674,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int
     const int r1 = min(n_rows, r0 + 64);
     for (int q = threadIdx.x; q < (D >> 2); q += 256) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int r = r0; r < r1; ++r) s += reinterpret_cast<const f32x4*>(m + (size_t)r * row_stride)[q];
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {  // eight independent loads in flight; fixed summation tree
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const f32x4*>(m + (size_t)(r + u) * row_stride)[q];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; r < r1; ++r) s += reinterpret_cast<const f32x4*>(m + (size_t)r * row_stride)[q];
         reinterpret_cast<f32x4*>(partials + (size_t)blockIdx.x * D)[q] = s;
     }
 }

@@ -134,27 +134,32 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
 }
 
-__global__ __launch_bounds__(1024) void dead_update_kernel(DeadArgs a) {
-    __shared__ int sh[16];
-    int c = 0;
-    for (int i = threadIdx.x; i < a.S; i += 1024) {
+__global__ __launch_bounds__(256) void dead_update_kernel(DeadArgs a) {
+    __shared__ int sh[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int d = 0;
+    if (i < a.S) {
         int64_t t = a.toks[i] + a.add_tokens;
         if (a.fired[i]) t = 0;
         a.fired[i] = 0;
         a.toks[i] = t;
-        const int d = (t >= a.threshold) ? 1 : 0;
+        d = (t >= a.threshold) ? 1 : 0;
         a.dead[i] = d;
-        c += d;
     }
-    c = wave_sum_i(c);
+    const int c = wave_sum_i(d);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int t = 0;
-        for (int i = 0; i < 16; ++i) t += sh[i];
-        *a.n_dead = t;
-        *a.k_use = min(a.k_aux, t);
-        if (a.stats) a.stats->n_dead = t;
+        atomicAdd(&a.scratch[0], sh[0] + sh[1] + sh[2] + sh[3]);  // integer sum: order does not matter
+        __threadfence();
+        if (atomicAdd(&a.scratch[1], 1) == (int)gridDim.x - 1) {  // last block: publish and reset
+            __threadfence();
+            const int t = atomicExch(&a.scratch[0], 0);
+            a.scratch[1] = 0;
+            *a.n_dead = t;
+            *a.k_use = min(a.k_aux, t);
+            if (a.stats) a.stats->n_dead = t;
+        }
     }
 }
 
@@ -269,7 +274,7 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(dead_update_kernel, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(dead_update_kernel, dim3((a.S + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream) {

@@ -62,11 +62,13 @@ typedef struct {
 #define SAEV_ENCODER_F32 0
 #define SAEV_ENCODER_F16X3 1
 #define SAEV_ENCODER_BF16 2
-/*   F16R  : one v_mfma_f32_32x32x16_f16 per product on fp16-rounded operands as a FIRST PASS whose error is bounded per
- *           row (|error| <= 1.2 * 2^-10 * ||x_row|| * max ||W_enc column||); candidates are kept down to the running
- *           bound minus twice that, and the select stage recomputes every survivor exactly in fp32 (dot product with
- *           the fp32 encoder column + bias) before the final cut.  Codes and values are those of exact fp32 arithmetic;
- *           a dense h (saev_encode_dense, overflow route) always comes from the exact fp32 kernel. */
+/*   F16R  : one v_mfma_f32_32x32x16_f16 per product on fp16-rounded operands as a FIRST PASS, run on activations
+ *           centred on the batch mean (the bias absorbs mean * W_enc), whose error is bounded per row
+ *           (|error| <= 1.05 * (2^-10 + d_model * 2^-22) * ||x_row - mean|| * max ||W_enc column|| + 2^-23 max |bias|);
+ *           candidates are kept down to the running bound minus twice that, and the select stage recomputes every
+ *           survivor exactly in fp32 (dot product of the uncentred row with the fp32 encoder column + b_enc) before the
+ *           final cut.  Codes and values are those of exact fp32 arithmetic; a dense h (saev_encode_dense, overflow
+ *           route) always comes from the exact fp32 kernel.  Default of the Python host. */
 #define SAEV_ENCODER_F16R 3
 
 /* Scalars of one step (nn/objectives.py:57-89 MatryoshkaLoss + train.py:356-362 grad norm). */

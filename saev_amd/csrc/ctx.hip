@@ -87,6 +87,7 @@ struct saev_ctx {
     int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
     float *f16r_scales = nullptr, *xabs = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *bmax = nullptr, *dot_part = nullptr, *xabs_part = nullptr, *sq_part = nullptr, *wmax_prev = nullptr;
     bool wmax_known = false;
+    bool mu_sum_ready = false;  // the step already put the column sums of x into mu
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -405,7 +406,8 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // centre the first pass on the batch's column mean: h = (x - mu) W + (mu W + b)
         (void)xmax_dev;
         const float inv_n = 1.0f / (float)n;
-        HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0));
+        if (!c->mu_sum_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0));
+        c->mu_sum_ready = false;
         HIPCHK(c, launch_scale_vec(c->mu, D, inv_n, s));  // mu, materialised once so every consumer sees the same fp32 values
         HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, c->xabs, s));
         HIPCHK(c, launch_f16r_scales(c->xabs, c->wmax_prev, c->f16r_scales, s));
@@ -630,7 +632,12 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
         if (rc != SAEV_OK) return rc;
     }
     HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));  // flags[0]: force-dense flag, unused by the step
-    HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {  // one pass: max|x| for the MSE and the column sums the encoder centres on
+        HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s));
+        c->mu_sum_ready = true;
+    } else {
+        HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
+    }
     (void)n_rows_global;
     int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s, c->upper);
     if (rc != SAEV_OK) return rc;

@@ -178,6 +178,8 @@ hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream
 // out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
                          const int32_t* k_dev, hipStream_t stream, long row_stride = 0);
+hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partials, float* out, float* wg_scratch,
+                                float* absmax_out, hipStream_t stream);  // + max |m| from the same pass
 
 // ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
 hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream);

@@ -667,9 +667,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // ------------------------------- column sums -----------------------------------------------
 
+template <bool ABSMAX>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int n_rows, int D, float* partials,
-                                                             const int32_t* k_dev, long row_stride) {
+                                                             const int32_t* k_dev, long row_stride, float* wg_absmax) {
     if (k_dev && *k_dev <= 0) return;
+    float amax = 0.f;
     const int r0 = blockIdx.x * 64;
     const int r1 = min(n_rows, r0 + 64);
     for (int q = threadIdx.x; q < (D >> 2); q += 256) {
@@ -680,9 +682,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const f32x4*>(m + (size_t)(r + u) * row_stride)[q];
             s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            if constexpr (ABSMAX) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[u][0])), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+            }
         }
-        for (; r < r1; ++r) s += reinterpret_cast<const f32x4*>(m + (size_t)r * row_stride)[q];
+        for (; r < r1; ++r) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(m + (size_t)r * row_stride)[q];
+            s += v;
+            if constexpr (ABSMAX) amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
         reinterpret_cast<f32x4*>(partials + (size_t)blockIdx.x * D)[q] = s;
+    }
+    if constexpr (ABSMAX) {  // the same pass also gives max |m| (one value per workgroup; max_reduce finishes)
+        __shared__ float sh[4];
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) wg_absmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     }
 }
 // 64 columns per workgroup, 4 threads per column each summing every 4th partial row with independent loads in
@@ -771,9 +789,20 @@ hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, flo
                          const int32_t* k_dev, hipStream_t stream, long row_stride) {
     const int nb = (n_rows + 63) / 64;
     if (nb <= 0) return hipSuccess;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev,
-                       row_stride > 0 ? row_stride : (long)D);
+    hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev,
+                       row_stride > 0 ? row_stride : (long)D, (float*)nullptr);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out,
                        accumulate, k_dev);
     return hipGetLastError();
+}
+// column sums and max |m| from one pass over m; wg_scratch holds ceil(n_rows / 64) floats
+hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partials, float* out, float* wg_scratch,
+                                float* absmax_out, hipStream_t stream) {
+    const int nb = (n_rows + 63) / 64;
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials,
+                       (const int32_t*)nullptr, (long)D, wg_scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out, 0,
+                       (const int32_t*)nullptr);
+    return launch_max_reduce(wg_scratch, nb, absmax_out, stream);
 }

@@ -83,11 +83,12 @@ struct saev_ctx {
     float *bias_dead = nullptr, *zero_bias = nullptr, *aux_scales = nullptr;  // aux_scales: {absmax, -, sA, 1, sg, 1}
     int aux_Dp2 = 0;
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
-    float *row_margin = nullptr, *wmax = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
+    float *row_margin = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
     int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
-    float *f16r_scales = nullptr, *xabs = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *bmax = nullptr, *dot_part = nullptr, *xabs_part = nullptr, *sq_part = nullptr, *wmax_prev = nullptr;
+    float *f16r_scales = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *dot_part = nullptr, *xabs_part = nullptr,
+          *sq_part = nullptr, *wmax_prev = nullptr;
     bool wmax_known = false;
-    bool mu_sum_ready = false;  // the step already put the column sums of x into mu
+    bool mu_ready = false;  // the step already put the column means of x into mu
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -221,7 +222,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
         A(zero_bias, std::max(S, D)); A(aux_scales, 16);
-        A(row_margin, MB); A(wmax, 1); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(xabs, 1); A(mu, D); A(xnorm, MB); A(b_shift, S); A(bmax, 1); A(xabs_part, (MB + 3) / 4);
+        A(row_margin, MB); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(mu, D); A(xnorm, MB); A(b_shift, S);
+        A(xabs_part, (MB + 3) / 4);
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)(c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
@@ -405,19 +407,18 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         }
         // centre the first pass on the batch's column mean: h = (x - mu) W + (mu W + b)
         (void)xmax_dev;
-        const float inv_n = 1.0f / (float)n;
-        if (!c->mu_sum_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0));
-        c->mu_sum_ready = false;
-        HIPCHK(c, launch_scale_vec(c->mu, D, inv_n, s));  // mu, materialised once so every consumer sees the same fp32 values
-        HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, c->xabs, s));
-        HIPCHK(c, launch_f16r_scales(c->xabs, c->wmax_prev, c->f16r_scales, s));
+        // (mu = column sums / n, scaled in the same kernel so that every consumer sees the same fp32 values)
+        if (!c->mu_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n));
+        c->mu_ready = false;
+        HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s));
+        HIPCHK(c, launch_f16r_scales(c->xabs_part, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
         HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
         HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
                                   c->mu, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
-                                     c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, c->bmax,
-                                     c->wmax, pre_flag, c->wmax_prev, s));
-        HIPCHK(c, launch_row_margins(c->xnorm, n, D, c->wmax, c->bmax, c->row_margin, s));
+                                     c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
+        HIPCHK(c, launch_row_margins(c->xnorm, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales + 1, pre_flag,
+                                     c->wmax_prev, c->row_margin, s));
         return SAEV_OK;
     }
     HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
@@ -633,8 +634,8 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     }
     HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));  // flags[0]: force-dense flag, unused by the step
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {  // one pass: max|x| for the MSE and the column sums the encoder centres on
-        HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s));
-        c->mu_sum_ready = true;
+        HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s, 1.0f / (float)n));
+        c->mu_ready = true;
     } else {
         HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
     }

@@ -78,13 +78,12 @@ hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream);
 hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream);
 hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream);
-hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream);
+hipError_t launch_f16r_scales(const float* xmax_part, int n_part, const float* wmax, float* scales, hipStream_t stream);
 hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream);
-hipError_t launch_scale_vec(float* v, int n, float scale, hipStream_t stream);
-hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_scratch,
-                               float* xabs, hipStream_t stream);
-hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin,
-                              hipStream_t stream);
+hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
+                               hipStream_t stream);  // ||x_b - mu|| per row, max |x - mu| per workgroup of 4 rows
+hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
+                              int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream);
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                  int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);
 
@@ -177,9 +176,9 @@ hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream
 
 // out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
-                         const int32_t* k_dev, hipStream_t stream, long row_stride = 0);
+                         const int32_t* k_dev, hipStream_t stream, long row_stride = 0, float out_scale = 1.0f);
 hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partials, float* out, float* wg_scratch,
-                                float* absmax_out, hipStream_t stream);  // + max |m| from the same pass
+                                float* absmax_out, hipStream_t stream, float out_scale = 1.0f);  // + max |m|, same pass
 
 // ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
 hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream);
@@ -261,11 +260,11 @@ hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, floa
                            // ||W*scale||^2 per column, W_T = fp32 transpose of W
                            const float* mu = nullptr, double* dot_part = nullptr, float* sq_part = nullptr,
                            float* W_T = nullptr);
-// f16r: b_shift = float(sum_ks dot_part / *w_scale + b_enc), bmax = max |b_shift|, wmax = largest column norm of W_enc;
-// raises *pre_flag when wmax * *w_scale is outside the safe fp16 window, then wmax_prev = wmax.  wg_scratch: 2*ceil(S/256)
+// f16r: b_shift = float(sum_ks dot_part / *w_scale + b_enc); wg_part[0..nwg) = per-workgroup max |b_shift|,
+// wg_part[nwg..2 nwg) = per-workgroup max column norm of W_enc (nwg = ceil(S/256)); launch_row_margins reduces them and
+// raises *pre_flag when the largest norm times *w_scale is outside the safe fp16 window, then wmax_prev = that norm
 hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int Dp, int S, int S_pad, const float* w_scale,
-                              const float* b_enc, float* b_shift, float* wg_scratch, float* bmax, float* wmax,
-                              int32_t* pre_flag, float* wmax_prev, hipStream_t stream);
+                              const float* b_enc, float* b_shift, float* wg_part, hipStream_t stream);
 hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream);
 
 // ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------

@@ -389,10 +389,6 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n,
 // streams carry a large common offset (and "massive activation" channels), which would otherwise inflate the margin
 // until every latent survives.  The exact refinement keeps using x and b_enc themselves.
 //
-__global__ void scale_vec_kernel(float* v, int n, float scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] *= scale;
-}
 // per row: ||x_b - mu||; per workgroup: max |x - mu| (thousands of same-address atomics would serialise: two stages)
 __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const float* mu, int n, int D,
                                                            float* xnorm, float* wg_max) {
@@ -431,11 +427,35 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
 // is covered) plus the rounding of the shifted bias.  The operands are pre-scaled so that their largest element sits in
 // [2^13, 2^14): whatever the matrix cores do with fp16 subnormals (flush or keep) then changes a pre-activation by less
 // than 3e-7 of the same product of norms.  DESIGN.md 3.1.
-__global__ void row_margin_kernel(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+//
+// wg_part holds the per-workgroup maxima bias_finish_kernel left behind: |b_shift| in [0, n_part), column norms in
+// [n_part, 2 n_part).  Every workgroup reduces them again (a few hundred values) instead of waiting for two more tiny
+// launches; workgroup 0 also runs the scale check: the W images of this step were scaled with the power of two derived
+// from the PREVIOUS call's largest column norm (so that one pass over W_enc suffices).  Parameters move a little per
+// step, but they belong to the caller and may have been replaced: if the largest column norm of the current W_enc
+// leaves the window in which the fp16 images are safe (no overflow; no more than two bits below the intended range),
+// raise the dense-route flag -- the step then runs on the exact fp32 kernel -- and in any case remember the current
+// norm for the next call.
+__global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int n, int D, const float* wg_part, int n_part,
+                                                         const float* w_scale, int32_t* pre_flag, float* wmax_prev,
+                                                         float* margin) {
+    __shared__ float sh[2][4];
+    float bm = 0.f, wm = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) { bm = fmaxf(bm, wg_part[i]); wm = fmaxf(wm, wg_part[n_part + i]); }
+    bm = wave_max(bm); wm = wave_max(wm);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = bm; sh[1][threadIdx.x >> 6] = wm; }
+    __syncthreads();
+    const float bmax = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
+    const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float t = wmax * (*w_scale);
+        if (!(t < 60000.0f && (t >= 2048.0f || wmax == 0.f))) *pre_flag = 1;  // (an all-zero W_enc has exact images)
+        *wmax_prev = wmax;
+    }
+    const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
-    margin[r] = coef * xnorm[r] * (*wmax) + 2.0f * 1.1920929e-07f * (*bmax);
+    margin[r] = coef * xnorm[r] * wmax + 2.0f * 1.1920929e-07f * bmax;
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)
@@ -447,9 +467,16 @@ __global__ void pow2_scale_kernel(const float* absmax, float* pair) {
     }
 }
 // power-of-two scales that put the largest |x| and the largest encoder column norm (>= largest |w|) into [2^13, 2^14)
-__global__ void f16r_scales_kernel(const float* xmax, const float* wmax, float* scales) {
+// (xmax_part: per-workgroup maxima of |x - mu| from center_stats_kernel, reduced here)
+__global__ __launch_bounds__(256) void f16r_scales_kernel(const float* xmax_part, int n_part, const float* wmax, float* scales) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) m = fmaxf(m, xmax_part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float xm = *xmax, wm = *wmax;
+        const float xm = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])), wm = *wmax;
         scales[0] = (xm > 0.f && xm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(xm))) : 1.0f;
         scales[1] = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
         scales[2] = scales[0];  // {x scale, 1}: for contractions whose second operand carries a fixed scale (AuxK)
@@ -515,32 +542,27 @@ hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch
     hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, wg_scratch, nwg, wmax);
     return hipGetLastError();
 }
-hipError_t launch_f16r_scales(const float* xmax, const float* wmax, float* scales, hipStream_t stream) {
-    hipLaunchKernelGGL(f16r_scales_kernel, dim3(1), dim3(64), 0, stream, xmax, wmax, scales);
+hipError_t launch_f16r_scales(const float* xmax_part, int n_part, const float* wmax, float* scales, hipStream_t stream) {
+    hipLaunchKernelGGL(f16r_scales_kernel, dim3(1), dim3(256), 0, stream, xmax_part, n_part, wmax, scales);
     return hipGetLastError();
 }
 hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream) {
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, stream, absmax, pair);
     return hipGetLastError();
 }
-hipError_t launch_scale_vec(float* v, int n, float scale, hipStream_t stream) {
-    hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, n, scale);
-    return hipGetLastError();
-}
-hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_scratch,
-                               float* xabs, hipStream_t stream) {
-    const int nwg = (n + 3) / 4;
-    hipLaunchKernelGGL(center_stats_kernel, dim3(nwg), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_scratch);
-    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, wg_scratch, nwg, xabs);
+hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_absmax);
     return hipGetLastError();
 }
 hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, v, n, out);
     return hipGetLastError();
 }
-hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wmax, const float* bmax, float* margin,
-                              hipStream_t stream) {
-    hipLaunchKernelGGL(row_margin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xnorm, n, D, wmax, bmax, margin);
+hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
+                              int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream) {
+    hipLaunchKernelGGL(row_margin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xnorm, n, D, wg_part, n_part, w_scale,
+                       pre_flag, wmax_prev, margin);
     return hipGetLastError();
 }
 

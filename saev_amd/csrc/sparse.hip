@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int
 // 64 columns per workgroup, 4 threads per column each summing every 4th partial row with independent loads in
 // flight, then a fixed-order LDS combine (deterministic).
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partials, int n_blocks, int D, float* out,
-                                                           int accumulate, const int32_t* k_dev) {
+                                                           int accumulate, const int32_t* k_dev, float out_scale) {
     if (k_dev && *k_dev <= 0) return;
     __shared__ float part[4][64];
     const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partials
     __syncthreads();
     if (slice == 0 && d < D) {
         const float s = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
-        out[d] = accumulate ? out[d] + s : s;
+        out[d] = accumulate ? out[d] + s * out_scale : s * out_scale;
     }
 }
 
@@ -786,23 +786,23 @@ hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream
     return hipGetLastError();
 }
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
-                         const int32_t* k_dev, hipStream_t stream, long row_stride) {
+                         const int32_t* k_dev, hipStream_t stream, long row_stride, float out_scale) {
     const int nb = (n_rows + 63) / 64;
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev,
                        row_stride > 0 ? row_stride : (long)D, (float*)nullptr);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out,
-                       accumulate, k_dev);
+                       accumulate, k_dev, out_scale);
     return hipGetLastError();
 }
 // column sums and max |m| from one pass over m; wg_scratch holds ceil(n_rows / 64) floats
 hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partials, float* out, float* wg_scratch,
-                                float* absmax_out, hipStream_t stream) {
+                                float* absmax_out, hipStream_t stream, float out_scale) {
     const int nb = (n_rows + 63) / 64;
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials,
                        (const int32_t*)nullptr, (long)D, wg_scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out, 0,
-                       (const int32_t*)nullptr);
+                       (const int32_t*)nullptr, out_scale);
     return launch_max_reduce(wg_scratch, nb, absmax_out, stream);
 }

@@ -170,18 +170,6 @@ __global__ __launch_bounds__(256) void bias_finish_kernel(const double* __restri
     }
 }
 
-// The W images of this step were scaled with the power of two derived from the PREVIOUS step's largest column norm
-// (so that one pass over W_enc suffices).  Parameters move a little per step, but they belong to the caller and may
-// have been replaced: if the largest column norm of the current W_enc leaves the window in which the fp16 images are
-// safe (no overflow; no more than two bits below the intended range), raise the dense-route flag -- the step then runs
-// on the exact fp32 kernel -- and in any case remember the current norm for the next step.
-__global__ void f16r_check_kernel(const float* wmax, const float* w_scale, int32_t* pre_flag, float* wmax_prev) {
-    if (threadIdx.x == 0) {
-        const float t = (*wmax) * (*w_scale);
-        if (!(t < 60000.0f && (t >= 2048.0f || *wmax == 0.f))) *pre_flag = 1;  // (an all-zero W_enc has exact images)
-        *wmax_prev = *wmax;
-    }
-}
 
 }  // namespace
 
@@ -209,15 +197,9 @@ hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, floa
 }
 
 hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int Dp, int S, int S_pad, const float* w_scale,
-                              const float* b_enc, float* b_shift, float* wg_scratch, float* bmax, float* wmax,
-                              int32_t* pre_flag, float* wmax_prev, hipStream_t stream) {
+                              const float* b_enc, float* b_shift, float* wg_part, hipStream_t stream) {
     const int nwg = (S + 255) / 256;
     hipLaunchKernelGGL(bias_finish_kernel, dim3(nwg), dim3(256), 0, stream, dot_part, sq_part, Dp / 32, S, S_pad, w_scale,
-                       b_enc, b_shift, wg_scratch);
-    hipError_t e = launch_max_reduce(wg_scratch, nwg, bmax, stream);
-    if (e != hipSuccess) return e;
-    e = launch_max_reduce(wg_scratch + nwg, nwg, wmax, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(f16r_check_kernel, dim3(1), dim3(64), 0, stream, wmax, w_scale, pre_flag, wmax_prev);
+                       b_enc, b_shift, wg_part);
     return hipGetLastError();
 }

@@ -164,7 +164,7 @@ def main():
         # HBM/fabric bytes per launch of that kernel come from rocprofv3 PMC passes (they cannot be collected inside the
         # timed run); the committed summaries are the source, and they only apply to the shape/encoder they were taken on
         tfile = {"f16x3": ROOT / "profiles" / "r01_d_encoder_traffic.json",
-                 "f16r": ROOT / "profiles" / "r01_f_encoder_traffic.json"}.get(eng.cfg.encoder)
+                 "f16r": ROOT / "profiles" / "r01_g_encoder_traffic.json"}.get(eng.cfg.encoder)
         if tfile is not None and B == BATCH and tfile.exists():
             tj = json.loads(tfile.read_text())
             roof["traffic"] = tj["traffic_bytes_per_launch"]

@@ -72,7 +72,9 @@ def test_topk_dense_ties_and_mask():
 
 
 @pytest.mark.parametrize("n,d,s,k", [(96, 48, 320, 8), (128, 64, 512, 8), (300, 128, 1024, 16), (5, 16, 24, 64),
-                                     (200, 64, 2048, 32), (130, 32, 4096, 64)])
+                                     (200, 64, 2048, 32), (130, 32, 4096, 64),
+                                     # ragged everything: d_model not a multiple of 32, d_sae not of 256, one row, k = 1
+                                     (1, 20, 36, 4), (3, 100, 1004, 33), (257, 772, 5004, 64), (64, 36, 260, 1)])
 def test_fused_encode_topk_matches_oracle(n, d, s, k):
     p = rand_params(d, s, seed=7 * n)
     x = torch.randn(n, d, generator=torch.Generator().manual_seed(n + 2))

@@ -140,6 +140,16 @@ int alloc(saev_ctx* c, T** p, size_t count) {
     return SAEV_OK;
 }
 
+// TopK bound of the fp16-image encoders: the minimum over 32 group maxima for top_k <= 32; 64 groups with the top_k-th
+// largest of the group maxima for 32 < top_k <= 64.  SAEV_AMD_NGROUPS=64 forces the second variant for small k as well: it
+// cuts the candidates per row from ~980 to ~360 at config 2, but its bound phase (32 published maxima per lane, a
+// bisection over packed 16-bit keys) costs more than the shorter lists save (encoder 1.43-1.51 vs 1.35-1.38 ms).
+int f16_ngroups(const saev_cfg& cfg) {
+    static const int forced = [] { const char* e = getenv("SAEV_AMD_NGROUPS"); return e ? atoi(e) : 0; }();
+    if (cfg.top_k > 32 || forced == 64) return 64;
+    return 32;
+}
+
 int encoder_splits(int n_rows, int S, int tile_rows, int tile_latents, int target_wgs) {
     const int nb = (n_rows + tile_rows - 1) / tile_rows;
     const int nst = (S + tile_latents - 1) / tile_latents;
@@ -441,7 +451,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.row_margin = f16r ? c->row_margin : nullptr;
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
         a.h_out = h_out;
-        a.ngroups = c->cfg.top_k <= 32 ? 32 : 64;
+        a.ngroups = f16_ngroups(c->cfg); a.top_k = c->cfg.top_k;
         a.gmax = c->gmax; a.gmax_stride = c->gmax_stride; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
         a.cand_cap = CAND_CAP; a.cand_stride = CAND_STRIDE;
         a.enable_flag = flag; a.enable_when = when;
@@ -505,7 +515,8 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         if (rc0 != SAEV_OK) return rc0;
     }
     if (fused_supported(c->cfg)) {
-        HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, (c->cfg.top_k <= 32 ? 32 : 64) * c->gmax_stride, s));
+        const int ng = c->cfg.encoder_mode == SAEV_ENCODER_F32 ? (c->cfg.top_k <= 32 ? 32 : 64) : f16_ngroups(c->cfg);
+        HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, s));
         timing_begin(c, s);  // the events bracket the encoder kernel alone
         int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
         if (rc != SAEV_OK) return rc;

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
         }
         // all slots are free.  Request the next tile's first two k-steps so they land during the epilogue
         // (the NG == 32 scratch only uses slots 2,3).
-        const bool prefetched = (NG == 32 || EPI == EPI_DENSE) && (st + 1 < st_end);
+        const bool prefetched = st + 1 < st_end;  // (both TopK variants keep their scratch inside slots 2,3)
         if (prefetched) {
             stage_kstep(0, s0 + HTS, kmap(0));
             if (nks > 1) stage_kstep(1, s0 + HTS, kmap(1));
@@ -255,80 +255,192 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             }
             __syncthreads();
         } else {
-            // group maxima of THIS tile only; the running maxima over earlier tiles (of this and of every other
-            // workgroup that owns the same rows) live in a.gmax and are merged below, so nothing is carried in
-            // registers across the contraction loop
-            float smax[2][NSLOT];
+            if constexpr (NG == 64) {
+                // ---- 64 groups, bound = K-th largest of the 64 merged group maxima (K = top_k) ----
+                // Any K distinct seen values bound the K-th largest pre-activation from below; with 64 group maxima
+                // the K-th largest of them is a much tighter bound than the minimum over 32 groups (candidates per row
+                // at config 2: ~360 instead of ~980, simulated and measured).  Group of a latent: a fixed function of
+                // its position modulo 64.  The tile's own maxima go through LDS as 16-bit keys (the ordered key shifted
+                // down: rounded towards -inf, still a lower bound), two per word, so the scratch is the same 64 KB as the
+                // 32-group variant and the next tile's first k-steps can still land during the epilogue.
+                typedef short short2v __attribute__((ext_vector_type(2)));
+                // bound phase: two lanes of one wave per row (lane and lane ^ 32), each owning 16 words = 32 groups.  The
+                // published maxima of the first 16 are requested now, so that they arrive while the tile's own maxima
+                // are formed; the other 16 follow after the barrier, while the first are merged.
+                const int trow = wid * 32 + l31;
+                const int tpart = lane >> 5;
+                const int tb = b0 + trow;
+                const bool share = tb < B;
+                const uint32_t boff = (uint32_t)tb * 4u;
+                // (group bases are wave-uniform -> SGPR pairs; the lane's half and row go into one 32-bit offset)
+                const uint32_t voff = ((uint32_t)(32 * tpart) * (uint32_t)a.gmax_stride + (uint32_t)min(tb, B - 1)) * 4u;
+                // (the empty asm makes each group's element offset an opaque uniform value: otherwise the compiler sees an
+                // arithmetic progression, turns the 32 addresses into 64-bit VGPR pairs, hoists them out of the tile loop and
+                // spills them; like this every access is "SGPR base + 32-bit lane offset")
+#define GPTR(i)                                                                          \
+    ({                                                                                   \
+        size_t go_ = (size_t)(i) * (size_t)a.gmax_stride;                                \
+        asm("" : "+s"(go_));                                                             \
+        reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + go_) + voff);        \
+    })
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
+                for (int jb = 0; jb < 2; ++jb) {
+                    float smax[32];
 #pragma unroll
-                for (int r = 0; r < NSLOT; ++r) smax[jb][r] = NEG_INF;
+                    for (int r = 0; r < 32; ++r) smax[r] = NEG_INF;
 #pragma unroll
-            for (int sb = 0; sb < 4; ++sb)
+                    for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
-                    const bool ok = (s0 + sl) < S;  // d_sae % 4 == 0: a float4 of latents is all in or all out
-                    // one 16-byte LDS read per four latents, unconditional (a per-element conditional read turns into
-                    // 128 branches with an LDS round trip each)
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(&sm.bias[sl]);
+                        for (int q = 0; q < 4; ++q) {
+                            const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
+                            const bool ok = (s0 + sl) < S;
+                            const f32x4 bq = *reinterpret_cast<const f32x4*>(&sm.bias[sl]);
 #pragma unroll
-                    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
-                            const float v = ok ? hv : NEG_INF;
-                            acc[sb][jb][4 * q + e] = v;
-                            const int slot = (NG == 32) ? (4 * q + e) : (16 * (sb & 1) + 4 * q + e);
-                            smax[jb][slot] = fmaxf(smax[jb][slot], v);
+                            for (int e = 0; e < 4; ++e) {
+                                const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
+                                const float v = ok ? hv : NEG_INF;
+                                acc[sb][jb][4 * q + e] = v;
+                                const int slot = 16 * (sb & 1) + 4 * q + e;
+                                smax[slot] = fmaxf(smax[slot], v);
+                            }
                         }
-                }
+                    const int bl_ = wb * 64 + jb * 32 + l31;
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-                const int bl_ = wb * 64 + jb * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < NSLOT; ++r) {
-                    if (NG == 32) sm.e32.slots32[ws][2 * r + half][bl_] = f2key(smax[jb][r]);
-                    else sm.slots64[ws][2 * r + half][bl_] = f2key(smax[jb][r]);
+                    for (int t = 0; t < 16; ++t) {  // word (2t + half): groups 2*(2t + half), 2*(2t + half) + 1
+                        sm.e32.slots32[ws][2 * t + half][bl_] = (int32_t)__builtin_amdgcn_perm(
+                            (uint32_t)f2key(smax[2 * t + 1]), (uint32_t)f2key(smax[2 * t]), 0x07060302u);  // {hi16(b), hi16(a)}
+                    }
                 }
+                __syncthreads();
+                {
+                    int32_t old[32];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {  // all global reads of this lane in flight together
+                        old[i] = __hip_atomic_load(GPTR(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (row clamped)
+                    }
+                    short2v mp[16];  // merged maxima, two 16-bit keys per register
+                    uint32_t improved = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int gp = 16 * tpart + j;
+                        const short2v w0 = __builtin_bit_cast(short2v, sm.e32.slots32[0][gp][trow]);
+                        const short2v w1 = __builtin_bit_cast(short2v, sm.e32.slots32[1][gp][trow]);
+                        const short2v wm = __builtin_elementwise_max(w0, w1);
+                        // the published halves of the two groups, packed like the tile's own
+                        const short2v o = __builtin_bit_cast(
+                            short2v, __builtin_amdgcn_perm((uint32_t)old[2 * j + 1], (uint32_t)old[2 * j], 0x07060302u));
+                        mp[j] = __builtin_elementwise_max(wm, o);
+                        improved |= __builtin_bit_cast(uint32_t, mp[j]) ^ __builtin_bit_cast(uint32_t, o);
+                    }
+                    if (share && improved != 0) {  // publish what this tile raised (late tiles: rarely anything)
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int32_t a0 = (int32_t)mp[j][0], a1 = (int32_t)mp[j][1];
+                            if (a0 > (old[2 * j] >> 16)) atomicMax(GPTR(2 * j), a0 << 16);
+                            if (a1 > (old[2 * j + 1] >> 16)) atomicMax(GPTR(2 * j + 1), a1 << 16);
+                        }
+                    }
+                    short2v mn = mp[0], mx = mp[0];
+#pragma unroll
+                    for (int j = 1; j < 16; ++j) { mn = __builtin_elementwise_min(mn, mp[j]); mx = __builtin_elementwise_max(mx, mp[j]); }
+                    int32_t lo = min((int32_t)mn[0], (int32_t)mn[1]), hi = max((int32_t)mx[0], (int32_t)mx[1]);
+                    lo = min(lo, __shfl_xor(lo, 32, 64));
+                    hi = max(hi, __shfl_xor(hi, 32, 64));
+                    // largest key T (to the resolution of four halvings of [lo, hi]) with at least top_k of the 64 maxima
+                    // >= T; lo always satisfies it (all 64 are >= the minimum, and top_k <= 64)
+                    const int K = a.top_k;
+#pragma unroll 1
+                    for (int it = 0; it < 4 && lo < hi && K < 64; ++it) {  // (K = 64: the minimum is the answer)
+                        const int32_t mid = lo + ((hi - lo + 1) >> 1);
+                        const short2v midp = {(short)mid, (short)mid};
+                        uint32_t lt = 0;  // packed counters of (m < mid): low half / high half of the words
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            lt += (__builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mp[j], midp)) >> 15) & 0x00010001u;
+                        int c = 32 - (int)((lt & 0xffffu) + (lt >> 16));
+                        c += __shfl_xor(c, 32, 64);
+                        if (c >= K) lo = mid; else hi = mid - 1;
+                    }
+                    if (tpart == 0) sm.tau_key[trow] = (int32_t)((uint32_t)lo << 16);
+                }
+#undef GPTR
+                __syncthreads();
+            } else {
+                // group maxima of THIS tile only; the running maxima over earlier tiles (of this and of every other
+                // workgroup that owns the same rows) live in a.gmax and are merged below, so nothing is carried in
+                // registers across the contraction loop
+                float smax[2][NSLOT];
+    #pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+    #pragma unroll
+                    for (int r = 0; r < NSLOT; ++r) smax[jb][r] = NEG_INF;
+    #pragma unroll
+                for (int sb = 0; sb < 4; ++sb)
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
+                        const bool ok = (s0 + sl) < S;  // d_sae % 4 == 0: a float4 of latents is all in or all out
+                        // one 16-byte LDS read per four latents, unconditional (a per-element conditional read turns into
+                        // 128 branches with an LDS round trip each)
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(&sm.bias[sl]);
+    #pragma unroll
+                        for (int jb = 0; jb < 2; ++jb)
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
+                                const float v = ok ? hv : NEG_INF;
+                                acc[sb][jb][4 * q + e] = v;
+                                const int slot = (NG == 32) ? (4 * q + e) : (16 * (sb & 1) + 4 * q + e);
+                                smax[jb][slot] = fmaxf(smax[jb][slot], v);
+                            }
+                    }
+    #pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const int bl_ = wb * 64 + jb * 32 + l31;
+    #pragma unroll
+                    for (int r = 0; r < NSLOT; ++r) {
+                        if (NG == 32) sm.e32.slots32[ws][2 * r + half][bl_] = f2key(smax[jb][r]);
+                        else sm.slots64[ws][2 * r + half][bl_] = f2key(smax[jb][r]);
+                    }
+                }
+                __syncthreads();
+                // bound per row = min over groups of the group maximum, where each group maximum is merged (a) across the
+                // two s-waves of this workgroup and (b) with what the row's other latent ranges have published so far in
+                // global memory (relaxed L2 reads: a stale value only gives a weaker, still valid bound).  Two threads per
+                // row, each owning half of the groups; improved maxima are published fire-and-forget.
+                if (tid < HTB) sm.tau_key[tid] = INT32_MAX;
+                __syncthreads();
+                {
+                    const int row = tid % HTB;
+                    const int part = __builtin_amdgcn_readfirstlane(tid / HTB);  // wave-uniform: group bases stay in SGPRs  // 512 threads = 2 x HTB rows
+                    constexpr int GPT = NG / 2;                     // groups per thread
+                    const int b = b0 + row;
+                    const bool share = b < B;
+                    const uint32_t boff = (uint32_t)b * 4u;
+                    int32_t m = INT32_MAX;
+                    int32_t old[GPT];
+    #pragma unroll
+                    for (int i = 0; i < GPT; ++i) {  // all global reads of this thread in flight together
+                        old[i] = INT32_MIN;
+                        if (share)
+                            old[i] = __hip_atomic_load(
+                                reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)(part * GPT + i) * a.gmax_stride) + boff),
+                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+    #pragma unroll
+                    for (int i = 0; i < GPT; ++i) {
+                        const int g = part * GPT + i;
+                        const int32_t v0 = (NG == 32) ? sm.e32.slots32[0][g][row] : sm.slots64[0][g][row];
+                        const int32_t v1 = (NG == 32) ? sm.e32.slots32[1][g][row] : sm.slots64[1][g][row];
+                        const int32_t v = max(v0, v1);
+                        if (share && v > old[i])
+                            atomicMax(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)g * a.gmax_stride) + boff), v);
+                        m = min(m, max(v, old[i]));
+                    }
+                    atomicMin(&sm.tau_key[row], m);
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            // bound per row = min over groups of the group maximum, where each group maximum is merged (a) across the
-            // two s-waves of this workgroup and (b) with what the row's other latent ranges have published so far in
-            // global memory (relaxed L2 reads: a stale value only gives a weaker, still valid bound).  Two threads per
-            // row, each owning half of the groups; improved maxima are published fire-and-forget.
-            if (tid < HTB) sm.tau_key[tid] = INT32_MAX;
-            __syncthreads();
-            {
-                const int row = tid % HTB;
-                const int part = __builtin_amdgcn_readfirstlane(tid / HTB);  // wave-uniform: group bases stay in SGPRs  // 512 threads = 2 x HTB rows
-                constexpr int GPT = NG / 2;                     // groups per thread
-                const int b = b0 + row;
-                const bool share = b < B;
-                const uint32_t boff = (uint32_t)b * 4u;
-                int32_t m = INT32_MAX;
-                int32_t old[GPT];
-#pragma unroll
-                for (int i = 0; i < GPT; ++i) {  // all global reads of this thread in flight together
-                    old[i] = INT32_MIN;
-                    if (share)
-                        old[i] = __hip_atomic_load(
-                            reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)(part * GPT + i) * a.gmax_stride) + boff),
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int i = 0; i < GPT; ++i) {
-                    const int g = part * GPT + i;
-                    const int32_t v0 = (NG == 32) ? sm.e32.slots32[0][g][row] : sm.slots64[0][g][row];
-                    const int32_t v1 = (NG == 32) ? sm.e32.slots32[1][g][row] : sm.slots64[1][g][row];
-                    const int32_t v = max(v0, v1);
-                    if (share && v > old[i])
-                        atomicMax(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)g * a.gmax_stride) + boff), v);
-                    m = min(m, max(v, old[i]));
-                }
-                atomicMin(&sm.tau_key[row], m);
-            }
-            __syncthreads();
             int npass[2], pos[2];
             float tau2[2];
 #pragma unroll

@@ -230,7 +230,9 @@ struct EncodeF16Args {
     const float* scale_dev;   // NULL or two device floats: extra power-of-two scales of the x and W images
     int s_splits;
     float* h_out;             // EPI_DENSE
-    int ngroups;              // EPI_TOPK
+    int ngroups;              // EPI_TOPK: 32 (bound = min over 32 group maxima; needs top_k <= 32) or 64 (bound = top_k-th
+                              // largest of 64 group maxima; top_k <= 64)
+    int top_k;
     int32_t* gmax;            // (ngroups, gmax_stride) shared per-row group maxima, init INT32_MIN
     int gmax_stride;
     int32_t* cand_cnt;

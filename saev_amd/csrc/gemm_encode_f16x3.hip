@@ -42,9 +42,9 @@ struct __attribute__((aligned(16))) HSmem {
         KSlot slot[NSLOTS];  // 128 KB
         struct {
             KSlot keep[2];                 // slots 0,1 receive the next tile's first k-steps during the epilogue
-            int32_t slots32[2][32][HTB];   // NG == 32 scratch: 64 KB (slots 2,3)
+            int32_t slots32[2][32][HTB];   // TopK scratch, 64 KB (slots 2,3): 32 group maxima per s-wave and row as int32
+                                           // keys, or 64 as packed 16-bit keys
         } e32;
-        int32_t slots64[2][64][HTB];       // NG == 64 scratch: 128 KB
     };
     int32_t tau_key[HTB];
     int32_t ref[4][HTB];   // first-tile bound refinement: row maximum (key) and three counters
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                                 const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
                                 const float v = ok ? hv : NEG_INF;
                                 acc[sb][jb][4 * q + e] = v;
-                                const int slot = (NG == 32) ? (4 * q + e) : (16 * (sb & 1) + 4 * q + e);
+                                const int slot = 4 * q + e;
                                 smax[jb][slot] = fmaxf(smax[jb][slot], v);
                             }
                     }
@@ -400,8 +400,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                     const int bl_ = wb * 64 + jb * 32 + l31;
     #pragma unroll
                     for (int r = 0; r < NSLOT; ++r) {
-                        if (NG == 32) sm.e32.slots32[ws][2 * r + half][bl_] = f2key(smax[jb][r]);
-                        else sm.slots64[ws][2 * r + half][bl_] = f2key(smax[jb][r]);
+                        sm.e32.slots32[ws][2 * r + half][bl_] = f2key(smax[jb][r]);
                     }
                 }
                 __syncthreads();
@@ -431,8 +430,8 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     #pragma unroll
                     for (int i = 0; i < GPT; ++i) {
                         const int g = part * GPT + i;
-                        const int32_t v0 = (NG == 32) ? sm.e32.slots32[0][g][row] : sm.slots64[0][g][row];
-                        const int32_t v1 = (NG == 32) ? sm.e32.slots32[1][g][row] : sm.slots64[1][g][row];
+                        const int32_t v0 = sm.e32.slots32[0][g][row];
+                        const int32_t v1 = sm.e32.slots32[1][g][row];
                         const int32_t v = max(v0, v1);
                         if (share && v > old[i])
                             atomicMax(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)g * a.gmax_stride) + boff), v);

@@ -174,6 +174,29 @@ __device__ __forceinline__ float wave_reduce_scatter8(float (&p)[8], int lane) {
     return r;
 }
 
+// 64 lanes each holding one (index, value) pair or (INT_MAX, 0): sort by index ascending and write the first k
+__device__ __forceinline__ void sort_by_idx_and_store(const SelectCandArgs& a, int row, int k, int32_t my_idx, float my_val,
+                                                      int lane) {
+    // bitonic sort of 64 lanes by idx ascending (unused lanes carry INT_MAX and end up last)
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int32_t o_idx = __shfl_xor(my_idx, stride, 64);
+            const float o_val = __shfl_xor(my_val, stride, 64);
+            const bool up = ((lane & size) == 0);          // ascending block
+            const bool lower = ((lane & stride) == 0);     // this lane keeps the smaller one (if up)
+            const bool take_other = (lower == up) ? (o_idx < my_idx) : (o_idx > my_idx);
+            if (take_other) { my_idx = o_idx; my_val = o_val; }
+        }
+    }
+    if (lane < a.k) {
+        const bool ok = lane < k;
+        a.idx_out[(size_t)row * a.out_stride + lane] = ok ? my_idx : -1;
+        a.val_out[(size_t)row * a.out_stride + lane] = ok ? my_val : 0.f;
+    }
+}
+
 template <int EPL>  // elements per lane: handles lists of up to 64*EPL candidates
 __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row, int n, int32_t (&s_idx)[4][64],
                                                 float (&s_val)[4][64]) {
@@ -256,26 +279,36 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
         if (sel && pos < 64) { s_idx[w][pos] = idx[e]; s_val[w][pos] = ukey2f(key[e]); }
         base += __popcll(m);
     }
-    int32_t my_idx = s_idx[w][lane];
-    float my_val = s_val[w][lane];
-    // bitonic sort of 64 lanes by idx ascending (unused lanes carry INT_MAX and end up last)
+    sort_by_idx_and_store(a, row, k, s_idx[w][lane], s_val[w][lane], lane);
+}
+
+// Lists of at most 64 entries (the second, exact pass of the f16r encoder: ~45 survivors per row): one entry per lane
+// and a 64-lane bitonic sort by (value descending, index ascending) instead of the 32-step bit search -- the first k lanes
+// are the winners, ties at the cut resolved towards the smaller index exactly as in select_cand_row.
+__device__ __forceinline__ void select_small_row(const SelectCandArgs& a, int row, int n) {
+    const int lane = threadIdx.x & 63;
+    const int k = min(a.k, n);
+    uint32_t key = 0u;            // sorts below every real float key
+    int32_t idx = 0x7fffffff;
+    if (lane < n) {
+        key = f2ukey(a.cand_val[(size_t)row * a.cand_stride + lane]);
+        idx = a.cand_idx[(size_t)row * a.cand_stride + lane];
+    }
 #pragma unroll
     for (int size = 2; size <= 64; size <<= 1) {
 #pragma unroll
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int32_t o_idx = __shfl_xor(my_idx, stride, 64);
-            const float o_val = __shfl_xor(my_val, stride, 64);
-            const bool up = ((lane & size) == 0);          // ascending block
-            const bool lower = ((lane & stride) == 0);     // this lane keeps the smaller one (if up)
-            const bool take_other = (lower == up) ? (o_idx < my_idx) : (o_idx > my_idx);
-            if (take_other) { my_idx = o_idx; my_val = o_val; }
+            const uint32_t o_key = __shfl_xor(key, stride, 64);
+            const int32_t o_idx = __shfl_xor(idx, stride, 64);
+            const bool other_first = (o_key > key) || (o_key == key && o_idx < idx);  // other sorts before mine
+            const bool up = ((lane & size) == 0);
+            const bool lower = ((lane & stride) == 0);
+            const bool take_other = (lower == up) ? other_first : !other_first;
+            if (take_other) { key = o_key; idx = o_idx; }
         }
     }
-    if (lane < a.k) {
-        const bool ok = lane < k;
-        a.idx_out[(size_t)row * a.out_stride + lane] = ok ? my_idx : -1;
-        a.val_out[(size_t)row * a.out_stride + lane] = ok ? my_val : 0.f;
-    }
+    const bool win = lane < k;
+    sort_by_idx_and_store(a, row, k, win ? idx : 0x7fffffff, win ? ukey2f(key) : 0.f, lane);
 }
 
 // one wave per row; the register footprint of the search is chosen from the row's list length
@@ -286,7 +319,8 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.n_rows) return;
     const int n = min(a.cand_cnt[row], a.cand_cap);  // wave-uniform
-    if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val);
+    if (n <= 64 && a.row_margin == nullptr) select_small_row(a, row, n);
+    else if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val);
     else if (n <= 1024) select_cand_row<16>(a, row, n, s_idx, s_val);
     else if (n <= 2048) select_cand_row<32>(a, row, n, s_idx, s_val);
     else select_cand_row<64>(a, row, n, s_idx, s_val);

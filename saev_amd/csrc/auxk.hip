@@ -22,31 +22,27 @@
 
 namespace {
 
-// dead mask (S) -> ascending list of dead latents; single workgroup
+// dead mask (S) -> ascending list of dead latents; single workgroup, every thread owns one contiguous chunk
 __global__ __launch_bounds__(1024) void dead_compact_kernel(const int32_t* dead, int S, int32_t* list) {
     __shared__ int wave_tot[16];
-    __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < S; base += 1024) {
-        const int i = base + tid;
-        const int v = (i < S && dead[i]) ? 1 : 0;
-        int incl = v;
+    const int per = (S + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(S, i0 + per);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += dead[i] ? 1 : 0;
+    int incl = cnt;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int n = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += n;
-        }
-        if (lane == 63) wave_tot[w] = incl;
-        __syncthreads();
-        int off = carry;
-        for (int j = 0; j < w; ++j) off += wave_tot[j];
-        if (v) list[off + incl - 1] = i;
-        __syncthreads();
-        if (tid == 1023) carry = off + incl;
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
     }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int pos = incl - cnt;
+    for (int j = 0; j < w; ++j) pos += wave_tot[j];
+    if (cnt > 0)
+        for (int i = i0; i < i1; ++i)
+            if (dead[i]) list[pos++] = i;
 }
 
 // Wenc_dead (D, ndp) = W_enc[:, dl] (zero columns beyond nd);  Wdec_dead (ndp, D) = W_dec[dl, :] (zero rows beyond nd)
@@ -135,6 +131,204 @@ __global__ __launch_bounds__(256) void aux_resid_kernel(float* E, const float* x
 __global__ __launch_bounds__(256) void mask_apply_kernel(float* dA, const uint8_t* mask, long n) {
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long)gridDim.x * 256)
         if (!mask[q]) dA[q] = 0.f;
+}
+
+// ---- a handful of dead latents (nd <= AUX_SMALL_MAX and nd <= k_aux: every dead latent is "selected") ---------------
+// Training runs spend most of their life with zero to a few dozen dead latents.  The dense path below pads the dead
+// set to 256 columns and runs five MFMA contractions plus their operand splits for it (+0.7 ms per step at nd = 8);
+// with so few columns the whole forward is one pass over x and x_hat per row, and the weight gradients one more.
+//
+// lane l ends up with the wave-wide sum of p[(l >> 3) & 7]
+__device__ __forceinline__ float aux_reduce_scatter8(float (&p)[8], int lane) {
+    int bit = 32;
+#pragma unroll
+    for (int h = 4; h >= 1; h >>= 1, bit >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const float keep = up ? p[i + h] : p[i];
+            const float send = up ? p[i] : p[i + h];
+            p[i] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    float r = p[0];
+    for (; bit >= 1; bit >>= 1) r += __shfl_xor(r, bit, 64);
+    return r;
+}
+
+// WencT_dead (ndp, D) = W_enc[:, dl]^T (zero rows beyond nd)
+__global__ __launch_bounds__(256) void gather_dead_t_kernel(const float* W_enc, const int32_t* dl, int nd, int ndp, int D, int S,
+                                                            float* WencT_dead) {
+    const long total = (long)ndp * D;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const int j = (int)(q / D), d = (int)(q % D);
+        WencT_dead[q] = (j < nd) ? W_enc[(size_t)d * S + dl[j]] : 0.f;
+    }
+}
+
+// One wave per pair of rows (every dead-latent row of W_enc^T / W_dec that is fetched serves both): H = x W_enc[:, dl] +
+// b_enc[dl] (= the auxiliary codes A, all dead latents being selected), E = A W_dec[dl] + b_dec, diff = E - (x - x_hat),
+// g_aux = gscale * diff, dA = g_aux W_dec[dl]^T, row loss sum diff^2.
+template <int NV>
+__global__ __launch_bounds__(256) void aux_small_fwd_kernel(const float* x, const float* x_hat, const float* WencT_dead,
+                                                            const float* Wdec_dead, const float* b_enc, const float* b_dec,
+                                                            const int32_t* dl, int n_rows, int D, int nd, int ndp, float gscale,
+                                                            float* A, float* dA, float* g_aux, RowStats* rowstats) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= n_rows) return;
+    const bool has1 = row0 + 1 < n_rows;
+    const int D4 = D >> 2;
+    f32x4 xv[2][NV], ev[2][NV];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)min(row0 + u, n_rows - 1) * D);
+        const f32x4* br = reinterpret_cast<const f32x4*>(b_dec);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            xv[u][n] = q < D4 ? xr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            ev[u][n] = q < D4 ? br[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // codes: lane j (< nd <= 16) keeps h_j of row u in my_h[u]
+    float my_h[2] = {0.f, 0.f};
+    for (int j0 = 0; j0 < nd; j0 += 4) {  // four latents x two rows per reduce-scatter
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            p[t] = 0.f; p[4 + t] = 0.f;
+            if (j0 + t >= nd) continue;
+            const f32x4* wr = reinterpret_cast<const f32x4*>(WencT_dead + (size_t)(j0 + t) * D);
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                if (q < D4) {
+                    const f32x4 w = wr[q];
+                    p[t] += xv[0][n][0] * w[0] + xv[0][n][1] * w[1] + xv[0][n][2] * w[2] + xv[0][n][3] * w[3];
+                    p[4 + t] += xv[1][n][0] * w[0] + xv[1][n][1] * w[1] + xv[1][n][2] * w[2] + xv[1][n][3] * w[3];
+                }
+            }
+        }
+        const float r = aux_reduce_scatter8(p, lane);  // lane l holds slot (l >> 3) & 7
+        const int t = lane - j0;
+        const float m0 = __shfl(r, (t & 3) << 3, 64), m1 = __shfl(r, (4 + (t & 3)) << 3, 64);
+        if (t >= 0 && t < 4 && lane < nd) {
+            const float bj = b_enc[dl[lane]];
+            my_h[0] = m0 + bj; my_h[1] = m1 + bj;
+        }
+    }
+    if (lane < ndp) {
+        A[(size_t)row0 * ndp + lane] = lane < nd ? my_h[0] : 0.f;
+        if (has1) A[(size_t)(row0 + 1) * ndp + lane] = lane < nd ? my_h[1] : 0.f;
+    }
+    // reconstruction of the codes
+    for (int j = 0; j < nd; ++j) {
+        const float h0 = __shfl(my_h[0], j, 64), h1 = __shfl(my_h[1], j, 64);
+        const f32x4* wr = reinterpret_cast<const f32x4*>(Wdec_dead + (size_t)j * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) {
+                const f32x4 w = wr[q];
+                ev[0][n] += h0 * w;
+                ev[1][n] += h1 * w;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = min(row0 + u, n_rows - 1);
+        const bool live = (u == 0) || has1;
+        float sse = 0.f;
+        const f32x4* hr = reinterpret_cast<const f32x4*>(x_hat + (size_t)row * D);
+        f32x4* gr = reinterpret_cast<f32x4*>(g_aux + (size_t)row * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) {
+                const f32x4 hv = hr[q];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float diff = ev[u][n][c] - (xv[u][n][c] - hv[c]);
+                    sse += diff * diff;
+                    ev[u][n][c] = gscale * diff;
+                }
+                if (live) gr[q] = ev[u][n];
+            } else {
+                ev[u][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        sse = wave_sum(sse);
+        if (lane == 0 && live) rowstats[row].aux_sse = sse;
+    }
+    // dA_j = <g_aux, W_dec[dl_j]>
+    float my_d[2] = {0.f, 0.f};
+    for (int j0 = 0; j0 < nd; j0 += 4) {
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            p[t] = 0.f; p[4 + t] = 0.f;
+            if (j0 + t >= nd) continue;
+            const f32x4* wr = reinterpret_cast<const f32x4*>(Wdec_dead + (size_t)(j0 + t) * D);
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                if (q < D4) {
+                    const f32x4 w = wr[q];
+                    p[t] += ev[0][n][0] * w[0] + ev[0][n][1] * w[1] + ev[0][n][2] * w[2] + ev[0][n][3] * w[3];
+                    p[4 + t] += ev[1][n][0] * w[0] + ev[1][n][1] * w[1] + ev[1][n][2] * w[2] + ev[1][n][3] * w[3];
+                }
+            }
+        }
+        const float r = aux_reduce_scatter8(p, lane);
+        const int t = lane - j0;
+        const float m0 = __shfl(r, (t & 3) << 3, 64), m1 = __shfl(r, (4 + (t & 3)) << 3, 64);
+        if (t >= 0 && t < 4) { my_d[0] = m0; my_d[1] = m1; }
+    }
+    if (lane < ndp) {
+        dA[(size_t)row0 * ndp + lane] = lane < nd ? my_d[0] : 0.f;
+        if (has1) dA[(size_t)(row0 + 1) * ndp + lane] = lane < nd ? my_d[1] : 0.f;
+    }
+}
+
+// Weight gradients of the same: per block of 64 rows, part[blk][0][j][:] = sum_b A[b][j] g_aux[b][:] and
+// part[blk][1][j][:] = sum_b dA[b][j] x[b][:] (rows in ascending order); a column sum over the blocks finishes them.
+__global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, const float* dA, const float* g_aux, const float* x,
+                                                              int n_rows, int D, int nd, int ndp, float* part) {
+    const int r0 = blockIdx.x * 64, r1 = min(n_rows, r0 + 64);
+    const int D4 = D >> 2;
+    for (int j0 = 0; j0 < nd; j0 += 8) {
+        for (int q = threadIdx.x; q < D4; q += 256) {
+            f32x4 ad[8], ae[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { ad[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ae[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int r = r0; r < r1; ++r) {
+                const f32x4 g4 = reinterpret_cast<const f32x4*>(g_aux + (size_t)r * D)[q];
+                const f32x4 x4 = reinterpret_cast<const f32x4*>(x + (size_t)r * D)[q];
+                // the row's coefficients: the same 16-byte words for every thread (ndp % 4 == 0, j0 % 8 == 0); columns past
+                // nd hold zeros (A) or are never written out (the loop below), so no per-column test is needed here
+                const f32x4* ar = reinterpret_cast<const f32x4*>(A + (size_t)r * ndp + j0);
+                const f32x4* dr = reinterpret_cast<const f32x4*>(dA + (size_t)r * ndp + j0);
+                const bool two = j0 + 4 < ndp;
+                const f32x4 a0 = ar[0], d0 = dr[0];
+                const f32x4 a1 = two ? ar[1] : f32x4{0.f, 0.f, 0.f, 0.f}, d1 = two ? dr[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ad[t] += a0[t] * g4; ae[t] += d0[t] * x4;
+                    ad[4 + t] += a1[t] * g4; ae[4 + t] += d1[t] * x4;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (j0 + t < nd) {
+                    float* base = part + (size_t)blockIdx.x * 2 * nd * D;
+                    reinterpret_cast<f32x4*>(base + (size_t)(j0 + t) * D)[q] = ad[t];
+                    reinterpret_cast<f32x4*>(base + (size_t)(nd + j0 + t) * D)[q] = ae[t];
+                }
+            }
+        }
+    }
 }
 
 // out[i] = sum_j parts[j][i] in the order j = 0, 1, ...: the contraction slices of a split product (fixed order, so the
@@ -227,6 +421,25 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
 }
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s) {
     hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for(n)), dim3(256), 0, s, dA, mask, n);
+    return hipGetLastError();
+}
+hipError_t launch_gather_dead_t(const float* W_enc, const int32_t* dl, int nd, int ndp, int D, int S, float* WencT_dead,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(gather_dead_t_kernel, dim3(grid_for((long)ndp * D)), dim3(256), 0, s, W_enc, dl, nd, ndp, D, S, WencT_dead);
+    return hipGetLastError();
+}
+hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead,
+                                const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D, int nd, int ndp,
+                                float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats, hipStream_t s) {
+    return dispatch_nv(D, [&](auto nv) {
+        hipLaunchKernelGGL(aux_small_fwd_kernel<decltype(nv)::value>, dim3((n_rows + 7) / 8), dim3(256), 0, s, x, x_hat,
+                           WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd, ndp, gscale, A, dA, g_aux, rowstats);
+    });
+}
+hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D, int nd,
+                                  int ndp, float* part, hipStream_t s) {
+    hipLaunchKernelGGL(aux_small_wgrad_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, s, A, dA, g_aux, x, n_rows, D, nd, ndp,
+                       part);
     return hipGetLastError();
 }
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s) {

@@ -74,7 +74,8 @@ struct saev_ctx {
     std::vector<void*> aux_allocs;
     int32_t* dead_list = nullptr;
     float *Wenc_dead = nullptr, *Wdec_dead = nullptr, *H_dead = nullptr, *A_dead = nullptr, *dWd = nullptr, *dWe = nullptr,
-          *dbe = nullptr, *aux_partials = nullptr;
+          *dbe = nullptr, *aux_partials = nullptr, *WencT_dead = nullptr, *aux_small_part = nullptr, *aux_small_part2 = nullptr;
+    bool aux_small = false;  // this step's AuxK ran on the few-dead-latents path
     uint8_t* A_mask = nullptr;
     // AuxK contractions on the f16x3 encoder kernel (F16X3 mode): operand images and compact vectors
     _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr, *aux_kA = nullptr, *aux_kD = nullptr;
@@ -733,6 +734,9 @@ int ensure_aux_capacity(saev_ctx* c, int ndp) {
     c->dWe = (float*)grab((size_t)cap * D * 4);
     c->dbe = (float*)grab((size_t)cap * 4);
     c->aux_partials = (float*)grab(((MB + 63) / 64) * (size_t)cap * 4);
+    c->WencT_dead = (float*)grab((size_t)AUX_SMALL_MAX * D * 4);
+    c->aux_small_part = (float*)grab(((MB + 63) / 64) * (size_t)2 * AUX_SMALL_MAX * D * 4);
+    c->aux_small_part2 = (float*)grab((size_t)(((MB + 63) / 64 + 63) / 64) * AUX_SMALL_MAX * D * 4);
     bool fast_ok = true;
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
         const size_t cap256 = ((size_t)cap + 255) / 256 * 256, D256 = (D + 255) / 256 * 256;
@@ -750,7 +754,7 @@ int ensure_aux_capacity(saev_ctx* c, int ndp) {
         fast_ok = c->aux_ws1 && c->aux_ws2 && c->aux_xsA && c->aux_xsg && c->bias_dead && c->aux_kA && c->aux_kD && c->aux_parts;
     }
     if (!fast_ok || !c->Wenc_dead || !c->Wdec_dead || !c->H_dead || !c->A_dead || !c->A_mask || !c->dWd || !c->dWe || !c->dbe ||
-        !c->aux_partials) {
+        !c->aux_partials || !c->WencT_dead || !c->aux_small_part || !c->aux_small_part2) {
         c->err = "AuxK: out of device memory for the dead-set buffers";
         c->nd_cap = 0;
         return SAEV_HIP_ERROR;
@@ -817,6 +821,16 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
     HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
                                  c->Wenc_dead, c->Wdec_dead, s));
+    // a handful of dead latents, all of them selected (k_use = n_dead): one row-wise pass instead of the dense algebra
+    c->aux_small = nd <= AUX_SMALL_MAX && ku == nd && D <= 2048;
+    if (c->aux_small) {
+        HIPCHK(c, launch_gather_dead_t(c->params + c->off_W_enc, c->dead_list, nd, ndp, D, S, c->WencT_dead, s));
+        HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
+                                       c->params + c->off_b_dec, c->dead_list, n, D, nd, ndp,
+                                       c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
+        HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
+        return SAEV_OK;
+    }
     if (fast) {
         // H = x W_enc[:, dl] + b_enc[dl]: the x images of this step are already there (prepare_encoder)
         HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, 0, s));
@@ -870,6 +884,16 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     BLASCHK(c, rocblas_set_stream(c->blas, s));
     float* dA = c->H_dead;  // H is dead after the select
     int rc;
+    if (c->aux_small) {  // dA is there already (auxk_forward); weight gradients block-wise, then two column sums
+        const int nb = (n + 63) / 64;
+        HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd, ndp, c->aux_small_part, s));
+        HIPCHK(c, launch_colsum(c->aux_small_part, nb, nd * D, c->aux_small_part2, c->dWd, 0, nullptr, s, (long)2 * nd * D));
+        HIPCHK(c, launch_colsum(c->aux_small_part + (size_t)nd * D, nb, nd * D, c->aux_small_part2, c->dWe, 0, nullptr, s,
+                                (long)2 * nd * D));
+        HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));
+        HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
+        return SAEV_OK;
+    }
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
         // dA = g_aux W_dec[dl]^T.  g_aux carries the factor alpha * 2 / (n D) (~1e-10) times a residual of unknown
         // magnitude: bring it to [2^13, 2^14) with an exact power of two from its device-side max before the fp16 split;

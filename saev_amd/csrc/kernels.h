@@ -280,6 +280,15 @@ hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, 
 hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const float* b_dec, int n_rows, int D,
                             float gscale, RowStats* rowstats, hipStream_t s);
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
+// a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
+constexpr int AUX_SMALL_MAX = 16;
+hipError_t launch_gather_dead_t(const float* W_enc, const int32_t* dl, int nd, int ndp, int D, int S, float* WencT_dead,
+                                hipStream_t s);
+hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead,
+                                const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D, int nd, int ndp,
+                                float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats, hipStream_t s);
+hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D, int nd,
+                                  int ndp, float* part, hipStream_t s);  // part: ceil(n/64) x 2 x nd x D
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s);  // out = sum_j parts[j], n % 4 == 0
 hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStream_t s);          // out = {*a, *b}
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(float* dA, const uint8_
         if (!mask[q]) dA[q] = 0.f;
 }
 
-// ---- a handful of dead latents (nd <= AUX_SMALL_MAX and nd <= k_aux: every dead latent is "selected") ---------------
+// ---- a handful of dead latents (nd <= AUX_SMALL_MAX = 24, the measured break-even, and nd <= k_aux: every dead latent is "selected") ---------------
 // Training runs spend most of their life with zero to a few dozen dead latents.  The dense path below pads the dead
 // set to 256 columns and runs five MFMA contractions plus their operand splits for it (+0.7 ms per step at nd = 8);
 // with so few columns the whole forward is one pass over x and x_hat per row, and the weight gradients one more.
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void aux_small_fwd_kernel(const float* x, cons
             ev[u][n] = q < D4 ? br[q] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // codes: lane j (< nd <= 16) keeps h_j of row u in my_h[u]
+    // codes: lane j (< nd <= 24) keeps h_j of row u in my_h[u]
     float my_h[2] = {0.f, 0.f};
     for (int j0 = 0; j0 < nd; j0 += 4) {  // four latents x two rows per reduce-scatter
         float p[8];

@@ -281,7 +281,7 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
                             float gscale, RowStats* rowstats, hipStream_t s);
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 // a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
-constexpr int AUX_SMALL_MAX = 16;
+constexpr int AUX_SMALL_MAX = 24;
 hipError_t launch_gather_dead_t(const float* W_enc, const int32_t* dl, int nd, int ndp, int D, int S, float* WencT_dead,
                                 hipStream_t s);
 hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead,

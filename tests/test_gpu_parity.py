@@ -493,3 +493,33 @@ def test_f16r_survives_replaced_parameters(encoder_mode):
         torch.testing.assert_close(val.cpu().sort(dim=-1, descending=True).values, want, rtol=1e-5, atol=1e-5 * scale)
         torch.testing.assert_close(h.gather(1, idx.cpu().long()).float(), val.cpu(), rtol=1e-5, atol=1e-5 * scale)
     assert routes == [0, 1, 0, 1, 0], routes
+
+
+@pytest.mark.parametrize("n_dead", [1, 5, 24, 25, 40])
+def test_auxk_gradients_across_the_small_dead_set_boundary(n_dead):
+    """Up to 24 dead latents (all of them selected: n_dead <= k_aux) the AuxK branch runs as two row-oriented kernels, above
+    that as dense algebra over the compacted dead set.  Both must give the oracle's loss and gradients."""
+    d, s, k, n, k_aux = 128, 1024, 8, 200, 64
+    p = rand_params(d, s, seed=60 + n_dead)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(61 + n_dead))
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=1000)
+    toks = torch.zeros(s, dtype=torch.int64)
+    dead = torch.randperm(s, generator=torch.Generator().manual_seed(62))[:n_dead]
+    toks[dead] = 1000
+    p["b_enc"][dead] = -100.0  # never among the top-k, so they stay dead in this step
+    eng = make_engine(d, s, k, k_aux=k_aux, thr=1000, max_batch=n)
+    eng.load_params(p)
+    eng.set_tracker(toks)
+    leaves = {k_: p[k_].clone().requires_grad_(True) for k_ in R.PARAM_ORDER}
+    leaves["W_dec"] = R.normalize_w_dec(p["W_dec"]).clone().requires_grad_(True)
+    out = R.objective_forward(leaves, x, cfg, toks_since_active=toks.clone(), training=True)
+    out.loss.backward()
+    eng.step_forward(x.cuda(), training=True)
+    eng.step_dead(n)
+    eng.step_backward()
+    st = eng.read_stats()
+    assert st.n_dead == out.n_dead == n_dead
+    assert math.isclose(st.aux, out.aux.item(), rel_tol=1e-4) and math.isclose(st.mse, out.mse.item(), rel_tol=1e-4)
+    gv = eng.grad_views()
+    for key in R.PARAM_ORDER:
+        torch.testing.assert_close(gv[key].cpu(), leaves[key].grad, rtol=2e-3, atol=1e-7, msg=lambda m: f"{key}: {m}")

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void dead_bias_kernel(float* H, long n_rows, i
 }
 
 // compact bias of the dead set for the fused dense contraction: out[j] = b_enc[dl[j]], -inf on the padding columns
-__global__ void dead_bias_vec_kernel(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out) {
+__global__ void dead_bias_vec_kernel(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, float pad) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < ndp) out[j] = (j < nd) ? b_enc[dl[j]] : NEG_INF;
+    if (j < ndp) out[j] = (j < nd) ? b_enc[dl[j]] : pad;
 }
 
 // A[b][idx] = val, mask[b][idx] = 1 for the selected codes (A and mask are zeroed by the caller)
@@ -402,8 +402,9 @@ hipError_t launch_dead_bias(float* H, int n_rows, int nd, int ndp, const float* 
                        b_enc, dl);
     return hipGetLastError();
 }
-hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(dead_bias_vec_kernel, dim3((ndp + 255) / 256), dim3(256), 0, s, b_enc, dl, nd, ndp, out);
+hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s, bool pad_zero) {
+    hipLaunchKernelGGL(dead_bias_vec_kernel, dim3((ndp + 255) / 256), dim3(256), 0, s, b_enc, dl, nd, ndp, out,
+                       pad_zero ? 0.f : NEG_INF);
     return hipGetLastError();
 }
 hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, int k, int stride, int ndp, float* A,

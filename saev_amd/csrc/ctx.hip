@@ -76,6 +76,7 @@ struct saev_ctx {
     float *Wenc_dead = nullptr, *Wdec_dead = nullptr, *H_dead = nullptr, *A_dead = nullptr, *dWd = nullptr, *dWe = nullptr,
           *dbe = nullptr, *aux_partials = nullptr, *WencT_dead = nullptr, *aux_small_part = nullptr, *aux_small_part2 = nullptr;
     bool aux_small = false;  // this step's AuxK ran on the few-dead-latents path
+    bool aux_all = false;    // dense branch with every dead latent selected (n_dead <= k_aux): no select, no mask
     uint8_t* A_mask = nullptr;
     // AuxK contractions on the f16x3 encoder kernel (F16X3 mode): operand images and compact vectors
     _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr, *aux_kA = nullptr, *aux_kD = nullptr;
@@ -823,6 +824,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
                                  c->Wenc_dead, c->Wdec_dead, s));
     // a handful of dead latents, all of them selected (k_use = n_dead): one row-wise pass instead of the dense algebra
     c->aux_small = nd <= AUX_SMALL_MAX && ku == nd && D <= 2048;
+    c->aux_all = false;
     if (c->aux_small) {
         HIPCHK(c, launch_gather_dead_t(c->params + c->off_W_enc, c->dead_list, nd, ndp, D, S, c->WencT_dead, s));
         HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
@@ -831,10 +833,12 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
         return SAEV_OK;
     }
+    // n_dead <= k_aux: every dead latent is selected, the codes are H itself (padding columns zero) and there is no mask
+    c->aux_all = fast && ku == nd;
     if (fast) {
         // H = x W_enc[:, dl] + b_enc[dl]: the x images of this step are already there (prepare_encoder)
         HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, 0, s));
-        HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s));
+        HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s, c->aux_all));
         const _Float16* xs_hl = c->xs;
         if (f16r) {  // the step's x images are single fp16 here: make the hi/lo ones (the buffer is free until the backward)
             // (with the step's power-of-two x scale, so that no activation magnitude can overflow fp16)
@@ -842,7 +846,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
             HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 6));
             xs_hl = c->aux_xsg;
         }
-        rc = dense_f16x3(c, xs_hl, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->H_dead, s,
+        rc = dense_f16x3(c, xs_hl, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->aux_all ? c->A_dead : c->H_dead, s,
                          f16r ? c->aux_scales + 6 : nullptr);
         if (rc != SAEV_OK) return rc;
     } else {
@@ -850,13 +854,15 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         if (rc != SAEV_OK) return rc;
         HIPCHK(c, launch_dead_bias(c->H_dead, n, nd, ndp, c->params + c->off_b_enc, c->dead_list, s));
     }
-    SelectDenseArgs sd{};
-    sd.h = c->H_dead; sd.n_rows = n; sd.S = ndp; sd.k = ku;
-    sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
-    HIPCHK(c, launch_select_dense(sd, s));
-    HIPCHK(c, hipMemsetAsync(c->A_dead, 0, (size_t)n * ndp * sizeof(float), s));
-    HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
-    HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
+    if (!c->aux_all) {
+        SelectDenseArgs sd{};
+        sd.h = c->H_dead; sd.n_rows = n; sd.S = ndp; sd.k = ku;
+        sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
+        HIPCHK(c, launch_select_dense(sd, s));
+        HIPCHK(c, hipMemsetAsync(c->A_dead, 0, (size_t)n * ndp * sizeof(float), s));
+        HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
+        HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
+    }
     if (fast) {
         // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
         // (the codes are pre-activations of unknown magnitude: power-of-two scale from their device-side max)
@@ -908,7 +914,7 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         rc = gemm_nt(c, n, ndp, D, c->g_aux, c->Wdec_dead, dA);  // dA = g_aux W_dec[dl]^T
     }
     if (rc != SAEV_OK) return rc;
-    HIPCHK(c, launch_mask_apply(dA, c->A_mask, (long)n * ndp, s));
+    if (!c->aux_all) HIPCHK(c, launch_mask_apply(dA, c->A_mask, (long)n * ndp, s));
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
         // operand scales: A from the forward (aux_scales + 2), g_aux from above (+ 4), x from max|x| (+ 6), dA fresh
         rc = ksplit_f16x3(c, c->A_dead, c->aux_scales + 2, ndp, c->g_aux, c->aux_scales + 4, D, n, c->dWd, s);

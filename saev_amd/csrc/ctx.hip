@@ -999,7 +999,7 @@ int saev_backward_rows(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, void* stream
     hipStream_t s = (hipStream_t)stream;
     DwRowsArgs a{};
     a.starts = c->starts; a.chunk_starts = c->chunk_starts; a.work_latent = c->work_latent;
-    a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = c->val; a.dval = c->dval;
+    a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = c->val; a.W_dec = c->params + c->off_W_dec;
     a.g = c->P_last > 1 ? c->G : c->g;  // Matryoshka: rows receive the suffix-summed gradients C_p
     a.x = c->x_last;
     a.D = D; a.S = S; a.k_dev = nullptr; a.accumulate = 0;

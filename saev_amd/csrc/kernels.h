@@ -155,7 +155,7 @@ struct DwRowsArgs {
     const int32_t* part_starts;   // (S) first partial slot of a multi-chunk latent
     const int2* pairs;
     const float* val;             // coefficient of g rows   (indexed by pairs[].y)
-    const float* dval;            // coefficient of x rows and db_enc
+    const float* W_dec;           // (S, D): dval = <g row, W_dec[latent]> is formed inside (coefficient of x rows and db_enc)
     const float* g;               // (n_rows, D), or (n_rows, P, D) suffix sums when P > 1
     const float* x;               // (n_rows, D)
     int D, S;

@@ -3,7 +3,7 @@
 // train.py:347-348) done as index-gathered row operations.
 //
 //   decode_kernel     x_hat = b_dec + sum_j val_j W_dec[idx_j]; scaled MSE (objectives.py:223-237);
-//                     g = dL/dx_hat; dval_j = <W_dec[idx_j], g>; fired flags; per-row stats.
+//                     g = dL/dx_hat; fired flags; per-row stats.  (dval_j = <W_dec[idx_j], g> is formed in dw_rows_kernel)
 //   decode_matry_kernel the same for P nested Matryoshka prefixes (objectives.py:125-138).
 //   csc_*             latent-major ordering of the (row, latent) pairs, deterministic (row-ascending
 //                     inside a latent) via an S x B bit map: atomicOr fill, per-latent popcounts + group
@@ -67,41 +67,6 @@ __device__ __forceinline__ float wave_reduce_scatter(float (&p)[KC], int lane) {
 }
 
 template <int NV>
-__device__ __forceinline__ void row_dots(const f32x4 (&g)[NV], const float* __restrict__ W, int D, int D4,
-                                         const int32_t* idx_row, float* dval_row, int k, int limit, int lane) {
-    for (int j0 = 0; j0 < k; j0 += 64) {
-        const int cnt = min(64, k - j0);
-        int32_t my_i = -1;
-        if (lane < cnt) my_i = idx_row[j0 + lane];
-        float my_d = 0.f;
-        // eight codes at a time: eight independent row loads in flight, then one reduce-scatter (11 shuffles
-        // instead of 48) leaves the dot product of code jj0 + ((lane >> 3) & 7) in every lane
-        for (int jj0 = 0; jj0 < cnt; jj0 += 8) {
-            float p[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int32_t i = __shfl(my_i, min(jj0 + t, 63), 64);
-                p[t] = 0.f;
-                if (jj0 + t >= cnt || i < 0 || i >= limit) continue;
-                const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
-#pragma unroll
-                for (int n = 0; n < NV; ++n) {
-                    const int q = lane + 64 * n;
-                    if (q < D4) {
-                        const f32x4 w = wr[q];
-                        p[t] += w[0] * g[n][0] + w[1] * g[n][1] + w[2] * g[n][2] + w[3] * g[n][3];
-                    }
-                }
-            }
-            const float r = wave_reduce_scatter<8>(p, lane);
-            const float mine = __shfl(r, (lane & 7) << 3, 64);  // lane l (jj0 <= l < jj0 + 8) takes code l's sum
-            if (lane >= jj0 && lane < jj0 + 8) my_d = mine;
-        }
-        if (lane < cnt) dval_row[j0 + lane] = my_d;
-    }
-}
-
-template <int NV>
 __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -150,9 +115,8 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
             if (a.training) reinterpret_cast<f32x4*>(a.g + (size_t)row * D)[q] = g[n];
         }
     }
-    if (a.training) {
-        row_dots<NV>(g, a.W_dec, D, D4, idx_row, a.dval + (size_t)row * a.code_stride, a.k, a.idx_limit, lane);
-    }
+    // (dval_j = <g, W_dec[idx_j]> is formed by dw_rows_kernel, latent-major, from the rows of g it reads anyway: no second
+    // gather of the k decoder rows here)
     // code statistics + fired flags
     float l0 = 0.f, l1 = 0.f;
     for (int j = lane; j < a.k; j += 64) {
@@ -262,42 +226,7 @@ __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryAr
                 }
             }
         }
-        // dval_j = <W_dec[idx_j], C_{p(j)}>; p(j) is non-decreasing along the (ascending) code list
-        int cur = -1;
-        float* dval_row = a.dval + (size_t)row * a.code_stride;
-        for (int j0 = 0; j0 < a.k; j0 += 64) {
-            const int cnt = min(64, a.k - j0);
-            int32_t my_i = -1;
-            if (lane < cnt) my_i = idx_row[j0 + lane];
-            float my_d = 0.f;
-            for (int jj = 0; jj < cnt; ++jj) {
-                const int32_t i = __shfl(my_i, jj, 64);
-                if (i < 0) continue;
-                int pj = 0;
-                while (pj < P - 1 && i >= m.cuts[pj]) ++pj;
-                if (pj != cur) {
-                    cur = pj;
-#pragma unroll
-                    for (int n = 0; n < NV; ++n) {
-                        const int q = lane + 64 * n;
-                        c[n] = (q < D4) ? Grow[(size_t)pj * D4 + q] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-                const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
-                float d = 0.f;
-#pragma unroll
-                for (int n = 0; n < NV; ++n) {
-                    const int q = lane + 64 * n;
-                    if (q < D4) {
-                        const f32x4 w = wr[q];
-                        d += w[0] * c[n][0] + w[1] * c[n][1] + w[2] * c[n][2] + w[3] * c[n][3];
-                    }
-                }
-                d = wave_sum(d);
-                if (lane == jj) my_d = d;
-            }
-            if (lane < cnt) dval_row[j0 + lane] = my_d;
-        }
+        // (dval_j = <W_dec[idx_j], C_{p(j)}> is formed by dw_rows_kernel from these suffix sums)
     }
     float l0 = 0.f, l1 = 0.f;
     for (int j = lane; j < a.k; j += 64) {
@@ -502,58 +431,82 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
     const float* gbase = a.g + (size_t)pblk * D;
     const int beg = seg_beg + c * DW_CHUNK;
     const int end = min(seg_end, beg + DW_CHUNK);
-    f32x4 accd[NV], acce[NV];
+    f32x4 accd[NV], acce[NV], wv[NV];
+    {
+        // this latent's decoder row: dval = <g_b, W_dec[i]> is formed here, from the very rows of g that dW_dec needs anyway
+        // (the decode kernel used to gather the row's k decoder rows a second time for it)
+        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
 #pragma unroll
-    for (int n = 0; n < NV; ++n) { accd[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acce[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int n = 0; n < NV; ++n) {
+            accd[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acce[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     int my_b = 0;
-    float my_v = 0.f, my_dv = 0.f;
+    float my_v = 0.f;
     const int cnt = end - beg;  // 0..64
     if (lane < cnt) {
         const int2 pr = a.pairs[beg + lane];
         my_b = pr.x;
         my_v = a.val[pr.y];
-        my_dv = a.dval[pr.y];
     }
-    int jj = 0;
-    for (; jj + 2 <= cnt; jj += 2) {
-        const int b0 = __shfl(my_b, jj, 64), b1 = __shfl(my_b, jj + 1, 64);
-        const float v0 = __shfl(my_v, jj, 64), v1 = __shfl(my_v, jj + 1, 64);
-        const float e0 = __shfl(my_dv, jj, 64), e1 = __shfl(my_dv, jj + 1, 64);
-        const f32x4* g0 = reinterpret_cast<const f32x4*>(gbase + (size_t)b0 * g_stride);
-        const f32x4* g1 = reinterpret_cast<const f32x4*>(gbase + (size_t)b1 * g_stride);
-        const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
-        const f32x4* x1 = reinterpret_cast<const f32x4*>(a.x + (size_t)b1 * D);
-        f32x4 tg0[NV], tg1[NV], tx0[NV], tx1[NV];
+    float dbs = 0.f;  // sum of dval over this chunk (wave-uniform)
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
+        // (1) eight rows of g: dW_dec accumulation + per-lane shares of the eight dot products
+        float p[8];
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = lane + 64 * n;
-            const bool ok = q < D4;
-            tg0[n] = ok ? g0[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-            tg1[n] = ok ? g1[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-            tx0[n] = ok ? x0[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-            tx1[n] = ok ? x1[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 8; t += 2) {
+            p[t] = 0.f; p[t + 1] = 0.f;
+            if (j0 + t >= cnt) continue;  // uniform
+            const bool two = j0 + t + 1 < cnt;
+            const int b0 = __shfl(my_b, j0 + t, 64), b1 = __shfl(my_b, min(j0 + t + 1, 63), 64);
+            const float v0 = __shfl(my_v, j0 + t, 64), v1 = two ? __shfl(my_v, min(j0 + t + 1, 63), 64) : 0.f;
+            const f32x4* g0 = reinterpret_cast<const f32x4*>(gbase + (size_t)b0 * g_stride);
+            const f32x4* g1 = reinterpret_cast<const f32x4*>(gbase + (size_t)(two ? b1 : b0) * g_stride);
+            f32x4 tg0[NV], tg1[NV];
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                const bool ok = q < D4;
+                tg0[n] = ok ? g0[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                tg1[n] = ok ? g1[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                accd[n] += v0 * tg0[n];
+                accd[n] += v1 * tg1[n];
+                p[t] += tg0[n][0] * wv[n][0] + tg0[n][1] * wv[n][1] + tg0[n][2] * wv[n][2] + tg0[n][3] * wv[n][3];
+                p[t + 1] += tg1[n][0] * wv[n][0] + tg1[n][1] * wv[n][1] + tg1[n][2] * wv[n][2] + tg1[n][3] * wv[n][3];
+            }
+            if (!two) p[t + 1] = 0.f;
         }
+        const float r = wave_reduce_scatter<8>(p, lane);  // lane l holds the dot product of entry j0 + ((l >> 3) & 7)
+        // (2) the same eight rows of x, weighted with the dot products just formed
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            accd[n] += v0 * tg0[n];
-            acce[n] += e0 * tx0[n];
-            accd[n] += v1 * tg1[n];
-            acce[n] += e1 * tx1[n];
+        for (int t = 0; t < 8; t += 2) {
+            if (j0 + t >= cnt) continue;
+            const bool two = j0 + t + 1 < cnt;
+            const float e0 = __shfl(r, t << 3, 64), e1 = two ? __shfl(r, (t + 1) << 3, 64) : 0.f;
+            dbs += e0 + e1;
+            const int b0 = __shfl(my_b, j0 + t, 64), b1 = __shfl(my_b, min(j0 + t + 1, 63), 64);
+            const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
+            const f32x4* x1 = reinterpret_cast<const f32x4*>(a.x + (size_t)(two ? b1 : b0) * D);
+            f32x4 tx0[NV], tx1[NV];
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                const bool ok = q < D4;
+                tx0[n] = ok ? x0[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                tx1[n] = ok ? x1[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                acce[n] += e0 * tx0[n];
+                acce[n] += e1 * tx1[n];
+            }
         }
     }
-    if (jj < cnt) {
-        const int b0 = __shfl(my_b, jj, 64);
-        const float v0 = __shfl(my_v, jj, 64), e0 = __shfl(my_dv, jj, 64);
-        const f32x4* g0 = reinterpret_cast<const f32x4*>(gbase + (size_t)b0 * g_stride);
-        const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = lane + 64 * n;
-            if (q < D4) { accd[n] += v0 * g0[q]; acce[n] += e0 * x0[q]; }
-        }
-    }
-    // db_enc partial: sum of dval over this chunk, fixed-shape tree
-    const float dbs = wave_sum(lane < cnt ? my_dv : 0.f);
 
     float *od, *oe;
     bool direct = (nch == 1);

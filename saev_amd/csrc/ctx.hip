@@ -44,7 +44,7 @@ struct saev_ctx {
     float* cand_val = nullptr;
     float* h_dense = nullptr;
     int32_t *idx = nullptr, *aux_idx = nullptr;
-    float *val = nullptr, *dval = nullptr, *aux_val = nullptr;
+    float *val = nullptr, *aux_val = nullptr;
     float *x_hat = nullptr, *g = nullptr, *g_aux = nullptr;
     RowStats* rowstats = nullptr;
     uint32_t* bitmap = nullptr;
@@ -209,7 +209,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     c->gmax_stride = (int)((MB + 255) / 256 * 256);  // (padding the group pitch changes nothing: measured)
     A(cand_cnt, MB); A(gmax, (size_t)64 * c->gmax_stride); A(cand_idx, MB * CAND_STRIDE); A(cand_val, MB * CAND_STRIDE);
     A(h_dense, MB * S);
-    A(idx, MB * K); A(val, MB * K); A(dval, MB * K);
+    A(idx, MB * K); A(val, MB * K);
     if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(g_aux, MB * D); A(dead_list, S); }
     A(x_hat, MB * D); A(g, MB * D);
     A(rowstats, MB);
@@ -663,7 +663,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.upper = c->upper;
     a.gscale = 2.0f / ((float)n * (float)D * (float)c->P);
     a.training = training ? 1 : 0;
-    a.g = c->g; a.x_hat = c->x_hat; a.dval = c->dval; a.fired = c->fired; a.rowstats = c->rowstats;
+    a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
     if (c->P > 1) {
         MatryArgs m{};
         m.P = c->P;

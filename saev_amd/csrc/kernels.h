@@ -108,10 +108,9 @@ struct DecodeArgs {
     int idx_limit;          // only latents < idx_limit contribute (Matryoshka prefix); S = all
     const float* upper;     // device scalar max|x|
     float gscale;           // 2 / (n_rows * D)
-    int training;           // write g/dval/fired
+    int training;           // write g/fired
     float* g;               // (n_rows, D)   d loss / d x_hat
     float* x_hat;           // (n_rows, D) or NULL
-    float* dval;            // (n_rows, code_stride)
     int32_t* fired;         // (S)
     RowStats* rowstats;     // (n_rows) or NULL
 };

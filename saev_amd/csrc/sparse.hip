@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
 // Matryoshka variant of decode_kernel: P nested reconstructions per row.  Codes are in ascending latent order, so
 // one sweep emits prefix p whenever the next code's latent reaches cuts[p].  Writes g_p = dL/dx_hat_p for every
 // prefix, turns them into suffix sums C_p (what a code in prefix block p receives from all reconstructions that
-// contain it) in place, and takes dval_j = <W_dec[idx_j], C_{p(j)}>.
+// contain it) in place (dw_rows_kernel takes dval_j = <W_dec[idx_j], C_{p(j)}> from them).
 template <int NV>
 __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryArgs m) {
     const int lane = threadIdx.x & 63;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 1
+#define SAEV_AMD_ABI_VERSION 2
 
 typedef enum {
     SAEV_OK = 0,
@@ -50,6 +50,9 @@ typedef struct {
     int32_t remove_parallel_grads; /* modeling.py:281                                       */
     int32_t max_batch;             /* scratch is sized for this many activation rows        */
     int32_t encoder_mode;          /* SAEV_ENCODER_F32, _F16X3, _BF16 or _F16R              */
+    int32_t aux_dead_cap;          /* largest dead set the AuxK buffers are sized for at saev_create (no allocation
+                                      happens inside a step); 0 = d_sae, i.e. never too small.  A step that meets more
+                                      dead latents than this fails with SAEV_UNSUPPORTED.                            */
 } saev_cfg;
 
 /* Encoder arithmetic.  F32, F16X3 and F16R are fp32-accurate (error vs fp64 at the level of a native fp32 GEMM):
@@ -159,9 +162,18 @@ int saev_set_prefixes(saev_ctx* ctx, const int64_t* prefixes_host, int32_t n);
 int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_rows_global, int32_t training,
                       void* stream);
 /* Phase 2: tracker update with `n_rows_global` tokens (objectives.py:118-120), dead mask, AuxK
- * forward (modeling.py:75-103).  Training mode only.  Once dead latents are possible this call reads
- * n_dead back (one stream synchronisation per step, as the reference's `.item()` does). */
+ * forward (modeling.py:75-103).  Training mode only.  The reference reads n_dead back on every step
+ * (`.item()`, modeling.py:92).  Here the update kernel leaves a record in pinned host memory each step; the
+ * call looks at the record of four steps earlier, which bounds the current count from above, and while that
+ * bound is <= min(24, k_aux) -- zero dead latents included -- it enqueues kernels that take the count from
+ * the device: no read-back, no stream synchronisation.  Only when the bound is larger (or no valid record
+ * exists yet: the first four steps after creation / saev_bind_tracker / saev_tracker_touched) does it read
+ * n_dead back and size the dense AuxK algebra on the host.  saev_last_aux_route tells which happened:
+ * 0 no auxiliary work, 1 few-dead-latents kernels without a read-back, 2 the same after a read-back,
+ * 3 dense algebra after a read-back; saev_dead_readbacks counts the read-backs so far. */
 int saev_step_dead(saev_ctx* ctx, int64_t n_rows_global, void* stream);
+int saev_last_aux_route(const saev_ctx* ctx);
+int64_t saev_dead_readbacks(const saev_ctx* ctx);
 /* Phase 3: all four parameter gradients into the bound grad buffer (replaces autograd,
  * train.py:347-348), un-projected and un-clipped. */
 int saev_step_backward(saev_ctx* ctx, void* stream);
@@ -193,8 +205,9 @@ const int32_t* saev_last_idx(saev_ctx* ctx);
 const float* saev_last_val(saev_ctx* ctx);
 const float* saev_last_x_hat(saev_ctx* ctx);
 
-/* Device-to-device copies of the same into caller buffers (any may be NULL). */
-int saev_copy_last(saev_ctx* ctx, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream);
+/* Device-to-device copies of the same into caller buffers (any may be NULL), which hold `n_rows` rows:
+ * n_rows must equal the batch of the last saev_step_forward (anything else is SAEV_INVALID_ARG). */
+int saev_copy_last(saev_ctx* ctx, int32_t n_rows, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream);
 
 /* Timing hooks for bench.py: wall duration in ms of the encoder kernel of the last step, measured
  * with HIP events on `stream` (call after the stream has been synchronised). */

@@ -23,6 +23,8 @@ Fixture index:
   G11 schedule         WarmupCosine lr lists and BatchLimiter step counts
   G12 checkpoint       header bytes/JSON written by the reference's nn.dump
   G13 matryoshka       objective fwd/bwd with 4 fixed prefixes (with and without dead latents)
+  G9c train_c          the train_b run with grad_clip = 0.02: the clip coefficient is < 1 on every step
+  G15 sample_prefixes  the reference's Matryoshka prefix draws under fixed seeds
   G14 inference        the reference's framework/inference.worker_fn over a small protocol-2.1 cache (with and
                        without labels.bin / ignore_labels): CSR token_acts, mean_values, sparsity, distributions,
                        metrics.json; plus Metadata.hash and IndexMap known answers for the same cache
@@ -256,7 +258,7 @@ class MemLoader:
                    "token_idx": torch.zeros(len(a), dtype=torch.int32)}
 
 
-def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm):
+def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm, grad_clip=1.0):
     import wandb
 
     T = ref.train
@@ -300,7 +302,7 @@ def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm):
             activation=ref.modeling.TopK(top_k=k, aux=ref.modeling.AuxK(k_aux=k_aux, alpha=1 / 32)),
         ),
         objective=ref.objectives.Matryoshka(n_prefixes=1, dead_threshold_tokens=thr),
-        lr=lr, n_lr_warmup=n_warm, track=False, log_every=1, device="cpu",
+        lr=lr, n_lr_warmup=n_warm, grad_clip=grad_clip, track=False, log_every=1, device="cpu",
     )
     init = {}
     orig_make = T.make_saes
@@ -332,7 +334,7 @@ def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm):
         traj["log_" + key.replace("/", "_")] = np.array(vals, dtype=np.float64)
     npz(
         f"g9_train_{tag}", acts=acts, val=val, d=d, s=s, k=k, bsz=bsz, n_train=n_train, thr=thr, k_aux=k_aux,
-        lr=lr, n_warm=n_warm, n_steps=steps, toks_final=toks,
+        lr=lr, n_warm=n_warm, grad_clip=grad_clip, n_steps=steps, toks_final=toks,
         **{"init_" + k_: v for k_, v in init.items()}, **{"final_" + k_: v for k_, v in final.items()}, **traj,
         ev_l0=ev.l0, ev_l1=ev.l1, ev_mse=ev.mse, ev_normalized_mse=ev.normalized_mse, ev_sse_sae=ev.sse_sae,
         ev_sse_baseline=ev.sse_baseline, ev_n_dead=ev.n_dead, ev_n_almost_dead=ev.n_almost_dead,
@@ -340,6 +342,20 @@ def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm):
     )
     print(f"  {tag}: {steps} steps, final mse {traj['log_loss_mse'][-1]:.6f}, n_dead {traj['log_loss_n_dead'][-1]}, "
           f"eval nmse {ev.normalized_mse:.6f}")
+
+
+def g15_sample_prefixes(ref):
+    """The reference's Matryoshka prefix draws (objectives.py:159-201) under torch.manual_seed: consecutive calls, as
+    the train loop makes them (one per SAE per step)."""
+    out = {}
+    cases = [(512, 4), (1024, 10), (32768, 10), (6144, 2), (64, 64), (300, 1)]
+    for seed in (0, 1, 42, 1234):
+        torch.manual_seed(seed)
+        for d_sae, n in cases:
+            out[f"s{seed}_{d_sae}_{n}"] = torch.stack([ref.objectives.sample_prefixes(d_sae, n) for _ in range(3)])
+    torch.manual_seed(7)
+    out["s7_alt_1000_8"] = torch.stack([ref.objectives.sample_prefixes(1000, 8, pareto_power=1.5) for _ in range(3)])
+    npz("g15_sample_prefixes", cases=np.array(cases), seeds=np.array([0, 1, 42, 1234]), **out)
 
 
 def g10_make_saes(ref):
@@ -472,13 +488,21 @@ def main():
         g14_inference(ref, "labels", True)
         return
     torch.set_num_threads(8)
+    if "--only-r2" in sys.argv:  # fixtures added in round 2 (the others regenerate bit-identically; skip them)
+        g9_train(ref, "c", d=128, s=1024, k=16, bsz=256, n_rows=2048, n_train=6144, thr=512, k_aux=32, lr=2e-3, n_warm=4,
+                 grad_clip=0.02)
+        g15_sample_prefixes(ref)
+        return
     g1_g2_g3(ref)
     g4_auxk(ref)
     g5_objective(ref)
     g6_g7_g8(ref)
     g9_train(ref, "a", d=64, s=512, k=8, bsz=128, n_rows=1024, n_train=2048, thr=10_000_000, k_aux=512, lr=4e-4, n_warm=5)
     g9_train(ref, "b", d=128, s=1024, k=16, bsz=256, n_rows=2048, n_train=6144, thr=512, k_aux=32, lr=2e-3, n_warm=4)
+    g9_train(ref, "c", d=128, s=1024, k=16, bsz=256, n_rows=2048, n_train=6144, thr=512, k_aux=32, lr=2e-3, n_warm=4,
+             grad_clip=0.02)
     g10_make_saes(ref)
+    g15_sample_prefixes(ref)
     g11_schedule(ref)
     g12_checkpoint(ref)
     g13_matryoshka(ref)

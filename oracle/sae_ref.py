@@ -180,13 +180,14 @@ def update_dead_tracker(toks_since_active: Tensor, f: Tensor, threshold: int) ->
     return toks_since_active >= threshold
 
 
-def sample_prefixes(d_sae: int, n_prefixes: int) -> Tensor:
-    """n_prefixes <= 1 -> [d_sae].  objectives.py:177-178.  (The stochastic Pareto sampler for
-    n_prefixes > 1 draws from torch's global RNG, objectives.py:183-201; parity runs use 1.)"""
+def sample_prefixes(d_sae: int, n_prefixes: int, min_prefix_length: int = 1, pareto_power: float = 0.5) -> Tensor:
+    """n_prefixes <= 1 -> [d_sae] (objectives.py:177-178); otherwise n_prefixes - 1 lengths drawn without replacement
+    from the discretised Pareto law with torch's global RNG, plus d_sae, sorted (objectives.py:183-201).  Pinned by
+    fixture G15 (the reference's draws under fixed seeds)."""
     if n_prefixes <= 1:
         return torch.tensor([d_sae], dtype=torch.int64)
     lengths = torch.arange(1, d_sae)
-    cdf = 1 - (1.0 / lengths.float()) ** 0.5
+    cdf = 1 - (min_prefix_length / lengths.float()) ** pareto_power
     pdf = torch.cat([cdf[:1], cdf[1:] - cdf[:-1]])
     pdf = pdf / pdf.sum()
     picks = torch.multinomial(pdf, num_samples=n_prefixes - 1, replacement=False)

@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SaevCfg(C.Structure):
@@ -21,7 +21,7 @@ class SaevCfg(C.Structure):
         ("d_model", C.c_int32), ("d_sae", C.c_int32), ("top_k", C.c_int32), ("k_aux", C.c_int32),
         ("alpha", C.c_float), ("dead_threshold_tokens", C.c_int64),
         ("normalize_w_dec", C.c_int32), ("remove_parallel_grads", C.c_int32),
-        ("max_batch", C.c_int32), ("encoder_mode", C.c_int32),
+        ("max_batch", C.c_int32), ("encoder_mode", C.c_int32), ("aux_dead_cap", C.c_int32),
     ]
 
 
@@ -61,6 +61,8 @@ _SIGNATURES = {
     "saev_gather_rows": (C.c_int, [P, P, P, C.c_int32, P, P]),
     "saev_step_forward": (C.c_int, [P, P, C.c_int32, C.c_int64, C.c_int32, P]),
     "saev_step_dead": (C.c_int, [P, C.c_int64, P]),
+    "saev_last_aux_route": (C.c_int, [P]),
+    "saev_dead_readbacks": (C.c_int64, [P]),
     "saev_step_backward": (C.c_int, [P, P]),
     "saev_backward_begin": (C.c_int, [P, P]),
     "saev_backward_rows": (C.c_int, [P, C.c_int32, C.c_int32, P]),
@@ -72,7 +74,7 @@ _SIGNATURES = {
     "saev_last_idx": (P, [P]),
     "saev_last_val": (P, [P]),
     "saev_last_x_hat": (P, [P]),
-    "saev_copy_last": (C.c_int, [P, P, P, P, P]),
+    "saev_copy_last": (C.c_int, [P, C.c_int32, P, P, P, P]),
     "saev_enable_kernel_timing": (C.c_int, [P, C.c_int32]),
     "saev_last_encoder_ms": (C.c_float, [P]),
 }

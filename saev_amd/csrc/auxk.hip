@@ -15,15 +15,18 @@
 //
 // These five products are unfused library GEMMs (the MFMA work that matters, the encoder, is hand-written in
 // gemm_encode*.hip); everything around them (compaction, gathers, bias, masking, residual, scatter-add) is
-// here.  n_dead is read back to the host once per step when dead latents are possible -- the reference does the
-// same (`int(dead_mask.sum().item())`, modeling.py:92).
+// here.  The reference reads n_dead back every step (`int(dead_mask.sum().item())`, modeling.py:92).  Here the host only
+// does so when a device-written bound says the dead set may be larger than AUX_SMALL_MAX (ctx.hip, saev_step_dead): the
+// few-dead-latents kernels below take the count from the device and exit when there is nothing to do.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 // dead mask (S) -> ascending list of dead latents; single workgroup, every thread owns one contiguous chunk
-__global__ __launch_bounds__(1024) void dead_compact_kernel(const int32_t* dead, int S, int32_t* list) {
+__global__ __launch_bounds__(1024) void dead_compact_kernel(const int32_t* dead, int S, int32_t* list,
+                                                            const int32_t* n_dead_dev) {
+    if (n_dead_dev != nullptr && *n_dead_dev <= 0) return;
     __shared__ int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (S + 1023) / 1024;
@@ -156,13 +159,19 @@ __device__ __forceinline__ float aux_reduce_scatter8(float (&p)[8], int lane) {
     return r;
 }
 
-// WencT_dead (ndp, D) = W_enc[:, dl]^T (zero rows beyond nd)
-__global__ __launch_bounds__(256) void gather_dead_t_kernel(const float* W_enc, const int32_t* dl, int nd, int ndp, int D, int S,
-                                                            float* WencT_dead) {
-    const long total = (long)ndp * D;
+// WencT_dead (AUX_SMALL_MAX, D) = W_enc[:, dl]^T and Wdec_dead (AUX_SMALL_MAX, D) = W_dec[dl] (zero rows beyond nd)
+__global__ __launch_bounds__(256) void gather_dead_small_kernel(const float* W_enc, const float* W_dec, const int32_t* dl,
+                                                                const int32_t* nd_dev, int D, int S, float* WencT_dead,
+                                                                float* Wdec_dead) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > AUX_SMALL_MAX) return;
+    const long total = (long)AUX_SMALL_MAX * D;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
         const int j = (int)(q / D), d = (int)(q % D);
-        WencT_dead[q] = (j < nd) ? W_enc[(size_t)d * S + dl[j]] : 0.f;
+        const bool in = j < nd;
+        const int i = in ? dl[j] : 0;
+        WencT_dead[q] = in ? W_enc[(size_t)d * S + i] : 0.f;
+        Wdec_dead[q] = in ? W_dec[(size_t)i * D + d] : 0.f;
     }
 }
 
@@ -172,8 +181,12 @@ __global__ __launch_bounds__(256) void gather_dead_t_kernel(const float* W_enc, 
 template <int NV>
 __global__ __launch_bounds__(256) void aux_small_fwd_kernel(const float* x, const float* x_hat, const float* WencT_dead,
                                                             const float* Wdec_dead, const float* b_enc, const float* b_dec,
-                                                            const int32_t* dl, int n_rows, int D, int nd, int ndp, float gscale,
-                                                            float* A, float* dA, float* g_aux, RowStats* rowstats) {
+                                                            const int32_t* dl, int n_rows, int D, const int32_t* nd_dev,
+                                                            float gscale, float* A, float* dA, float* g_aux,
+                                                            RowStats* rowstats) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > AUX_SMALL_MAX) return;
+    constexpr int ndp = AUX_SMALL_MAX;
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     if (row0 >= n_rows) return;
@@ -295,7 +308,10 @@ __global__ __launch_bounds__(256) void aux_small_fwd_kernel(const float* x, cons
 // Weight gradients of the same: per block of 64 rows, part[blk][0][j][:] = sum_b A[b][j] g_aux[b][:] and
 // part[blk][1][j][:] = sum_b dA[b][j] x[b][:] (rows in ascending order); a column sum over the blocks finishes them.
 __global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, const float* dA, const float* g_aux, const float* x,
-                                                              int n_rows, int D, int nd, int ndp, float* part) {
+                                                              int n_rows, int D, const int32_t* nd_dev, float* part) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > AUX_SMALL_MAX) return;
+    constexpr int ndp = AUX_SMALL_MAX;
     const int r0 = blockIdx.x * 64, r1 = min(n_rows, r0 + 64);
     const int D4 = D >> 2;
     for (int j0 = 0; j0 < nd; j0 += 8) {
@@ -322,9 +338,9 @@ __global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, co
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if (j0 + t < nd) {
-                    float* base = part + (size_t)blockIdx.x * 2 * nd * D;
+                    float* base = part + (size_t)blockIdx.x * 2 * ndp * D;
                     reinterpret_cast<f32x4*>(base + (size_t)(j0 + t) * D)[q] = ad[t];
-                    reinterpret_cast<f32x4*>(base + (size_t)(nd + j0 + t) * D)[q] = ae[t];
+                    reinterpret_cast<f32x4*>(base + (size_t)(ndp + j0 + t) * D)[q] = ae[t];
                 }
             }
         }
@@ -348,7 +364,9 @@ __global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
 // gW_dec[dl[j], :] += dWd[j, :]; gW_encT[dl[j], :] += dWe[j, :]; gb_enc[dl[j]] += dbe[j]   (one wave per dead latent)
 __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl, int nd, int D, const float* dWd,
                                                                const float* dWe, const float* dbe, float* gW_dec,
-                                                               float* gW_encT, float* gb_enc, int lat_lo, int lat_hi) {
+                                                               float* gW_encT, float* gb_enc, int lat_lo, int lat_hi,
+                                                               const int32_t* nd_dev) {
+    if (nd_dev != nullptr) nd = min(nd, *nd_dev);
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= nd) return;
@@ -387,8 +405,8 @@ hipError_t dispatch_nv(int D, F&& f) {
 
 }  // namespace
 
-hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s) {
-    hipLaunchKernelGGL(dead_compact_kernel, dim3(1), dim3(1024), 0, s, dead, S, list);
+hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s, const int32_t* n_dead_dev) {
+    hipLaunchKernelGGL(dead_compact_kernel, dim3(1), dim3(1024), 0, s, dead, S, list, n_dead_dev);
     return hipGetLastError();
 }
 hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int32_t* dl, int nd, int ndp, int D, int S,
@@ -424,22 +442,24 @@ hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t
     hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for(n)), dim3(256), 0, s, dA, mask, n);
     return hipGetLastError();
 }
-hipError_t launch_gather_dead_t(const float* W_enc, const int32_t* dl, int nd, int ndp, int D, int S, float* WencT_dead,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(gather_dead_t_kernel, dim3(grid_for((long)ndp * D)), dim3(256), 0, s, W_enc, dl, nd, ndp, D, S, WencT_dead);
+hipError_t launch_gather_dead_small(const float* W_enc, const float* W_dec, const int32_t* dl, const int32_t* nd_dev, int D,
+                                    int S, float* WencT_dead, float* Wdec_dead, hipStream_t s) {
+    hipLaunchKernelGGL(gather_dead_small_kernel, dim3(grid_for((long)AUX_SMALL_MAX * D)), dim3(256), 0, s, W_enc, W_dec, dl,
+                       nd_dev, D, S, WencT_dead, Wdec_dead);
     return hipGetLastError();
 }
 hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead,
-                                const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D, int nd, int ndp,
-                                float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats, hipStream_t s) {
+                                const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D,
+                                const int32_t* nd_dev, float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats,
+                                hipStream_t s) {
     return dispatch_nv(D, [&](auto nv) {
         hipLaunchKernelGGL(aux_small_fwd_kernel<decltype(nv)::value>, dim3((n_rows + 7) / 8), dim3(256), 0, s, x, x_hat,
-                           WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd, ndp, gscale, A, dA, g_aux, rowstats);
+                           WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev, gscale, A, dA, g_aux, rowstats);
     });
 }
-hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D, int nd,
-                                  int ndp, float* part, hipStream_t s) {
-    hipLaunchKernelGGL(aux_small_wgrad_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, s, A, dA, g_aux, x, n_rows, D, nd, ndp,
+hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
+                                  const int32_t* nd_dev, float* part, hipStream_t s) {
+    hipLaunchKernelGGL(aux_small_wgrad_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, s, A, dA, g_aux, x, n_rows, D, nd_dev,
                        part);
     return hipGetLastError();
 }
@@ -452,9 +472,10 @@ hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStre
     return hipGetLastError();
 }
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
-                                   float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s) {
+                                   float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
+                                   const int32_t* nd_dev) {
     if (nd <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_add_dead_kernel, dim3((nd + 3) / 4), dim3(256), 0, s, dl, nd, D, dWd, dWe, dbe, gW_dec,
-                       gW_encT, gb_enc, lat_lo, lat_hi);
+                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev);
     return hipGetLastError();
 }

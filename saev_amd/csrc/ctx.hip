@@ -23,6 +23,11 @@ constexpr int CAND_CAP = 4096;
 // stable; 1 KB it is.
 constexpr int CAND_STRIDE = CAND_CAP + 256;
 constexpr int TIMING_RING = 512;
+// saev_step_dead decides between "nothing / a handful of dead latents" (kernels that take the count from the device) and
+// "read the count back and run the dense algebra" from the record the device wrote DEAD_LAG steps earlier.
+constexpr int DEAD_LAG = 4;
+constexpr int DEAD_RING = 16;
+enum { AUX_NONE = 0, AUX_SMALL_DEVICE = 1, AUX_SMALL_HOST = 2, AUX_DENSE = 3 };
 }
 
 struct saev_ctx {
@@ -39,6 +44,7 @@ struct saev_ctx {
     long off_W_dec = 0, off_b_dec = 0, off_W_enc = 0, off_b_enc = 0;
     // scratch
     std::vector<void*> allocs;
+    int cuts_last[MAX_PREFIXES] = {0};  // the cut points the forward in flight used (the backward must see the same)
     int32_t *cand_cnt = nullptr, *gmax = nullptr, *cand_idx = nullptr;
     int gmax_stride = 0;
     float* cand_val = nullptr;
@@ -57,7 +63,7 @@ struct saev_ctx {
     double *sumsq_partials = nullptr, *sumsq_total = nullptr;
     int64_t* toks = nullptr;
     int32_t *fired = nullptr, *dead = nullptr;
-    int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use [6,7] dead_update scratch
+    int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use [6,7,8] dead_update scratch
     int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
     float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
     // Matryoshka prefixes of the step (P == 1: plain objective)
@@ -71,6 +77,15 @@ struct saev_ctx {
     int64_t tokens_seen = 0;
     bool tracker_dirty = false;
     int nd_cap = 0;
+    // per-step records of the dead set in pinned host memory (written by dead_update_kernel), one event per record
+    DeadRecord* rec_host = nullptr;
+    DeadRecord* rec_dev = nullptr;
+    hipEvent_t dead_ev[DEAD_RING];
+    bool dead_ev_created = false;
+    int64_t dead_steps = 0;      // saev_step_dead calls so far (the current step's 1-based id during the call)
+    int64_t rec_valid_from = 1;  // records of earlier steps predate a host write to the tracker
+    int aux_route = AUX_NONE;    // what the step in flight does for the auxiliary loss
+    int64_t n_readbacks = 0;     // blocking reads of n_dead so far (diagnostics: saev_dead_readbacks)
     std::vector<void*> aux_allocs;
     int32_t* dead_list = nullptr;
     float *Wenc_dead = nullptr, *Wdec_dead = nullptr, *H_dead = nullptr, *A_dead = nullptr, *dWd = nullptr, *dWe = nullptr,
@@ -161,6 +176,8 @@ int encoder_splits(int n_rows, int S, int tile_rows, int tile_latents, int targe
 
 bool fused_supported(const saev_cfg& c) { return c.top_k <= 64; }
 
+int alloc_aux_buffers(saev_ctx* c, int cap);  // (below, with the AuxK launch sequences)
+
 void timing_begin(saev_ctx* c, hipStream_t s) {
     if (c->timing) hipEventRecord(c->ev_start[c->ev_count % TIMING_RING], s);
 }
@@ -239,7 +256,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)(c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
-    A(toks, S); A(fired, S); A(dead, S); A(flags, 8); A(upper, 1); A(stats, 1);
+    A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
 #undef A
     if (rc != SAEV_OK) {
         // keep the context so the caller can read the message, but report failure
@@ -250,11 +267,38 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     hipMemset(c->toks, 0, S * sizeof(int64_t));
     hipMemset(c->fired, 0, S * sizeof(int32_t));
     hipMemset(c->dead, 0, S * sizeof(int32_t));
-    hipMemset(c->flags, 0, 8 * sizeof(int32_t));
+    hipMemset(c->flags, 0, 16 * sizeof(int32_t));
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
     hipMemset(c->rowstats, 0, MB * sizeof(RowStats));
     if (c->xs) hipMemset(c->xs, 0, (size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
     if (c->zero_bias) hipMemset(c->zero_bias, 0, std::max(S, D) * sizeof(float));
+    if (KA > 0) {
+        // Every AuxK buffer is sized here, once, for the largest dead set the context accepts (aux_dead_cap, default
+        // d_sae): no allocation ever happens inside a step.
+        const int s4 = (int)((S + 3) / 4 * 4);
+        const int cap = cfg->aux_dead_cap > 0 ? std::min((cfg->aux_dead_cap + 3) / 4 * 4, s4) : s4;
+        rc = alloc_aux_buffers(c, cap);
+        if (rc == SAEV_OK) {
+            void* h = nullptr;
+            if (hipHostMalloc(&h, DEAD_RING * sizeof(DeadRecord), hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(reinterpret_cast<void**>(&c->rec_dev), h, 0) != hipSuccess) {
+                rc = SAEV_HIP_ERROR;
+            } else {
+                c->rec_host = static_cast<DeadRecord*>(h);
+                std::memset(h, 0, DEAD_RING * sizeof(DeadRecord));
+                for (int i = 0; i < DEAD_RING && rc == SAEV_OK; ++i)
+                    if (hipEventCreateWithFlags(&c->dead_ev[i], hipEventDisableTiming) != hipSuccess) rc = SAEV_HIP_ERROR;
+                c->dead_ev_created = rc == SAEV_OK;
+            }
+        }
+        if (rc != SAEV_OK) {
+            for (void* q : c->allocs) hipFree(q);
+            for (void* q : c->aux_allocs) hipFree(q);
+            if (c->rec_host) hipHostFree(c->rec_host);
+            delete c;
+            return rc;
+        }
+    }
     hipDeviceSynchronize();
     *out = c;
     return SAEV_OK;
@@ -267,6 +311,9 @@ void saev_destroy(saev_ctx* c) {
     for (void* p : c->allocs) hipFree(p);
     for (void* p : c->aux_allocs) hipFree(p);
     if (c->G) hipFree(c->G);
+    if (c->rec_host) hipHostFree(c->rec_host);
+    if (c->dead_ev_created)
+        for (int i = 0; i < DEAD_RING; ++i) hipEventDestroy(c->dead_ev[i]);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_created)
         for (int i = 0; i < TIMING_RING; ++i) {
@@ -293,6 +340,7 @@ int saev_bind_tracker(saev_ctx* c, int64_t* toks, int32_t* fired) {
     c->toks = toks;
     c->fired = fired;
     c->tracker_dirty = true;
+    c->rec_valid_from = c->dead_steps + 1;
     return SAEV_OK;
 }
 
@@ -331,12 +379,18 @@ int saev_set_prefixes(saev_ctx* c, const int64_t* prefixes_host, int32_t n) {
 int saev_tracker_touched(saev_ctx* c) {
     if (!c) return SAEV_INVALID_ARG;
     c->tracker_dirty = true;
+    c->rec_valid_from = c->dead_steps + 1;  // older records describe a tracker that no longer exists
     return SAEV_OK;
 }
 
-int saev_copy_last(saev_ctx* c, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream) {
+int saev_last_aux_route(const saev_ctx* c) { return c ? c->aux_route : -1; }
+int64_t saev_dead_readbacks(const saev_ctx* c) { return c ? c->n_readbacks : -1; }
+
+int saev_copy_last(saev_ctx* c, int32_t n_rows, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream) {
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, c->n_last > 0, SAEV_INVALID_ARG, "saev_copy_last: no forward has run");
+    REQUIRE(c, n_rows == c->n_last, SAEV_INVALID_ARG,
+            "saev_copy_last: n_rows differs from the batch of the last forward (the caller's buffers are sized by it)");
     hipStream_t s = (hipStream_t)stream;
     const size_t nk = (size_t)c->n_last * c->cfg.top_k, nd = (size_t)c->n_last * c->cfg.d_model;
     if (idx_out) HIPCHK(c, hipMemcpyAsync(idx_out, c->idx, nk * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
@@ -674,6 +728,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
         HIPCHK(c, launch_decode(a, s));
     }
     c->P_last = c->P;
+    for (int p = 0; p < c->P; ++p) c->cuts_last[p] = c->cuts[p];  // a later saev_set_prefixes must not reach this step's backward
     HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper, c->flags + 2, c->stats, s));
     return SAEV_OK;
 }
@@ -706,35 +761,29 @@ int gemm_tn(saev_ctx* c, int M, int N, int K, const float* A, const float* B, fl
     return SAEV_OK;
 }
 
-int ensure_aux_capacity(saev_ctx* c, int ndp) {
-    if (!c->blas) {
+int alloc_aux_buffers(saev_ctx* c, int cap) {
+    if (c->cfg.encoder_mode == SAEV_ENCODER_F32 || c->cfg.encoder_mode == SAEV_ENCODER_BF16) {
         BLASCHK(c, rocblas_create_handle(&c->blas));
         BLASCHK(c, rocblas_set_atomics_mode(c->blas, rocblas_atomics_not_allowed));  // deterministic sums
         BLASCHK(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
     }
-    if (ndp <= c->nd_cap) return SAEV_OK;
-    int cap = std::max(256, c->nd_cap);
-    while (cap < ndp) cap *= 2;
-    cap = std::min(cap, (c->cfg.d_sae + 3) / 4 * 4);
-    hipDeviceSynchronize();
-    for (void* p : c->aux_allocs) hipFree(p);
-    c->aux_allocs.clear();
     const size_t MB = c->cfg.max_batch, D = c->cfg.d_model;
+    const size_t capA = std::max(cap, AUX_SMALL_MAX);  // the few-dead-latents kernels use AUX_SMALL_MAX columns / rows
     auto grab = [&](size_t bytes) -> void* {
         void* q = nullptr;
         if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
         c->aux_allocs.push_back(q);
         return q;
     };
-    c->Wenc_dead = (float*)grab(D * cap * 4);
-    c->Wdec_dead = (float*)grab((size_t)cap * D * 4);
-    c->H_dead = (float*)grab(MB * cap * 4);
-    c->A_dead = (float*)grab(MB * cap * 4);
-    c->A_mask = (uint8_t*)grab(MB * cap);
-    c->dWd = (float*)grab((size_t)cap * D * 4);
-    c->dWe = (float*)grab((size_t)cap * D * 4);
-    c->dbe = (float*)grab((size_t)cap * 4);
-    c->aux_partials = (float*)grab(((MB + 63) / 64) * (size_t)cap * 4);
+    c->Wenc_dead = (float*)grab(D * capA * 4);
+    c->Wdec_dead = (float*)grab(capA * D * 4);
+    c->H_dead = (float*)grab(MB * capA * 4);
+    c->A_dead = (float*)grab(MB * capA * 4);
+    c->A_mask = (uint8_t*)grab(MB * capA);
+    c->dWd = (float*)grab(capA * D * 4);
+    c->dWe = (float*)grab(capA * D * 4);
+    c->dbe = (float*)grab(capA * 4);
+    c->aux_partials = (float*)grab(((MB + 63) / 64) * capA * 4);
     c->WencT_dead = (float*)grab((size_t)AUX_SMALL_MAX * D * 4);
     c->aux_small_part = (float*)grab(((MB + 63) / 64) * (size_t)2 * AUX_SMALL_MAX * D * 4);
     c->aux_small_part2 = (float*)grab((size_t)(((MB + 63) / 64 + 63) / 64) * AUX_SMALL_MAX * D * 4);
@@ -756,8 +805,7 @@ int ensure_aux_capacity(saev_ctx* c, int ndp) {
     }
     if (!fast_ok || !c->Wenc_dead || !c->Wdec_dead || !c->H_dead || !c->A_dead || !c->A_mask || !c->dWd || !c->dWe || !c->dbe ||
         !c->aux_partials || !c->WencT_dead || !c->aux_small_part || !c->aux_small_part2) {
-        c->err = "AuxK: out of device memory for the dead-set buffers";
-        c->nd_cap = 0;
+        c->err = "AuxK: out of device memory for the dead-set buffers (lower saev_cfg.aux_dead_cap)";
         return SAEV_HIP_ERROR;
     }
     c->nd_cap = cap;
@@ -808,31 +856,40 @@ int ksplit_f16x3(saev_ctx* c, const float* P, const float* sP, int R, const floa
     return SAEV_OK;
 }
 
-// forward of the auxiliary loss for n_dead_host > 0 dead latents (see auxk.hip)
+// A handful of dead latents, all of them selected (n_dead <= min(AUX_SMALL_MAX, k_aux)): one row-wise pass instead of the
+// dense algebra.  Every kernel takes the count from the device (flags[4]) and exits when it is zero, so this sequence is
+// what a step enqueues when the host only knows a bound of the count.
+int auxk_small_forward(saev_ctx* c, hipStream_t s) {
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, n = c->n_last;
+    const int32_t* nd_dev = c->flags + 4;
+    c->aux_small = true;
+    c->aux_all = false;
+    HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s, nd_dev));
+    HIPCHK(c, launch_gather_dead_small(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd_dev, D, S,
+                                       c->WencT_dead, c->Wdec_dead, s));
+    HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
+                                   c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
+                                   c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper, c->flags + 2, c->stats, s, nd_dev));
+    return SAEV_OK;
+}
+
+// forward of the auxiliary loss as dense algebra over n_dead_host dead latents (see auxk.hip)
 int auxk_forward(saev_ctx* c, hipStream_t s) {
     const int S = c->cfg.d_sae, D = c->cfg.d_model, n = c->n_last;
     const int nd = c->n_dead_host, ku = c->k_use_host;
     const int ndp = (nd + 3) / 4 * 4;
-    int rc = ensure_aux_capacity(c, ndp);
-    if (rc != SAEV_OK) return rc;
+    REQUIRE(c, ndp <= c->nd_cap, SAEV_UNSUPPORTED, "AuxK: more dead latents than saev_cfg.aux_dead_cap allows");
+    int rc = SAEV_OK;
     const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
     const bool fast = c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || f16r;
     const int ndp256 = (ndp + 255) / 256 * 256, Dp2 = (ndp + 31) / 32 * 32;
-    BLASCHK(c, rocblas_set_stream(c->blas, s));
+    if (c->blas) BLASCHK(c, rocblas_set_stream(c->blas, s));
     HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
     HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
                                  c->Wenc_dead, c->Wdec_dead, s));
-    // a handful of dead latents, all of them selected (k_use = n_dead): one row-wise pass instead of the dense algebra
-    c->aux_small = nd <= AUX_SMALL_MAX && ku == nd && D <= 2048;
+    c->aux_small = false;
     c->aux_all = false;
-    if (c->aux_small) {
-        HIPCHK(c, launch_gather_dead_t(c->params + c->off_W_enc, c->dead_list, nd, ndp, D, S, c->WencT_dead, s));
-        HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
-                                       c->params + c->off_b_dec, c->dead_list, n, D, nd, ndp,
-                                       c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
-        HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
-        return SAEV_OK;
-    }
     // n_dead <= k_aux: every dead latent is selected, the codes are H itself (padding columns zero) and there is no mask
     c->aux_all = fast && ku == nd;
     if (fast) {
@@ -887,17 +944,19 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     const int D = c->cfg.d_model, n = c->n_last;
     const int nd = c->n_dead_host;
     const int ndp = (nd + 3) / 4 * 4;
-    BLASCHK(c, rocblas_set_stream(c->blas, s));
+    if (c->blas) BLASCHK(c, rocblas_set_stream(c->blas, s));
     float* dA = c->H_dead;  // H is dead after the select
     int rc;
-    if (c->aux_small) {  // dA is there already (auxk_forward); weight gradients block-wise, then two column sums
-        const int nb = (n + 63) / 64;
-        HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd, ndp, c->aux_small_part, s));
-        HIPCHK(c, launch_colsum(c->aux_small_part, nb, nd * D, c->aux_small_part2, c->dWd, 0, nullptr, s, (long)2 * nd * D));
-        HIPCHK(c, launch_colsum(c->aux_small_part + (size_t)nd * D, nb, nd * D, c->aux_small_part2, c->dWe, 0, nullptr, s,
-                                (long)2 * nd * D));
-        HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));
-        HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
+    if (c->aux_small) {  // dA is there already (auxk_small_forward); weight gradients block-wise, then two column sums;
+                         // all predicated on the device-side count like the forward (rows past it are never scattered)
+        const int nb = (n + 63) / 64, L = AUX_SMALL_MAX;
+        const int32_t* nd_dev = c->flags + 4;
+        HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
+        HIPCHK(c, launch_colsum(c->aux_small_part, nb, L * D, c->aux_small_part2, c->dWd, 0, nd_dev, s, (long)2 * L * D));
+        HIPCHK(c, launch_colsum(c->aux_small_part + (size_t)L * D, nb, L * D, c->aux_small_part2, c->dWe, 0, nd_dev, s,
+                                (long)2 * L * D));
+        HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s));
+        HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nd_dev, s));
         return SAEV_OK;
     }
     if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
@@ -944,26 +1003,52 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_step_dead: no training forward in flight");
     hipStream_t s = (hipStream_t)stream;
     const int S = c->cfg.d_sae;
+    const int64_t step = ++c->dead_steps;
+    c->tokens_seen += n_rows_global;
     DeadArgs d{};
     d.toks = c->toks; d.fired = c->fired; d.dead = c->dead; d.S = S;
     d.add_tokens = n_rows_global; d.threshold = c->cfg.dead_threshold_tokens; d.k_aux = c->cfg.k_aux;
     d.n_dead = c->flags + 4; d.k_use = c->flags + 5; d.stats = c->stats; d.scratch = c->flags + 6;
+    d.horizon_tokens = (int64_t)DEAD_LAG * n_rows_global;
+    d.step = step; d.cum_tokens = c->tokens_seen;
+    d.rec = c->rec_dev ? c->rec_dev + step % DEAD_RING : nullptr;
     HIPCHK(c, launch_dead_update(d, s));
     c->n_dead_host = 0;
     c->k_use_host = 0;
-    c->tokens_seen += n_rows_global;
+    c->aux_route = AUX_NONE;
+    c->aux_small = false;
+    if (c->cfg.k_aux <= 0) return SAEV_OK;
+    HIPCHK(c, hipEventRecord(c->dead_ev[step % DEAD_RING], s));
     // A latent can only be dead once `threshold` tokens went by since the tracker was last known to be all-zero.
-    // Until then nothing is read back; afterwards n_dead comes to the host once per step (the reference does the
-    // same: modeling.py:92).
-    if (c->cfg.k_aux > 0 && (c->tracker_dirty || c->tokens_seen >= c->cfg.dead_threshold_tokens)) {
-        int32_t host[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(host, c->flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        c->n_dead_host = host[0];
-        c->k_use_host = host[1];
-        if (c->n_dead_host > 0) return auxk_forward(c, s);
+    if (!c->tracker_dirty && c->tokens_seen < c->cfg.dead_threshold_tokens) return SAEV_OK;
+    // The reference reads n_dead back every step (modeling.py:92).  Here the record the device wrote DEAD_LAG steps ago
+    // bounds it: a latent dead now had at most DEAD_LAG steps' worth of tokens to go then (n_near counts those).  While
+    // the bound fits the few-dead-latents kernels -- which covers zero, the usual state of a healthy run -- they are
+    // enqueued with the count left on the device and nothing is read back.  The wait below is for an event DEAD_LAG
+    // steps in the past; it only ever blocks a host that has run further ahead than that, and never drains the queue.
+    const int small_max = std::min(AUX_SMALL_MAX, c->cfg.k_aux);
+    const int64_t s0 = step - DEAD_LAG;
+    if (s0 >= c->rec_valid_from && c->cfg.d_model <= 2048) {
+        HIPCHK(c, hipEventSynchronize(c->dead_ev[s0 % DEAD_RING]));
+        const volatile DeadRecord* r = c->rec_host + s0 % DEAD_RING;
+        if (r->step == s0 && c->tokens_seen - r->cum_tokens <= r->horizon_tokens && r->n_near <= small_max) {
+            c->aux_route = AUX_SMALL_DEVICE;
+            return auxk_small_forward(c, s);
+        }
     }
-    return SAEV_OK;
+    int32_t host[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(host, c->flags + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->n_readbacks++;
+    c->n_dead_host = host[0];
+    c->k_use_host = host[1];
+    if (c->n_dead_host <= 0) return SAEV_OK;
+    if (c->n_dead_host <= small_max && c->cfg.d_model <= 2048) {
+        c->aux_route = AUX_SMALL_HOST;
+        return auxk_small_forward(c, s);
+    }
+    c->aux_route = AUX_DENSE;
+    return auxk_forward(c, s);
 }
 
 // ---- backward in three pieces (saev_step_backward = all of them over the full latent range) -------------------------
@@ -984,7 +1069,7 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0); the AuxK contractions add theirs
     const float* gmat = c->P_last > 1 ? c->G : c->g;
     HIPCHK(c, launch_colsum(gmat, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s, (long)c->P_last * D));
-    if (c->n_dead_host > 0) {
+    if (c->aux_route != AUX_NONE) {
         int rc = auxk_backward(c, s);
         if (rc != SAEV_OK) return rc;
     }
@@ -1004,16 +1089,19 @@ int saev_backward_rows(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, void* stream
     a.x = c->x_last;
     a.D = D; a.S = S; a.k_dev = nullptr; a.accumulate = 0;
     a.P = c->P_last;
-    for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts[p];
+    for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts_last[p];
     a.dW_dec = c->grads + c->off_W_dec; a.dW_encT = c->dW_encT; a.db_enc = c->grads + c->off_b_enc;
     a.partials = c->partials; a.db_partials = c->db_partials;
     a.lat_lo = lat_lo; a.lat_hi = lat_hi;
     // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
     const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
     HIPCHK(c, launch_dw_rows(a, max_work, s));
-    if (c->n_dead_host > 0)
+    if (c->aux_route == AUX_DENSE)
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s));
+    else if (c->aux_route != AUX_NONE)  // few dead latents: the device knows how many
+        HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
+                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4));
     return SAEV_OK;
 }
 

@@ -195,6 +195,16 @@ struct AdamArgs {
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
 
+// what the host learns about the dead set of a step without waiting for it (saev_step_dead reads the record of an
+// earlier step): n_near bounds the dead count of any later step by which at most horizon_tokens more tokens went by
+struct DeadRecord {
+    int64_t step;            // 1-based step id the record belongs to
+    int64_t cum_tokens;      // tokens seen up to and including that step
+    int64_t horizon_tokens;
+    int32_t n_dead;
+    int32_t n_near;          // latents with toks_since_active >= threshold - horizon_tokens after that step's update
+};
+
 struct DeadArgs {
     int64_t* toks;          // (S)
     int32_t* fired;         // (S) consumed and reset to 0
@@ -205,7 +215,10 @@ struct DeadArgs {
     int32_t* n_dead;        // device scalar out
     int32_t* k_use;         // device scalar out: min(k_aux, n_dead)
     saev_step_stats* stats;
-    int32_t* scratch;       // two ints, zero between launches: running count and block ticket
+    int32_t* scratch;       // three ints, zero between launches: running count, block ticket, running near-count
+    int64_t horizon_tokens; // see DeadRecord
+    int64_t step, cum_tokens;
+    DeadRecord* rec;        // device-visible pointer into pinned host memory, or NULL
 };
 hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream);
 hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream);
@@ -213,8 +226,10 @@ hipError_t launch_gather_rows(const float* pool, const int64_t* rows, int n_rows
 hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows, int k, int stride, int S, float* f,
                                 hipStream_t stream);
 // reduce rowstats[0..n_rows) into *stats (mse, l0, l1, aux, sse, sum_sq)
+// with_aux: 0 no auxiliary term, 1 add it, 2 add it iff *n_dead_dev > 0 (and do nothing at all otherwise)
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
-                               const int32_t* n_overflow_and_max, saev_step_stats* stats, hipStream_t stream);
+                               const int32_t* n_overflow_and_max, saev_step_stats* stats, hipStream_t stream,
+                               const int32_t* n_dead_dev = nullptr);
 
 // ---- f16x3 encoder (fp32-accurate split-fp16 MFMA) -------------------------------------------------
 struct EncodeF16Args {
@@ -269,7 +284,8 @@ hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int 
 hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream);
 
 // ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------
-hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s);
+hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s,
+                               const int32_t* n_dead_dev = nullptr);  // exits at once when *n_dead_dev == 0
 hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int32_t* dl, int nd, int ndp, int D, int S,
                               float* Wenc_dead, float* Wdec_dead, hipStream_t s);
 hipError_t launch_dead_bias(float* H, int n_rows, int nd, int ndp, const float* b_enc, const int32_t* dl, hipStream_t s);
@@ -282,14 +298,20 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 // a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
 constexpr int AUX_SMALL_MAX = 24;
-hipError_t launch_gather_dead_t(const float* W_enc, const int32_t* dl, int nd, int ndp, int D, int S, float* WencT_dead,
-                                hipStream_t s);
+// The few-dead-latents kernels take the dead count from the device (*nd_dev; they exit unless 1 <= nd <= AUX_SMALL_MAX), so
+// the host can enqueue them without knowing it.  Leading dimension of A / dA and row count of the compact weight buffers:
+// AUX_SMALL_MAX.
+hipError_t launch_gather_dead_small(const float* W_enc, const float* W_dec, const int32_t* dl, const int32_t* nd_dev, int D,
+                                    int S, float* WencT_dead, float* Wdec_dead, hipStream_t s);
 hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead,
-                                const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D, int nd, int ndp,
-                                float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats, hipStream_t s);
-hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D, int nd,
-                                  int ndp, float* part, hipStream_t s);  // part: ceil(n/64) x 2 x nd x D
+                                const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D,
+                                const int32_t* nd_dev, float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats,
+                                hipStream_t s);
+hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
+                                  const int32_t* nd_dev, float* part, hipStream_t s);  // part: ceil(n/64) x 2 x AUX_SMALL_MAX x D
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s);  // out = sum_j parts[j], n % 4 == 0
 hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStream_t s);          // out = {*a, *b}
+// nd rows are scattered; with nd_dev the count is *nd_dev (<= nd, which then only sizes the grid)
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
-                                   float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s);
+                                   float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
+                                   const int32_t* nd_dev = nullptr);

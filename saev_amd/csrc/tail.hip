@@ -135,30 +135,41 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 }
 
 __global__ __launch_bounds__(256) void dead_update_kernel(DeadArgs a) {
-    __shared__ int sh[4];
+    __shared__ int sh[2][4];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int d = 0;
+    int d = 0, near = 0;
     if (i < a.S) {
         int64_t t = a.toks[i] + a.add_tokens;
         if (a.fired[i]) t = 0;
         a.fired[i] = 0;
         a.toks[i] = t;
         d = (t >= a.threshold) ? 1 : 0;
+        near = (t >= a.threshold - a.horizon_tokens) ? 1 : 0;  // dead now or within horizon_tokens more tokens of it
         a.dead[i] = d;
     }
-    const int c = wave_sum_i(d);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    const int c = wave_sum_i(d), cn = wave_sum_i(near);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = c; sh[1][threadIdx.x >> 6] = cn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&a.scratch[0], sh[0] + sh[1] + sh[2] + sh[3]);  // integer sum: order does not matter
+        atomicAdd(&a.scratch[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);  // integer sums: order does not matter
+        atomicAdd(&a.scratch[2], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
         __threadfence();
         if (atomicAdd(&a.scratch[1], 1) == (int)gridDim.x - 1) {  // last block: publish and reset
             __threadfence();
             const int t = atomicExch(&a.scratch[0], 0);
+            const int tn = atomicExch(&a.scratch[2], 0);
             a.scratch[1] = 0;
             *a.n_dead = t;
             *a.k_use = min(a.k_aux, t);
             if (a.stats) a.stats->n_dead = t;
+            if (a.rec) {  // host-visible record of this step (pinned memory; the host reads it a few steps later, after
+                          // the event recorded behind this kernel has fired -- see saev_step_dead)
+                a.rec->n_dead = t;
+                a.rec->n_near = tn;
+                a.rec->horizon_tokens = a.horizon_tokens;
+                a.rec->cum_tokens = a.cum_tokens;
+                a.rec->step = a.step;
+            }
         }
     }
 }
@@ -203,7 +214,11 @@ __global__ __launch_bounds__(256) void scatter_dense_kernel(const int32_t* idx, 
 
 __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, int n_rows, int D, int P, float alpha,
                                                             int with_aux, const float* upper,
-                                                            const int32_t* n_overflow, saev_step_stats* stats) {
+                                                            const int32_t* n_overflow, saev_step_stats* stats,
+                                                            const int32_t* n_dead_dev) {
+    // with_aux == 2: the AuxK pass of a step whose dead count only the device knows -- nothing to add when it is zero
+    // (the forward's call has already written every other field)
+    if (with_aux == 2 && *n_dead_dev <= 0) return;
     __shared__ double sh[16][6];
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (int r = threadIdx.x; r < n_rows; r += 1024) {
@@ -296,8 +311,9 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
     return hipGetLastError();
 }
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
-                               const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream) {
+                               const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream,
+                               const int32_t* n_dead_dev) {
     hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, rs, n_rows, D, P, alpha, with_aux, upper,
-                       n_overflow, stats);
+                       n_overflow, stats, n_dead_dev);
     return hipGetLastError();
 }

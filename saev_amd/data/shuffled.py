@@ -81,6 +81,7 @@ class DataLoader:
                 d_model=pool.shape[1], n_examples=pool.shape[0], max_tokens_per_shard=max(pool.shape[0], 1))
             self.n_samples = pool.shape[0]
             rows = torch.arange(rank, pool.shape[0], world_size)
+            self._n_epoch = pool.shape[0] // world_size  # the same on every rank (see n_epoch)
             self.pool = pool[rows].to(self.device, torch.float32).contiguous()
             self.example_idx = rows.to(torch.int32).to(self.device)
             self.token_idx = torch.zeros_like(self.example_idx)
@@ -127,15 +128,23 @@ class DataLoader:
         # shard order: seeded permutation, as the reference's manager does (shuffled.py:327-328);
         # ranks take shards round-robin
         order = np.random.default_rng(cfg.seed).permutation(len(info))
-        mine = [int(si) for pos, si in enumerate(order) if pos % self.world == self.rank]
-        if not mine:
+        if len(info) < self.world:
             raise ValueError(f"rank {self.rank} of {self.world} received no shards ({len(info)} shards in cache)")
         ex_base = np.cumsum([0] + [n for _, n in info.shards])
         rows_per_example = len(tok) * len(layer_ids)
-        if labels is None:
-            self._n_local = sum(info.shards[si][1] for si in mine) * rows_per_example
-        else:
-            self._n_local = int(sum(keep_all[ex_base[si] : ex_base[si] + info.shards[si][1]].sum() for si in mine))
+
+        def rows_of_rank(r: int) -> int:
+            sis = [int(si) for pos, si in enumerate(order) if pos % self.world == r]
+            if labels is None:
+                return sum(info.shards[si][1] for si in sis) * rows_per_example
+            return int(sum(keep_all[ex_base[si] : ex_base[si] + info.shards[si][1]].sum() for si in sis))
+
+        mine = [int(si) for pos, si in enumerate(order) if pos % self.world == self.rank]
+        self._n_local = rows_of_rank(self.rank)
+        # every rank can work out every rank's share: an epoch is cut at the smallest one so that all ranks take the
+        # same number of steps with the same batch sizes (the surplus rows of the larger shares are the ones the
+        # epoch's permutation puts last, so they differ from epoch to epoch)
+        self._n_epoch = min(rows_of_rank(r) for r in range(self.world))
         tok_arr = np.asarray(tok)
         tok_contiguous = tok == list(range(tok[0], tok[0] + len(tok)))
         tok_out = (tok_arr - first * (cfg.tokens == "content")).astype(np.int32)
@@ -232,8 +241,14 @@ class DataLoader:
     def n_local(self) -> int:
         return self.pool.shape[0] if self.pool is not None else self._n_local
 
+    @property
+    def n_epoch(self) -> int:
+        """Rows this rank delivers per epoch: its share, cut to the smallest share over all ranks (equal step counts
+        and batch sizes on every rank are what keeps the per-step collectives of a data-parallel run matched)."""
+        return self._n_epoch
+
     def __len__(self) -> int:
-        n = self.n_local
+        n = self.n_epoch
         return n // self.local_batch if self.drop_last else math.ceil(n / self.local_batch)
 
     def _shard_fd(self, path) -> int:
@@ -265,14 +280,16 @@ class DataLoader:
         res = self.reservoir
         self._epoch += 1
         res.start_epoch()
+        left = self.n_epoch
         try:
-            while True:
-                got = res.get(self.local_batch)
+            while left > 0:
+                got = res.get(min(self.local_batch, left))
                 if got is None:
                     return
                 act, ex, tk = got
                 if act.shape[0] < self.local_batch and self.drop_last:
                     return
+                left -= act.shape[0]
                 yield {"act": act, "example_idx": ex, "token_idx": tk}
         finally:
             res.stop()
@@ -284,9 +301,9 @@ class DataLoader:
         # host-side permutation: the row order is then independent of the device type (tests replay it on CPU)
         g = torch.Generator().manual_seed(self.cfg.seed + 1000 * self._epoch + self.rank)
         self._epoch += 1
-        perm = torch.randperm(self.n_local, generator=g).to(self.device)
+        perm = torch.randperm(self.n_local, generator=g)[: self.n_epoch].to(self.device)
         B = self.local_batch
-        for lo in range(0, self.n_local, B):
+        for lo in range(0, self.n_epoch, B):
             rows = perm[lo : lo + B]
             if rows.shape[0] < B and self.drop_last:
                 return

@@ -32,6 +32,7 @@ class EngineConfig:
     normalize_w_dec: bool = True
     remove_parallel_grads: bool = True
     max_batch: int = 16384
+    aux_dead_cap: int = 0      # largest dead set the AuxK buffers are sized for at creation; 0 = d_sae (always enough)
     # "f32": exact fp32 MFMA; "f16x3": split-fp16 MFMA at fp32 accuracy (16/3 of the f32 matrix rate);
     # "bf16": bf16-rounded encoder operands, one MFMA product, fp32 accumulate (everything else stays fp32);
     # "f16r": one fp16 MFMA product as a bounded-error first pass + exact fp32 recomputation of the surviving candidates.
@@ -92,6 +93,7 @@ class SaeEngine:
                 dead_threshold_tokens=cfg.dead_threshold_tokens,
                 normalize_w_dec=int(cfg.normalize_w_dec), remove_parallel_grads=int(cfg.remove_parallel_grads),
                 max_batch=cfg.max_batch, encoder_mode={"f32": 0, "f16x3": 1, "bf16": 2, "f16r": 3}[cfg.encoder],
+                aux_dead_cap=cfg.aux_dead_cap,
             )
             ctx = C.c_void_p()
             rc = self.lib.saev_create(C.byref(ccfg), self.device.index, C.byref(ctx))
@@ -265,8 +267,17 @@ class SaeEngine:
         idx = torch.empty(n_rows, k, device=self.device, dtype=torch.int32)
         val = torch.empty(n_rows, k, device=self.device, dtype=torch.float32)
         x_hat = torch.empty(n_rows, self.cfg.d_model, device=self.device, dtype=torch.float32)
-        self._chk(self.lib.saev_copy_last(self.ctx, _ptr(idx), _ptr(val), _ptr(x_hat), _stream()), "saev_copy_last")
+        self._chk(self.lib.saev_copy_last(self.ctx, n_rows, _ptr(idx), _ptr(val), _ptr(x_hat), _stream()), "saev_copy_last")
         return idx, val, x_hat
+
+    def aux_route(self) -> int:
+        """What the last step_dead did for the auxiliary loss: 0 nothing, 1 few-dead-latents kernels without reading
+        n_dead back, 2 the same after a read-back, 3 dense algebra after a read-back."""
+        return int(self.lib.saev_last_aux_route(self.ctx))
+
+    def dead_readbacks(self) -> int:
+        """Blocking reads of n_dead so far."""
+        return int(self.lib.saev_dead_readbacks(self.ctx))
 
     def enable_kernel_timing(self, on: bool = True):
         self._chk(self.lib.saev_enable_kernel_timing(self.ctx, int(on)), "saev_enable_kernel_timing")

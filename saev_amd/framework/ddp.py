@@ -63,12 +63,23 @@ class DataParallelStepper:
             w.wait()
         eng.backward_end()  # reduced transposed gradient -> W_enc segment of the flat buffer
 
-    def train_step(self, x_local: torch.Tensor, lr: float, max_norm: float = 1.0) -> None:
+    def train_step(self, x_local: torch.Tensor, lr: float, max_norm: float = 1.0, pre_tail=None) -> None:
+        """One optimizer step.  ``pre_tail`` (log steps) is called after the backward and before rpg / clip / Adam --
+        the point where the reference's log block looks at the parameters (train.py:365-442 sits between
+        ``clip_grad_norm_`` and ``opt.step()``)."""
         eng = self.engine
         if self.dist is None:
-            eng.train_step(x_local, lr, max_norm)
+            if pre_tail is None:
+                eng.train_step(x_local, lr, max_norm)
+                return
+            n = x_local.shape[0]
+            eng.step_forward(x_local, training=True, n_rows_global=n)
+            eng.step_dead(n)
+            eng.step_backward()
+            pre_tail()
+            eng.step_tail(lr, max_norm)
             return
-        n_global = x_local.shape[0] * self.world  # equal shards by construction
+        n_global = x_local.shape[0] * self.world  # equal shards by construction (data.ShuffledDataLoader.n_epoch)
         eng.step_forward(x_local, training=True, n_rows_global=n_global)
         self.dist.all_reduce(eng.fired, op=self.dist.ReduceOp.MAX)
         eng.step_dead(n_global)
@@ -77,4 +88,6 @@ class DataParallelStepper:
         else:
             eng.step_backward()
             self.dist.all_reduce(eng.grads, op=self.dist.ReduceOp.SUM)
+        if pre_tail is not None:
+            pre_tail()
         eng.step_tail(lr, max_norm, grad_scale=1.0 / self.world)

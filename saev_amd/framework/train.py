@@ -189,7 +189,7 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
     device = torch.device("cuda", torch.cuda.current_device())
 
     dataloader = _make_loader(cfg.train_data, device, rank, world, train_pool)
-    limiter = scheduling.BatchLimiter(dataloader, cfg.n_train)
+    limiter = scheduling.BatchLimiter(dataloader, cfg.n_train, rows_scale=world)
     torch.manual_seed(cfg.seed)
     saes, objs, _ = make_saes([(c.sae, c.objective) for c in cfgs], limiter, device)
     run = RunLog(cfgs, len(cfgs))
@@ -219,9 +219,12 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
             # (objectives.py:125); every rank draws the same sequence (same seed, same call order)
             if c.objective.n_prefixes > 1:
                 st.engine.set_prefixes(objectives.sample_prefixes(c.sae.d_sae, c.objective.n_prefixes))
-            st.train_step(x, lrs[i], c.grad_clip)
             if log_now:
-                metrics.append(_log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c))
+                pre = {}
+                st.train_step(x, lrs[i], c.grad_clip, pre_tail=lambda sae=sae, pre=pre, c=c: pre.update(_decoder_metrics(sae, c)))
+                metrics.append(_log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c, pre, dataloader, dist, world))
+            else:
+                st.train_step(x, lrs[i], c.grad_clip)
             lrs[i] = scheds[i].step()
         if log_now and rank == 0:
             run.log(metrics, step=global_step)
@@ -233,33 +236,59 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
 
 
 @torch.no_grad()
-def _log_metrics(sae, eng, x: Tensor, lr: float, n_patches_seen: int, cfg: Config) -> dict[str, object]:
-    """The reference's log block (train.py:365-442), from the step's device-side statistics."""
-    st = eng.read_stats()
-    n = x.shape[0]
-    idx, val, x_hat = eng.last_codes(n)
-    sum_vec = x.to(torch.float64).sum(dim=0)
-    sse_baseline = st.sum_sq - torch.dot(sum_vec, sum_vec).item() / n
-    assert sse_baseline > 0, f"Batch baseline variance non-positive: sse_baseline={sse_baseline:.6e}"
-    residual = x - x_hat
-    explained = 1 - residual.var() / x.var()
-    live = torch.zeros(sae.cfg.d_sae, device=x.device, dtype=torch.bool)
-    live[idx[val.abs() > 1e-12].long()] = True
-    out = {
-        "loss/loss": st.mse + st.aux, "loss/mse": st.mse, "loss/l0": st.l0, "loss/l1": st.l1, "loss/sparsity": 0.0,
-        "loss/aux": st.aux, "loss/n_dead": st.n_dead,
-        "progress/n_patches_seen": n_patches_seen, "progress/learning_rate": lr,
-        "metrics/explained_variance": explained.item(),
-        "metrics/dead_unit_pct": (~live).float().mean().item(),
-        "metrics/avg_decoder_row_norm": sae.W_dec.norm(dim=1).mean().item(),
-        "metrics/grad_norm": st.grad_norm,
-        "metrics/sse_sae": st.sse, "metrics/sse_baseline": sse_baseline,
-        "metrics/normalized_mse": st.sse / sse_baseline,
-        "loader/buffer_fill": 1.0,
-    }
+def _decoder_metrics(sae, cfg: Config) -> dict[str, object]:
+    """The two log-block metrics that look at W_dec.  The reference evaluates them after the backward and BEFORE the
+    optimizer step (train.py:365-442 precedes opt.step() at :444), i.e. on the rows normalised at the top of the step."""
+    out = {"metrics/avg_decoder_row_norm": sae.W_dec.norm(dim=1).mean().item()}
     if cfg.log_coherence:
         out["metrics/dictionary_coherence"] = _coherence(sae.W_dec)
     return out
+
+
+@torch.no_grad()
+def _log_metrics(sae, eng, x: Tensor, lr: float, n_patches_seen: int, cfg: Config, pre: dict[str, object],
+                 dataloader=None, dist=None, world: int = 1) -> dict[str, object]:
+    """The reference's log block (train.py:365-442) from the step's device-side statistics.  Under data parallelism
+    the batch is the union of the ranks' shards: every quantity is formed from sums that are all-reduced first (one
+    collective of D + 8 doubles and one of d_sae flags per log step), so all ranks log the global-batch values."""
+    st = eng.read_stats()
+    n = x.shape[0]
+    idx, val, x_hat = eng.last_codes(n)
+    x64 = x.to(torch.float64)
+    residual = x - x_hat
+    r64 = residual.to(torch.float64)
+    # [sum_vec (D) | sum x | sum r | sum r^2 (centred later) | sse | sum_sq | mse | aux | l0 | l1 | n]
+    sums = torch.cat([x64.sum(dim=0), torch.stack([x64.sum(), r64.sum(), (r64 * r64).sum()]),
+                      torch.tensor([st.sse, st.sum_sq, st.mse * n, st.aux * n, st.l0 * n, st.l1 * n, float(n)],
+                                   dtype=torch.float64, device=x.device)])
+    live = torch.zeros(sae.cfg.d_sae, device=x.device, dtype=torch.int32)
+    live[idx[val.abs() > 1e-12].long()] = 1
+    if dist is not None:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(live, op=dist.ReduceOp.MAX)
+    D = x.shape[1]
+    sum_vec, (sx, sr, srr, sse, sum_sq, mse_n, aux_n, l0_n, l1_n, n_all) = sums[:D], sums[D:].tolist()
+    sse_baseline = sum_sq - torch.dot(sum_vec, sum_vec).item() / n_all
+    assert sse_baseline > 0, f"Batch baseline variance non-positive: sse_baseline={sse_baseline:.6e}"
+    if dist is None:  # the reference's own expression, in fp32 (train.py:402)
+        explained = (1 - residual.var() / x.var()).item()
+    else:  # same quantity from the reduced sums (unbiased variances over all n_all * D elements)
+        m = n_all * D
+        explained = 1 - ((srr - sr * sr / m) / (m - 1)) / ((sum_sq - sx * sx / m) / (m - 1))
+    mse, aux = mse_n / n_all, aux_n / n_all
+    fill = dataloader.reservoir.fill() if getattr(dataloader, "reservoir", None) is not None else 1.0
+    return {
+        "loss/loss": mse + aux, "loss/mse": mse, "loss/l0": l0_n / n_all, "loss/l1": l1_n / n_all, "loss/sparsity": 0.0,
+        "loss/aux": aux, "loss/n_dead": st.n_dead,
+        "progress/n_patches_seen": n_patches_seen, "progress/learning_rate": lr,
+        "metrics/explained_variance": explained,
+        "metrics/dead_unit_pct": (live == 0).float().mean().item(),
+        "metrics/grad_norm": st.grad_norm,
+        "metrics/sse_sae": sse, "metrics/sse_baseline": sse_baseline,
+        "metrics/normalized_mse": sse / sse_baseline,
+        "loader/buffer_fill": fill,
+        **pre,
+    }
 
 
 def _coherence(W: Tensor, block: int = 4096) -> float:
@@ -318,7 +347,7 @@ def evaluate(cfgs: list[Config], saes: torch.nn.ModuleList, objs: torch.nn.Modul
     device = torch.device("cuda", torch.cuda.current_device())
     dataloader = _make_loader(cfg.val_data, device, rank, world, val_pool)
     n_val = min(dataloader.n_samples, cfg.n_val)
-    limiter = scheduling.BatchLimiter(dataloader, n_val)
+    limiter = scheduling.BatchLimiter(dataloader, n_val, rows_scale=world)
     S, D = saes[0].cfg.d_sae, saes[0].cfg.d_model
     n_fired = torch.zeros(len(cfgs), S, device=device)
     values = torch.zeros(len(cfgs), S, device=device)

@@ -352,3 +352,61 @@ def test_train_from_a_shard_directory(tmp_path, monkeypatch, budget_gb):
     after = M().load(run.ckpt, device="cuda")
     mse = [((m(x).x_hats[:, -1] - x) ** 2).mean().item() for m in (before, after)]
     assert mse[1] < mse[0], mse
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_log_block_matches_the_reference_values(tmp_path, tag):
+    """The train loop's log block (reference train.py:365-442) on the reference's own batch order, step by step,
+    against the values the reference logged (golden G9, log_every = 1): explained variance, normalised MSE, dead-unit
+    share, dictionary coherence, decoder row norm, grad norm -- not just the key names."""
+    from saev_amd.framework import train as T
+    from saev_amd.framework.ddp import DataParallelStepper
+
+    g = load_golden(f"g9_train_{tag}")
+    bsz, k = int(g["bsz"]), int(g["k"])
+    cfg = dataclasses.replace(small_cfg(tmp_path, g), grad_clip=float(g.get("grad_clip", 1.0)))
+    sae = M().SparseAutoencoder(cfg.sae)
+    sae.load_state_dict({key: g["init_" + key] for key in R.PARAM_ORDER})
+    sae = sae.cuda().train()
+    obj = O().get_objective(cfg.objective).train()
+    st = DataParallelStepper(obj._bind(sae, bsz))
+    sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, math.ceil(cfg.n_train / bsz), 0.0)
+    lr, seen, logs = 0.0, 0, []
+    for x in R.limited_batches([b.cuda() for b in g["acts"].split(bsz)], cfg.n_train, bsz, drop_last=False):
+        seen += len(x)
+        pre = {}
+        st.train_step(x, lr, cfg.grad_clip, pre_tail=lambda: pre.update(T._decoder_metrics(sae, cfg)))
+        logs.append(T._log_metrics(sae, st.engine, x, lr, seen, cfg, pre))
+        lr = sched.step()
+    assert len(logs) == g["n_steps"]
+    flip = 4.0 / (bsz * k)
+    bands = {"loss/mse": max(1e-4, flip), "loss/l1": max(1e-4, flip), "loss/l0": 1e-6, "loss/loss": max(1e-4, flip),
+             "metrics/grad_norm": 2e-3, "progress/learning_rate": 0.0, "metrics/normalized_mse": max(1e-4, flip),
+             "metrics/sse_sae": max(1e-4, flip), "metrics/sse_baseline": 1e-9, "metrics/explained_variance": max(1e-4, flip),
+             "metrics/avg_decoder_row_norm": 1e-6, "metrics/dictionary_coherence": 2e-3}
+    for key, rtol in bands.items():
+        want = g["log_" + key.replace("/", "_")].numpy()
+        got = np.array([rec[key] for rec in logs], dtype=np.float64)
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-12, err_msg=key)
+    np.testing.assert_allclose([rec["loss/aux"] for rec in logs], g["log_loss_aux"].numpy(), rtol=max(1e-3, flip), atol=1e-8)
+    dead = np.array([rec["metrics/dead_unit_pct"] for rec in logs])
+    assert np.abs(dead - g["log_metrics_dead_unit_pct"].numpy()).max() <= 4.0 / int(g["s"])
+    assert np.abs(np.array([rec["loss/n_dead"] for rec in logs]) - g["log_loss_n_dead"].numpy()).max() <= 1
+    assert all(rec["loader/buffer_fill"] == 1.0 for rec in logs)  # resident feed
+
+
+def test_streaming_feed_reports_its_fill(tmp_path, monkeypatch):
+    """loader/buffer_fill is the reservoir's real fill in streaming mode (it was a constant)."""
+    from saev_amd import data
+    from saev_amd.framework import train as T
+
+    monkeypatch.setenv("SAEV_AMD_RESIDENT_GB", "0")
+    g = load_golden("g9_train_a")
+    d, bsz = int(g["d"]), int(g["bsz"])
+    acts = g["acts"].numpy().reshape(-1, 1, 8, d)
+    shards = data.write_shards(tmp_path, acts, layers=(11,), cls_token=False, max_tokens_per_shard=8 * 20)
+    dc = data.ShuffledConfig(shards=shards, layer=11, batch_size=bsz, seed=3, buffer_size=4)
+    cfg = dataclasses.replace(small_cfg(tmp_path, g), train_data=dc, val_data=dc, log_every=2)
+    saes, objs, run, steps = T.train([cfg])
+    fills = [m["loader/buffer_fill"] for _, m in run.records[0]]
+    assert fills and all(0.0 <= f <= 1.0 for f in fills) and any(f < 1.0 for f in fills)

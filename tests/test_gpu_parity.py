@@ -146,7 +146,7 @@ def test_g5_golden_eval_mode():
     assert (eng.toks_since_active == 0).all()
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_g9_golden_train_trajectory(tag):
     """Free-running trajectory vs the reference's.  TopK is discontinuous at near-ties: a last-bit
     difference in h can swap one selected latent for another, which moves the batch loss by about
@@ -160,8 +160,9 @@ def test_g9_golden_train_trajectory(tag):
     sched = R.WarmupCosine(0.0, int(g["n_warm"]), float(g["lr"]), math.ceil(int(g["n_train"]) / bsz), 0.0)
     batches = [b.cuda() for b in g["acts"].split(bsz)]
     lr, log = 0.0, []
+    clip = float(g.get("grad_clip", 1.0))  # fixture c: 0.02, below every gradient norm of the run (coef < 1 throughout)
     for x in R.limited_batches(batches, int(g["n_train"]), bsz, drop_last=False):
-        eng.train_step(x, lr, 1.0)
+        eng.train_step(x, lr, clip)
         st = eng.read_stats()
         log.append((st.mse, st.aux, st.l0, st.l1, st.n_dead, st.grad_norm, lr))
         lr = sched.step()
@@ -187,19 +188,21 @@ def test_g9_golden_train_trajectory(tag):
         assert bad.float().mean() < 2e-3, f"{key}: {bad.sum().item()} of {bad.numel()} elements off"
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_teacher_forced_steps_match_oracle(tag):
     """Every step: copy the HIP engine's state to the CPU oracle, run ONE oracle step and ONE HIP step
     from that identical state, compare losses, gradients norm and updated parameters tightly."""
     g = load_golden(f"g9_train_{tag}")
     d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
-    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=int(g["k_aux"]), dead_threshold_tokens=int(g["thr"]))
+    clip = float(g.get("grad_clip", 1.0))
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=int(g["k_aux"]), dead_threshold_tokens=int(g["thr"]), grad_clip=clip)
     eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz)
     eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
     sched = R.WarmupCosine(0.0, int(g["n_warm"]), float(g["lr"]), math.ceil(int(g["n_train"]) / bsz), 0.0)
     batches = list(g["acts"].split(bsz))
     lr = 0.0
     n_flip_steps = 0
+    n_clipped = 0
     for i, x in enumerate(R.limited_batches(batches, int(g["n_train"]), bsz, drop_last=False)):
         state = R.TrainState(
             params={k_: v.cpu().clone() for k_, v in eng.param_views().items()},
@@ -208,8 +211,9 @@ def test_teacher_forced_steps_match_oracle(tag):
             toks_since_active=eng.toks_since_active.cpu().clone(), adam_steps=eng.adam_steps, lr=lr,
         )
         ref = R.train_step(state, x, cfg)
-        eng.train_step(x.cuda(), lr, 1.0)
+        eng.train_step(x.cuda(), lr, clip)
         st = eng.read_stats()
+        n_clipped += ref["grad_norm"] > clip
         flipped = not math.isclose(st.mse, ref["mse"], rel_tol=2e-6)
         n_flip_steps += flipped
         assert math.isclose(st.mse, ref["mse"], rel_tol=4.0 / (bsz * k)), (i, st.mse, ref["mse"])
@@ -223,6 +227,46 @@ def test_teacher_forced_steps_match_oracle(tag):
                                            msg=lambda m: f"step {i} {key}: {m}")
         lr = sched.step()
     assert n_flip_steps <= 2
+    assert n_clipped == (i + 1 if tag == "c" else 0), "fixture c runs the coef < 1 branch of the fused tail on every step"
+
+
+@pytest.mark.parametrize("max_norm,grad_scale", [(0.01, 1.0), (0.05, 1.0), (1.0, 0.5), (0.02, 0.25), (1e-4, 1.0)])
+def test_tail_clip_and_grad_scale_branches(max_norm, grad_scale):
+    """saev_step_tail with the clip coefficient below one and / or grad_scale != 1 (what a data-parallel run passes:
+    1 / world) against the oracle's rpg -> clip_grad_norm -> Adam on the same gradients scaled on the host.  Three
+    steps, so that the Adam moments carry clipped history.  reference train.py:351-362, 444-446."""
+    g = load_golden("g9_train_b")
+    d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=int(g["k_aux"]), dead_threshold_tokens=int(g["thr"]), grad_clip=max_norm)
+    eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz)
+    eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
+    state = R.TrainState.create({key: g["init_" + key] for key in R.PARAM_ORDER})
+    clipped = 0
+    for i, x in enumerate(g["acts"].split(bsz)[:3]):
+        lr = 1e-3 * (i + 1)
+        eng.step_forward(x.cuda(), training=True)
+        eng.step_dead(bsz)
+        eng.step_backward()
+        raw = {k_: v.cpu().clone() for k_, v in eng.grad_views().items()}  # un-projected, un-clipped, un-scaled
+        params = {k_: v.cpu().clone() for k_, v in eng.param_views().items()}  # W_dec rows already normalised
+        eng.step_tail(lr, max_norm, grad_scale=grad_scale)
+        st = eng.read_stats()
+        # oracle tail on the engine's own gradients: scale, project, clip, Adam
+        grads = {k_: raw[k_] * grad_scale for k_ in R.PARAM_ORDER}
+        grads["W_dec"] = R.remove_parallel_grads(grads["W_dec"], params["W_dec"])
+        scaled, total = R.clip_grad_norm([grads[k_] for k_ in R.PARAM_ORDER], max_norm)
+        clipped += total.item() > max_norm
+        state.adam_steps += 1
+        for k_, gk in zip(R.PARAM_ORDER, scaled):
+            state.params[k_] = params[k_]
+            R.adam_update(state.params[k_], gk, state.m[k_], state.v[k_], state.adam_steps, lr)
+        assert math.isclose(st.grad_norm, total.item(), rel_tol=1e-5), (st.grad_norm, total.item())
+        for k_ in R.PARAM_ORDER:
+            torch.testing.assert_close(eng.view(k_).cpu(), state.params[k_], rtol=1e-5, atol=1e-7, msg=lambda m: f"step {i} {k_}: {m}")
+            torch.testing.assert_close(eng.view(k_, eng.adam_m).cpu(), state.m[k_], rtol=1e-5, atol=1e-9, msg=lambda m: f"step {i} m {k_}: {m}")
+            torch.testing.assert_close(eng.view(k_, eng.adam_v).cpu(), state.v[k_], rtol=1e-5, atol=1e-12, msg=lambda m: f"step {i} v {k_}: {m}")
+    if max_norm < 0.1:
+        assert clipped == 3, "the clip must be active for this case to mean anything"
 
 
 @pytest.mark.parametrize("tag", ["nodead", "dead"])
@@ -523,3 +567,83 @@ def test_auxk_gradients_across_the_small_dead_set_boundary(n_dead):
     gv = eng.grad_views()
     for key in R.PARAM_ORDER:
         torch.testing.assert_close(gv[key].cpu(), leaves[key].grad, rtol=2e-3, atol=1e-7, msg=lambda m: f"{key}: {m}")
+
+
+@pytest.mark.parametrize("n_dead", [0, 3, 24])
+def test_steady_state_needs_no_readback_of_n_dead(n_dead):
+    """saev_step_dead without the reference's per-step `.item()` (modeling.py:92): four steps after the tracker was last
+    written by the host, the record the device left four steps earlier bounds the dead count; while that bound fits the
+    few-dead-latents kernels the step reads nothing back (route 1) and still gives the oracle's losses, gradients and
+    parameters -- including when the count is zero.  Teacher-forced against the oracle on every step."""
+    d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
+    p = rand_params(d, s, seed=80 + n_dead)
+    gen = torch.Generator().manual_seed(81 + n_dead)
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
+    toks = torch.zeros(s, dtype=torch.int64)
+    dead = torch.randperm(s, generator=torch.Generator().manual_seed(82))[:n_dead]
+    toks[dead] = thr
+    p["b_enc"][dead] = -100.0  # never selected: they stay dead
+    eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)
+    eng.load_params(p)
+    eng.set_tracker(toks)
+    routes = []
+    for i in range(9):
+        x = torch.randn(n, d, generator=gen)
+        lr = 1e-3
+        state = R.TrainState(
+            params={k_: v.cpu().clone() for k_, v in eng.param_views().items()},
+            m={k_: eng.view(k_, eng.adam_m).cpu().clone() for k_ in R.PARAM_ORDER},
+            v={k_: eng.view(k_, eng.adam_v).cpu().clone() for k_ in R.PARAM_ORDER},
+            toks_since_active=eng.toks_since_active.cpu().clone(), adam_steps=eng.adam_steps, lr=lr)
+        ref = R.train_step(state, x, cfg)
+        eng.train_step(x.cuda(), lr, 1.0)
+        routes.append(eng.aux_route())
+        st = eng.read_stats()
+        assert st.n_dead == ref["n_dead"] == n_dead, (i, st.n_dead, ref["n_dead"])
+        assert math.isclose(st.mse, ref["mse"], rel_tol=1e-4)
+        assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-12), (i, st.aux, ref["aux"])
+        assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-4)
+        for key in R.PARAM_ORDER:
+            torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6, msg=lambda m: f"step {i} {key}: {m}")
+    # steps 1-4 have no record of their own tracker yet (the host wrote it): exact read-backs; from step 5 on none
+    first = 2 if n_dead else 0
+    assert routes == [first] * 4 + [1] * 5, routes
+    assert eng.dead_readbacks() == 4
+
+
+def test_growing_dead_set_switches_to_the_dense_route_in_time():
+    """The bound comes from four steps back: latents that will cross the threshold within four steps count as near-dead,
+    so the step in which the dead set outgrows the few-dead-latents kernels already runs the exact read-back + dense
+    algebra.  40 latents die at once in step 6."""
+    d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
+    p = rand_params(d, s, seed=90)
+    gen = torch.Generator().manual_seed(91)
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
+    toks = torch.zeros(s, dtype=torch.int64)
+    late = torch.randperm(s, generator=torch.Generator().manual_seed(92))[:40]
+    toks[late] = thr - 6 * n  # dead after six more steps of n tokens
+    p["b_enc"][late] = -100.0
+    eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)
+    eng.load_params(p)
+    eng.set_tracker(toks)
+    routes, deads = [], []
+    for i in range(9):
+        x = torch.randn(n, d, generator=gen)
+        state = R.TrainState(
+            params={k_: v.cpu().clone() for k_, v in eng.param_views().items()},
+            m={k_: eng.view(k_, eng.adam_m).cpu().clone() for k_ in R.PARAM_ORDER},
+            v={k_: eng.view(k_, eng.adam_v).cpu().clone() for k_ in R.PARAM_ORDER},
+            toks_since_active=eng.toks_since_active.cpu().clone(), adam_steps=eng.adam_steps, lr=1e-3)
+        ref = R.train_step(state, x, cfg)
+        eng.train_step(x.cuda(), 1e-3, 1.0)
+        routes.append(eng.aux_route())
+        st = eng.read_stats()
+        deads.append(st.n_dead)
+        assert st.n_dead == ref["n_dead"]
+        assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-12), (i, st.aux, ref["aux"])
+        for key in R.PARAM_ORDER:
+            torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6, msg=lambda m: f"step {i} {key}: {m}")
+    assert deads == [0] * 5 + [40] * 4, deads
+    # steps 1-4: read-backs (no record yet, nothing dead); step 5: the record of step 1 has nobody within four steps of
+    # the threshold -> no read-back; step 6 on: the record of step 2 counts the 40 as near-dead -> read-back -> dense
+    assert routes == [0, 0, 0, 0, 1, 3, 3, 3, 3], routes

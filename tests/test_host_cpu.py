@@ -38,14 +38,25 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert set(_lib.EXPORTED_SYMBOLS) == set(declared), set(_lib.EXPORTED_SYMBOLS) ^ set(declared)
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of saev_cfg / saev_step_stats against what a C compiler makes of include/saev_amd.h."""
     import ctypes
 
     from saev_amd import _lib
 
-    assert ctypes.sizeof(_lib.SaevCfg) == 48
-    assert ctypes.sizeof(_lib.SaevStepStats) == 56
-    assert _lib.SaevStepStats.sse.offset == 40
+    fields = {"saev_cfg": [f for f, _ in _lib.SaevCfg._fields_], "saev_step_stats": [f for f, _ in _lib.SaevStepStats._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "saev_amd.h"', "int main(void) {"]
+    for st, fs in fields.items():
+        src.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        src += [f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));' for f in fs]
+    src.append("return 0; }")
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(tmp_path / "layout.c"), "-o", str(tmp_path / "layout")], check=True)
+    want = dict(line.split() for line in subprocess.run([str(tmp_path / "layout")], check=True, capture_output=True, text=True).stdout.splitlines())
+    for st, cls in (("saev_cfg", _lib.SaevCfg), ("saev_step_stats", _lib.SaevStepStats)):
+        assert ctypes.sizeof(cls) == int(want[st]), st
+        for f in fields[st]:
+            assert getattr(cls, f).offset == int(want[f"{st}.{f}"]), f"{st}.{f}"
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -94,8 +105,34 @@ def test_schedules_match_golden_and_oracle():
         sizes = [len(b["act"]) for b in lim]
         assert (len(lim), len(sizes), sum(sizes)) == (ln, n_steps, n_seen)
     assert lim.batch_size == 128 and lim.n == 4096  # attribute pass-through
-    w = S.Warmup(0.0, 1.0, 4)
-    assert [w.step() for _ in range(5)] == [0.25, 0.5, 0.75, 1.0, 1.0]
+    # data parallel: each rank sees batch_size / world rows per step but the limiter counts global rows, so the step
+    # count equals the single-process one (the limiter used to run world x too many steps)
+    class Half(DL):
+        def __iter__(self):
+            for b in DL.__iter__(self):
+                yield {"act": b["act"][: len(b["act"]) // 2]}
+
+    for n_rows, bsz, n_train, ln, n_steps, _ in g["limiter"].tolist():
+        if n_rows % bsz == 0:
+            lim2 = S.BatchLimiter(Half(n_rows, bsz), n_train, rows_scale=2)
+            assert (len(lim2), sum(1 for _ in lim2)) == (ln, n_steps)
+
+
+def test_sample_prefixes_equals_the_reference_draws():
+    """Fixture G15: the reference's own Matryoshka prefix draws (objectives.py:159-201) under fixed seeds; the product
+    and the oracle must consume torch's global RNG identically (same draws, same order)."""
+    from saev_amd.nn import objectives as O
+
+    g = load_golden("g15_sample_prefixes")
+    for impl in (O.sample_prefixes, R.sample_prefixes):
+        for seed in g["seeds"].tolist():
+            torch.manual_seed(seed)
+            for d_sae, n in g["cases"].tolist():
+                got = torch.stack([impl(d_sae, n) for _ in range(3)])
+                assert got.dtype == torch.int64 and torch.equal(got, g[f"s{seed}_{d_sae}_{n}"]), (seed, d_sae, n)
+        torch.manual_seed(7)
+        got = torch.stack([impl(1000, 8, pareto_power=1.5) for _ in range(3)])
+        assert torch.equal(got, g["s7_alt_1000_8"])
 
 
 # ---- checkpoints -----------------------------------------------------------------------------
@@ -257,7 +294,7 @@ def test_streaming_reservoir_feed_delivers_every_row_once(tmp_path, world):
     acts = rng.standard_normal((37, 2, 5, 8)).astype(np.float32)
     d = data.write_shards(tmp_path, acts, layers=(6, 11), cls_token=True, max_tokens_per_shard=5 * 5 * 2)
     cfg = data.ShuffledConfig(shards=d, layer=11, tokens="content", batch_size=16, seed=3, buffer_size=3, min_buffer_fill=0.5)
-    seen_all = set()
+    seen_all, steps = set(), []
     for rank in range(world):
         dl = data.ShuffledDataLoader(cfg, device="cpu", rank=rank, world_size=world, resident=False)
         assert dl.reservoir is not None and dl.pool is None and dl.n_samples == 37 * 4
@@ -270,14 +307,19 @@ def test_streaming_reservoir_feed_delivers_every_row_once(tmp_path, world):
                     assert (e, t) not in seen
                     seen[(e, t)] = True
                     np.testing.assert_array_equal(a.numpy(), acts[e, 1, t + 1])
-            assert len(seen) == dl.n_local and len(sizes) == len(dl)
+            # an epoch is the rank's share cut to the smallest share over all ranks (equal step counts and batch sizes on
+            # every rank: the per-step collectives of a data-parallel run must stay matched)
+            assert len(seen) == dl.n_epoch <= dl.n_local and len(sizes) == len(dl)
             assert all(n == dl.local_batch for n in sizes[:-1]) and sizes[-1] <= dl.local_batch
+            steps.append(sizes)
             if epoch == 0:
                 order0 = list(seen)
             else:
                 assert list(seen) != order0
         seen_all |= set(seen)
-    assert len(seen_all) == 37 * 4
+    assert all(s == steps[0] for s in steps), "every rank, every epoch: the same batch sizes in the same order"
+    if world == 1:
+        assert len(seen_all) == 37 * 4
     # same rows, same once-per-epoch contract as the resident mode
     res = data.ShuffledDataLoader(cfg, device="cpu")
     assert res.reservoir is None and res.n_local == 37 * 4
@@ -368,3 +410,36 @@ def test_make_saes_datapoint_init_matches_reference(golden):
     small = type("L", (), {"n_samples": s - 1, "__iter__": lambda self: iter(())})()
     with pytest.raises(AssertionError, match="samples for datapoint init"):
         T.make_saes(cfgs, small, device="cpu")
+
+
+def test_data_parallel_ranks_take_the_same_steps(tmp_path):
+    """with uneven shard shares the ranks of a data-parallel run took different numbers of steps with
+    different ragged batches, and the limiter counted local rows against the global n_train (world x too many steps).
+    Now: every rank yields the same batch-size sequence, and as many steps as one process with the global batch does
+    on the same number of rows per epoch."""
+    from saev_amd import data
+    from saev_amd.utils import scheduling as S
+
+    rng = np.random.default_rng(2)
+    acts = rng.standard_normal((37, 1, 4, 8)).astype(np.float32)
+    d = data.write_shards(tmp_path, acts, layers=(11,), cls_token=False, max_tokens_per_shard=4 * 5)
+    cfg = data.ShuffledConfig(shards=d, layer=11, batch_size=16, seed=3)
+    for resident in (True, False):
+        seqs = []
+        for rank in range(2):
+            dl = data.ShuffledDataLoader(cfg, device="cpu", rank=rank, world_size=2, resident=resident)
+            lim = S.BatchLimiter(dl, 400, rows_scale=2)
+            seqs.append([len(b["act"]) for b in lim])
+            assert len(lim) == 25
+            dl.shutdown()
+        assert seqs[0] == seqs[1] and len(seqs[0]) >= len(lim)
+        n_epoch = data.ShuffledDataLoader(cfg, device="cpu", rank=0, world_size=2).n_epoch
+
+        class One:  # one process, global batch 16, 2 * n_epoch rows per epoch
+            batch_size, drop_last = 16, False
+
+            def __iter__(self):
+                for lo in range(0, 2 * n_epoch, 16):
+                    yield {"act": torch.zeros(min(16, 2 * n_epoch - lo), 1)}
+
+        assert len(seqs[0]) == sum(1 for _ in S.BatchLimiter(One(), 400))

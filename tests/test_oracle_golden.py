@@ -126,12 +126,14 @@ def test_g8_adam_five_steps_first_lr_zero():
     assert torch.equal(g["p"][0], g["p0"]), "lr = 0 on the first step leaves p unchanged"
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_g9_train_trajectory_and_eval(tag):
     g = load_golden(f"g9_train_{tag}")
     d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=int(g["k_aux"]), dead_threshold_tokens=int(g["thr"]),
-                      lr=float(g["lr"]), n_lr_warmup=int(g["n_warm"]))
+                      lr=float(g["lr"]), n_lr_warmup=int(g["n_warm"]), grad_clip=float(g.get("grad_clip", 1.0)))
+    if tag == "c":  # the reference's own run with the clip active on every step (train.py:356-362)
+        assert (g["log_metrics_grad_norm"].numpy() > cfg.grad_clip).all()
     init = {key: g["init_" + key] for key in R.PARAM_ORDER}
     batches = list(g["acts"].split(bsz))
     state, log = R.train_loop(init, batches, cfg, n_train=int(g["n_train"]), batch_size=bsz)

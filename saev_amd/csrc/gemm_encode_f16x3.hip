@@ -48,7 +48,7 @@ struct __attribute__((aligned(16))) HSmem {
     };
     int32_t tau_key[HTB];
     int32_t ref[4][HTB];   // first-tile bound refinement: row maximum (key) and three counters
-    float bias[HTS];
+    float bias[2][HTS];  // per tile parity: a wave that is already in the next tile must not overwrite what a slower one still reads
 };
 
 template <int N, typename F>
@@ -166,7 +166,8 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        if (tid < HTS) sm.bias[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : 0.f;
+        float* const bias_t = sm.bias[st & 1];
+        if (tid < HTS) bias_t[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : 0.f;
         __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
         if (nks > 2) stage_kstep(2, s0, kmap(2));
 
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                         if (s < S) {
                             f32x4 v;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[sb][jb][4 * q + e] * unscale + sm.bias[sl + e];
+                            for (int e = 0; e < 4; ++e) v[e] = acc[sb][jb][4 * q + e] * unscale + bias_t[sl + e];
                             *reinterpret_cast<f32x4*>(a.h_out + (size_t)blockIdx.y * a.out_bstride + (size_t)b * S + s) = v;
                         }
                     }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                         for (int q = 0; q < 4; ++q) {
                             const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
                             const bool ok = (s0 + sl) < S;
-                            const f32x4 bq = *reinterpret_cast<const f32x4*>(&sm.bias[sl]);
+                            const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_t[sl]);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
@@ -367,14 +368,14 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
 #undef GPTR
                 __syncthreads();
             } else {
-                // group maxima of THIS tile only; the running maxima over earlier tiles (of this and of every other
-                // workgroup that owns the same rows) live in a.gmax and are merged below, so nothing is carried in
-                // registers across the contraction loop
-                float smax[2][NSLOT];
-    #pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-    #pragma unroll
-                    for (int r = 0; r < NSLOT; ++r) smax[jb][r] = NEG_INF;
+                // The bound is refreshed on a workgroup's first four tiles and on every fourth one after that; in between the
+                // row bounds of the last refresh (still in sm.tau_key) are used as they are.  A bound only has to be a lower
+                // bound of the row's k-th largest value, which an older one is; after the first few tiles it hardly moves any
+                // more, and the refresh -- per-group maxima, their exchange through LDS and global memory, three barriers --
+                // costs about as much as the candidate stores it saves from then on.
+                const int tile_no = st - st_begin;
+                const bool refresh = tile_no < 4 || (tile_no & 3) == 3;
+                // pre-activations of the tile (one code path for every tile: the accumulators are rewritten in one place)
     #pragma unroll
                 for (int sb = 0; sb < 4; ++sb)
     #pragma unroll
@@ -383,18 +384,25 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                         const bool ok = (s0 + sl) < S;  // d_sae % 4 == 0: a float4 of latents is all in or all out
                         // one 16-byte LDS read per four latents, unconditional (a per-element conditional read turns into
                         // 128 branches with an LDS round trip each)
-                        const f32x4 bq = *reinterpret_cast<const f32x4*>(&sm.bias[sl]);
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_t[sl]);
     #pragma unroll
                         for (int jb = 0; jb < 2; ++jb)
     #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
-                                const float v = ok ? hv : NEG_INF;
-                                acc[sb][jb][4 * q + e] = v;
-                                const int slot = 4 * q + e;
-                                smax[jb][slot] = fmaxf(smax[jb][slot], v);
+                                acc[sb][jb][4 * q + e] = ok ? hv : NEG_INF;
                             }
                     }
+                if (refresh) {
+                // group maxima of THIS tile only; the running maxima over earlier tiles (of this and of every other
+                // workgroup that owns the same rows) live in a.gmax and are merged below, so nothing is carried in
+                // registers across the contraction loop
+                float smax[2][NSLOT];
+    #pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+    #pragma unroll
+                    for (int r = 0; r < NSLOT; ++r)
+                        smax[jb][r] = fmaxf(fmaxf(acc[0][jb][r], acc[1][jb][r]), fmaxf(acc[2][jb][r], acc[3][jb][r]));
     #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
                     const int bl_ = wb * 64 + jb * 32 + l31;
@@ -440,6 +448,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                     atomicMin(&sm.tau_key[row], m);
                 }
                 __syncthreads();
+                }
             }
             if (NG == 32 && st == st_begin && a.top_k <= HTS / 4) {
                 // First tile of this workgroup: the rows' other latent ranges start at the same moment, so the shared group

@@ -3,8 +3,8 @@
     python tools/ablate_encoder.py            # writes build/abl/lib_<VARIANT>.so
     SAEV_AMD_LIB=build/abl/lib_NOEPI.so python tools/time_encoder.py
 
-Variants: NOEPI (no TopK epilogue), NOSTAGE (no in-loop operand staging), NOCAND (no candidate count/reserve/store),
-and combinations.  The patches are textual and applied to a temporary copy of the kernel source.
+Variants: NOEPI (no TopK epilogue), NOSTAGE (no in-loop operand staging), NOLDS (fragments from registers), NOMFMA (no matrix
+instructions), NOBAR (no k-loop barrier), NOCAND (no candidate count/reserve/store), and combinations.  The patches are textual and applied to a temporary copy of the kernel source.
 """
 import pathlib
 import subprocess
@@ -34,11 +34,16 @@ def patched(text: str) -> str:
         "#ifdef ABL_NOLDS\n            fb[0][0] = fb[0][1] = fb[1][0] = fb[1][1] = fconst;\n#endif\n#ifndef ABL_NOLDS\n#pragma unroll\n            for (int jb = 0; jb < 2; ++jb) {\n                fb[jb][0] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((0 + half) ^ bsw)]);")
     sub("                fb[jb][1] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((2 + half) ^ bsw)]);\n            }",
         "                fb[jb][1] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 32 * jb][8 * ((2 + half) ^ bsw)]);\n            }\n#endif")
-    sub("        } else {\n            // group maxima of THIS tile only;",
+    sub("        } else {\n            if constexpr (NG == 64) {",
         "        } else {\n#ifdef ABL_NOEPI\n            { float chk = 0.f;\n"
         "              for (int sb = 0; sb < 4; ++sb) for (int jb = 0; jb < 2; ++jb) for (int r = 0; r < 16; ++r) chk += acc[sb][jb][r];\n"
         "              if (chk == 12345.f) a.cand_cnt[0] = 1; }\n            __syncthreads();\n            skip_epi = true;\n#endif\n"
-        "            if (!skip_epi) {\n            // group maxima of THIS tile only;")
+        "            if (!skip_epi) {\n            if constexpr (NG == 64) {")
+    # NOBAR: no workgroup barrier inside the k-loop (races: timing only); NOMFMA: no matrix instructions (AR != 0)
+    sub("            else asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n            __builtin_amdgcn_s_barrier();",
+        "            else asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n#ifndef ABL_NOBAR\n            __builtin_amdgcn_s_barrier();\n#endif")
+    sub("    if constexpr (AR == 1) return mfma_bf16(a, b, c);",
+        "#ifdef ABL_NOMFMA\n    asm volatile(\"\" :: \"v\"(a), \"v\"(b));\n    return c;\n#endif\n    if constexpr (AR == 1) return mfma_bf16(a, b, c);")
     sub("            int npass[2], pos[2];\n",
         "#ifdef ABL_NOCAND\n            if (sm.tau_key[0] == 12345) a.cand_cnt[0] = (int)acc[0][0][0] + (int)acc[1][1][1] + (int)acc[2][0][2] + (int)acc[3][1][3];\n"
         "            if (sm.tau_key[1] != 777777) goto tile_done;\n#endif\n            int npass[2], pos[2];\n")
@@ -53,7 +58,7 @@ def main():
     OUT.mkdir(parents=True, exist_ok=True)
     tmp = OUT / "gemm_encode_f16x3_abl.hip"
     tmp.write_text(patched(SRC.read_text()))
-    variants = sys.argv[1:] or ["NOEPI", "NOSTAGE", "NOCAND", "NOSTAGE+NOEPI", "NOLDS+NOEPI", "NOSTAGE+NOLDS+NOEPI"]
+    variants = sys.argv[1:] or ["NOEPI", "NOCAND", "NOSTAGE+NOEPI", "NOLDS+NOEPI", "NOSTAGE+NOLDS+NOEPI", "NOMFMA+NOEPI", "NOMFMA+NOLDS+NOEPI", "NOMFMA+NOSTAGE+NOEPI"]
     objs = [str(ROOT / "build" / f"{n}.o") for n in ("ctx", "gemm_encode", "split", "select", "sparse", "tail", "auxk")]
     for v in variants:
         defs = [f"-DABL_{x}" for x in v.split("+")]

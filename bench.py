@@ -103,8 +103,11 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="length of the steady-state segment timed after the headline steps (0 = skip); it starts after "
                          "--sustained-after further steps, past the (lowered) dead-latent threshold")
-    ap.add_argument("--sustained-after", type=int, default=600)
+    ap.add_argument("--sustained-after", type=int, default=625)
     ap.add_argument("--no-auxk-probe", action="store_true", help="skip the AuxK-active sub-records (forced dead sets)")
+    ap.add_argument("--n-saes", type=int, default=1,
+                    help="train this many SAEs on every batch (the reference's parallel groups); the extra ones differ in "
+                         "parameters only and share the first one's x statistics / operand images.  value still counts each batch once")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,10 +131,10 @@ def main():
     from saev_amd.framework.ddp import DataParallelStepper
 
     B = args.batch
-    # The reference's dead-latent threshold is 10 M tokens (objectives.py:24) = 610 of these steps; a default run cannot
-    # wait that long, so the threshold is 200 steps' worth of tokens: the sustained segment below then runs entirely in
-    # the post-threshold regime (tracker consulted every step, AuxK on whatever is dead), like the bulk of a real run.
-    dead_thr = 200 * B * world
+    # The reference's dead-latent threshold, 10 M tokens (objectives.py:24), is 611 of these steps: the sustained segment
+    # below starts after it, so it runs in the regime a real run spends its life in (tracker consulted every step, AuxK on
+    # whatever is dead).
+    dead_thr = 10_000_000
     ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B, dead_threshold_tokens=dead_thr)
     if args.encoder:
         import dataclasses
@@ -152,12 +155,22 @@ def main():
     perm = torch.randperm(pool.shape[0], device=dev, generator=g)
     x = torch.empty(B, D_MODEL, device=dev)
     stepper = DataParallelStepper(eng, dist, world, force=args.force_dist, overlap=args.overlap)
+    extra = []  # further SAEs of the group (--n-saes): same batches, their own parameters
+    for j in range(1, args.n_saes):
+        import dataclasses as _dc
+
+        e2 = SaeEngine(ecfg, dev)
+        e2.params.copy_(eng.params)
+        e2.share_x(eng)
+        extra.append(DataParallelStepper(e2, dist, world, force=args.force_dist, overlap=args.overlap))
     lr_sched = lambda i: 4e-4 * min(1.0, i / 500)  # noqa: E731  warm-up region of the reference schedule
 
     def one_step(i):
         rows = perm[(i % POOL_BATCHES) * B : (i % POOL_BATCHES + 1) * B]
         eng.gather_rows(pool, rows, out=x)
         stepper.train_step(x, lr_sched(i), 1.0)
+        for st2 in extra:
+            st2.train_step(x, lr_sched(i), 1.0)
 
     for i in range(args.warmup):
         one_step(i)
@@ -290,7 +303,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[1]: d_in={D_MODEL}, d_sae={D_SAE} (32x), k={TOP_K}, batch={B}/GPU, "
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder, "n_saes": args.n_saes,
                        "grad_exchange": ("none" if stepper.dist is None else
                                          ("bucketed all-reduce overlapped with the backward" if stepper.overlap else "one flat all-reduce"))},
             "mse_last": stats.mse, "n_overflow_rows": stats.n_overflow_rows, "cand_max": stats.cand_max,

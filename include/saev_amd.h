@@ -155,6 +155,16 @@ int saev_gather_rows(saev_ctx* ctx, const float* pool, const int64_t* rows, int3
  * objective.  (The host samples them per step: objectives.py:159-201.) */
 int saev_set_prefixes(saev_ctx* ctx, const int64_t* prefixes_host, int32_t n);
 
+/* Several SAEs trained on the same batches (the reference's answer to an I/O-bound loop: one batch feeds every SAE of
+ * a parallel group, train.py:3, :334-348): everything a step derives from x alone -- max|x| of the MSE rescale, the
+ * column means the f16r encoder centres on, the centred row norms behind its error margins, the power-of-two x scale
+ * and the fp16 / bf16 operand images -- is built once, by `leader`, and read by every context that shares with it.
+ * A saev_step_forward of `ctx` borrows them when `leader`'s last saev_step_forward was given the same x pointer and
+ * row count and nothing has borrowed-or-rebuilt in between; otherwise it builds its own, so results never depend on
+ * the sharing.  Same device, d_model and encoder mode; both contexts on one stream (or ordered by the caller); the
+ * leader must outlive the link.  leader = NULL detaches. */
+int saev_share_x(saev_ctx* ctx, saev_ctx* leader);
+
 /* Phase 1: renormalise W_dec (train.py:334-335), encode + TopK, fired flags, sparse decode, MSE,
  * main-path gradient pieces.  `training` = 0 gives the eval-mode forward (no tracker, no aux).
  * `n_rows_global` = rows of this step summed over all data-parallel ranks (= n_rows on one GPU);

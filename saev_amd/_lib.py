@@ -47,6 +47,7 @@ _SIGNATURES = {
     "saev_bind_tracker": (C.c_int, [P, P, P]),
     "saev_tracker_touched": (C.c_int, [P]),
     "saev_set_prefixes": (C.c_int, [P, P, C.c_int32]),
+    "saev_share_x": (C.c_int, [P, P]),
     "saev_toks_since_active": (P, [P]),
     "saev_fired_flags": (P, [P]),
     "saev_stats_device": (P, [P]),

@@ -106,6 +106,16 @@ struct saev_ctx {
           *sq_part = nullptr, *wmax_prev = nullptr;
     bool wmax_known = false;
     bool mu_ready = false;  // the step already put the column means of x into mu
+    // Where the step in flight finds what was derived from x alone: max|x|, the column means, the centred row norms, the
+    // per-workgroup maxima behind the x scale, and the fp16 / bf16 images.  Its own buffers -- or those of the context it
+    // shares a batch with (saev_share_x: several SAEs trained on the same batches form them once).
+    float *upper_c = nullptr, *mu_c = nullptr, *xnorm_c = nullptr, *xabs_c = nullptr;
+    _Float16* xs_c = nullptr;
+    saev_ctx* leader = nullptr;
+    const float* xprep_x = nullptr;  // what this context's own x-derived buffers currently describe
+    int xprep_n = 0;
+    int64_t xprep_serial = 0;        // bumped every time they are rebuilt
+    int64_t leader_serial_seen = 0;  // the leader's serial this context last borrowed
     // f16x3 encoder operands
     _Float16 *xs = nullptr, *ws = nullptr;
     int Dp = 0, S_pad = 0, MB_pad = 0;
@@ -383,6 +393,17 @@ int saev_tracker_touched(saev_ctx* c) {
     return SAEV_OK;
 }
 
+int saev_share_x(saev_ctx* c, saev_ctx* leader) {
+    if (!c) return SAEV_INVALID_ARG;
+    if (leader == nullptr || leader == c) { c->leader = nullptr; return SAEV_OK; }
+    REQUIRE(c, leader->device == c->device && leader->cfg.d_model == c->cfg.d_model && leader->cfg.encoder_mode == c->cfg.encoder_mode,
+            SAEV_INVALID_ARG, "saev_share_x: both contexts must live on one device with the same d_model and encoder mode");
+    REQUIRE(c, leader->leader == nullptr, SAEV_INVALID_ARG, "saev_share_x: the leader must build its own x-derived buffers");
+    c->leader = leader;
+    c->leader_serial_seen = leader->xprep_serial;  // nothing built before this call is borrowed
+    return SAEV_OK;
+}
+
 int saev_last_aux_route(const saev_ctx* c) { return c ? c->aux_route : -1; }
 int64_t saev_dead_readbacks(const saev_ctx* c) { return c ? c->n_readbacks : -1; }
 
@@ -454,10 +475,21 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
     return SAEV_OK;
 }
 
+// Points the *_c members at this context's own x-derived buffers, or at the leader's when they describe exactly this
+// batch (same pointer, same row count, built since this context last borrowed them).  Returns true when borrowed.
+static bool bind_x_sources(saev_ctx* c, const float* x, int n, bool allow_borrow) {
+    saev_ctx* l = c->leader;
+    const bool borrow = allow_borrow && l != nullptr && l->xprep_x == x && l->xprep_n == n && l->xprep_serial != c->leader_serial_seen;
+    saev_ctx* src = borrow ? l : c;
+    c->upper_c = src->upper; c->mu_c = src->mu; c->xnorm_c = src->xnorm; c->xabs_c = src->xabs_part; c->xs_c = src->xs;
+    if (borrow) c->leader_serial_seen = l->xprep_serial;
+    return borrow;
+}
+
 // operand preparation for the f16 encoders: x and W_enc^T rewritten as fp16 / bf16 images (no-op for the f32 encoder).
 // `xmax_dev` = device scalar max|x| when the caller has it already (the step computes it for the MSE), else NULL.
 static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag, hipStream_t s,
-                           const float* xmax_dev = nullptr) {
+                           const float* xmax_dev = nullptr, bool x_borrowed = false) {
     if (c->cfg.encoder_mode == SAEV_ENCODER_F32) return SAEV_OK;
     const int D = c->cfg.d_model, S = c->cfg.d_sae;
     const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
@@ -474,20 +506,24 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // centre the first pass on the batch's column mean: h = (x - mu) W + (mu W + b)
         (void)xmax_dev;
         // (mu = column sums / n, scaled in the same kernel so that every consumer sees the same fp32 values)
-        if (!c->mu_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n));
+        if (!x_borrowed) {
+            if (!c->mu_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n));
+            HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s));
+        }
         c->mu_ready = false;
-        HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s));
-        HIPCHK(c, launch_f16r_scales(c->xabs_part, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
-        HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
+        // (the x scale depends on x alone: a borrowing context recomputes the same value from the leader's maxima, next
+        // to its own W scale)
+        HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
+        if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
         HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
-                                  c->mu, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
+                                  c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
                                      c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
-        HIPCHK(c, launch_row_margins(c->xnorm, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales + 1, pre_flag,
+        HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales + 1, pre_flag,
                                      c->wmax_prev, c->row_margin, s));
         return SAEV_OK;
     }
-    HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
+    if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
     HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, bf ? 1.0f : 256.0f, c->ws, bf ? 1 : 0, s));
     return SAEV_OK;
 }
@@ -499,7 +535,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32 && !(f16r && epi == EPI_DENSE)) {
         const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
         EncodeF16Args a{};
-        a.xs = c->xs; a.ws = c->ws;
+        a.xs = c->xs_c; a.ws = c->ws;
         a.b_enc = f16r ? c->b_shift : c->params + c->off_b_enc;  // f16r: images are centred, the bias carries mu W
         a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = (bf || f16r) ? 1.0f : 256.0f;
         a.scale_dev = f16r ? c->f16r_scales : nullptr;
@@ -542,6 +578,8 @@ int saev_encode_dense(saev_ctx* c, const float* x, int32_t n, float* h_out, void
     REQUIRE(c, x && h_out && n > 0, SAEV_INVALID_ARG, "saev_encode_dense: bad arguments");
     REQUIRE(c, n <= c->cfg.max_batch || c->cfg.encoder_mode == SAEV_ENCODER_F32, SAEV_INVALID_ARG,
             "saev_encode_dense: n_rows > max_batch");
+    bind_x_sources(c, x, n, false);
+    c->xprep_x = nullptr;  // the images below are rebuilt for this call: nothing to lend
     if (c->cfg.encoder_mode != SAEV_ENCODER_F16R) {  // (f16r: a dense h comes from the fp32 kernel, no images needed)
         int rc = prepare_encoder(c, x, n, nullptr, (hipStream_t)stream);
         if (rc != SAEV_OK) return rc;
@@ -563,11 +601,11 @@ int saev_topk_dense(saev_ctx* c, const float* h, int32_t n, int32_t k, const int
 
 // encode + top-k into (idx_out, val_out); fused path with exact dense fallback on overflow
 static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out, float* val_out,
-                            const int32_t* pre_flag, hipStream_t s, const float* xmax_dev = nullptr) {
+                            const int32_t* pre_flag, hipStream_t s, const float* xmax_dev = nullptr, bool x_borrowed = false) {
     const int K = c->cfg.top_k;
     int32_t* need_dense = c->flags + 1;
     {
-        int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev);
+        int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev, x_borrowed);
         if (rc0 != SAEV_OK) return rc0;
     }
     if (fused_supported(c->cfg)) {
@@ -619,6 +657,8 @@ int saev_encode_topk(saev_ctx* c, const float* x, int32_t n, int32_t* idx_out, f
             "saev_encode_topk: bad arguments (n_rows must be in 1..max_batch)");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int32_t), s));
+    bind_x_sources(c, x, n, false);
+    c->xprep_x = nullptr;
     return encode_topk_impl(c, x, n, idx_out, val_out, c->flags, s);
 }
 
@@ -700,21 +740,28 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
         if (rc != SAEV_OK) return rc;
     }
     HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));  // flags[0]: force-dense flag, unused by the step
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {  // one pass: max|x| for the MSE and the column sums the encoder centres on
-        HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s, 1.0f / (float)n));
-        c->mu_ready = true;
-    } else {
-        HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
+    // everything that depends on x alone comes from the context this one shares its batches with, if that one has just
+    // built it for this very batch (saev_share_x); otherwise it is built here
+    const bool borrowed = bind_x_sources(c, x, n, true);
+    if (!borrowed) {
+        c->xprep_x = nullptr;
+        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {  // one pass: max|x| for the MSE and the column sums the encoder centres on
+            HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s, 1.0f / (float)n));
+            c->mu_ready = true;
+        } else {
+            HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
+        }
     }
     (void)n_rows_global;
-    int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s, c->upper);
+    int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s, c->upper_c, borrowed);
     if (rc != SAEV_OK) return rc;
+    if (!borrowed) { c->xprep_x = x; c->xprep_n = n; c->xprep_serial++; }
 
     DecodeArgs a{};
     a.x = x; a.idx = c->idx; a.val = c->val; a.code_stride = K; a.k = K;
     a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
     a.n_rows = n; a.D = D; a.S = S; a.idx_limit = S;
-    a.upper = c->upper;
+    a.upper = c->upper_c;
     a.gscale = 2.0f / ((float)n * (float)D * (float)c->P);
     a.training = training ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
@@ -729,7 +776,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     }
     c->P_last = c->P;
     for (int p = 0; p < c->P; ++p) c->cuts_last[p] = c->cuts[p];  // a later saev_set_prefixes must not reach this step's backward
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper, c->flags + 2, c->stats, s));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper_c, c->flags + 2, c->stats, s));
     return SAEV_OK;
 }
 
@@ -870,7 +917,7 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s) {
     HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                    c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
                                    c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper, c->flags + 2, c->stats, s, nd_dev));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, c->flags + 2, c->stats, s, nd_dev));
     return SAEV_OK;
 }
 
@@ -896,10 +943,10 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         // H = x W_enc[:, dl] + b_enc[dl]: the x images of this step are already there (prepare_encoder)
         HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, 0, s));
         HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s, c->aux_all));
-        const _Float16* xs_hl = c->xs;
+        const _Float16* xs_hl = c->xs_c;
         if (f16r) {  // the step's x images are single fp16 here: make the hi/lo ones (the buffer is free until the backward)
             // (with the step's power-of-two x scale, so that no activation magnitude can overflow fp16)
-            HIPCHK(c, launch_pow2_scale(c->upper, c->aux_scales + 6, s));  // from max|x| of the step (uncentred here)
+            HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));  // from max|x| of the step (uncentred here)
             HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 6));
             xs_hl = c->aux_xsg;
         }
@@ -935,7 +982,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
                                c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper, c->flags + 2, c->stats, s));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper_c, c->flags + 2, c->stats, s));
     return SAEV_OK;
 }
 
@@ -981,7 +1028,7 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
         HIPCHK(c, launch_absmax(dA, (long)n * ndp, c->aux_scales, s));
         HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 10, s));
-        HIPCHK(c, launch_pow2_scale(c->upper, c->aux_scales + 6, s));
+        HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));
         rc = ksplit_f16x3(c, dA, c->aux_scales + 10, ndp, c->x_last, c->aux_scales + 6, D, n, c->dWe, s);
         if (rc != SAEV_OK) return rc;
     } else {

@@ -112,6 +112,8 @@ class SaeEngine:
 
     def close(self):
         if getattr(self, "ctx", None):
+            if getattr(self, "_leader", None) is not None and getattr(self._leader, "ctx", None):
+                self.lib.saev_share_x(self.ctx, None)
             self.lib.saev_destroy(self.ctx)
             self.ctx = None
 
@@ -148,6 +150,12 @@ class SaeEngine:
         pre = [int(p) for p in prefixes]
         arr = (C.c_int64 * len(pre))(*pre)
         self._chk(self.lib.saev_set_prefixes(self.ctx, arr, len(pre)), "saev_set_prefixes")
+
+    def share_x(self, leader: "SaeEngine | None") -> None:
+        """Borrow what a step derives from x alone (statistics, centring, operand images) from ``leader`` whenever it has
+        just run its forward on the same batch tensor: several SAEs on the same batches (train()'s parallel groups)."""
+        self._leader = leader  # keeps it alive for as long as the link exists
+        self._chk(self.lib.saev_share_x(self.ctx, leader.ctx if leader is not None else None), "saev_share_x")
 
     def load_params(self, params: dict[str, torch.Tensor]) -> None:
         for k in self.offsets:

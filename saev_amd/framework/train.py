@@ -202,6 +202,8 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
         eng = obj._bind(sae, dataloader.local_batch)
         if world > 1:  # identical replicas: rank 0's initial parameters everywhere
             dist.broadcast(eng.params, src=0)
+        if steppers:  # one batch feeds every SAE of the group (train.py:334-348): the first engine's x statistics,
+            eng.share_x(steppers[0].engine)  # centring and operand images serve the others
         steppers.append(DataParallelStepper(eng, dist, world))
         scheds.append(scheduling.WarmupCosine(0.0, c.n_lr_warmup, c.lr, len(limiter), 0.0))
         lrs.append(0.0)  # first optimizer step is pure warm-up (train.py:118)

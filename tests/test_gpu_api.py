@@ -410,3 +410,93 @@ def test_streaming_feed_reports_its_fill(tmp_path, monkeypatch):
     saes, objs, run, steps = T.train([cfg])
     fills = [m["loader/buffer_fill"] for _, m in run.records[0]]
     assert fills and all(0.0 <= f <= 1.0 for f in fills) and any(f < 1.0 for f in fills)
+
+
+def test_group_of_saes_shares_the_batch_work_and_matches_single_runs(tmp_path):
+    """Several SAEs trained on the same batches (reference train.py:334-348; grouping :669-695): the group builds the
+    x statistics / centring / operand images once (saev_share_x) and every member ends with bit-for-bit the parameters
+    it gets when trained alone on the same batches from the same start -- different top_k, learning rates and AuxK sizes
+    included (AuxK is active in this fixture)."""
+    from saev_amd.engine import EngineConfig, SaeEngine
+    from saev_amd.framework import train as T
+
+    g = load_golden("g9_train_b")
+    d, s, bsz, thr = int(g["d"]), int(g["s"]), int(g["bsz"]), int(g["thr"])
+    variants = [(16, 2e-3, 32), (8, 1e-3, 64), (24, 4e-3, 16)]  # (top_k, lr, k_aux)
+    gen = torch.Generator().manual_seed(5)
+    starts = []
+    for _ in variants:
+        p = {key: g["init_" + key].clone() for key in R.PARAM_ORDER}
+        p["W_enc"] = p["W_enc"] + 0.01 * torch.randn(p["W_enc"].shape, generator=gen)
+        starts.append(p)
+    batches = [b.cuda() for b in g["acts"].split(bsz)] * 2
+
+    def make(i):
+        k, _, k_aux = variants[i]
+        e = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr, max_batch=bsz))
+        e.load_params(starts[i])
+        return e
+
+    group = [make(i) for i in range(3)]
+    for e in group[1:]:
+        e.share_x(group[0])
+    dead_seen = 0
+    for t, x in enumerate(batches):
+        for i, e in enumerate(group):
+            e.train_step(x, 0.0 if t == 0 else variants[i][1], 1.0)
+        dead_seen = max(dead_seen, group[0].read_stats().n_dead)
+    assert dead_seen > 0, "the fixture is meant to exercise AuxK"
+    for i in range(3):
+        alone = make(i)
+        for t, x in enumerate(batches):
+            alone.train_step(x, 0.0 if t == 0 else variants[i][1], 1.0)
+        assert torch.equal(alone.params, group[i].params), f"SAE {i}: group run differs from the single run"
+        assert torch.equal(alone.adam_v, group[i].adam_v) and torch.equal(alone.toks_since_active, group[i].toks_since_active)
+
+    # train() links the members of a parallel group the same way
+    base = small_cfg(tmp_path, g)
+    m = M()
+    cfgs = [dataclasses.replace(base, lr=lr, sae=dataclasses.replace(base.sae, activation=m.TopK(top_k=k, aux=m.AuxK(k_aux=ka, alpha=1 / 32))))
+            for k, lr, ka in variants]
+    assert len(T.split_cfgs(cfgs)) == 1
+    saes, objs, run, steps = T.train(cfgs, train_pool=g["acts"])
+    engines = [o.__dict__["_eng_ref"] for o in objs]
+    assert engines[1]._leader is engines[0] and engines[2]._leader is engines[0]
+    assert len(run.records) == 3 and all(len(r) == len(run.records[0]) > 0 for r in run.records)
+
+
+def test_shared_x_is_only_borrowed_for_the_same_batch():
+    """saev_share_x never changes results: a follower borrows only what the leader built for the very same batch tensor,
+    once; any other call order makes it build its own."""
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    d, s, n = 64, 512, 128
+    gen = torch.Generator().manual_seed(3)
+    p = R.init_params(R.RefConfig(d_model=d, d_sae=s), gen)
+    xa, xb = torch.randn(n, d, generator=gen).cuda(), (3.0 * torch.randn(n, d, generator=gen) + 1.0).cuda()
+    lead = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=8, max_batch=n))
+    foll = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=4, max_batch=n))
+    solo = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=4, max_batch=n))
+    for e in (lead, foll, solo):
+        e.load_params(p)
+    foll.share_x(lead)
+
+    def codes(e, x):
+        e.step_forward(x, training=False)
+        i, v, xh = e.last_codes(n)
+        return i.clone(), v.clone(), xh.clone(), e.read_stats().mse
+
+    def same(a, b):
+        return all(torch.equal(u, w) for u, w in zip(a[:3], b[:3])) and a[3] == b[3]
+
+    lead.step_forward(xa, training=False)
+    assert same(codes(foll, xa), codes(solo, xa))          # borrowed
+    assert same(codes(foll, xb), codes(solo, xb))          # other tensor: built its own
+    assert same(codes(foll, xa), codes(solo, xa))          # leader has not rebuilt since the last borrow: own again
+    buf = xa.clone()
+    lead.step_forward(buf, training=False)
+    buf.copy_(xb)                                          # same address, new contents, leader not re-run ...
+    lead.step_forward(buf, training=False)                 # ... then re-run: the follower may borrow again
+    assert same(codes(foll, buf), codes(solo, xb))
+    foll.share_x(None)
+    assert same(codes(foll, xa), codes(solo, xa))

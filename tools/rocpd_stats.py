@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 rocpd SQLite database (kernel-trace) into a per-kernel stats table.
 
-    python tools/rocpd_stats.py gpurun_out/prof/run_results.db [--skip N]  > profiles/rNN_kernels.txt
+    python tools/rocpd_stats.py gpurun_out/prof/run_results.db [--last N]  > profiles/rNN_kernels.txt
+
+--last N: per kernel, only its last N dispatches (the steady-state tail of a long run).
 """
 import re
 import sqlite3
@@ -16,8 +18,14 @@ def main():
     cols = [r[1] for r in db.execute(f"pragma table_info({kd})")]
     scols = [r[1] for r in db.execute(f"pragma table_info({ks})")]
     name_col = "kernel_name" if "kernel_name" in scols else "display_name"
-    q = f"select s.{name_col}, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id"
+    q = f"select s.{name_col}, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"
     rows = db.execute(q).fetchall()
+    last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0
+    if last > 0:
+        per = {}
+        for name, dur in rows:
+            per.setdefault(name, []).append(dur)
+        rows = [(name, dur) for name, durs in per.items() for dur in durs[-last:]]
     agg = {}
     for name, dur in rows:
         name = re.sub(r"\(.*", "", name)

@@ -100,6 +100,10 @@ def main():
                     help="bucketed gradient all-reduce overlapped with the backward instead of one flat all-reduce after it")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL init + per-step collectives) even with one rank")
+    ap.add_argument("--tail", choices=["auto", "replicated", "sharded"], default="auto",
+                    help="data-parallel optimizer tail: every rank all of it after an all-reduce, or reduce-scatter -> 1/N of "
+                         "the tail per rank -> all-gather (framework/ddp.py).  auto: sharded when a start-up self-check on a "
+                         "small problem reproduces the all-reduce path on every rank, else replicated")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="length of the steady-state segment timed after the headline steps (0 = skip); it starts after "
                          "--sustained-after further steps, past the (lowered) dead-latent threshold")
@@ -130,12 +134,47 @@ def main():
     from saev_amd.engine import EngineConfig, SaeEngine
     from saev_amd.framework.ddp import DataParallelStepper
 
+    def sharded_tail_ok() -> bool:
+        """Three steps of a small SAE with the sharded tail against the all-reduce path on identical data, on every rank."""
+        try:
+            outs = []
+            for mode in ("replicated", "sharded"):
+                e = SaeEngine(EngineConfig(d_model=64, d_sae=512, top_k=8, k_aux=16, dead_threshold_tokens=256, max_batch=128,
+                                           shard_world=world if mode == "sharded" else 1), dev)
+                gg = torch.Generator(device=dev).manual_seed(3)
+                W0 = torch.randn(512, 64, device=dev, generator=gg)
+                W0 /= W0.norm(dim=1, keepdim=True)
+                e.view("W_dec").copy_(W0); e.view("W_enc").copy_(W0.t())
+                st = DataParallelStepper(e, dist, world, force=args.force_dist, tail=mode)
+                gx = torch.Generator(device=dev).manual_seed(100 + rank)
+                for i in range(4):
+                    st.train_step(torch.randn(128, 64, device=dev, generator=gx), 1e-3 * i, 0.05)
+                torch.cuda.synchronize()
+                outs.append({k: v.clone() for k, v in e.param_views().items()})
+            ok = all(torch.allclose(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-7) for k in outs[0])
+            # every rank must hold the same parameters as rank 0
+            ref0 = torch.cat([v.reshape(-1) for v in outs[1].values()]).clone()
+            dist.broadcast(ref0, src=0)
+            ok = ok and torch.equal(ref0, torch.cat([v.reshape(-1) for v in outs[1].values()]))
+        except Exception as exc:  # any failure of the new path means: use the old one
+            print(f"[bench] sharded-tail self-check failed on rank {rank}: {exc!r}", file=sys.stderr)
+            ok = False
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    tail_mode = "replicated"
+    if dist is not None and not args.overlap:
+        if args.tail == "sharded" or (args.tail == "auto" and sharded_tail_ok()):
+            tail_mode = "sharded"
+
     B = args.batch
     # The reference's dead-latent threshold, 10 M tokens (objectives.py:24), is 611 of these steps: the sustained segment
     # below starts after it, so it runs in the regime a real run spends its life in (tracker consulted every step, AuxK on
     # whatever is dead).
     dead_thr = 10_000_000
-    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B, dead_threshold_tokens=dead_thr)
+    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B, dead_threshold_tokens=dead_thr,
+                        shard_world=world if tail_mode == "sharded" else 1)
     if args.encoder:
         import dataclasses
 
@@ -154,7 +193,7 @@ def main():
     pool = torch.randn(POOL_BATCHES * B, D_MODEL, device=dev, generator=g) + mu
     perm = torch.randperm(pool.shape[0], device=dev, generator=g)
     x = torch.empty(B, D_MODEL, device=dev)
-    stepper = DataParallelStepper(eng, dist, world, force=args.force_dist, overlap=args.overlap)
+    stepper = DataParallelStepper(eng, dist, world, force=args.force_dist, overlap=args.overlap, tail=tail_mode)
     extra = []  # further SAEs of the group (--n-saes): same batches, their own parameters
     for j in range(1, args.n_saes):
         import dataclasses as _dc
@@ -162,7 +201,7 @@ def main():
         e2 = SaeEngine(ecfg, dev)
         e2.params.copy_(eng.params)
         e2.share_x(eng)
-        extra.append(DataParallelStepper(e2, dist, world, force=args.force_dist, overlap=args.overlap))
+        extra.append(DataParallelStepper(e2, dist, world, force=args.force_dist, overlap=args.overlap, tail=tail_mode))
     lr_sched = lambda i: 4e-4 * min(1.0, i / 500)  # noqa: E731  warm-up region of the reference schedule
 
     def one_step(i):
@@ -305,7 +344,10 @@ def main():
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder, "n_saes": args.n_saes,
                        "grad_exchange": ("none" if stepper.dist is None else
-                                         ("bucketed all-reduce overlapped with the backward" if stepper.overlap else "one flat all-reduce"))},
+                                         ("bucketed all-reduce overlapped with the backward" if stepper.overlap else
+                                          ("reduce-scatter of the two gradient halves, tail on 1/N of the elements per rank, all-gather of "
+                                           "the parameter halves (decoder half on a side stream); verified at start-up against the "
+                                           "all-reduce path" if stepper.tail == "sharded" else "one flat all-reduce, replicated tail")))},
             "mse_last": stats.mse, "n_overflow_rows": stats.n_overflow_rows, "cand_max": stats.cand_max,
             "roofline": roof,
             "headline_note": f"value = the {args.steps} steps after {args.warmup} warm-up steps from random init (the contract's "

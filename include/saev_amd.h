@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 2
+#define SAEV_AMD_ABI_VERSION 3
 
 typedef enum {
     SAEV_OK = 0,
@@ -53,7 +53,20 @@ typedef struct {
     int32_t aux_dead_cap;          /* largest dead set the AuxK buffers are sized for at saev_create (no allocation
                                       happens inside a step); 0 = d_sae, i.e. never too small.  A step that meets more
                                       dead latents than this fails with SAEV_UNSUPPORTED.                            */
+    int32_t shard_world;           /* 0 / 1: the flat buffers are exactly the layout above.  N > 1: each half of it,
+                                      [W_dec | b_dec] and [W_enc | b_enc], is padded with zeros to N equal chunks (chunks
+                                      of the first half are whole decoder rows) so that N data-parallel ranks can
+                                      reduce-scatter the gradient, run the tail on 1/N each and all-gather the parameters
+                                      (saev_tail_prepare / saev_tail_apply); see saev_layout.                        */
 } saev_cfg;
+
+/* Element offsets of the four tensors inside each flat buffer, its total length, and the per-rank chunk lengths of the
+ * two halves (all in floats) for this configuration.  Without shard_world: off_W_dec 0, off_b_dec S*D, off_W_enc
+ * S*D + D, off_b_enc 2*S*D + D, n_total 2*S*D + S + D. */
+typedef struct {
+    int64_t off_W_dec, off_b_dec, off_W_enc, off_b_enc, n_total, chunk_a, chunk_b;
+} saev_layout_t;
+int saev_layout(const saev_cfg* cfg, saev_layout_t* out);
 
 /* Encoder arithmetic.  F32, F16X3 and F16R are fp32-accurate (error vs fp64 at the level of a native fp32 GEMM):
  *   F32   : v_mfma_f32_32x32x2_f32, exact fp32 products;
@@ -205,6 +218,24 @@ int saev_bind_w_enc_t(saev_ctx* ctx, float* scratch);
  * (train.py:351-352), global-norm clip (train.py:356-362, max_norm <= 0 disables), Adam with torch
  * defaults (train.py:294,444-446). `adam_step` is the 1-based step count. */
 int saev_step_tail(saev_ctx* ctx, float lr, float max_norm, float grad_scale, int64_t adam_step, void* stream);
+/* Phase 4 in two parts, over everything (shard_rank < 0: saev_step_tail == prepare + apply) or over rank
+ * `shard_rank`'s chunk of each half of the flat buffers (saev_cfg.shard_world ranks; the gradient chunks must hold the
+ * cross-rank SUM, e.g. after a reduce-scatter):
+ *   saev_tail_prepare  remove_parallel_grads on the decoder rows of the range and the sum of squares of the range's
+ *                      (projected, unscaled) gradient into saev_sumsq_device -- the caller all-reduces that one double
+ *                      (SUM) when the ranges are per-rank, so that every rank clips with the same global norm;
+ *   saev_tail_apply    clip coefficient from that sum, Adam on the range.
+ * saev_bind_sumsq hands the context a caller-owned device double (a torch tensor a collective can run on). */
+int saev_tail_prepare(saev_ctx* ctx, int32_t shard_rank, void* stream);
+int saev_tail_apply(saev_ctx* ctx, float lr, float max_norm, float grad_scale, int64_t adam_step, int32_t shard_rank,
+                    void* stream);
+double* saev_sumsq_device(saev_ctx* ctx);
+int saev_bind_sumsq(saev_ctx* ctx, double* sumsq);
+/* One-shot: the next saev_step_forward waits for this hipEvent_t (on its stream) before it first touches W_dec, and
+ * renormalises W_dec there instead of at its top -- for a caller whose decoder half of the parameter all-gather is
+ * still running on another stream.  NULL cancels. */
+int saev_wdec_ready_event(saev_ctx* ctx, void* event);
+
 /* Phases 1-4 back to back for the single-GPU case. */
 int saev_train_step(saev_ctx* ctx, const float* x, int32_t n_rows, float lr, float max_norm,
                     int64_t adam_step, void* stream);

@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SaevCfg(C.Structure):
@@ -22,7 +22,12 @@ class SaevCfg(C.Structure):
         ("alpha", C.c_float), ("dead_threshold_tokens", C.c_int64),
         ("normalize_w_dec", C.c_int32), ("remove_parallel_grads", C.c_int32),
         ("max_batch", C.c_int32), ("encoder_mode", C.c_int32), ("aux_dead_cap", C.c_int32),
+        ("shard_world", C.c_int32),
     ]
+
+
+class SaevLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("off_W_dec", "off_b_dec", "off_W_enc", "off_b_enc", "n_total", "chunk_a", "chunk_b")]
 
 
 class SaevStepStats(C.Structure):
@@ -41,6 +46,7 @@ P = C.c_void_p
 _SIGNATURES = {
     "saev_abi_version": (C.c_int, []),
     "saev_last_error": (C.c_char_p, [P]),
+    "saev_layout": (C.c_int, [C.POINTER(SaevCfg), C.POINTER(SaevLayout)]),
     "saev_create": (C.c_int, [C.POINTER(SaevCfg), C.c_int, C.POINTER(P)]),
     "saev_destroy": (None, [P]),
     "saev_bind": (C.c_int, [P, P, P, P, P]),
@@ -71,6 +77,11 @@ _SIGNATURES = {
     "saev_grad_w_enc_t": (P, [P]),
     "saev_bind_w_enc_t": (C.c_int, [P, P]),
     "saev_step_tail": (C.c_int, [P, C.c_float, C.c_float, C.c_float, C.c_int64, P]),
+    "saev_tail_prepare": (C.c_int, [P, C.c_int32, P]),
+    "saev_tail_apply": (C.c_int, [P, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int32, P]),
+    "saev_sumsq_device": (P, [P]),
+    "saev_bind_sumsq": (C.c_int, [P, P]),
+    "saev_wdec_ready_event": (C.c_int, [P, P]),
     "saev_train_step": (C.c_int, [P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
     "saev_last_idx": (P, [P]),
     "saev_last_val": (P, [P]),

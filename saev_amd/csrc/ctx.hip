@@ -40,8 +40,12 @@ struct saev_ctx {
     float* adam_m = nullptr;
     float* adam_v = nullptr;
     // derived
-    long n_params = 0;
+    long n_params = 0;  // floats in each flat buffer, padding included
     long off_W_dec = 0, off_b_dec = 0, off_W_enc = 0, off_b_enc = 0;
+    int shard_world = 1;
+    long chunk_a = 0, chunk_b = 0;  // floats per rank of the [W_dec | b_dec] half and of the [W_enc | b_enc] half
+    double* sumsq_bound = nullptr;  // caller-owned replacement of sumsq_total (so that a collective can reach it)
+    hipEvent_t wdec_ready = nullptr;  // one-shot: the next forward waits for it before it touches W_dec
     // scratch
     std::vector<void*> allocs;
     int cuts_last[MAX_PREFIXES] = {0};  // the cut points the forward in flight used (the backward must see the same)
@@ -204,6 +208,19 @@ extern "C" {
 
 int saev_abi_version(void) { return SAEV_AMD_ABI_VERSION; }
 
+int saev_layout(const saev_cfg* cfg, saev_layout_t* out) {
+    if (!cfg || !out || cfg->d_model <= 0 || cfg->d_sae <= 0) return SAEV_INVALID_ARG;
+    const int64_t S = cfg->d_sae, D = cfg->d_model, N = std::max(1, cfg->shard_world);
+    out->chunk_a = (S + 1 + N - 1) / N * D;
+    out->chunk_b = ((D * S + S + N - 1) / N + 3) / 4 * 4;
+    out->off_W_dec = 0;
+    out->off_b_dec = S * D;
+    out->off_W_enc = N * out->chunk_a;
+    out->off_b_enc = out->off_W_enc + D * S;
+    out->n_total = N * out->chunk_a + N * out->chunk_b;
+    return SAEV_OK;
+}
+
 const char* saev_last_error(const saev_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
@@ -226,11 +243,18 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         return SAEV_HIP_ERROR;
     }
     const long S = cfg->d_sae, D = cfg->d_model, MB = cfg->max_batch, K = c->cfg.top_k, KA = cfg->k_aux;
-    c->off_W_dec = 0;
-    c->off_b_dec = S * D;
-    c->off_W_enc = S * D + D;
-    c->off_b_enc = S * D + D + D * S;
-    c->n_params = 2 * S * D + S + D;
+    // Flat layout [W_dec | b_dec | pad | W_enc | b_enc | pad].  With shard_world = N > 1 each half is padded to N equal
+    // chunks -- chunks of the first half are whole decoder rows -- so that a data-parallel run can reduce-scatter the
+    // gradient halves, let every rank run the tail on its chunk of each, and all-gather the parameter halves separately
+    // (the encoder half first: the next forward needs it first).  N = 1: no padding, the state_dict order as it is.
+    {
+        saev_layout_t lay;
+        saev_layout(cfg, &lay);
+        c->shard_world = std::max(1, cfg->shard_world);
+        c->chunk_a = lay.chunk_a; c->chunk_b = lay.chunk_b;
+        c->off_W_dec = lay.off_W_dec; c->off_b_dec = lay.off_b_dec; c->off_W_enc = lay.off_W_enc; c->off_b_enc = lay.off_b_enc;
+        c->n_params = lay.n_total;
+    }
     int rc = SAEV_OK;
 #define A(p, n) if (rc == SAEV_OK) rc = alloc(c, &c->p, (size_t)(n))
     c->gmax_stride = (int)((MB + 255) / 256 * 256);  // (padding the group pitch changes nothing: measured)
@@ -253,7 +277,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(chunk_starts, S + 1); A(part_starts, S); A(work_latent, c->max_work);
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part);
     A(colsum_partials, ((MB + 63) / 64) * D);
-    A(sumsq_partials, 1024); A(sumsq_total, 1);
+    A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8); A(sumsq_total, 1);
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
         c->Dp = (int)((D + 31) / 32 * 32);
         c->S_pad = (int)((S + 255) / 256 * 256);
@@ -735,7 +759,13 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     c->x_last = x;
     c->n_last = n;
     c->training_last = training;
-    if (training) {
+    // Rows of W_dec are renormalised at the top of a training step (train.py:334-335); nothing before the decode reads
+    // W_dec.  When the caller has announced that W_dec is still arriving (saev_wdec_ready_event: the decoder half of a
+    // sharded tail's all-gather runs on a side stream) the renormalisation moves behind the encoder and the selects, and
+    // the stream waits for the event only there: the encoder hides the transfer.
+    hipEvent_t wdec_ev = c->wdec_ready;
+    c->wdec_ready = nullptr;
+    if (training && wdec_ev == nullptr) {
         int rc = saev_normalize_w_dec(c, stream);
         if (rc != SAEV_OK) return rc;
     }
@@ -756,6 +786,13 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s, c->upper_c, borrowed);
     if (rc != SAEV_OK) return rc;
     if (!borrowed) { c->xprep_x = x; c->xprep_n = n; c->xprep_serial++; }
+    if (wdec_ev != nullptr) {
+        HIPCHK(c, hipStreamWaitEvent(s, wdec_ev, 0));
+        if (training) {
+            rc = saev_normalize_w_dec(c, stream);
+            if (rc != SAEV_OK) return rc;
+        }
+    }
 
     DecodeArgs a{};
     a.x = x; a.idx = c->idx; a.val = c->val; a.code_stride = K; a.k = K;
@@ -1175,23 +1212,89 @@ int saev_step_backward(saev_ctx* c, void* stream) {
     return saev_backward_end(c, stream);
 }
 
-int saev_step_tail(saev_ctx* c, float lr, float max_norm, float grad_scale, int64_t adam_step, void* stream) {
+// The element ranges a tail call works on: everything (shard_rank < 0), or rank `shard_rank`'s chunk of each half.
+namespace {
+struct TailRanges { long a_lo, a_hi, b_lo, b_hi; };
+int tail_ranges(saev_ctx* c, int shard_rank, TailRanges* r) {
+    if (shard_rank < 0) {
+        *r = {0, c->off_W_enc, c->off_W_enc, c->n_params};
+        return SAEV_OK;
+    }
+    REQUIRE(c, shard_rank < c->shard_world, SAEV_INVALID_ARG, "shard_rank >= saev_cfg.shard_world");
+    r->a_lo = (long)shard_rank * c->chunk_a; r->a_hi = r->a_lo + c->chunk_a;
+    r->b_lo = c->off_W_enc + (long)shard_rank * c->chunk_b; r->b_hi = r->b_lo + c->chunk_b;
+    return SAEV_OK;
+}
+}  // namespace
+
+double* saev_sumsq_device(saev_ctx* c) { return c ? (c->sumsq_bound ? c->sumsq_bound : c->sumsq_total) : nullptr; }
+
+int saev_bind_sumsq(saev_ctx* c, double* sumsq) {
+    if (!c) return SAEV_INVALID_ARG;
+    c->sumsq_bound = sumsq;
+    return SAEV_OK;
+}
+
+int saev_wdec_ready_event(saev_ctx* c, void* event) {
+    if (!c) return SAEV_INVALID_ARG;
+    c->wdec_ready = (hipEvent_t)event;
+    return SAEV_OK;
+}
+
+int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->params && c->grads, SAEV_NOT_BOUND, "saev_tail_prepare: params/grads not bound");
+    TailRanges r;
+    int rc = tail_ranges(c, shard_rank, &r);
+    if (rc != SAEV_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long S = c->cfg.d_sae, D = c->cfg.d_model;
+    // decoder rows of the range: projection (modeling.py:419-445) and their squares in one pass over the gradient
+    const long row_lo = std::min(r.a_lo / D, S), row_hi = std::min(r.a_hi / D, S);
+    const int n_rows = (int)(row_hi - row_lo);
+    const int nb = sumsq_blocks();
+    double* part = c->sumsq_partials;  // [0, nb): rest of the first half; [nb, 2 nb): second half; then one per 4 rows
+    HIPCHK(c, launch_rpg(c->grads + row_lo * D, c->params + row_lo * D, n_rows, (int)D, s, part + 2 * nb,
+                         c->cfg.remove_parallel_grads ? 1 : 0));
+    const long rest_lo = std::max(r.a_lo, S * D);
+    HIPCHK(c, launch_sumsq_partials(c->grads + rest_lo, std::max(0L, r.a_hi - rest_lo), part, s));
+    HIPCHK(c, launch_sumsq_partials(c->grads + r.b_lo, r.b_hi - r.b_lo, part + nb, s));
+    HIPCHK(c, launch_sumsq_final(part, 2 * nb + (n_rows + 3) / 4, saev_sumsq_device(c), s));
+    return SAEV_OK;
+}
+
+int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int64_t adam_step, int32_t shard_rank,
+                    void* stream) {
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, c->params && c->grads && c->adam_m && c->adam_v, SAEV_NOT_BOUND,
-            "saev_step_tail: params/grads/adam state not bound");
+            "saev_tail_apply: params/grads/adam state not bound");
     REQUIRE(c, adam_step >= 1, SAEV_INVALID_ARG, "adam_step is 1-based");
-    hipStream_t s = (hipStream_t)stream;
-    int rc = saev_remove_parallel_grads(c, stream);
+    TailRanges r;
+    int rc = tail_ranges(c, shard_rank, &r);
     if (rc != SAEV_OK) return rc;
-    HIPCHK(c, launch_sumsq(c->grads, c->n_params, c->sumsq_partials, c->sumsq_total, s));
+    hipStream_t s = (hipStream_t)stream;
     AdamArgs a{};
-    a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = c->n_params;
     a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
     a.bc1 = (float)(1.0 - std::pow(0.9, (double)adam_step));
     a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, (double)adam_step));
-    a.grad_scale = grad_scale; a.max_norm = max_norm; a.sumsq = c->sumsq_total; a.stats = c->stats;
-    HIPCHK(c, launch_adam(a, s));
+    a.grad_scale = grad_scale; a.max_norm = max_norm; a.sumsq = saev_sumsq_device(c); a.stats = c->stats;
+    const long lo[2] = {r.a_lo, r.b_lo}, hi[2] = {r.a_hi, r.b_hi};
+    if (shard_rank < 0) {  // one contiguous stream over everything
+        a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = c->n_params;
+        HIPCHK(c, launch_adam(a, s));
+        return SAEV_OK;
+    }
+    for (int h = 0; h < 2; ++h) {
+        a.p = c->params + lo[h]; a.g = c->grads + lo[h]; a.m = c->adam_m + lo[h]; a.v = c->adam_v + lo[h]; a.n = hi[h] - lo[h];
+        HIPCHK(c, launch_adam(a, s));
+    }
     return SAEV_OK;
+}
+
+int saev_step_tail(saev_ctx* c, float lr, float max_norm, float grad_scale, int64_t adam_step, void* stream) {
+    int rc = saev_tail_prepare(c, -1, stream);
+    if (rc != SAEV_OK) return rc;
+    return saev_tail_apply(c, lr, max_norm, grad_scale, adam_step, -1, stream);
 }
 
 int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_norm, int64_t adam_step,

@@ -181,7 +181,13 @@ hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partia
 
 // ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
 hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream);
-hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream);
+// rows [0, S) of gW projected orthogonal to the rows of W (project != 0); with sq_partials, ceil(S / 4) doubles: the sums
+// of squares of the rows as written (the clip norm's share of W_dec, from the same pass)
+hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream, double* sq_partials = nullptr,
+                      int project = 1);
+int sumsq_blocks();  // partial sums one launch_sumsq_partials writes
+hipError_t launch_sumsq_partials(const float* g, long n, double* partials, hipStream_t stream);
+hipError_t launch_sumsq_final(const double* partials, int nb, double* total, hipStream_t stream);
 // total[0] = sum of squares of g[0..n) (deterministic two-stage; `partials` >= 1024 floats... doubles)
 hipError_t launch_sumsq(const float* g, long n, double* partials, double* total, hipStream_t stream);
 struct AdamArgs {

@@ -36,33 +36,53 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, in
     }
 }
 
+// remove_parallel_grads (modeling.py:419-445) on rows [0, S) of gW; with `sq_partials` the same pass also leaves the sum
+// of squares of the rows AS WRITTEN (one double per workgroup of four rows) for the clip norm, so the gradient of W_dec is
+// not streamed a second time by the norm pass.  project == 0: squares only.
 template <int NV>
-__global__ __launch_bounds__(256) void rpg_kernel(float* gW, const float* W, int S, int D) {
+__global__ __launch_bounds__(256) void rpg_kernel(float* gW, const float* W, int S, int D, double* sq_partials, int project) {
+    __shared__ float sh[4];
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= S) return;
     const int D4 = D >> 2;
-    f32x4* gr = reinterpret_cast<f32x4*>(gW + (size_t)i * D);
-    const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
-    f32x4 g[NV], w[NV];
-    float dot = 0.f, nsq = 0.f;
+    float sq = 0.f;
+    if (i < S) {
+        f32x4* gr = reinterpret_cast<f32x4*>(gW + (size_t)i * D);
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
+        f32x4 g[NV], w[NV];
+        float dot = 0.f, nsq = 0.f;
 #pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const int q = lane + 64 * n;
-        const bool ok = q < D4;
-        g[n] = ok ? gr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-        w[n] = ok ? wr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            const bool ok = q < D4;
+            g[n] = ok ? gr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            w[n] = (ok && project) ? wr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dot += g[n][e] * w[n][e]; nsq += w[n][e] * w[n][e]; }
+            for (int e = 0; e < 4; ++e) { dot += g[n][e] * w[n][e]; nsq += w[n][e] * w[n][e]; }
+        }
+        dot = wave_sum(dot);
+        nsq = wave_sum(nsq);
+        if (project && nsq > 0.f) {
+            const float sc = dot / nsq;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = lane + 64 * n;
+                g[n] = g[n] - sc * w[n];
+                if (q < D4) gr[q] = g[n];
+            }
+        }
+        if (sq_partials != nullptr) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sq += g[n][e] * g[n][e];
+            sq = wave_sum(sq);
+        }
     }
-    dot = wave_sum(dot);
-    nsq = wave_sum(nsq);
-    if (!(nsq > 0.f)) return;
-    const float sc = dot / nsq;
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const int q = lane + 64 * n;
-        if (q < D4) gr[q] = g[n] - sc * w[n];
+    if (sq_partials != nullptr) {
+        if (lane == 0) sh[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) sq_partials[blockIdx.x] = ((double)sh[0] + (double)sh[1]) + ((double)sh[2] + (double)sh[3]);
     }
 }
 
@@ -84,9 +104,11 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+// total = sum of nb partials: every thread adds its strided share in index order, then a fixed tree (deterministic)
 __global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* partials, int nb, double* total) {
     __shared__ double sh[16];
-    double s = (threadIdx.x < nb) ? partials[threadIdx.x] : 0.0;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 1024) s += partials[i];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -272,10 +294,21 @@ hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream) {
         hipLaunchKernelGGL(normalize_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, W, S, D);
     });
 }
-hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream) {
+hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream, double* sq_partials, int project) {
+    if (S <= 0) return hipSuccess;
     return dispatch_nv(D, [&](auto nv) {
-        hipLaunchKernelGGL(rpg_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, gW, W, S, D);
+        hipLaunchKernelGGL(rpg_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, gW, W, S, D, sq_partials,
+                           project);
     });
+}
+int sumsq_blocks() { return SUMSQ_BLOCKS; }
+hipError_t launch_sumsq_partials(const float* g, long n, double* partials, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, g, n, partials);  // n == 0: zeros
+    return hipGetLastError();
+}
+hipError_t launch_sumsq_final(const double* partials, int nb, double* total, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, stream, partials, nb, total);
+    return hipGetLastError();
 }
 hipError_t launch_sumsq(const float* g, long n, double* partials, double* total, hipStream_t stream) {
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, g, n, partials);

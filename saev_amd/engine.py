@@ -33,6 +33,7 @@ class EngineConfig:
     remove_parallel_grads: bool = True
     max_batch: int = 16384
     aux_dead_cap: int = 0      # largest dead set the AuxK buffers are sized for at creation; 0 = d_sae (always enough)
+    shard_world: int = 1       # > 1: flat buffers padded so that this many data-parallel ranks can each own 1/N of the tail
     # "f32": exact fp32 MFMA; "f16x3": split-fp16 MFMA at fp32 accuracy (16/3 of the f32 matrix rate);
     # "bf16": bf16-rounded encoder operands, one MFMA product, fp32 accumulate (everything else stays fp32);
     # "f16r": one fp16 MFMA product as a bounded-error first pass + exact fp32 recomputation of the surviving candidates.
@@ -60,6 +61,16 @@ class StepStats:
         return self.mse + self.aux
 
 
+def flat_layout(cfg: EngineConfig) -> "_lib.SaevLayout":
+    """Offsets of the four tensors in the flat buffers, their length and the per-rank chunk lengths (saev_layout)."""
+    lay = _lib.SaevLayout()
+    ccfg = _lib.SaevCfg(d_model=cfg.d_model, d_sae=cfg.d_sae, shard_world=cfg.shard_world)
+    rc = _lib.load().saev_layout(C.byref(ccfg), C.byref(lay))
+    if rc != 0:
+        raise _lib.SaevError(f"saev_layout failed with status {rc} for {cfg}")
+    return lay
+
+
 def _ptr(t: torch.Tensor | None):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -78,8 +89,11 @@ class SaeEngine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         S, D = cfg.d_sae, cfg.d_model
-        self.n_params = 2 * S * D + S + D
-        self.offsets = {"W_dec": 0, "b_dec": S * D, "W_enc": S * D + D, "b_enc": 2 * S * D + D}
+        lay = flat_layout(cfg)
+        self.n_params = lay.n_total  # floats per flat buffer (zero padding included when shard_world > 1)
+        self.shard_world = cfg.shard_world
+        self.chunk_a, self.chunk_b = lay.chunk_a, lay.chunk_b
+        self.offsets = {"W_dec": lay.off_W_dec, "b_dec": lay.off_b_dec, "W_enc": lay.off_W_enc, "b_enc": lay.off_b_enc}
         self.shapes = {"W_dec": (S, D), "b_dec": (D,), "W_enc": (D, S), "b_enc": (S,)}
         with torch.cuda.device(self.device):
             self.params = torch.zeros(self.n_params, device=self.device, dtype=torch.float32)
@@ -93,7 +107,7 @@ class SaeEngine:
                 dead_threshold_tokens=cfg.dead_threshold_tokens,
                 normalize_w_dec=int(cfg.normalize_w_dec), remove_parallel_grads=int(cfg.remove_parallel_grads),
                 max_batch=cfg.max_batch, encoder_mode={"f32": 0, "f16x3": 1, "bf16": 2, "f16r": 3}[cfg.encoder],
-                aux_dead_cap=cfg.aux_dead_cap,
+                aux_dead_cap=cfg.aux_dead_cap, shard_world=cfg.shard_world,
             )
             ctx = C.c_void_p()
             rc = self.lib.saev_create(C.byref(ccfg), self.device.index, C.byref(ctx))
@@ -102,6 +116,9 @@ class SaeEngine:
             self.ctx = ctx
             self._chk(self.lib.saev_bind(ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v)), "saev_bind")
             self._chk(self.lib.saev_bind_tracker(ctx, _ptr(self.toks_since_active), _ptr(self.fired)), "saev_bind_tracker")
+            # the tail's sum of squares lives in a torch tensor from the start, so that a collective can reach it
+            self.sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
+            self._chk(self.lib.saev_bind_sumsq(ctx, _ptr(self.sumsq)), "saev_bind_sumsq")
         self.adam_steps = 0
         self._x_keepalive = None
         self._w_enc_t = None
@@ -257,6 +274,26 @@ class SaeEngine:
     def step_tail(self, lr: float, max_norm: float = 1.0, grad_scale: float = 1.0):
         self.adam_steps += 1
         self._chk(self.lib.saev_step_tail(self.ctx, lr, max_norm, grad_scale, self.adam_steps, _stream()), "saev_step_tail")
+
+    # tail in two parts over this rank's chunks (data-parallel runs with a sharded tail, framework/ddp.py)
+    def halves(self, flat: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """The [W_dec | b_dec | pad] and [W_enc | b_enc | pad] halves of a flat buffer (shard_world equal chunks each)."""
+        a = self.chunk_a * self.cfg.shard_world
+        return flat[:a], flat[a:]
+
+
+    def tail_prepare(self, shard_rank: int = -1):
+        self._chk(self.lib.saev_tail_prepare(self.ctx, shard_rank, _stream()), "saev_tail_prepare")
+
+    def tail_apply(self, lr: float, max_norm: float = 1.0, grad_scale: float = 1.0, shard_rank: int = -1):
+        self.adam_steps += 1
+        self._chk(self.lib.saev_tail_apply(self.ctx, lr, max_norm, grad_scale, self.adam_steps, shard_rank, _stream()), "saev_tail_apply")
+
+    def wdec_ready_after(self, event: "torch.cuda.Event | None"):
+        """The next step_forward waits for ``event`` before it first touches W_dec (and renormalises W_dec there)."""
+        self._wdec_event = event  # keep the handle alive until it has been consumed
+        self._chk(self.lib.saev_wdec_ready_event(self.ctx, C.c_void_p(event.cuda_event) if event is not None else None),
+                  "saev_wdec_ready_event")
 
     def train_step(self, x: torch.Tensor, lr: float, max_norm: float = 1.0):
         """Phases 1-4 on one GPU (reference train.py:332-460 loop body for one SAE)."""

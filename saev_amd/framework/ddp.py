@@ -20,7 +20,19 @@ Gradient exchange, two ways:
     It is parity-tested (gloo with two ranks, RCCL with one) and left opt-in until it can be measured on a multi-GPU
     node.
 
-`dist` may be any object with torch.distributed's all_reduce/ReduceOp API (gloo on CPU in tests).
+Tail, two ways (``tail=``, ``SAEV_AMD_DDP_TAIL``):
+
+  * ``"replicated"`` (default): the gradient is all-reduced and every rank runs the whole tail (rpg, clip norm, Adam:
+    1.88 GB of streaming at configs[1]) -- replicas stay bit-identical by construction;
+  * ``"sharded"``: the engine's flat buffers are laid out as two halves of ``world`` equal chunks
+    (``EngineConfig.shard_world``).  The gradient halves are reduce-scattered (half the bytes of an all-reduce each
+    way), every rank projects / squares / Adam-updates only its own chunk of each half (1/world of the streaming), one
+    double -- the sum of squares -- is all-reduced so that all ranks clip with the same global norm, and the parameter
+    halves are all-gathered: the encoder half first, on the compute stream (the next forward starts with it), the decoder
+    half on a side stream, waited for only right before the next step's decode (``saev_wdec_ready_event``), so the
+    encoder hides it.  Same bytes on the wire as the all-reduce, less tail, part of the gather off the critical path.
+
+`dist` may be any object with torch.distributed's collectives / ReduceOp API (gloo on CPU in tests).
 """
 
 from __future__ import annotations
@@ -32,7 +44,7 @@ import torch
 
 class DataParallelStepper:
     def __init__(self, engine, dist=None, world_size: int = 1, force: bool = False, overlap: bool | None = None,
-                 n_buckets: int = 2):
+                 n_buckets: int = 2, tail: str | None = None, rank: int | None = None):
         """``force`` keeps the collective path even for one rank (exercises RCCL on a single-GPU box)."""
         self.engine = engine
         self.dist = dist if (world_size > 1 or force) else None
@@ -41,6 +53,47 @@ class DataParallelStepper:
             overlap = os.environ.get("SAEV_AMD_DDP_OVERLAP", "0") == "1"
         self.overlap = overlap and hasattr(engine, "backward_rows")
         self.n_buckets = max(1, n_buckets)
+        if tail is None:
+            tail = os.environ.get("SAEV_AMD_DDP_TAIL", "replicated")
+        if tail not in ("replicated", "sharded"):
+            raise ValueError(f"tail must be 'replicated' or 'sharded', got {tail!r}")
+        self.tail = tail if self.dist is not None else "replicated"
+        self.rank = rank if rank is not None else (self.dist.get_rank() if self.dist is not None else 0)
+        self._side = None
+        if self.tail == "sharded":
+            if self.overlap:
+                raise ValueError("the sharded tail reduce-scatters whole halves after the backward; overlap=True is the all-reduce variant")
+            got = getattr(engine, "shard_world", None)
+            if got != self.world:
+                raise ValueError(f"tail='sharded' needs an engine laid out for {self.world} ranks (shard_world), got {got}")
+
+    def _tail_sharded(self, lr: float, max_norm: float, pre_tail=None) -> None:
+        eng, dist, r = self.engine, self.dist, self.rank
+        for half in eng.halves(eng.grads):  # [W_dec | b_dec | pad], [W_enc | b_enc | pad]: `world` equal chunks each
+            c = half.numel() // self.world
+            dist.reduce_scatter_tensor(half[r * c : (r + 1) * c], half, op=dist.ReduceOp.SUM)
+        if pre_tail is not None:
+            pre_tail()
+        eng.tail_prepare(r)                                   # rpg on my decoder rows, sum of squares of my chunks
+        dist.all_reduce(eng.sumsq, op=dist.ReduceOp.SUM)      # one double: every rank clips with the global norm
+        eng.tail_apply(lr, max_norm, 1.0 / self.world, r)     # Adam on my chunks
+        p_a, p_b = eng.halves(eng.params)
+        cb = p_b.numel() // self.world
+        dist.all_gather_into_tensor(p_b, p_b[r * cb : (r + 1) * cb])  # encoder half: the next forward starts with it
+        ca = p_a.numel() // self.world
+        if p_a.is_cuda:
+            import torch
+
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=p_a.device)
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                dist.all_gather_into_tensor(p_a, p_a[r * ca : (r + 1) * ca])
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            eng.wdec_ready_after(ev)                          # the next forward waits for it right before its decode
+        else:
+            dist.all_gather_into_tensor(p_a, p_a[r * ca : (r + 1) * ca])
 
     def _exchange_overlapped(self) -> None:
         eng, dist = self.engine, self.dist
@@ -87,7 +140,11 @@ class DataParallelStepper:
             self._exchange_overlapped()
         else:
             eng.step_backward()
-            self.dist.all_reduce(eng.grads, op=self.dist.ReduceOp.SUM)
+            if self.tail != "sharded":
+                self.dist.all_reduce(eng.grads, op=self.dist.ReduceOp.SUM)
+        if self.tail == "sharded":
+            self._tail_sharded(lr, max_norm, pre_tail)
+            return
         if pre_tail is not None:
             pre_tail()
         eng.step_tail(lr, max_norm, grad_scale=1.0 / self.world)

@@ -198,13 +198,17 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
     saes = saes.to(device)
     objs.train()
     steppers, scheds, lrs = [], [], []
+    # how the optimizer tail is spread over data-parallel ranks (framework/ddp.py): every rank all of it, or 1/world each
+    tail_mode = os.environ.get("SAEV_AMD_DDP_TAIL", "replicated") if world > 1 else "replicated"
     for sae, obj, c in zip(saes, objs, cfgs):
+        if tail_mode == "sharded":
+            sae._shard_world = world  # the engine lays its flat buffers out in `world` equal chunks per half
         eng = obj._bind(sae, dataloader.local_batch)
         if world > 1:  # identical replicas: rank 0's initial parameters everywhere
             dist.broadcast(eng.params, src=0)
         if steppers:  # one batch feeds every SAE of the group (train.py:334-348): the first engine's x statistics,
             eng.share_x(steppers[0].engine)  # centring and operand images serve the others
-        steppers.append(DataParallelStepper(eng, dist, world))
+        steppers.append(DataParallelStepper(eng, dist, world, tail=tail_mode))
         scheds.append(scheduling.WarmupCosine(0.0, c.n_lr_warmup, c.lr, len(limiter), 0.0))
         lrs.append(0.0)  # first optimizer step is pure warm-up (train.py:118)
     dataloader.engine = steppers[0].engine

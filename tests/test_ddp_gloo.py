@@ -1,4 +1,4 @@
-"""World-size-2 check of the data-parallel step protocol (saev_amd/framework/ddp.py) on CPU with gloo.
+"""World-size-2 and -4 checks of the data-parallel step protocol (saev_amd/framework/ddp.py) on CPU with gloo.
 
 The HIP engine needs a GPU, so each rank drives a test-local stand-in engine that implements the same
 phase interface (step_forward / step_dead / step_backward / step_tail, .fired, .grads) with the CPU
@@ -20,23 +20,40 @@ from saev_amd.framework.ddp import DataParallelStepper
 
 
 class OracleEngine:
-    """Phase-split restatement of R.train_step for ONE rank's rows."""
+    """Phase-split restatement of R.train_step for ONE rank's rows.  Parameters, Adam moments and gradients live in flat
+    buffers laid out by saev_layout (the product's own layout function; with shard_world > 1 it pads the two halves to
+    equal per-rank chunks), and state.params / m / v are views into them -- so the sharded tail's collectives run on the
+    same memory pattern as on the GPU."""
 
-    def __init__(self, params, cfg: R.RefConfig):
+    def __init__(self, params, cfg: R.RefConfig, shard_world: int = 1):
+        from saev_amd.engine import EngineConfig, flat_layout
+
         self.cfg = cfg
-        self.state = R.TrainState.create(params)
-        S = cfg.d_sae
-        self.fired = torch.zeros(S, dtype=torch.int32)
-        n = sum(p.numel() for p in params.values())
-        self.grads = torch.zeros(n)
+        self.ecfg = EngineConfig(d_model=cfg.d_model, d_sae=cfg.d_sae, shard_world=shard_world)
+        lay = flat_layout(self.ecfg)
+        self.chunk_a, self.chunk_b, self.n_total = lay.chunk_a, lay.chunk_b, lay.n_total
+        self._off = {"W_dec": lay.off_W_dec, "b_dec": lay.off_b_dec, "W_enc": lay.off_W_enc, "b_enc": lay.off_b_enc}
+        self.params, self.adam_m, self.adam_v = (torch.zeros(self.n_total) for _ in range(3))
+        self.grads = torch.zeros(self.n_total)
+
+        def views(flat):
+            return {k: flat[self._off[k] : self._off[k] + params[k].numel()].view(params[k].shape) for k in R.PARAM_ORDER}
+
+        self.state = R.TrainState(params=views(self.params), m=views(self.adam_m), v=views(self.adam_v),
+                                  toks_since_active=torch.zeros(cfg.d_sae, dtype=torch.int64))
+        for k in R.PARAM_ORDER:
+            self.state.params[k].copy_(params[k])
+        self.fired = torch.zeros(cfg.d_sae, dtype=torch.int32)
+        self.sumsq = torch.zeros(1, dtype=torch.float64)
+        self.shard_world = shard_world
         self.calls = []
 
     def step_forward(self, x, *, training=True, n_rows_global=None):
         self.calls.append("forward")
         P = self.state.params
         if self.cfg.normalize_w_dec:
-            P["W_dec"] = R.normalize_w_dec(P["W_dec"])
-        self.leaves = {k: P[k].detach().requires_grad_(True) for k in R.PARAM_ORDER}
+            P["W_dec"].copy_(R.normalize_w_dec(P["W_dec"]))
+        self.leaves = {k: P[k].detach().clone().requires_grad_(True) for k in R.PARAM_ORDER}
         self.x = x
         self.h = R.encode_pre(x, self.leaves["W_enc"], self.leaves["b_enc"])
         self.f = R.topk_activation(self.h, self.cfg.top_k)
@@ -58,21 +75,16 @@ class OracleEngine:
     def step_backward(self):
         self.calls.append("backward")
         self.loss.backward()
-        off = 0
+        self.grads.zero_()
         for k in R.PARAM_ORDER:
             g = self.leaves[k].grad
-            g = torch.zeros_like(self.leaves[k]) if g is None else g
-            self.grads[off : off + g.numel()] = g.reshape(-1)
-            off += g.numel()
+            if g is not None:
+                self.view(k).copy_(g)
 
     # ---- backward in latent ranges (what the overlapped exchange drives) ----
     @property
     def offsets(self):
-        off, out = 0, {}
-        for k in R.PARAM_ORDER:
-            out[k] = off
-            off += self.state.params[k].numel()
-        return out
+        return self._off
 
     def view(self, name, flat=None):
         flat = self.grads if flat is None else flat
@@ -101,20 +113,46 @@ class OracleEngine:
         self.calls.append("backward_end")
         self.view("W_enc").copy_(self.grad_w_enc_t().T)
 
+    # ---- tail: whole (shard_rank < 0) or this rank's chunk of each half, as saev_tail_prepare / saev_tail_apply ----
+    def halves(self, flat):
+        a = self.chunk_a * self.ecfg.shard_world
+        return flat[:a], flat[a:]
+
+    def _ranges(self, r):
+        if r < 0:
+            a = self.chunk_a * self.ecfg.shard_world
+            return (0, a), (a, self.n_total)
+        a0 = self.chunk_a * self.ecfg.shard_world
+        return (r * self.chunk_a, (r + 1) * self.chunk_a), (a0 + r * self.chunk_b, a0 + (r + 1) * self.chunk_b)
+
+    def tail_prepare(self, shard_rank=-1):
+        self.calls.append(f"prepare[{shard_rank}]")
+        (a_lo, a_hi), (b_lo, b_hi) = self._ranges(shard_rank)
+        S, D = self.cfg.d_sae, self.cfg.d_model
+        r0, r1 = min(a_lo // D, S), min(a_hi // D, S)
+        if self.cfg.remove_parallel_grads and r1 > r0:
+            g = self.view("W_dec")[r0:r1]
+            g.copy_(R.remove_parallel_grads(g, self.state.params["W_dec"][r0:r1]))
+        sq = self.grads[a_lo:a_hi].double().pow(2).sum() + self.grads[b_lo:b_hi].double().pow(2).sum()
+        self.sumsq[0] = sq
+
+    def tail_apply(self, lr, max_norm=1.0, grad_scale=1.0, shard_rank=-1):
+        self.calls.append(f"apply[{shard_rank}]")
+        total = grad_scale * float(self.sumsq[0].sqrt())
+        self.grad_norm = total
+        coef = min(max_norm / (total + 1e-6), 1.0)
+        self.state.adam_steps += 1
+        for lo, hi in self._ranges(shard_rank):
+            R.adam_update(self.params[lo:hi], self.grads[lo:hi] * (grad_scale * coef), self.adam_m[lo:hi], self.adam_v[lo:hi],
+                          self.state.adam_steps, lr)
+
+    def wdec_ready_after(self, event):
+        self.calls.append("wdec_ready_after")
+
     def step_tail(self, lr, max_norm=1.0, grad_scale=1.0):
         self.calls.append("tail")
-        P = self.state.params
-        grads, off = {}, 0
-        for k in R.PARAM_ORDER:
-            n = P[k].numel()
-            grads[k] = (self.grads[off : off + n] * grad_scale).view_as(P[k]).clone()
-            off += n
-        if self.cfg.remove_parallel_grads:
-            grads["W_dec"] = R.remove_parallel_grads(grads["W_dec"], P["W_dec"])
-        clipped, self.grad_norm = R.clip_grad_norm([grads[k] for k in R.PARAM_ORDER], max_norm)
-        self.state.adam_steps += 1
-        for k, g in zip(R.PARAM_ORDER, clipped):
-            R.adam_update(P[k], g, self.state.m[k], self.state.v[k], self.state.adam_steps, lr)
+        self.tail_prepare(-1)
+        self.tail_apply(lr, max_norm, grad_scale, -1)
 
     def train_step(self, x, lr, max_norm=1.0):
         self.step_forward(x)
@@ -138,13 +176,13 @@ def _problem():
     return cfg, params, batches
 
 
-def _worker(rank, world, port, out, overlap=False):
+def _worker(rank, world, port, out, overlap=False, tail="replicated"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     cfg, params, batches = _problem()
-    eng = OracleEngine(params, cfg)
-    stepper = DataParallelStepper(eng, dist, world, overlap=overlap, n_buckets=3)
+    eng = OracleEngine(params, cfg, shard_world=world if tail == "sharded" else 1)
+    stepper = DataParallelStepper(eng, dist, world, overlap=overlap, n_buckets=3, tail=tail)
     sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, len(batches), 0.0)
     lr, dead_counts = 0.0, []
     for x in batches:
@@ -156,9 +194,17 @@ def _worker(rank, world, port, out, overlap=False):
         if overlap:
             assert eng.calls[:7] == ["forward", "dead", "backward_begin", "rows[0:85]", "rows[85:170]", "rows[170:256]",
                                      "backward_end"] and eng.calls[7] == "tail"
+        elif tail == "sharded":
+            assert eng.calls[:5] == ["forward", "dead", "backward", "prepare[0]", "apply[0]"] and "tail" not in eng.calls
         else:
             assert eng.calls[:4] == ["forward", "dead", "backward", "tail"]
-    torch.save({"params": eng.state.params, "toks": eng.state.toks_since_active, "n_dead": dead_counts}, out.format(rank=rank))
+    # padding of a sharded layout stays zero
+    pad = torch.ones(eng.n_total, dtype=torch.bool)
+    for k in R.PARAM_ORDER:
+        pad[eng.offsets[k] : eng.offsets[k] + eng.state.params[k].numel()] = False
+    assert (eng.params[pad] == 0).all() and (eng.adam_v[pad] == 0).all()
+    torch.save({"params": {k: v.clone() for k, v in eng.state.params.items()}, "toks": eng.state.toks_since_active,
+                "n_dead": dead_counts}, out.format(rank=rank))
     dist.destroy_process_group()
 
 
@@ -168,17 +214,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.timeout(180)
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_ranks_reproduce_single_process_step(tmp_path, overlap):
-    world = 2
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,overlap,tail", [(2, False, "replicated"), (2, True, "replicated"), (2, False, "sharded"),
+                                                (4, False, "sharded"), (4, False, "replicated")])
+def test_ranks_reproduce_single_process_step(tmp_path, world, overlap, tail):
+    """2 (4) ranks x B/2 (B/4) rows == one process on B rows, for the all-reduce exchange (flat and bucketed / overlapped)
+    and for the sharded tail (reduce-scatter -> tail on 1/world of the elements -> all-gather)."""
     out = str(tmp_path / "rank{rank}.pt")
-    mp.spawn(_worker, args=(world, _free_port(), out, overlap), nprocs=world, join=True)
-    r0, r1 = (torch.load(out.format(rank=r)) for r in range(world))
+    mp.spawn(_worker, args=(world, _free_port(), out, overlap, tail), nprocs=world, join=True)
+    rs = [torch.load(out.format(rank=r)) for r in range(world)]
+    r0 = rs[0]
     # replicas stay bit-identical
-    for k in R.PARAM_ORDER:
-        assert torch.equal(r0["params"][k], r1["params"][k]), k
-    assert torch.equal(r0["toks"], r1["toks"]) and r0["n_dead"] == r1["n_dead"]
+    for other in rs[1:]:
+        for k in R.PARAM_ORDER:
+            assert torch.equal(r0["params"][k], other["params"][k]), k
+        assert torch.equal(r0["toks"], other["toks"]) and r0["n_dead"] == other["n_dead"]
     # and match the single-process step on the full batches
     cfg, params, batches = _problem()
     single = OracleEngine(params, cfg)

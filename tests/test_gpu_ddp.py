@@ -80,3 +80,75 @@ def test_overlapped_exchange_matches_plain_step_on_one_rank(encoder_mode):
                 assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_tail_matches_plain_step_on_one_rank(encoder_mode):
+    """world_size 1 through RCCL with tail='sharded': the in-place reduce-scatter / all-gather of the two halves are the
+    identity, rank 0's chunks are everything, the decoder half's gather runs on a side stream and the next forward waits
+    for it -- the run must end in exactly the parameters of eng.train_step."""
+    if encoder_mode != "f16r":
+        pytest.skip("one encoder mode is enough here")
+    import torch.distributed as dist
+
+    from saev_amd.framework.ddp import DataParallelStepper
+
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        out = []
+        for mode in ("plain", "sharded"):
+            eng, x, s = _setup()
+            stepper = DataParallelStepper(eng, dist if mode != "plain" else None, 1, force=mode != "plain",
+                                          tail="sharded" if mode == "sharded" else "replicated")
+            for i in range(4):
+                stepper.train_step(x, 1e-3 * i, 1.0 if i == 1 else 0.02)  # clip active from the first step on
+            torch.cuda.synchronize()
+            out.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.toks_since_active.clone(),
+                        eng.read_stats().grad_norm))
+        for a, b in zip(out[0][:4], out[1][:4]):
+            assert torch.equal(a, b)
+        assert out[0][4] == out[1][4]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_chunked_tail_covers_the_padded_layout_exactly(world, encoder_mode):
+    """The flat layout for `world` ranks (two halves of `world` equal chunks, zero padding) on ONE GPU: running
+    saev_tail_prepare / saev_tail_apply for every rank in turn, with the per-rank sums of squares added up as the
+    all-reduce would, gives the parameters of the ordinary tail of an unpadded engine; padding stays zero."""
+    if encoder_mode != "f16r":
+        pytest.skip("one encoder mode is enough here")
+    import ctypes as C
+
+    from saev_amd.engine import _stream
+
+    ref, x, s = _setup()
+    eng, _, _ = _setup(shard_world=world)
+    assert eng.n_params > ref.n_params and eng.offsets["W_enc"] == world * eng.chunk_a
+    for step in range(3):
+        lr, clip = 1e-3 * step, (0.02 if step == 1 else 1.0)
+        ref.train_step(x, lr, clip)
+        eng.step_forward(x, training=True)
+        eng.step_dead(x.shape[0])
+        eng.step_backward()
+        total = torch.zeros(1, device="cuda", dtype=torch.float64)
+        sq = eng.sumsq
+        for r in range(world):
+            eng.tail_prepare(r)
+            total += sq
+        sq.copy_(total)
+        eng.adam_steps += 1
+        for r in range(world):
+            rc = eng.lib.saev_tail_apply(eng.ctx, lr, clip, 1.0, eng.adam_steps, r, _stream())
+            assert rc == 0
+        assert abs(eng.read_stats().grad_norm - ref.read_stats().grad_norm) <= 1e-6 * ref.read_stats().grad_norm
+        for name in R.PARAM_ORDER:
+            torch.testing.assert_close(eng.view(name), ref.view(name), rtol=1e-6, atol=1e-9, msg=lambda m: f"step {step} {name}: {m}")
+            torch.testing.assert_close(eng.view(name, eng.adam_v), ref.view(name, ref.adam_v), rtol=1e-6, atol=1e-12)
+    pad = torch.ones(eng.n_params, dtype=torch.bool, device="cuda")
+    for name in R.PARAM_ORDER:
+        pad[eng.offsets[name] : eng.offsets[name] + eng.view(name).numel()] = False
+    assert pad.sum() == eng.n_params - ref.n_params
+    for flat in (eng.params, eng.grads, eng.adam_m, eng.adam_v):
+        assert (flat[pad] == 0).all()

@@ -13,7 +13,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/common.h include/saev_amd.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 saev_amd/libsaev_amd.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
 clean:
 	rm -rf build saev_amd/libsaev_amd.so

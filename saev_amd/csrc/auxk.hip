@@ -5,17 +5,17 @@
 // move 2 * B * k_aux * 4D bytes per pass (68 GB at config 2), while the same contractions as GEMMs over the
 // compacted dead set are a few hundred GFLOP.  So, with dl = ascending list of dead latents (nd of them):
 //
-//   H  = x @ W_enc[:, dl] + b_enc[dl]                 (B x nd)   plain GEMM  (rocBLAS sgemm)
+//   H  = x @ W_enc[:, dl] + b_enc[dl]                 (B x nd)   dense contraction
 //   A  = H masked to the k_use = min(k_aux, nd) largest entries per row   (select.hip radix select)
-//   E  = A @ W_dec[dl] + b_dec                        (B x D)    plain GEMM
+//   E  = A @ W_dec[dl] + b_dec                        (B x D)    dense contraction
 //   aux = alpha * mean((E - (x - x_hat))^2)            g_aux = d aux / dE
-//   dA = (g_aux @ W_dec[dl]^T) * mask                 (B x nd)   plain GEMM
-//   dW_dec[dl] += A^T @ g_aux,  dW_enc^T[dl] += dA^T @ x         plain GEMMs (K = B)
+//   dA = (g_aux @ W_dec[dl]^T) * mask                 (B x nd)   dense contraction
+//   dW_dec[dl] += A^T @ g_aux,  dW_enc^T[dl] += dA^T @ x         dense contractions over the batch axis
 //   db_enc[dl] += colsum(dA),   db_dec += colsum(g_aux)
 //
-// These five products are unfused library GEMMs (the MFMA work that matters, the encoder, is hand-written in
-// gemm_encode*.hip); everything around them (compaction, gathers, bias, masking, residual, scatter-add) is
-// here.  The reference reads n_dead back every step (`int(dead_mask.sum().item())`, modeling.py:92).  Here the host only
+// The five products run on the split-fp16 MFMA kernel of gemm_encode_f16x3.hip with its dense epilogue (fp32-accurate:
+// three f16 products per fp32 product; ctx.hip, dense_f16x3 / ksplit_f16x3), in every encoder mode -- no library GEMM is
+// linked.  Everything around them (compaction, gathers, bias, masking, residual, scatter-add) is here.  The reference reads n_dead back every step (`int(dead_mask.sum().item())`, modeling.py:92).  Here the host only
 // does so when a device-written bound says the dead set may be larger than AUX_SMALL_MAX (ctx.hip, saev_step_dead): the
 // few-dead-latents kernels below take the count from the device and exit when there is nothing to do.
 #include "common.h"
@@ -65,16 +65,6 @@ __global__ __launch_bounds__(256) void gather_dead_kernel(const float* W_enc, co
             if (j < nd) v = reinterpret_cast<const f32x4*>(W_dec + (size_t)dl[j] * D)[c];
             reinterpret_cast<f32x4*>(Wdec_dead + (size_t)j * D)[c] = v;
         }
-    }
-}
-
-// H[b][j] += b_enc[dl[j]]; padding columns become -inf so the select never takes them
-__global__ __launch_bounds__(256) void dead_bias_kernel(float* H, long n_rows, int nd, int ndp, const float* b_enc,
-                                                        const int32_t* dl) {
-    const long total = n_rows * ndp;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
-        const int j = (int)(q % ndp);
-        H[q] = (j < nd) ? H[q] + b_enc[dl[j]] : NEG_INF;
     }
 }
 
@@ -413,11 +403,6 @@ hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int3
                               float* Wenc_dead, float* Wdec_dead, hipStream_t s) {
     hipLaunchKernelGGL(gather_dead_kernel, dim3(grid_for((long)D * ndp + (long)ndp * (D >> 2))), dim3(256), 0, s, W_enc,
                        W_dec, dl, nd, ndp, D, S, Wenc_dead, Wdec_dead);
-    return hipGetLastError();
-}
-hipError_t launch_dead_bias(float* H, int n_rows, int nd, int ndp, const float* b_enc, const int32_t* dl, hipStream_t s) {
-    hipLaunchKernelGGL(dead_bias_kernel, dim3(grid_for((long)n_rows * ndp)), dim3(256), 0, s, H, (long)n_rows, nd, ndp,
-                       b_enc, dl);
     return hipGetLastError();
 }
 hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s, bool pad_zero) {

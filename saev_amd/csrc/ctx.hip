@@ -1,7 +1,6 @@
 // C ABI of libsaev_amd.so (see include/saev_amd.h): context, scratch, and the launch sequences of
 // the train step.  No torch types; plain device pointers and a hipStream_t per call.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <cmath>
@@ -76,7 +75,6 @@ struct saev_ctx {
     float* G = nullptr;  // (max_batch, P_cap, D)
     int P_cap = 0;
     // AuxK dense-over-dead-set path (auxk.hip)
-    rocblas_handle blas = nullptr;
     int n_dead_host = 0, k_use_host = 0;
     int64_t tokens_seen = 0;
     bool tracker_dirty = false;
@@ -278,13 +276,15 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part);
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8); A(sumsq_total, 1);
-    if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
+    if (c->cfg.encoder_mode != SAEV_ENCODER_F32 || KA > 0) {  // (the f32 encoder needs the image geometry for AuxK only)
         c->Dp = (int)((D + 31) / 32 * 32);
         c->S_pad = (int)((S + 255) / 256 * 256);
         c->MB_pad = (int)((MB + 255) / 256 * 256);
+        A(zero_bias, std::max(S, D)); A(aux_scales, 16);
+    }
+    if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
-        A(zero_bias, std::max(S, D)); A(aux_scales, 16);
         A(row_margin, MB); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(mu, D); A(xnorm, MB); A(b_shift, S);
         A(xabs_part, (MB + 3) / 4);
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)(c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
@@ -348,7 +348,6 @@ void saev_destroy(saev_ctx* c) {
     if (c->rec_host) hipHostFree(c->rec_host);
     if (c->dead_ev_created)
         for (int i = 0; i < DEAD_RING; ++i) hipEventDestroy(c->dead_ev[i]);
-    if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev_created)
         for (int i = 0; i < TIMING_RING; ++i) {
             hipEventDestroy(c->ev_start[i]);
@@ -819,38 +818,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
 
 namespace {
 
-#define BLASCHK(ctx, expr)                                                                   \
-    do {                                                                                     \
-        rocblas_status _st = (expr);                                                         \
-        if (_st != rocblas_status_success) {                                                 \
-            (ctx)->err = std::string(#expr) + ": rocblas status " + std::to_string((int)_st); \
-            return SAEV_HIP_ERROR;                                                           \
-        }                                                                                    \
-    } while (0)
-
-// row-major GEMM helpers on top of column-major rocBLAS
-int gemm_nn(saev_ctx* c, int M, int N, int K, const float* A, const float* B, float* C) {  // C = A (MxK) B (KxN)
-    const float one = 1.f, zero = 0.f;
-    BLASCHK(c, rocblas_sgemm(c->blas, rocblas_operation_none, rocblas_operation_none, N, M, K, &one, B, N, A, K, &zero, C, N));
-    return SAEV_OK;
-}
-int gemm_nt(saev_ctx* c, int M, int N, int K, const float* A, const float* B, float* C) {  // C = A (MxK) B^T, B is (NxK)
-    const float one = 1.f, zero = 0.f;
-    BLASCHK(c, rocblas_sgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, B, K, A, K, &zero, C, N));
-    return SAEV_OK;
-}
-int gemm_tn(saev_ctx* c, int M, int N, int K, const float* A, const float* B, float* C) {  // C = A^T B, A is (KxM), B (KxN)
-    const float one = 1.f, zero = 0.f;
-    BLASCHK(c, rocblas_sgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, M, K, &one, B, N, A, M, &zero, C, N));
-    return SAEV_OK;
-}
-
 int alloc_aux_buffers(saev_ctx* c, int cap) {
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F32 || c->cfg.encoder_mode == SAEV_ENCODER_BF16) {
-        BLASCHK(c, rocblas_create_handle(&c->blas));
-        BLASCHK(c, rocblas_set_atomics_mode(c->blas, rocblas_atomics_not_allowed));  // deterministic sums
-        BLASCHK(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
-    }
     const size_t MB = c->cfg.max_batch, D = c->cfg.d_model;
     const size_t capA = std::max(cap, AUX_SMALL_MAX);  // the few-dead-latents kernels use AUX_SMALL_MAX columns / rows
     auto grab = [&](size_t bytes) -> void* {
@@ -872,7 +840,7 @@ int alloc_aux_buffers(saev_ctx* c, int cap) {
     c->aux_small_part = (float*)grab(((MB + 63) / 64) * (size_t)2 * AUX_SMALL_MAX * D * 4);
     c->aux_small_part2 = (float*)grab((size_t)(((MB + 63) / 64 + 63) / 64) * AUX_SMALL_MAX * D * 4);
     bool fast_ok = true;
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
+    {  // operand images of the five contractions (every encoder mode runs them on the split-fp16 MFMA kernel)
         const size_t cap256 = ((size_t)cap + 255) / 256 * 256, D256 = (D + 255) / 256 * 256;
         c->aux_Dp2 = (int)(((size_t)cap + 31) / 32 * 32);
         c->aux_ws1 = (_Float16*)grab(cap256 * 2 * c->Dp * sizeof(_Float16));          // W_enc[:, dl]^T, later W_dec[dl]
@@ -965,35 +933,32 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     const int ndp = (nd + 3) / 4 * 4;
     REQUIRE(c, ndp <= c->nd_cap, SAEV_UNSUPPORTED, "AuxK: more dead latents than saev_cfg.aux_dead_cap allows");
     int rc = SAEV_OK;
-    const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
-    const bool fast = c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || f16r;
+    // Every encoder mode runs the five contractions on the split-fp16 MFMA kernel (three products per fp32 product:
+    // fp32-accurate, gemm_encode_f16x3.hip), whatever arithmetic its own encoder uses: the auxiliary loss is defined on
+    // the exact pre-activations (the bf16 mode's oracle does the same).  Only the f16x3 mode already has hi/lo x images.
+    const bool own_images = c->cfg.encoder_mode != SAEV_ENCODER_F16X3;
     const int ndp256 = (ndp + 255) / 256 * 256, Dp2 = (ndp + 31) / 32 * 32;
-    if (c->blas) BLASCHK(c, rocblas_set_stream(c->blas, s));
     HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
     HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
                                  c->Wenc_dead, c->Wdec_dead, s));
     c->aux_small = false;
     c->aux_all = false;
     // n_dead <= k_aux: every dead latent is selected, the codes are H itself (padding columns zero) and there is no mask
-    c->aux_all = fast && ku == nd;
-    if (fast) {
-        // H = x W_enc[:, dl] + b_enc[dl]: the x images of this step are already there (prepare_encoder)
+    c->aux_all = ku == nd;
+    {
+        // H = x W_enc[:, dl] + b_enc[dl]: in f16x3 mode the x images of this step are already there (prepare_encoder)
         HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, 0, s));
         HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s, c->aux_all));
         const _Float16* xs_hl = c->xs_c;
-        if (f16r) {  // the step's x images are single fp16 here: make the hi/lo ones (the buffer is free until the backward)
+        if (own_images) {  // the step's x images are single fp16 / bf16 or absent: make the hi/lo ones (the buffer is free until the backward)
             // (with the step's power-of-two x scale, so that no activation magnitude can overflow fp16)
             HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));  // from max|x| of the step (uncentred here)
             HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 6));
             xs_hl = c->aux_xsg;
         }
         rc = dense_f16x3(c, xs_hl, c->aux_ws1, c->bias_dead, n, c->Dp, ndp, 256.0f, c->aux_all ? c->A_dead : c->H_dead, s,
-                         f16r ? c->aux_scales + 6 : nullptr);
+                         own_images ? c->aux_scales + 6 : nullptr);
         if (rc != SAEV_OK) return rc;
-    } else {
-        rc = gemm_nn(c, n, ndp, D, c->x_last, c->Wenc_dead, c->H_dead);  // H = x W_enc[:, dl]
-        if (rc != SAEV_OK) return rc;
-        HIPCHK(c, launch_dead_bias(c->H_dead, n, nd, ndp, c->params + c->off_b_enc, c->dead_list, s));
     }
     if (!c->aux_all) {
         SelectDenseArgs sd{};
@@ -1004,7 +969,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
         HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
     }
-    if (fast) {
+    {
         // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
         // (the codes are pre-activations of unknown magnitude: power-of-two scale from their device-side max)
         HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
@@ -1013,8 +978,6 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, 0, s, 1.0f, c->aux_scales + 2));
         HIPCHK(c, launch_split_wT(c->Wdec_dead, ndp, D, (D + 255) / 256 * 256, Dp2, 256.0f, c->aux_ws2, 0, s));
         rc = dense_f16x3(c, c->aux_xsA, c->aux_ws2, c->zero_bias, n, Dp2, D, 256.0f, c->g_aux, s, c->aux_scales + 2);
-    } else {
-        rc = gemm_nn(c, n, D, ndp, c->A_dead, c->Wdec_dead, c->g_aux);  // E = A W_dec[dl]
     }
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
@@ -1028,7 +991,6 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     const int D = c->cfg.d_model, n = c->n_last;
     const int nd = c->n_dead_host;
     const int ndp = (nd + 3) / 4 * 4;
-    if (c->blas) BLASCHK(c, rocblas_set_stream(c->blas, s));
     float* dA = c->H_dead;  // H is dead after the select
     int rc;
     if (c->aux_small) {  // dA is there already (auxk_small_forward); weight gradients block-wise, then two column sums;
@@ -1043,7 +1005,7 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nd_dev, s));
         return SAEV_OK;
     }
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
+    {
         // dA = g_aux W_dec[dl]^T.  g_aux carries the factor alpha * 2 / (n D) (~1e-10) times a residual of unknown
         // magnitude: bring it to [2^13, 2^14) with an exact power of two from its device-side max before the fp16 split;
         // W_dec[dl] rows are already "latent-major", so they split like x.
@@ -1053,12 +1015,10 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 4));
         HIPCHK(c, launch_split_rows(c->Wdec_dead, ndp, D, c->Dp, c->aux_ws1, 0, s, 256.0f));
         rc = dense_f16x3(c, c->aux_xsg, c->aux_ws1, c->zero_bias, n, c->Dp, ndp, 256.0f, dA, s, c->aux_scales + 4);
-    } else {
-        rc = gemm_nt(c, n, ndp, D, c->g_aux, c->Wdec_dead, dA);  // dA = g_aux W_dec[dl]^T
     }
     if (rc != SAEV_OK) return rc;
     if (!c->aux_all) HIPCHK(c, launch_mask_apply(dA, c->A_mask, (long)n * ndp, s));
-    if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3 || c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
+    {
         // operand scales: A from the forward (aux_scales + 2), g_aux from above (+ 4), x from max|x| (+ 6), dA fresh
         rc = ksplit_f16x3(c, c->A_dead, c->aux_scales + 2, ndp, c->g_aux, c->aux_scales + 4, D, n, c->dWd, s);
         if (rc != SAEV_OK) return rc;
@@ -1067,11 +1027,6 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 10, s));
         HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));
         rc = ksplit_f16x3(c, dA, c->aux_scales + 10, ndp, c->x_last, c->aux_scales + 6, D, n, c->dWe, s);
-        if (rc != SAEV_OK) return rc;
-    } else {
-        rc = gemm_tn(c, ndp, D, n, c->A_dead, c->g_aux, c->dWd);  // dW_dec[dl] = A^T g_aux
-        if (rc != SAEV_OK) return rc;
-        rc = gemm_tn(c, ndp, D, n, dA, c->x_last, c->dWe);  // dW_enc^T[dl] = dA^T x
         if (rc != SAEV_OK) return rc;
     }
     HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));

@@ -294,7 +294,6 @@ hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStr
                                const int32_t* n_dead_dev = nullptr);  // exits at once when *n_dead_dev == 0
 hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int32_t* dl, int nd, int ndp, int D, int S,
                               float* Wenc_dead, float* Wdec_dead, hipStream_t s);
-hipError_t launch_dead_bias(float* H, int n_rows, int nd, int ndp, const float* b_enc, const int32_t* dl, hipStream_t s);
 hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s,
                                 bool pad_zero = false);  // padding columns: -inf (never selected) or 0 (all-selected mode)
 hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, int k, int stride, int ndp, float* A,

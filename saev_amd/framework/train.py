@@ -173,10 +173,11 @@ def _make_loader(cfg_data, device, rank, world, pool=None):
     return saev_data.ShuffledDataLoader(cfg_data, device=device, rank=rank, world_size=world, pool=pool)
 
 
-def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torch.nn.ModuleList, torch.nn.ModuleList, RunLog, int]:
+def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=None) -> tuple[torch.nn.ModuleList, torch.nn.ModuleList, RunLog, int]:
     """Train all SAEs of one parallel group on the same batches (train.py:238-462).
 
-    ``train_pool`` optionally supplies an in-memory (n, d_model) activation pool instead of a shard dir."""
+    ``train_pool`` optionally supplies an in-memory (n, d_model) activation pool instead of a shard dir; ``train_feed`` a
+    ready loader-shaped object (e.g. data.ExtractionFeed: activations straight out of a transformer's forward hooks)."""
     if len(split_cfgs(cfgs)) != 1:
         raise ValueError(f"Configs are not parallelizeable: {cfgs}.")
     cfg = cfgs[0]
@@ -188,7 +189,7 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None) -> tuple[torc
     dist, rank, world = _dist()
     device = torch.device("cuda", torch.cuda.current_device())
 
-    dataloader = _make_loader(cfg.train_data, device, rank, world, train_pool)
+    dataloader = train_feed if train_feed is not None else _make_loader(cfg.train_data, device, rank, world, train_pool)
     limiter = scheduling.BatchLimiter(dataloader, cfg.n_train, rows_scale=world)
     torch.manual_seed(cfg.seed)
     saes, objs, _ = make_saes([(c.sae, c.objective) for c in cfgs], limiter, device)

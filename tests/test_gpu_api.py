@@ -500,3 +500,55 @@ def test_shared_x_is_only_borrowed_for_the_same_batch():
     assert same(codes(foll, buf), codes(solo, xb))
     foll.share_x(None)
     assert same(codes(foll, xa), codes(solo, xa))
+
+
+def test_extraction_hand_off_equals_the_cache_round_trip_and_trains(tmp_path):
+    """BASELINE configs[4] on one GPU: a (small, randomly initialised) vision transformer's forward hooks fill the HBM
+    reservoir and train() draws from it.  (1) Every (example, token) arrives exactly once per epoch and carries bit for
+    bit the row a protocol-2.1 cache holds when the same recorded blocks are written to disk and read back through the
+    shuffled loader (the reference's route: shards.py:697-850 -> shuffled.py); (2) train() runs from the feed."""
+    from saev_amd import data
+    from saev_amd.data.vit import VisionTransformer
+    from saev_amd.framework import train as T
+
+    torch.manual_seed(0)
+    d, n_img, patches = 64, 96, 16
+    vit = VisionTransformer(d_model=d, depth=4, heads=4, patch=4, image=16).cuda().eval()
+    rec = data.ActivationRecorder(vit, vit.blocks, layers=(1, 3), content_tokens_per_example=patches, cls_token=True)
+    imgs = torch.randn(n_img, 3, 16, 16)
+
+    def images():
+        for lo in range(0, n_img, 8):
+            yield imgs[lo : lo + 8], torch.arange(lo, min(lo + 8, n_img))
+
+    # the disk route: record every block, write a cache, read it back
+    with torch.no_grad():
+        blocks = [rec(b.cuda())[1].cpu().clone() for b, _ in images()]
+    acts = torch.cat(blocks).numpy()  # (n_img, 2, 17, d)
+    shards = data.write_shards(tmp_path, acts, layers=(1, 3), cls_token=True, max_tokens_per_shard=17 * 2 * 20)
+    dl = data.ShuffledDataLoader(data.ShuffledConfig(shards=shards, layer=3, batch_size=256, seed=3), device="cuda")
+    disk = {(e, t): a.clone() for b in dl for a, e, t in zip(b["act"].cpu(), b["example_idx"].tolist(), b["token_idx"].tolist())}
+    assert len(disk) == n_img * patches
+    # the direct route
+    cfg_x = data.ExtractConfig(layer=3, batch_size=256, buffer_size=3, seed=5)
+    feed = data.ExtractionFeed(cfg_x, rec, images, n_examples=n_img, d_model=d, device="cuda")
+    direct = {}
+    for b in feed:
+        assert b["act"].is_cuda
+        for a, e, t in zip(b["act"].cpu(), b["example_idx"].tolist(), b["token_idx"].tolist()):
+            assert (e, t) not in direct
+            direct[(e, t)] = a
+    assert direct.keys() == disk.keys()
+    assert all(torch.equal(direct[key], disk[key]) for key in disk)
+    # train from the hooks: two epochs' worth of rows
+    m, o = M(), O()
+    cfg = T.Config(n_train=2 * n_img * patches, sae=m.SparseAutoencoderConfig(d_model=d, d_sae=512, reinit_blend=0.0,
+                                                                              activation=m.TopK(top_k=8, aux=m.AuxK(k_aux=32))),
+                   objective=o.Matryoshka(n_prefixes=1), lr=2e-3, n_lr_warmup=2, log_every=3, track=False, runs_root=tmp_path / "runs",
+                   train_data=data.ShuffledConfig(batch_size=256), val_data=data.ShuffledConfig(batch_size=256))
+    saes, objs, run, steps = T.train([cfg], train_feed=feed)
+    assert steps == math.ceil(cfg.n_train / 256) == 12
+    mses = [rec_["loss/mse"] for _, rec_ in run.records[0]]
+    fills = [rec_["loader/buffer_fill"] for _, rec_ in run.records[0]]
+    assert len(mses) == 4 and all(math.isfinite(v) for v in mses) and mses[-1] < mses[0]
+    assert all(0.0 <= f <= 1.0 for f in fills)

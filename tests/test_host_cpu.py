@@ -443,3 +443,56 @@ def test_data_parallel_ranks_take_the_same_steps(tmp_path):
                     yield {"act": torch.zeros(min(16, 2 * n_epoch - lo), 1)}
 
         assert len(seqs[0]) == sum(1 for _ in S.BatchLimiter(One(), 400))
+
+
+def _tiny_vit_setup(device="cpu", n_img=37):
+    from saev_amd import data
+    from saev_amd.data.vit import VisionTransformer
+
+    torch.manual_seed(0)
+    vit = VisionTransformer(d_model=32, depth=4, heads=4, patch=4, image=16).to(device).eval()  # 16 patches + CLS
+    rec = data.ActivationRecorder(vit, vit.blocks, layers=(1, 3), content_tokens_per_example=16, cls_token=True)
+    imgs = torch.randn(n_img, 3, 16, 16)
+
+    def images():
+        for lo in range(0, n_img, 5):
+            yield imgs[lo : lo + 5], torch.arange(lo, min(lo + 5, n_img))
+
+    return data, rec, imgs, images
+
+
+def test_extraction_feed_delivers_every_token_once_with_the_hooked_values():
+    """BASELINE configs[4] hand-off on CPU (the host logic: hooks, token selection, reservoir bookkeeping): every
+    (example, token) of the selected layer arrives exactly once per epoch, in a different order each epoch, carrying
+    the activation the hooked block produced; `special` / `all` token choices and drop_last as in the shuffled loader."""
+    data, rec, imgs, images = _tiny_vit_setup()
+    with torch.no_grad():
+        full = rec(imgs)[1].clone()  # (37, 2 layers, 17 tokens, 32)
+    assert full.shape == (37, 2, 17, 32)
+    feed = data.ExtractionFeed(data.ExtractConfig(layer=3, batch_size=64, buffer_size=3, seed=1), rec, images, n_examples=37,
+                               d_model=32, device="cpu")
+    assert feed.n_samples == 37 * 16 and len(feed) == 10 and feed.metadata.n_examples == 37
+    orders = []
+    for epoch in range(2):
+        seen, sizes = {}, []
+        for b in feed:
+            sizes.append(len(b["act"]))
+            assert b["act"].dtype == torch.float32 and b["example_idx"].dtype == torch.int32 and b["token_idx"].dtype == torch.int32
+            assert 0.0 <= feed.reservoir.fill() <= 1.0
+            for a, e, t in zip(b["act"], b["example_idx"].tolist(), b["token_idx"].tolist()):
+                assert (e, t) not in seen
+                seen[(e, t)] = True
+                torch.testing.assert_close(a, full[e, 1, t + 1], rtol=1e-5, atol=1e-6)  # content token t sits after CLS
+        assert len(seen) == 37 * 16 and sizes == [64] * 9 + [16]
+        orders.append(list(seen))
+    assert orders[0] != orders[1]
+    cls = data.ExtractionFeed(data.ExtractConfig(layer=1, tokens="special", batch_size=8, buffer_size=4), rec, images,
+                              n_examples=37, d_model=32, device="cpu")
+    got = {e: a for b in cls for a, e in zip(b["act"], b["example_idx"].tolist())}
+    assert len(got) == 37
+    torch.testing.assert_close(got[5], full[5, 0, 0], rtol=1e-5, atol=1e-6)
+    dl = data.ExtractionFeed(data.ExtractConfig(layer=3, tokens="all", batch_size=64, buffer_size=3, drop_last=True), rec, images,
+                             n_examples=37, d_model=32, device="cpu")
+    assert [len(b["act"]) for b in dl] == [64] * (37 * 17 // 64)
+    with pytest.raises(ValueError, match="not in recorded layers"):
+        data.ExtractionFeed(data.ExtractConfig(layer=2), rec, images, n_examples=37, d_model=32, device="cpu")

@@ -65,8 +65,8 @@ def main():
         obj = OUT / f"f16_{v}.o"
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-unused-value",
                                f"-I{ROOT / 'include'}", f"-I{ROOT / 'saev_amd' / 'csrc'}", *defs, "-c", str(tmp), "-o", str(obj)])
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, str(obj), "-L/opt/rocm/lib", "-lrocblas",
-                               "-Wl,-rpath,/opt/rocm/lib", "-o", str(OUT / f"lib_{v}.so")])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, str(obj),
+                               "-o", str(OUT / f"lib_{v}.so")])
         print("built", OUT / f"lib_{v}.so")
 
 

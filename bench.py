@@ -349,6 +349,9 @@ def main():
                                            "the parameter halves (decoder half on a side stream); verified at start-up against the "
                                            "all-reduce path" if stepper.tail == "sharded" else "one flat all-reduce, replicated tail")))},
             "mse_last": stats.mse, "n_overflow_rows": stats.n_overflow_rows, "cand_max": stats.cand_max,
+            "topk_bounds": dict(eng.bound_state(), mode=eng.cfg.bounds,
+                                note="predicted row bounds verified by the select stage; `repeats` launches (of `launches`, whole "
+                                     "run) had a failed prediction and were re-run with guaranteed bounds on the device"),
             "roofline": roof,
             "headline_note": f"value = the {args.steps} steps after {args.warmup} warm-up steps from random init (the contract's "
                              "timed region); see `sustained` for the steady-state figure of the same loop",

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 3
+#define SAEV_AMD_ABI_VERSION 4
 
 typedef enum {
     SAEV_OK = 0,
@@ -58,6 +58,14 @@ typedef struct {
                                       of the first half are whole decoder rows) so that N data-parallel ranks can
                                       reduce-scatter the gradient, run the tail on 1/N each and all-gather the parameters
                                       (saev_tail_prepare / saev_tail_apply); see saev_layout.                        */
+    int32_t bound_mode;            /* TopK candidate bounds of the fused fp16-image encoders (top_k <= 32):
+                                      0 guaranteed bounds only (running minimum over group maxima);
+                                      1 predicted bounds first -- each row's bound is mean + z * sigma of its
+                                        pre-activations over a sample of the latents -- verified by the select stage
+                                        (the k-th largest candidate found must reach every bound used for the row),
+                                        with an automatic second launch on guaranteed bounds whenever a prediction
+                                        fails; codes and values are the same either way (saev_bound_state reports z
+                                        and how often the second launch was needed).                                 */
 } saev_cfg;
 
 /* Element offsets of the four tensors inside each flat buffer, its total length, and the per-rank chunk lengths of the
@@ -188,7 +196,7 @@ int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_r
  * forward (modeling.py:75-103).  Training mode only.  The reference reads n_dead back on every step
  * (`.item()`, modeling.py:92).  Here the update kernel leaves a record in pinned host memory each step; the
  * call looks at the record of four steps earlier, which bounds the current count from above, and while that
- * bound is <= min(24, k_aux) -- zero dead latents included -- it enqueues kernels that take the count from
+ * bound is <= min(48, k_aux) -- zero dead latents included -- it enqueues kernels that take the count from
  * the device: no read-back, no stream synchronisation.  Only when the bound is larger (or no valid record
  * exists yet: the first four steps after creation / saev_bind_tracker / saev_tracker_touched) does it read
  * n_dead back and size the dense AuxK algebra on the host.  saev_last_aux_route tells which happened:
@@ -249,6 +257,11 @@ const float* saev_last_x_hat(saev_ctx* ctx);
 /* Device-to-device copies of the same into caller buffers (any may be NULL), which hold `n_rows` rows:
  * n_rows must equal the batch of the last saev_step_forward (anything else is SAEV_INVALID_ARG). */
 int saev_copy_last(saev_ctx* ctx, int32_t n_rows, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream);
+
+/* State of the predicted-bound mechanism (saev_cfg.bound_mode = 1), read back from the device (synchronises `stream`):
+ * the current z, how many fused-encoder launches used predicted bounds and how many of those had to be repeated with
+ * guaranteed bounds, and the mean candidate-list length of the last launch. */
+int saev_bound_state(saev_ctx* ctx, float* z, int64_t* launches, int64_t* repeats, float* mean_candidates, void* stream);
 
 /* Timing hooks for bench.py: wall duration in ms of the encoder kernel of the last step, measured
  * with HIP events on `stream` (call after the stream has been synchronised). */

@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SaevCfg(C.Structure):
@@ -22,7 +22,7 @@ class SaevCfg(C.Structure):
         ("alpha", C.c_float), ("dead_threshold_tokens", C.c_int64),
         ("normalize_w_dec", C.c_int32), ("remove_parallel_grads", C.c_int32),
         ("max_batch", C.c_int32), ("encoder_mode", C.c_int32), ("aux_dead_cap", C.c_int32),
-        ("shard_world", C.c_int32),
+        ("shard_world", C.c_int32), ("bound_mode", C.c_int32),
     ]
 
 
@@ -87,6 +87,7 @@ _SIGNATURES = {
     "saev_last_val": (P, [P]),
     "saev_last_x_hat": (P, [P]),
     "saev_copy_last": (C.c_int, [P, C.c_int32, P, P, P, P]),
+    "saev_bound_state": (C.c_int, [P, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_float), P]),
     "saev_enable_kernel_timing": (C.c_int, [P, C.c_int32]),
     "saev_last_encoder_ms": (C.c_float, [P]),
 }

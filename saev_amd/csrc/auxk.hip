@@ -155,13 +155,12 @@ __global__ __launch_bounds__(256) void gather_dead_small_kernel(const float* W_e
                                                                 float* Wdec_dead) {
     const int nd = *nd_dev;
     if (nd <= 0 || nd > AUX_SMALL_MAX) return;
-    const long total = (long)AUX_SMALL_MAX * D;
+    const long total = (long)nd * D;  // rows past nd are never read (every consumer loops to the device-side count)
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
         const int j = (int)(q / D), d = (int)(q % D);
-        const bool in = j < nd;
-        const int i = in ? dl[j] : 0;
-        WencT_dead[q] = in ? W_enc[(size_t)d * S + i] : 0.f;
-        Wdec_dead[q] = in ? W_dec[(size_t)i * D + d] : 0.f;
+        const int i = dl[j];
+        WencT_dead[q] = W_enc[(size_t)d * S + i];
+        Wdec_dead[q] = W_dec[(size_t)i * D + d];
     }
 }
 

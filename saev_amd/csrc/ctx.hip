@@ -104,6 +104,8 @@ struct saev_ctx {
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
     float *row_margin = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
     int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
+    int32_t* tau_max = nullptr;   // (max_batch) largest predicted bound used per row
+    float* heur_state = nullptr;  // [0] z  [1] failed predictions  [2] predicted-bound launches  [3] mean list length
     float *f16r_scales = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *dot_part = nullptr, *xabs_part = nullptr,
           *sq_part = nullptr, *wmax_prev = nullptr;
     bool wmax_known = false;
@@ -291,6 +293,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
+    A(tau_max, MB); A(heur_state, 8);
 #undef A
     if (rc != SAEV_OK) {
         // keep the context so the caller can read the message, but report failure
@@ -303,6 +306,10 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     hipMemset(c->dead, 0, S * sizeof(int32_t));
     hipMemset(c->flags, 0, 16 * sizeof(int32_t));
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
+    {
+        const float init[8] = {2.6f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // z starts where a Gaussian row of 32 k latents has ~8 k values above its bound
+        hipMemcpy(c->heur_state, init, sizeof(init), hipMemcpyHostToDevice);
+    }
     hipMemset(c->rowstats, 0, MB * sizeof(RowStats));
     if (c->xs) hipMemset(c->xs, 0, (size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
     if (c->zero_bias) hipMemset(c->zero_bias, 0, std::max(S, D) * sizeof(float));
@@ -458,6 +465,19 @@ int saev_read_stats(saev_ctx* c, saev_step_stats* out_host, void* stream) {
     return SAEV_OK;
 }
 
+int saev_bound_state(saev_ctx* c, float* z, int64_t* launches, int64_t* repeats, float* mean_candidates, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    float h[4] = {0.f, 0.f, 0.f, 0.f};
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipMemcpyAsync(h, c->heur_state, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (z) *z = h[0];
+    if (repeats) *repeats = (int64_t)h[1];
+    if (launches) *launches = (int64_t)h[2];
+    if (mean_candidates) *mean_candidates = h[3];
+    return SAEV_OK;
+}
+
 int saev_enable_kernel_timing(saev_ctx* c, int32_t enable) {
     if (!c) return SAEV_INVALID_ARG;
     if (enable && !c->ev_created) {
@@ -552,7 +572,7 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
 }
 
 static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out, const int32_t* flag, int when,
-                       hipStream_t s) {
+                       hipStream_t s, bool predicted = false) {
     // F16R: only the TopK pass is approximate-then-refined; a dense h must be exact, so it comes from the fp32 kernel
     const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32 && !(f16r && epi == EPI_DENSE)) {
@@ -570,6 +590,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.gmax = c->gmax; a.gmax_stride = c->gmax_stride; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
         a.cand_cap = CAND_CAP; a.cand_stride = CAND_STRIDE;
         a.enable_flag = flag; a.enable_when = when;
+        if (predicted) { a.heur_z = c->heur_state; a.tau_max = c->tau_max; }
         HIPCHK(c, launch_encode_f16x3(a, epi, s));
         return SAEV_OK;
     }
@@ -633,29 +654,64 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     }
     if (fused_supported(c->cfg)) {
         const int ng = c->cfg.encoder_mode == SAEV_ENCODER_F32 ? (c->cfg.top_k <= 32 ? 32 : 64) : f16_ngroups(c->cfg);
-        HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, s));
-        timing_begin(c, s);  // the events bracket the encoder kernel alone
-        int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
-        if (rc != SAEV_OK) return rc;
-        timing_end(c, s);
-        HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
-        SelectCandArgs sc{};
-        sc.cand_cnt = c->cand_cnt; sc.cand_val = c->cand_val; sc.cand_idx = c->cand_idx;
-        sc.cand_cap = CAND_CAP; sc.cand_stride = CAND_STRIDE; sc.n_rows = n; sc.k = K;
-        sc.idx_out = idx_out; sc.val_out = val_out; sc.out_stride = K;
-        sc.enable_flag = need_dense; sc.enable_when = 0;
-        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
-            // approximate values: (1) survivors of the cut lowered by the row margin, (2) their exact fp32 values,
-            // (3) the final cut on exact values.  A row with more than REFINE_CAP survivors raises need_dense.
-            sc.row_margin = c->row_margin; sc.x = x; sc.W_encT = c->dW_encT; sc.b_enc = c->params + c->off_b_enc;
-            sc.D = c->cfg.d_model; sc.refine_overflow = need_dense;
-            sc.surv_idx = c->surv_idx; sc.surv_val = c->surv_val; sc.surv_cnt = c->surv_cnt;
+        const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
+        // select -> (f16r: exact refinement -> select) on the candidate lists, predicated on `flag == when`
+        auto select_stage = [&](const int32_t* flag, int when, int32_t* bad, const int32_t* tau_max) -> int {
+            SelectCandArgs sc{};
+            sc.cand_cnt = c->cand_cnt; sc.cand_val = c->cand_val; sc.cand_idx = c->cand_idx;
+            sc.cand_cap = CAND_CAP; sc.cand_stride = CAND_STRIDE; sc.n_rows = n; sc.k = K;
+            sc.idx_out = idx_out; sc.val_out = val_out; sc.out_stride = K;
+            sc.enable_flag = flag; sc.enable_when = when;
+            sc.tau_max = tau_max; sc.invalid = bad;
+            if (f16r) {
+                // approximate values: (1) survivors of the cut lowered by the row margin, (2) their exact fp32 values,
+                // (3) the final cut on exact values.  A row with more than REFINE_CAP survivors raises `bad`.
+                sc.row_margin = c->row_margin; sc.x = x; sc.W_encT = c->dW_encT; sc.b_enc = c->params + c->off_b_enc;
+                sc.D = c->cfg.d_model; sc.refine_overflow = bad;
+                sc.surv_idx = c->surv_idx; sc.surv_val = c->surv_val; sc.surv_cnt = c->surv_cnt;
+                HIPCHK(c, launch_select_cand(sc, s));
+                HIPCHK(c, launch_refine_exact(sc, s));
+                sc.row_margin = nullptr; sc.tau_max = nullptr;
+                sc.cand_cnt = c->surv_cnt; sc.cand_val = c->surv_val; sc.cand_idx = c->surv_idx; sc.cand_cap = REFINE_CAP; sc.cand_stride = REFINE_CAP;
+            }
             HIPCHK(c, launch_select_cand(sc, s));
-            HIPCHK(c, launch_refine_exact(sc, s));
-            sc.row_margin = nullptr;
-            sc.cand_cnt = c->surv_cnt; sc.cand_val = c->surv_val; sc.cand_idx = c->surv_idx; sc.cand_cap = REFINE_CAP; sc.cand_stride = REFINE_CAP;
+            return SAEV_OK;
+        };
+        // Predicted bounds (gemm_encode_f16x3.hip, heur_z) for the fp16-image encoders with k <= 32: first a launch whose row
+        // bounds are a prediction, verified by the select stage; only if that fails anywhere -- flag `bad1` -- the launch
+        // with guaranteed bounds, which is otherwise skipped on the device (every kernel of it exits at once).
+        const bool predict = c->cfg.bound_mode != 0 && ng == 32 && c->cfg.encoder_mode != SAEV_ENCODER_F32;
+        int32_t *bad1 = c->flags + 9, *run2 = c->flags + 10, *gate = c->flags + 11;
+        if (predict) {
+            HIPCHK(c, launch_heur_gate(c->heur_state, pre_flag, gate, s));  // gate: no prediction this time
+            HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, 0, s, c->tau_max));
+            timing_begin(c, s);  // the events bracket the encoder kernel alone
+            int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, gate, 0, s, true);
+            if (rc != SAEV_OK) return rc;
+            timing_end(c, s);
+            HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, gate, bad1, c->flags + 2, c->flags + 3, s, need_dense,
+                                            nullptr, c->heur_state + 3, nullptr, pre_flag));
+            rc = select_stage(bad1, 0, bad1, c->tau_max);
+            if (rc != SAEV_OK) return rc;
+            HIPCHK(c, launch_heur_update(c->heur_state, bad1, c->heur_state + 3, K, gate, s));
+            // the retry with guaranteed bounds
+            HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, s, nullptr, bad1, 1));
+            rc = run_encoder(c, x, n, EPI_TOPK, nullptr, bad1, 1, s);
+            if (rc != SAEV_OK) return rc;
+            HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s, need_dense,
+                                            run2, nullptr, bad1));
+            rc = select_stage(run2, 1, need_dense, nullptr);
+            if (rc != SAEV_OK) return rc;
+        } else {
+            HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, s));
+            timing_begin(c, s);  // the events bracket the encoder kernel alone
+            int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
+            if (rc != SAEV_OK) return rc;
+            timing_end(c, s);
+            HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
+            rc = select_stage(need_dense, 0, need_dense, nullptr);
+            if (rc != SAEV_OK) return rc;
         }
-        HIPCHK(c, launch_select_cand(sc, s));
     } else {
         HIPCHK(c, launch_init_i32(need_dense, 1, 1, s));
         HIPCHK(c, hipMemsetAsync(c->flags + 2, 0, 2 * sizeof(int32_t), s));
@@ -998,10 +1054,10 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         const int nb = (n + 63) / 64, L = AUX_SMALL_MAX;
         const int32_t* nd_dev = c->flags + 4;
         HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
-        HIPCHK(c, launch_colsum(c->aux_small_part, nb, L * D, c->aux_small_part2, c->dWd, 0, nd_dev, s, (long)2 * L * D));
+        HIPCHK(c, launch_colsum(c->aux_small_part, nb, L * D, c->aux_small_part2, c->dWd, 0, nd_dev, s, (long)2 * L * D, 1.0f, D));
         HIPCHK(c, launch_colsum(c->aux_small_part + (size_t)L * D, nb, L * D, c->aux_small_part2, c->dWe, 0, nd_dev, s,
-                                (long)2 * L * D));
-        HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s));
+                                (long)2 * L * D, 1.0f, D));
+        HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
         HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nd_dev, s));
         return SAEV_OK;
     }

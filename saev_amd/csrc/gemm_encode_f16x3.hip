@@ -80,7 +80,9 @@ __device__ __forceinline__ void glds16h(const char* gsrc, void* lds_wave_base) {
 // v_mfma_f32_32x32x16_{bf16,f16} per block, fp32 accumulate; everything after the contraction is identical.  AR = 2
 // is the first pass of SAEV_ENCODER_F16R: its pre-activations carry a bounded rounding error, the candidate cut is
 // lowered by a per-row margin (a.row_margin) and select.hip recomputes the survivors exactly in fp32.
-template <int EPI, int NG, int AR>
+// HEUR: predicted row bounds (EncodeF16Args::heur_z) -- its own instantiation, so that the guaranteed-bound kernel's
+// register allocation is not disturbed by code it never runs.
+template <int EPI, int NG, int AR, bool HEUR = false>
 __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     HSmem& sm = *reinterpret_cast<HSmem*>(smem_raw);
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
         }
 
         // ---------------- epilogue ----------------
+        constexpr bool heur = HEUR;
         // lane owns batch rows bl(jb) = wb*64 + jb*32 + l31; latent of acc[sb][jb][r]:
         //   sl = ws*128 + sb*32 + 8*(r>>2) + 4*half + (r&3);   acc holds 2^8 * (x . w)
         const float unscale = a.scale_dev != nullptr ? 1.0f / (a.w_scale * a.scale_dev[0] * a.scale_dev[1]) : 1.0f / a.w_scale;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 // more, and the refresh -- per-group maxima, their exchange through LDS and global memory, three barriers --
                 // costs about as much as the candidate stores it saves from then on.
                 const int tile_no = st - st_begin;
-                const bool refresh = tile_no < 4 || (tile_no & 3) == 3;
+                const bool refresh = !heur && (tile_no < 4 || (tile_no & 3) == 3);
                 // pre-activations of the tile (one code path for every tile: the accumulators are rewritten in one place)
     #pragma unroll
                 for (int sb = 0; sb < 4; ++sb)
@@ -450,7 +453,86 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 __syncthreads();
                 }
             }
-            if (NG == 32 && st == st_begin && a.top_k <= HTS / 4) {
+            if constexpr (HEUR) if (st == st_begin) {
+                // Predicted bound (EncodeF16Args::heur_z): the row's pre-activations over THIS tile's 256 latents are a
+                // sample of its 32 k; their mean and standard deviation put the bound at mean + z * sigma, where z (a device
+                // scalar the host side adapts from step to step) is chosen so that a small multiple of top_k values exceed
+                // it.  Nothing guarantees that k values do -- so the largest bound any workgroup used for a row is
+                // published in tau_max and the select stage checks that the k-th largest candidate it found is not below
+                // it; when that fails for any row the launch is repeated with the guaranteed bounds above.  The pay-off: no
+                // group maxima, no exchange, no barrier in the epilogue of any later tile, and an order of magnitude
+                // fewer candidates to store and to select from.  Two passes (mean, then centred squares): the values can
+                // share a large offset.
+                // Both moments are taken twice: over everything, then over the values within two of those standard
+                // deviations of that mean -- a handful of far-out values (latents with a large negative bias, a few strongly
+                // active features) must not set the scale of the bulk the bound is extrapolated from.
+                float* const mom = reinterpret_cast<float*>(&sm.ref[0][0]);  // [0] sum  [1] centred squares  [2] count  (per row)
+                const int n_valid = min(HTS, S - s0);  // real latents of the tile (padding carries -inf)
+                float lo[2] = {-3.0e38f, -3.0e38f}, hi[2] = {3.4e38f, 3.4e38f};
+                float mean2[2] = {0.f, 0.f}, sd2[2] = {0.f, 0.f};
+#pragma unroll 1
+                for (int round = 0; round < 2; ++round) {
+                    if (tid < HTB) { mom[tid] = 0.f; mom[HTB + tid] = 0.f; mom[2 * HTB + tid] = 0.f; }
+                    __syncthreads();
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+                        for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[sb][jb][r];
+                                const bool in = v > lo[jb] && v < hi[jb];
+                                s1 += in ? v : 0.f;
+                                cnt += in ? 1.f : 0.f;
+                            }
+                        atomicAdd(&mom[wb * 64 + jb * 32 + l31], s1);
+                        atomicAdd(&mom[2 * HTB + wb * 64 + jb * 32 + l31], cnt);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const int row = wb * 64 + jb * 32 + l31;
+                        const float mean = mom[row] / fmaxf(mom[2 * HTB + row], 1.f);
+                        float s2 = 0.f;
+#pragma unroll
+                        for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[sb][jb][r];
+                                const float dv = (v > lo[jb] && v < hi[jb]) ? v - mean : 0.f;
+                                s2 = fmaf(dv, dv, s2);
+                            }
+                        atomicAdd(&mom[HTB + row], s2);
+                        mean2[jb] = mean;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const int row = wb * 64 + jb * 32 + l31;
+                        sd2[jb] = sqrtf(mom[HTB + row] / fmaxf(mom[2 * HTB + row], 1.f));
+                        lo[jb] = fmaxf(mean2[jb] - 2.0f * sd2[jb], -3.0e38f);
+                        hi[jb] = mean2[jb] + 2.0f * sd2[jb];
+                    }
+                    __syncthreads();
+                }
+                (void)n_valid;
+                if (ws == 0 && half == 0) {
+                    // (every latent range of the row estimates its own bound and the largest one is what the verification
+                    // holds the row to: the more ranges, the further that maximum sits above a single estimate, whose
+                    // standard error from 256 samples is about 0.12 sigma)
+                    const float z_eff = *a.heur_z - 0.12f * sqrtf(2.0f * logf((float)a.s_splits));
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const int row = wb * 64 + jb * 32 + l31;
+                        const int32_t key = f2key(mean2[jb] + z_eff * sd2[jb]);
+                        sm.tau_key[row] = key;
+                        if (b0 + row < B) atomicMax(&a.tau_max[b0 + row], key);
+                    }
+                }
+                __syncthreads();
+            }
+            if (NG == 32 && !heur && st == st_begin && a.top_k <= HTS / 4) {
                 // First tile of this workgroup: the rows' other latent ranges start at the same moment, so the shared group
                 // maxima are still empty and the bound above is only "the minimum of 32 maxima of 8 values" -- about the median
                 // of the tile, where the k-th largest of its 256 values is what one would like.  Any threshold that at
@@ -569,7 +651,10 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
     const size_t smem = sizeof(HSmem);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[9] = {reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 0>),
+        const void* fns[12] = {reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 0, true>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 1, true>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 2, true>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 0>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 0>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 64, 0>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 1>),
@@ -592,7 +677,11 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
         else LAUNCH_ENC(E, G, 0);                         \
     } while (0)
     if (epi == EPI_DENSE) LAUNCH_AR(EPI_DENSE, 32);
-    else if (a.ngroups <= 32) LAUNCH_AR(EPI_TOPK, 32);
+    else if (a.ngroups <= 32 && a.heur_z != nullptr) {
+        if (a.arith == 1) hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 1, true>), grid, block, smem, stream, a);
+        else if (a.arith == 2) hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 2, true>), grid, block, smem, stream, a);
+        else hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 0, true>), grid, block, smem, stream, a);
+    } else if (a.ngroups <= 32) LAUNCH_AR(EPI_TOPK, 32);
     else LAUNCH_AR(EPI_TOPK, 64);
 #undef LAUNCH_AR
 #undef LAUNCH_ENC

@@ -70,12 +70,20 @@ struct SelectCandArgs {
     float* surv_val;          // (n_rows, REFINE_CAP) their exact pre-activations (refine_exact_kernel)
     int32_t* surv_cnt;        // (n_rows)
     int32_t* refine_overflow; // set to 1 when a row has more than REFINE_CAP survivors (caller re-runs it densely)
+    // predicted bounds (EncodeF16Args::heur_z): the lists hold everything >= the bounds used; they contain the row's true
+    // top-k iff the k-th largest entry found is >= the largest bound used for the row.  Rows that fail raise *invalid.
+    const int32_t* tau_max;   // (n_rows) ordered-int keys or NULL (guaranteed bounds: nothing to verify)
+    int32_t* invalid;         // device flag
 };
 hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream);
 constexpr int REFINE_CAP = 512;
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
-hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream);
+hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream,
+                               int32_t* tau_max = nullptr, const int32_t* enable_flag = nullptr, int enable_when = 0);
+hipError_t launch_heur_gate(float* state, const int32_t* pre_flag, int32_t* gate, hipStream_t stream);
+hipError_t launch_heur_update(float* state, const int32_t* bad, const float* cand_mean, int k, const int32_t* gate,
+                              hipStream_t stream);
 hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream);
 hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream);
 hipError_t launch_f16r_scales(const float* xmax_part, int n_part, const float* wmax, float* scales, hipStream_t stream);
@@ -84,8 +92,11 @@ hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, fl
                                hipStream_t stream);  // ||x_b - mu|| per row, max |x - mu| per workgroup of 4 rows
 hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
                               int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream);
+// see overflow_check_kernel (select.hip) for the two-stage use
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
-                                 int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream);
+                                 int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream,
+                                 int32_t* dense_out = nullptr, int32_t* run_out = nullptr, float* cand_mean = nullptr,
+                                 const int32_t* enable_flag = nullptr, const int32_t* dense_src = nullptr);
 
 // per-row statistics produced by the decode kernels (reduced by stats_reduce)
 struct __attribute__((aligned(8))) RowStats {
@@ -173,9 +184,11 @@ struct DwRowsArgs {
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream);
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream);
 
-// out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats
+// out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats.  k_dev: optional device count -- nothing runs
+// when it is <= 0, and with col_mult > 0 only the first *k_dev * col_mult columns are summed (the rest is not touched)
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
-                         const int32_t* k_dev, hipStream_t stream, long row_stride = 0, float out_scale = 1.0f);
+                         const int32_t* k_dev, hipStream_t stream, long row_stride = 0, float out_scale = 1.0f,
+                         int col_mult = 0);
 hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partials, float* out, float* wg_scratch,
                                 float* absmax_out, hipStream_t stream, float out_scale = 1.0f);  // + max |m|, same pass
 
@@ -261,6 +274,11 @@ struct EncodeF16Args {
     int cand_cap, cand_stride;
     const int32_t* enable_flag;
     int enable_when;
+    // EPI_TOPK, ngroups == 32: predicted row bounds instead of guaranteed ones.  heur_z: device scalar z of "bound = mean +
+    // z * sigma of the row's pre-activations over the workgroup's first tile"; tau_max: (n_rows) ordered-int keys, init
+    // INT32_MIN, receives the largest bound used for each row (the select stage verifies the prediction against it)
+    const float* heur_z;
+    int32_t* tau_max;
     // EPI_DENSE only: a batch of independent products (grid.y), used to split a long contraction into slices whose
     // partial outputs are summed afterwards (AuxK weight gradients contract over the batch axis).  Batch j reads the
     // k-steps [j*nks, (j+1)*nks) of every row block -- blk_imgs is the number of images a row block has in memory
@@ -302,7 +320,7 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
                             float gscale, RowStats* rowstats, hipStream_t s);
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 // a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
-constexpr int AUX_SMALL_MAX = 24;
+constexpr int AUX_SMALL_MAX = 48;
 // The few-dead-latents kernels take the dead count from the device (*nd_dev; they exit unless 1 <= nd <= AUX_SMALL_MAX), so
 // the host can enqueue them without knowing it.  Leading dimension of A / dA and row count of the compact weight buffers:
 // AUX_SMALL_MAX.

@@ -228,6 +228,7 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
         return t;
     };
     uint32_t T = kth_largest();
+    if (a.tau_max != nullptr && lane == 0 && (n < a.k || ukey2f(T) < key2f(a.tau_max[row]))) *a.invalid = 1;
     if (a.row_margin != nullptr) {
         // The values are approximate (first pass of SAEV_ENCODER_F16R).  Every member of the exact top-k has an
         // approximate value >= (k-th largest approximate value) - row_margin: emit those survivors; refine_exact_kernel
@@ -307,6 +308,10 @@ __device__ __forceinline__ void select_small_row(const SelectCandArgs& a, int ro
             if (take_other) { key = o_key; idx = o_idx; }
         }
     }
+    if (a.tau_max != nullptr) {
+        const float kth = ukey2f(__shfl(key, max(k - 1, 0), 64));
+        if (lane == 0 && (n < a.k || kth < key2f(a.tau_max[row]))) *a.invalid = 1;
+    }
     const bool win = lane < k;
     sort_by_idx_and_store(a, row, k, win ? idx : 0x7fffffff, win ? ukey2f(key) : 0.f, lane);
 }
@@ -331,11 +336,15 @@ __global__ void init_i32_kernel(int32_t* p, int32_t v, int n) {
     if (i < n) p[i] = v;
 }
 
-// per-launch state of the fused encoder in one pass: candidate counters to 0, shared group maxima to "-inf"
-__global__ void encoder_init_kernel(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax) {
+// per-launch state of the fused encoder in one pass: candidate counters to 0, shared group maxima / largest predicted
+// bounds to "-inf"; optionally predicated on a device flag
+__global__ void encoder_init_kernel(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, int32_t* tau_max,
+                                    const int32_t* enable_flag, int enable_when) {
+    if (enable_flag != nullptr && (*enable_flag != 0) != (enable_when != 0)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rows) cand_cnt[i] = 0;
     if (i < n_gmax) gmax[i] = INT32_MIN;
+    if (tau_max != nullptr && i < n_rows) tau_max[i] = INT32_MIN;
 }
 // per-step scalars in one pass: the stats block, max|x| and the force-dense flag
 __global__ void step_zero_kernel(saev_step_stats* stats, float* upper, int32_t* flag0) {
@@ -518,24 +527,74 @@ __global__ __launch_bounds__(256) void f16r_scales_kernel(const float* xmax_part
     }
 }
 
-// need_dense = pre_flag || any(cand_cnt > cap); also counts overflowing rows
+// bad = pre_flag || any(cand_cnt > cap); also counts overflowing rows, the longest list and the mean list length.
+// Stage 1 of a predicted-bound launch (`pre_flag` = the prediction gate): *bad_out = gate || overflow, *dense_out =
+// *dense_src (only a failed scale check sends the step straight to the dense route; an overflow of the predicted-bound
+// attempt is first retried with guaranteed bounds).
+// Stage 2 (the retry; `enable_flag` = stage 1's bad flag): when enabled *dense_out |= overflow and *run_out = !*dense_out,
+// when disabled *run_out = 0 and nothing else is touched.
 __global__ void overflow_check_kernel(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
-                                      int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max) {
-    __shared__ int sh, shmax;
-    if (threadIdx.x == 0) { sh = 0; shmax = 0; }
+                                      int32_t* bad_out, int32_t* n_overflow, int32_t* cand_max, int32_t* dense_out,
+                                      int32_t* run_out, float* cand_mean, const int32_t* enable_flag,
+                                      const int32_t* dense_src) {
+    if (enable_flag != nullptr && *enable_flag == 0) {
+        if (threadIdx.x == 0 && run_out != nullptr) *run_out = 0;
+        return;
+    }
+    __shared__ int sh, shmax, shsum;
+    if (threadIdx.x == 0) { sh = 0; shmax = 0; shsum = 0; }
     __syncthreads();
-    int c = 0, m = 0;
-    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) { const int v = cand_cnt[i]; c += (v > cap); m = max(m, v); }
+    int c = 0, m = 0, t = 0;
+    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) { const int v = cand_cnt[i]; c += (v > cap); m = max(m, v); t += min(v, cap); }
     c = wave_sum_i(c);
+    t = wave_sum_i(t);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) { if (c) atomicAdd(&sh, c); atomicMax(&shmax, m); }
+    if ((threadIdx.x & 63) == 0) { if (c) atomicAdd(&sh, c); atomicMax(&shmax, m); atomicAdd(&shsum, t); }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const int pre = (pre_flag && *pre_flag) ? 1 : 0;
         *n_overflow = sh;
         *cand_max = shmax;
-        *need_dense = ((pre_flag && *pre_flag) || sh > 0) ? 1 : 0;
+        if (cand_mean != nullptr) *cand_mean = (float)shsum / (float)max(n_rows, 1);
+        if (run_out == nullptr) {  // a single-stage launch, or stage 1
+            *bad_out = (pre || sh > 0) ? 1 : 0;
+            if (dense_out != nullptr) *dense_out = dense_src != nullptr ? (*dense_src != 0 ? 1 : 0) : pre;
+        } else {                   // stage 2
+            const int dense = (*dense_out != 0 || sh > 0) ? 1 : 0;
+            *dense_out = dense;
+            *run_out = dense ? 0 : 1;
+        }
     }
+}
+
+// The z of the predicted bounds (mean + z sigma) follows what the launches show: a failed prediction (some row's k-th
+// largest candidate below a bound that was used for it, or an overflow) costs a second, guaranteed-bound launch, so z
+// drops by a lot and climbs back slowly (150 launches for one drop).  Three failures in a row (data
+// the extrapolation does not fit) switch prediction off for 256 launches -- `gate` then sends them straight to the
+// guaranteed bounds -- after which it starts again from a cautious z.
+// state: [0] z  [1] failed predictions  [2] predicted launches  [3] mean list length  [4] failures in a row  [5] launches
+// left without prediction  (floats; counts are exact up to 2^24)
+__global__ void heur_gate_kernel(float* state, const int32_t* pre_flag, int32_t* gate) {
+    if (threadIdx.x != 0) return;
+    int g = (pre_flag != nullptr && *pre_flag != 0) ? 1 : 0;
+    if (state[5] > 0.f) { state[5] -= 1.f; g = 1; }
+    *gate = g;
+}
+__global__ void heur_update_kernel(float* state, const int32_t* bad, const float* cand_mean, int k, const int32_t* gate) {
+    if (threadIdx.x != 0 || *gate != 0) return;
+    float z = state[0];
+    state[2] += 1.f;
+    if (*bad != 0) {
+        z -= 0.3f;
+        state[1] += 1.f;
+        state[4] += 1.f;
+        if (state[4] >= 3.f) { state[4] = 0.f; state[5] = 256.f; z = 1.5f; }
+    } else {
+        state[4] = 0.f;
+        if (*cand_mean > 3.f * (float)k) z += 0.002f;
+    }
+    state[0] = fminf(fmaxf(z, 0.5f), 3.5f);
 }
 
 }  // namespace
@@ -559,10 +618,21 @@ hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream) {
+hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream, int32_t* tau_max,
+                               const int32_t* enable_flag, int enable_when) {
     const int n = n_rows > n_gmax ? n_rows : n_gmax;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encoder_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cand_cnt, n_rows, gmax, n_gmax);
+    hipLaunchKernelGGL(encoder_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cand_cnt, n_rows, gmax, n_gmax, tau_max,
+                       enable_flag, enable_when);
+    return hipGetLastError();
+}
+hipError_t launch_heur_gate(float* state, const int32_t* pre_flag, int32_t* gate, hipStream_t stream) {
+    hipLaunchKernelGGL(heur_gate_kernel, dim3(1), dim3(64), 0, stream, state, pre_flag, gate);
+    return hipGetLastError();
+}
+hipError_t launch_heur_update(float* state, const int32_t* bad, const float* cand_mean, int k, const int32_t* gate,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(heur_update_kernel, dim3(1), dim3(64), 0, stream, state, bad, cand_mean, k, gate);
     return hipGetLastError();
 }
 hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0, hipStream_t stream) {
@@ -613,8 +683,10 @@ hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
-                                 int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream) {
+                                 int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream,
+                                 int32_t* dense_out, int32_t* run_out, float* cand_mean, const int32_t* enable_flag,
+                                 const int32_t* dense_src) {
     hipLaunchKernelGGL(overflow_check_kernel, dim3(1), dim3(1024), 0, stream, cand_cnt, n_rows, cap, pre_flag,
-                       need_dense, n_overflow, cand_max);
+                       need_dense, n_overflow, cand_max, dense_out, run_out, cand_mean, enable_flag, dense_src);
     return hipGetLastError();
 }

@@ -622,8 +622,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 template <bool ABSMAX>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int n_rows, int D, float* partials,
-                                                             const int32_t* k_dev, long row_stride, float* wg_absmax) {
+                                                             const int32_t* k_dev, long row_stride, float* wg_absmax,
+                                                             int col_mult) {
     if (k_dev && *k_dev <= 0) return;
+    const int Dfull = D;
+    if (k_dev && col_mult > 0) D = min(D, (*k_dev * col_mult + 3) & ~3);  // only the first *k_dev * col_mult columns are live
     float amax = 0.f;
     const int r0 = blockIdx.x * 64;
     const int r1 = min(n_rows, r0 + 64);
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int
             s += v;
             if constexpr (ABSMAX) amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
-        reinterpret_cast<f32x4*>(partials + (size_t)blockIdx.x * D)[q] = s;
+        reinterpret_cast<f32x4*>(partials + (size_t)blockIdx.x * Dfull)[q] = s;
     }
     if constexpr (ABSMAX) {  // the same pass also gives max |m| (one value per workgroup; max_reduce finishes)
         __shared__ float sh[4];
@@ -659,8 +662,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int
 // 64 columns per workgroup, 4 threads per column each summing every 4th partial row with independent loads in
 // flight, then a fixed-order LDS combine (deterministic).
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partials, int n_blocks, int D, float* out,
-                                                           int accumulate, const int32_t* k_dev, float out_scale) {
+                                                           int accumulate, const int32_t* k_dev, float out_scale, int col_mult) {
     if (k_dev && *k_dev <= 0) return;
+    if (k_dev && col_mult > 0 && (int)blockIdx.x * 64 >= *k_dev * col_mult) return;  // columns past the live ones
     __shared__ float part[4][64];
     const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + col;
@@ -739,13 +743,13 @@ hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream
     return hipGetLastError();
 }
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
-                         const int32_t* k_dev, hipStream_t stream, long row_stride, float out_scale) {
+                         const int32_t* k_dev, hipStream_t stream, long row_stride, float out_scale, int col_mult) {
     const int nb = (n_rows + 63) / 64;
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev,
-                       row_stride > 0 ? row_stride : (long)D, (float*)nullptr);
+                       row_stride > 0 ? row_stride : (long)D, (float*)nullptr, col_mult);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out,
-                       accumulate, k_dev, out_scale);
+                       accumulate, k_dev, out_scale, col_mult);
     return hipGetLastError();
 }
 // column sums and max |m| from one pass over m; wg_scratch holds ceil(n_rows / 64) floats
@@ -754,8 +758,8 @@ hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partia
     const int nb = (n_rows + 63) / 64;
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials,
-                       (const int32_t*)nullptr, (long)D, wg_scratch);
+                       (const int32_t*)nullptr, (long)D, wg_scratch, 0);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out, 0,
-                       (const int32_t*)nullptr, out_scale);
+                       (const int32_t*)nullptr, out_scale, 0);
     return launch_max_reduce(wg_scratch, nb, absmax_out, stream);
 }

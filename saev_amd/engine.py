@@ -34,6 +34,10 @@ class EngineConfig:
     max_batch: int = 16384
     aux_dead_cap: int = 0      # largest dead set the AuxK buffers are sized for at creation; 0 = d_sae (always enough)
     shard_world: int = 1       # > 1: flat buffers padded so that this many data-parallel ranks can each own 1/N of the tail
+    # TopK candidate bounds of the fused encoder: "guaranteed" (default), or "predicted": verified extrapolated bounds
+    # with an automatic guaranteed-bound re-run when a prediction fails -- same codes either way; measured no faster over
+    # a training run (tools/experiments/README.md), kept as an option.  SAEV_AMD_BOUNDS overrides the default
+    bounds: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_BOUNDS", "guaranteed"))
     # "f32": exact fp32 MFMA; "f16x3": split-fp16 MFMA at fp32 accuracy (16/3 of the f32 matrix rate);
     # "bf16": bf16-rounded encoder operands, one MFMA product, fp32 accumulate (everything else stays fp32);
     # "f16r": one fp16 MFMA product as a bounded-error first pass + exact fp32 recomputation of the surviving candidates.
@@ -108,6 +112,7 @@ class SaeEngine:
                 normalize_w_dec=int(cfg.normalize_w_dec), remove_parallel_grads=int(cfg.remove_parallel_grads),
                 max_batch=cfg.max_batch, encoder_mode={"f32": 0, "f16x3": 1, "bf16": 2, "f16r": 3}[cfg.encoder],
                 aux_dead_cap=cfg.aux_dead_cap, shard_world=cfg.shard_world,
+                bound_mode={"guaranteed": 0, "predicted": 1}[cfg.bounds],
             )
             ctx = C.c_void_p()
             rc = self.lib.saev_create(C.byref(ccfg), self.device.index, C.byref(ctx))
@@ -323,6 +328,13 @@ class SaeEngine:
     def dead_readbacks(self) -> int:
         """Blocking reads of n_dead so far."""
         return int(self.lib.saev_dead_readbacks(self.ctx))
+
+    def bound_state(self) -> dict:
+        """z of the predicted bounds, launches that used them, how many had to be repeated, mean list length of the last."""
+        z, mc = C.c_float(), C.c_float()
+        n, r = C.c_int64(), C.c_int64()
+        self._chk(self.lib.saev_bound_state(self.ctx, C.byref(z), C.byref(n), C.byref(r), C.byref(mc), _stream()), "saev_bound_state")
+        return {"z": z.value, "launches": n.value, "repeats": r.value, "mean_candidates": mc.value}
 
     def enable_kernel_timing(self, on: bool = True):
         self._chk(self.lib.saev_enable_kernel_timing(self.ctx, int(on)), "saev_enable_kernel_timing")

@@ -539,9 +539,9 @@ def test_f16r_survives_replaced_parameters(encoder_mode):
     assert routes == [0, 1, 0, 1, 0], routes
 
 
-@pytest.mark.parametrize("n_dead", [1, 5, 24, 25, 40])
+@pytest.mark.parametrize("n_dead", [1, 5, 24, 48, 49, 60])
 def test_auxk_gradients_across_the_small_dead_set_boundary(n_dead):
-    """Up to 24 dead latents (all of them selected: n_dead <= k_aux) the AuxK branch runs as two row-oriented kernels, above
+    """Up to 48 dead latents (all of them selected: n_dead <= k_aux) the AuxK branch runs as two row-oriented kernels, above
     that as dense algebra over the compacted dead set.  Both must give the oracle's loss and gradients."""
     d, s, k, n, k_aux = 128, 1024, 8, 200, 64
     p = rand_params(d, s, seed=60 + n_dead)
@@ -569,7 +569,7 @@ def test_auxk_gradients_across_the_small_dead_set_boundary(n_dead):
         torch.testing.assert_close(gv[key].cpu(), leaves[key].grad, rtol=2e-3, atol=1e-7, msg=lambda m: f"{key}: {m}")
 
 
-@pytest.mark.parametrize("n_dead", [0, 3, 24])
+@pytest.mark.parametrize("n_dead", [0, 3, 48])
 def test_steady_state_needs_no_readback_of_n_dead(n_dead):
     """saev_step_dead without the reference's per-step `.item()` (modeling.py:92): four steps after the tracker was last
     written by the host, the record the device left four steps earlier bounds the dead count; while that bound fits the
@@ -616,13 +616,13 @@ def test_steady_state_needs_no_readback_of_n_dead(n_dead):
 def test_growing_dead_set_switches_to_the_dense_route_in_time():
     """The bound comes from four steps back: latents that will cross the threshold within four steps count as near-dead,
     so the step in which the dead set outgrows the few-dead-latents kernels already runs the exact read-back + dense
-    algebra.  40 latents die at once in step 6."""
+    algebra.  60 latents die at once in step 6."""
     d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
     p = rand_params(d, s, seed=90)
     gen = torch.Generator().manual_seed(91)
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
     toks = torch.zeros(s, dtype=torch.int64)
-    late = torch.randperm(s, generator=torch.Generator().manual_seed(92))[:40]
+    late = torch.randperm(s, generator=torch.Generator().manual_seed(92))[:60]
     toks[late] = thr - 6 * n  # dead after six more steps of n tokens
     p["b_enc"][late] = -100.0
     eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)
@@ -645,7 +645,58 @@ def test_growing_dead_set_switches_to_the_dense_route_in_time():
         assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-12), (i, st.aux, ref["aux"])
         for key in R.PARAM_ORDER:
             torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6, msg=lambda m: f"step {i} {key}: {m}")
-    assert deads == [0] * 5 + [40] * 4, deads
+    assert deads == [0] * 5 + [60] * 4, deads
     # steps 1-4: read-backs (no record yet, nothing dead); step 5: the record of step 1 has nobody within four steps of
-    # the threshold -> no read-back; step 6 on: the record of step 2 counts the 40 as near-dead -> read-back -> dense
+    # the threshold -> no read-back; step 6 on: the record of step 2 counts the 60 as near-dead -> read-back -> dense
     assert routes == [0, 0, 0, 0, 1, 3, 3, 3, 3], routes
+
+
+def test_failed_bound_prediction_is_caught_and_repeated(encoder_mode):
+    """Predicted TopK bounds (mean + z sigma of a sample of the row's pre-activations) are verified, not trusted: here
+    the first 256 latents -- the sample of the first latent range -- have encoder columns a hundred times larger than the
+    rest, so the predicted bound of every row is far above its true k-th largest value; the select stage must notice, the
+    launch must be repeated with guaranteed bounds on the device, and the codes must be the exact top-k as always."""
+    if encoder_mode == "f32":
+        pytest.skip("the exact-fp32 MFMA encoder has guaranteed bounds only")
+    d, s, k, n = 128, 4096, 16, 300
+    p = rand_params(d, s, seed=70)
+    # the sample of the first latent range: biases of +-50, i.e. a spread of 50 where the rest of the row has about 1 ->
+    # predicted bound ~ mean + 2 * 50, far above everything the row contains
+    p["b_enc"][:256] = 50.0 * (1.0 - 2.0 * (torch.arange(256) % 2).float())
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(71))
+    eng = make_engine(d, s, k, k_aux=0, max_batch=n, bounds="predicted")
+    eng.load_params(p)
+    before = eng.bound_state()
+    idx, val = eng.encode_topk(x.cuda())
+    after = eng.bound_state()
+    assert after["launches"] == before["launches"] + 1 and after["repeats"] == before["repeats"] + 1
+    assert after["z"] < before["z"]
+    h = x.double() @ p["W_enc"].double() + p["b_enc"].double()
+    want = torch.topk(h, k, dim=-1)
+    torch.testing.assert_close(val.cpu().sort(dim=-1, descending=True).values, want.values.float(), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(h.gather(1, idx.cpu().long()).float(), val.cpu(), rtol=1e-5, atol=1e-4)
+    # an ordinary launch afterwards predicts fine again (z dropped, the lists are just longer)
+    eng.load_params(rand_params(d, s, seed=72))
+    eng.encode_topk(x.cuda())
+    again = eng.bound_state()
+    assert again["launches"] == after["launches"] + 1 and again["repeats"] == after["repeats"]
+
+
+def test_guaranteed_and_predicted_bounds_give_the_same_codes(encoder_mode):
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    if encoder_mode == "f32":
+        pytest.skip("the exact-fp32 MFMA encoder has guaranteed bounds only")
+    d, s, k, n = 256, 8192, 32, 700
+    p = rand_params(d, s, seed=73)
+    x = (torch.randn(n, d, generator=torch.Generator().manual_seed(74)) + 0.5).cuda()
+    out = []
+    for bounds in ("guaranteed", "predicted"):
+        eng = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, k_aux=0, max_batch=n, bounds=bounds))
+        eng.load_params(p)
+        codes = [eng.encode_topk(x) for _ in range(3)]  # (a failed prediction lowers z: later launches predict again)
+        out.append(([c[0].clone() for c in codes], [c[1].clone() for c in codes], eng.bound_state()))
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert torch.equal(a, b)
+    assert out[0][2]["launches"] == 0 and out[1][2]["launches"] == 3 and out[1][2]["repeats"] <= 1
+    assert 32 <= out[1][2]["mean_candidates"] < 2000

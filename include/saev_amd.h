@@ -223,7 +223,8 @@ int saev_backward_end(saev_ctx* ctx, void* stream);
 float* saev_grad_w_enc_t(saev_ctx* ctx);
 int saev_bind_w_enc_t(saev_ctx* ctx, float* scratch);
 /* Phase 4: grads *= grad_scale (1/world_size after a sum all-reduce), remove_parallel_grads
- * (train.py:351-352), global-norm clip (train.py:356-362, max_norm <= 0 disables), Adam with torch
+ * (train.py:351-352), global-norm clip (train.py:356-362; torch's formula for max_norm >= 0, so 0 zeroes the
+ * gradient as in the reference; max_norm < 0 disables clipping), Adam with torch
  * defaults (train.py:294,444-446). `adam_step` is the 1-based step count. */
 int saev_step_tail(saev_ctx* ctx, float lr, float max_norm, float grad_scale, int64_t adam_step, void* stream);
 /* Phase 4 in two parts, over everything (shard_rank < 0: saev_step_tail == prepare + apply) or over rank

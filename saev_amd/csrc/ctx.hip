@@ -591,6 +591,15 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.cand_cap = CAND_CAP; a.cand_stride = CAND_STRIDE;
         a.enable_flag = flag; a.enable_when = when;
         if (predicted) { a.heur_z = c->heur_state; a.tau_max = c->tau_max; }
+        {
+            static const int rf = [] { const char* e = getenv("SAEV_AMD_REFRESH_FIRST"); return e ? atoi(e) : 8; }();
+            static const int re = [] { const char* e = getenv("SAEV_AMD_REFRESH_EVERY"); return e ? atoi(e) : 2; }();
+            a.refresh_first = std::max(1, rf);
+            a.refresh_every = (re >= 1 && (re & (re - 1)) == 0) ? re : 2;
+            // the 64-group variant (32 < k <= 64, e.g. 82 k latents at k = 64) refreshes on every tile: with twice the codes
+            // per row and many more tiles per workgroup its lists would outgrow their 4 096 entries otherwise
+            if (a.ngroups > 32 && getenv("SAEV_AMD_REFRESH_EVERY") == nullptr) a.refresh_every = 1;
+        }
         HIPCHK(c, launch_encode_f16x3(a, epi, s));
         return SAEV_OK;
     }

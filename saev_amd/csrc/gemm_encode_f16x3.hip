@@ -288,27 +288,31 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
         asm("" : "+s"(go_));                                                             \
         reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + go_) + voff);        \
     })
+                // pre-activations of the tile (every tile); the bound is refreshed on a subset of tiles only (see the
+                // 32-group variant below)
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
+                        const bool ok = (s0 + sl) < S;
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_t[sl]);
+#pragma unroll
+                        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
+                                acc[sb][jb][4 * q + e] = ok ? hv : NEG_INF;
+                            }
+                    }
+                const int tile_no64 = st - st_begin;
+                const bool refresh64 = tile_no64 < a.refresh_first || (tile_no64 & (a.refresh_every - 1)) == a.refresh_every - 1;
+                if (refresh64) {
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
                     float smax[32];
 #pragma unroll
-                    for (int r = 0; r < 32; ++r) smax[r] = NEG_INF;
-#pragma unroll
-                    for (int sb = 0; sb < 4; ++sb)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
-                            const bool ok = (s0 + sl) < S;
-                            const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_t[sl]);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
-                                const float v = ok ? hv : NEG_INF;
-                                acc[sb][jb][4 * q + e] = v;
-                                const int slot = 16 * (sb & 1) + 4 * q + e;
-                                smax[slot] = fmaxf(smax[slot], v);
-                            }
-                        }
+                    for (int r = 0; r < 32; ++r) smax[r] = fmaxf(acc[r >> 4][jb][r & 15], acc[(r >> 4) + 2][jb][r & 15]);
                     const int bl_ = wb * 64 + jb * 32 + l31;
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {  // word (2t + half): groups 2*(2t + half), 2*(2t + half) + 1
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 }
 #undef GPTR
                 __syncthreads();
+                }
             } else {
                 // The bound is refreshed on a workgroup's first four tiles and on every fourth one after that; in between the
                 // row bounds of the last refresh (still in sm.tau_key) are used as they are.  A bound only has to be a lower
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 // more, and the refresh -- per-group maxima, their exchange through LDS and global memory, three barriers --
                 // costs about as much as the candidate stores it saves from then on.
                 const int tile_no = st - st_begin;
-                const bool refresh = !heur && (tile_no < 4 || (tile_no & 3) == 3);
+                const bool refresh = !heur && (tile_no < a.refresh_first || (tile_no & (a.refresh_every - 1)) == a.refresh_every - 1);
                 // pre-activations of the tile (one code path for every tile: the accumulators are rewritten in one place)
     #pragma unroll
                 for (int sb = 0; sb < 4; ++sb)

@@ -208,7 +208,7 @@ struct AdamArgs {
     long n;
     float lr, beta1, beta2, eps, bc1, bc2_sqrt;  // bias corrections for this step
     float grad_scale;       // applied to g before everything else (1/world_size)
-    float max_norm;         // <= 0 disables clipping
+    float max_norm;         // torch semantics for >= 0 (0 zeroes the gradient); < 0 disables clipping
     const double* sumsq;    // device: sum of squares of the *unscaled* grads
     saev_step_stats* stats; // grad_norm written here by block 0
 };
@@ -279,6 +279,9 @@ struct EncodeF16Args {
     // INT32_MIN, receives the largest bound used for each row (the select stage verifies the prediction against it)
     const float* heur_z;
     int32_t* tau_max;
+    // EPI_TOPK: the guaranteed bound of a row is refreshed on a workgroup's first `refresh_first` tiles and on every
+    // `refresh_every`-th (a power of two) after that
+    int refresh_first, refresh_every;
     // EPI_DENSE only: a batch of independent products (grid.y), used to split a long contraction into slices whose
     // partial outputs are summed afterwards (AuxK weight gradients contract over the batch axis).  Batch j reads the
     // k-steps [j*nks, (j+1)*nks) of every row block -- blk_imgs is the number of images a row block has in memory

@@ -122,8 +122,10 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* partial
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     // clip coefficient from the global norm of the (scaled) gradient; torch semantics
     const float norm = a.grad_scale * (float)sqrt(*a.sumsq);
+    // torch.nn.utils.clip_grad_norm_: coef = min(max_norm / (norm + 1e-6), 1) -- max_norm = 0 therefore zeroes the
+    // gradient, as it does in the reference; a NEGATIVE max_norm means "no clipping" here (torch has no such value)
     float coef = 1.f;
-    if (a.max_norm > 0.f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.f);
+    if (a.max_norm >= 0.f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.f);
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.stats) a.stats->grad_norm = norm;
     const float gs = a.grad_scale * coef;
     const float step_size = a.lr / a.bc1;

@@ -700,3 +700,66 @@ def test_guaranteed_and_predicted_bounds_give_the_same_codes(encoder_mode):
         assert torch.equal(a, b)
     assert out[0][2]["launches"] == 0 and out[1][2]["launches"] == 3 and out[1][2]["repeats"] <= 1
     assert 32 <= out[1][2]["mean_candidates"] < 2000
+
+
+def test_max_norm_zero_follows_torch_and_negative_disables():
+    """clip_grad_norm_(max_norm=0) scales every gradient by 0 / (norm + 1e-6) = 0 (what the reference would do with
+    grad_clip = 0): the Adam moments receive zeros and the parameters do not move; a negative max_norm means no clipping."""
+    g = load_golden("g9_train_a")
+    d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
+    x = g["acts"][:bsz].cuda()
+    outs = {}
+    for max_norm in (0.0, -1.0, 1e9):
+        eng = make_engine(d, s, k, k_aux=0, max_batch=bsz)
+        eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
+        eng.train_step(x, 1e-3, max_norm)
+        outs[max_norm] = (eng.params.clone(), eng.adam_m.clone(), eng.read_stats().grad_norm)
+        if max_norm == 0.0:
+            before = eng.params.clone()  # W_dec rows renormalised at the top of the step, nothing else changed
+            eng2 = make_engine(d, s, k, k_aux=0, max_batch=bsz)
+            eng2.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
+            eng2.normalize_w_dec()
+            assert torch.equal(before, eng2.params) and (eng.adam_m == 0).all() and (eng.adam_v == 0).all()
+    assert outs[0.0][2] > 0  # the norm itself is still reported
+    assert torch.equal(outs[-1.0][0], outs[1e9][0]) and torch.equal(outs[-1.0][1], outs[1e9][1])
+
+
+@pytest.mark.parametrize("tag", ["b"])
+def test_teacher_forced_matryoshka_steps_match_oracle(tag):
+    """Teacher-forced steps with the reference's default-style objective: several Matryoshka prefixes (drawn per step from
+    torch's global RNG, the same draw handed to both sides), AuxK active, clip below the gradient norm."""
+    g = load_golden(f"g9_train_{tag}")
+    d, s, k, bsz, n_pre = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"]), 5
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=int(g["k_aux"]), dead_threshold_tokens=int(g["thr"]), grad_clip=0.02,
+                      n_prefixes=n_pre)
+    eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz)
+    eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
+    sched = R.WarmupCosine(0.0, int(g["n_warm"]), float(g["lr"]), math.ceil(int(g["n_train"]) / bsz), 0.0)
+    lr, flips, dead_max, routes = 0.0, 0, 0, set()
+    for i, x in enumerate(R.limited_batches(list(g["acts"].split(bsz)), int(g["n_train"]), bsz, drop_last=False)):
+        state = R.TrainState(
+            params={k_: v.cpu().clone() for k_, v in eng.param_views().items()},
+            m={k_: eng.view(k_, eng.adam_m).cpu().clone() for k_ in R.PARAM_ORDER},
+            v={k_: eng.view(k_, eng.adam_v).cpu().clone() for k_ in R.PARAM_ORDER},
+            toks_since_active=eng.toks_since_active.cpu().clone(), adam_steps=eng.adam_steps, lr=lr)
+        torch.manual_seed(1000 + i)
+        prefixes = R.sample_prefixes(s, n_pre)
+        torch.manual_seed(1000 + i)
+        ref = R.train_step(state, x, cfg)  # draws the same prefixes
+        eng.set_prefixes(prefixes)
+        eng.train_step(x.cuda(), lr, cfg.grad_clip)
+        st = eng.read_stats()
+        routes.add(eng.aux_route())
+        dead_max = max(dead_max, st.n_dead)
+        flipped = not math.isclose(st.mse, ref["mse"], rel_tol=2e-6)
+        flips += flipped
+        assert math.isclose(st.mse, ref["mse"], rel_tol=4.0 / (bsz * k)), (i, st.mse, ref["mse"])
+        assert st.n_dead == ref["n_dead"]
+        if not flipped:
+            assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-9), (i, st.aux, ref["aux"])
+            assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-4), (i, st.grad_norm, ref["grad_norm"])
+            for key in R.PARAM_ORDER:
+                bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6)
+                assert bad.float().mean() <= 1e-4, f"step {i} {key}: {bad.sum().item()} of {bad.numel()} elements off"
+        lr = sched.step()
+    assert flips <= 3 and dead_max > 0 and routes & {1, 2, 3}, (flips, dead_max, routes)

@@ -169,7 +169,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         float* const bias_t = sm.bias[st & 1];
-        if (tid < HTS) bias_t[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : 0.f;
+        // (latents past d_sae get a bias of -inf: their pre-activation is -inf without a select per accumulator; the dense
+        // epilogue never stores them)
+        if (tid < HTS) bias_t[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : NEG_INF;
         __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
         if (nks > 2) stage_kstep(2, s0, kmap(2));
 
@@ -295,15 +297,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
-                        const bool ok = (s0 + sl) < S;
                         const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_t[sl]);
 #pragma unroll
                         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
-                                acc[sb][jb][4 * q + e] = ok ? hv : NEG_INF;
-                            }
+                            for (int e = 0; e < 4; ++e) acc[sb][jb][4 * q + e] = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
                     }
                 const int tile_no64 = st - st_begin;
                 const bool refresh64 = tile_no64 < a.refresh_first || (tile_no64 & (a.refresh_every - 1)) == a.refresh_every - 1;
@@ -389,17 +387,13 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int sl = ws * 128 + sb * 32 + 8 * q + 4 * half;
-                        const bool ok = (s0 + sl) < S;  // d_sae % 4 == 0: a float4 of latents is all in or all out
                         // one 16-byte LDS read per four latents, unconditional (a per-element conditional read turns into
                         // 128 branches with an LDS round trip each)
                         const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_t[sl]);
     #pragma unroll
                         for (int jb = 0; jb < 2; ++jb)
     #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float hv = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
-                                acc[sb][jb][4 * q + e] = ok ? hv : NEG_INF;
-                            }
+                            for (int e = 0; e < 4; ++e) acc[sb][jb][4 * q + e] = fmaf(acc[sb][jb][4 * q + e], unscale, bq[e]);
                     }
                 if (refresh) {
                 // group maxima of THIS tile only; the running maxima over earlier tiles (of this and of every other

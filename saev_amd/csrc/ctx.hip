@@ -584,7 +584,8 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.scale_dev = f16r ? c->f16r_scales : nullptr;
         a.arith = bf ? 1 : (f16r ? 2 : 0);
         a.row_margin = f16r ? c->row_margin : nullptr;
-        a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
+        static const int enc_wgs = [] { const char* e = getenv("SAEV_AMD_ENC_WGS"); return e ? atoi(e) : 256; }();
+        a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), enc_wgs);
         a.h_out = h_out;
         a.ngroups = f16_ngroups(c->cfg); a.top_k = c->cfg.top_k;
         a.gmax = c->gmax; a.gmax_stride = c->gmax_stride; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;

@@ -230,15 +230,16 @@ def test_teacher_forced_steps_match_oracle(tag):
     assert n_clipped == (i + 1 if tag == "c" else 0), "fixture c runs the coef < 1 branch of the fused tail on every step"
 
 
+@pytest.mark.parametrize("rpg", [True, False])
 @pytest.mark.parametrize("max_norm,grad_scale", [(0.01, 1.0), (0.05, 1.0), (1.0, 0.5), (0.005, 0.25), (1e-4, 1.0)])
-def test_tail_clip_and_grad_scale_branches(max_norm, grad_scale):
+def test_tail_clip_and_grad_scale_branches(max_norm, grad_scale, rpg):
     """saev_step_tail with the clip coefficient below one and / or grad_scale != 1 (what a data-parallel run passes:
     1 / world) against the oracle's rpg -> clip_grad_norm -> Adam on the same gradients scaled on the host.  Three
     steps, so that the Adam moments carry clipped history.  reference train.py:351-362, 444-446."""
     g = load_golden("g9_train_b")
     d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=int(g["k_aux"]), dead_threshold_tokens=int(g["thr"]), grad_clip=max_norm)
-    eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz)
+    eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz, remove_parallel_grads=rpg)
     eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
     state = R.TrainState.create({key: g["init_" + key] for key in R.PARAM_ORDER})
     clipped = 0
@@ -253,7 +254,8 @@ def test_tail_clip_and_grad_scale_branches(max_norm, grad_scale):
         st = eng.read_stats()
         # oracle tail on the engine's own gradients: scale, project, clip, Adam
         grads = {k_: raw[k_] * grad_scale for k_ in R.PARAM_ORDER}
-        grads["W_dec"] = R.remove_parallel_grads(grads["W_dec"], params["W_dec"])
+        if rpg:  # (without it the same pass over the decoder gradient only takes its squares for the norm)
+            grads["W_dec"] = R.remove_parallel_grads(grads["W_dec"], params["W_dec"])
         scaled, total = R.clip_grad_norm([grads[k_] for k_ in R.PARAM_ORDER], max_norm)
         clipped += total.item() > max_norm
         state.adam_steps += 1

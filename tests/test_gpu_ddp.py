@@ -152,3 +152,63 @@ def test_chunked_tail_covers_the_padded_layout_exactly(world, encoder_mode):
     assert pad.sum() == eng.n_params - ref.n_params
     for flat in (eng.params, eng.grads, eng.adam_m, eng.adam_v):
         assert (flat[pad] == 0).all()
+
+
+def _two_rank_worker(rank, world, port, out, tail):
+    import os
+
+    import torch.distributed as dist
+
+    from saev_amd.framework.ddp import DataParallelStepper
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng, x, s = _setup(shard_world=world if tail == "sharded" else 1)
+        g = load_golden("g9_train_b")
+        bsz = int(g["bsz"])
+        stepper = DataParallelStepper(eng, dist, world, tail=tail)
+        n_dead = []
+        for i, xb in enumerate(g["acts"].split(bsz)[:5]):
+            stepper.train_step(xb[rank::world].contiguous().cuda(), 1e-3 * i, 0.05)
+            n_dead.append(eng.read_stats().n_dead)
+        torch.cuda.synchronize()
+        torch.save({"params": {k: v.cpu().clone() for k, v in eng.param_views().items()}, "toks": eng.toks_since_active.cpu(),
+                    "n_dead": n_dead}, out.format(rank=rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tail", ["replicated", "sharded"])
+def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, tail, encoder_mode):
+    """The REAL engines under a real two-rank exchange: two processes share the one GPU of the test box and talk over
+    gloo (RCCL refuses two ranks on one device; gloo stages device tensors through the host, which is all this needs).
+    Rank r trains on rows r::2 of every batch; both tails must leave both ranks with identical parameters that match one
+    process on the full batches -- fired-flag MAX, 1/world gradient scale, global clip norm, dead tracker, AuxK included."""
+    if encoder_mode != "f16r":
+        pytest.skip("one encoder mode is enough here")
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "rank{rank}.pt")
+    try:
+        mp.spawn(_two_rank_worker, args=(2, _free_port(), out, tail), nprocs=2, join=True)
+    except Exception as exc:  # a gloo build without device-tensor support for these collectives
+        if "gloo" in str(exc).lower() and ("not support" in str(exc).lower() or "unsupported" in str(exc).lower()):
+            pytest.skip(f"gloo cannot run this collective on device tensors here: {exc}")
+        raise
+    r0, r1 = (torch.load(out.format(rank=r)) for r in range(2))
+    for k in R.PARAM_ORDER:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    assert torch.equal(r0["toks"], r1["toks"]) and r0["n_dead"] == r1["n_dead"]
+    eng, x, s = _setup()
+    g = load_golden("g9_train_b")
+    bsz = int(g["bsz"])
+    n_dead = []
+    for i, xb in enumerate(g["acts"].split(bsz)[:5]):
+        eng.train_step(xb.cuda(), 1e-3 * i, 0.05)
+        n_dead.append(eng.read_stats().n_dead)
+    assert n_dead == r0["n_dead"] and max(n_dead) > 0
+    assert torch.equal(eng.toks_since_active.cpu(), r0["toks"])
+    for k in R.PARAM_ORDER:
+        bad = ~torch.isclose(eng.view(k).cpu(), r0["params"][k], rtol=2e-4, atol=2e-6)
+        assert bad.float().mean() <= 1e-4, f"{k}: {bad.sum().item()} of {bad.numel()} elements off"

@@ -100,6 +100,9 @@ def main():
                     help="bucketed gradient all-reduce overlapped with the backward instead of one flat all-reduce after it")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL init + per-step collectives) even with one rank")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank "
+                                                      "code path with several ranks on ONE device, see --same-device)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--tail", choices=["auto", "replicated", "sharded"], default="auto",
                     help="data-parallel optimizer tail: every rank all of it after an all-reduce, or reduce-scatter -> 1/N of "
                          "the tail per rank -> all-gather (framework/ddp.py).  auto: sharded when a start-up self-check on a "
@@ -120,6 +123,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -129,7 +134,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from saev_amd.engine import EngineConfig, SaeEngine
     from saev_amd.framework.ddp import DataParallelStepper

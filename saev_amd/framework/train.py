@@ -229,7 +229,11 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
             if log_now:
                 pre = {}
                 st.train_step(x, lrs[i], c.grad_clip, pre_tail=lambda sae=sae, pre=pre, c=c: pre.update(_decoder_metrics(sae, c)))
-                metrics.append(_log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c, pre, dataloader, dist, world))
+                m = _log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c, pre, dataloader, dist, world)
+                if "example_idx" in batch and getattr(dataloader, "metadata", None) is not None:
+                    md = dataloader.metadata
+                    m.update(batch_entropy(batch["example_idx"], batch["token_idx"], md.n_examples, md.content_tokens_per_example))
+                metrics.append(m)
             else:
                 st.train_step(x, lrs[i], c.grad_clip)
             lrs[i] = scheds[i].step()
@@ -240,6 +244,24 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
         global_step += 1
     logger.info("trained %d steps in %.1fs", global_step, time.time() - t_start)
     return saes, objs, run, global_step
+
+
+@torch.no_grad()
+def batch_entropy(example_idx: Tensor, token_idx: Tensor, n_examples: int, content_tokens_per_example: int) -> dict[str, float]:
+    """How well a batch covers the examples and the token positions (reference utils/statistics.py:57-122, logged next to
+    the loader metrics at train.py:371-377): entropy of the empirical distribution of the indices in natural-log units,
+    the same divided by log(support), and the share of the support that occurs at all."""
+    out = {}
+    for name, idx, support in (("loader/example", example_idx, n_examples), ("loader/token", token_idx, content_tokens_per_example)):
+        if support <= 0:
+            raise ValueError(f"{name}: support must be positive.")
+        counts = torch.unique(idx.to(torch.int64), return_counts=True)[1].to(torch.float64)
+        probs = counts / counts.sum()
+        ent = -(probs * probs.log()).sum().item()
+        out[f"{name}_entropy"] = ent
+        out[f"{name}_entropy_normalized"] = 0.0 if support <= 1 else ent / math.log(support)
+        out[f"{name}_coverage"] = counts.numel() / support
+    return out
 
 
 @torch.no_grad()

@@ -496,3 +496,26 @@ def test_extraction_feed_delivers_every_token_once_with_the_hooked_values():
     assert [len(b["act"]) for b in dl] == [64] * (37 * 17 // 64)
     with pytest.raises(ValueError, match="not in recorded layers"):
         data.ExtractionFeed(data.ExtractConfig(layer=2), rec, images, n_examples=37, d_model=32, device="cpu")
+
+
+def test_batch_entropy_known_answers():
+    """The loader-coverage metrics of the log block (reference utils/statistics.py:57-122): known answers."""
+    from saev_amd.framework.train import batch_entropy
+
+    m = batch_entropy(torch.tensor([0, 0, 1, 1], dtype=torch.int32), torch.tensor([3, 3, 3, 3], dtype=torch.int32), 8, 4)
+    assert math.isclose(m["loader/example_entropy"], math.log(2)) and math.isclose(m["loader/example_entropy_normalized"], math.log(2) / math.log(8))
+    assert m["loader/example_coverage"] == 0.25 and m["loader/token_entropy"] == 0.0 and m["loader/token_coverage"] == 0.25
+    u = batch_entropy(torch.arange(16), torch.arange(16) % 4, 16, 4)
+    assert math.isclose(u["loader/example_entropy_normalized"], 1.0) and math.isclose(u["loader/token_entropy_normalized"], 1.0)
+    assert u["loader/example_coverage"] == 1.0 and batch_entropy(torch.zeros(3), torch.zeros(3), 1, 1)["loader/token_entropy_normalized"] == 0.0
+
+
+def test_batch_entropy_equals_the_reference_values():
+    from saev_amd.framework.train import batch_entropy
+
+    g = load_golden("g16_batch_entropy")
+    for tag in "abc":
+        n_ex, n_tok = g[f"{tag}_support"].tolist()
+        got = batch_entropy(g[f"{tag}_example_idx"], g[f"{tag}_token_idx"], n_ex, n_tok)
+        assert sorted(got) == g[f"{tag}_keys"].tolist()
+        np.testing.assert_allclose([got[k] for k in sorted(got)], g[f"{tag}_vals"].numpy(), rtol=1e-12, atol=0)

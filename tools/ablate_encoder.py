@@ -44,6 +44,22 @@ def patched(text: str) -> str:
         "            else asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n#ifndef ABL_NOBAR\n            __builtin_amdgcn_s_barrier();\n#endif")
     sub("    if constexpr (AR == 1) return mfma_bf16(a, b, c);",
         "#ifdef ABL_NOMFMA\n    asm volatile(\"\" :: \"v\"(a), \"v\"(b));\n    return c;\n#endif\n    if constexpr (AR == 1) return mfma_bf16(a, b, c);")
+    # MFMA16: every 32x32x16 instruction of the single-product modes becomes two 16x16x32 ones on quarter accumulators (same
+    # flops, same fragment reads, wrong results): does the shape's lower power draw (tools/ubench/mfma_issue.hip) survive in
+    # the full kernel?
+    sub("template <int AR>\n__device__ __forceinline__ f32x16 mfma1(half8 a, half8 b, f32x16 c) {",
+        "typedef float f32x4 __attribute__((ext_vector_type(4)));\n"
+        "template <int Q>\n__device__ __forceinline__ f32x16 mfma16x2(half8 a, half8 b, f32x16 c) {\n"
+        "    f32x4 q0 = {c[8 * Q + 0], c[8 * Q + 1], c[8 * Q + 2], c[8 * Q + 3]}, q1 = {c[8 * Q + 4], c[8 * Q + 5], c[8 * Q + 6], c[8 * Q + 7]};\n"
+        "    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);\n    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, q1, 0, 0, 0);\n"
+        "    for (int e = 0; e < 4; ++e) { c[8 * Q + e] = q0[e]; c[8 * Q + 4 + e] = q1[e]; }\n    return c;\n}\n"
+        "template <int AR>\n__device__ __forceinline__ f32x16 mfma1(half8 a, half8 b, f32x16 c) {")
+    sub("                    acc[sb][0] = mfma1<AR>(fa[as][0], fb[0][0], acc[sb][0]);",
+        "#ifdef ABL_MFMA16\n#define MF(Q, A, B, C) mfma16x2<Q>(A, B, C)\n#else\n#define MF(Q, A, B, C) mfma1<AR>(A, B, C)\n#endif\n"
+        "                    acc[sb][0] = MF(0, fa[as][0], fb[0][0], acc[sb][0]);")
+    sub("                    acc[sb][1] = mfma1<AR>(fa[as][0], fb[1][0], acc[sb][1]);", "                    acc[sb][1] = MF(0, fa[as][0], fb[1][0], acc[sb][1]);")
+    sub("                    acc[sb][0] = mfma1<AR>(fa[as][1], fb[0][1], acc[sb][0]);", "                    acc[sb][0] = MF(1, fa[as][1], fb[0][1], acc[sb][0]);")
+    sub("                    acc[sb][1] = mfma1<AR>(fa[as][1], fb[1][1], acc[sb][1]);", "                    acc[sb][1] = MF(1, fa[as][1], fb[1][1], acc[sb][1]);")
     sub("            int npass[2], pos[2];\n",
         "#ifdef ABL_NOCAND\n            if (sm.tau_key[0] == 12345) a.cand_cnt[0] = (int)acc[0][0][0] + (int)acc[1][1][1] + (int)acc[2][0][2] + (int)acc[3][1][3];\n"
         "            if (sm.tau_key[1] != 777777) goto tile_done;\n#endif\n            int npass[2], pos[2];\n")

@@ -47,6 +47,58 @@ __global__ __launch_bounds__(THREADS) void k(const half8* frag, float* out, int 
     out[blockIdx.x * THREADS + tid] = s;
 }
 
+// the same flops as 16x16x32 instructions (twice as many, 4 accumulator registers each)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k16(const half8* frag, float* out, int iters) {
+    const int tid = threadIdx.x;
+    half8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = frag[(tid * 8 + i) & 4095];
+        b[i] = frag[(tid * 8 + 4 + i) & 4095];
+    }
+    f32x4 acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 3], b[(u >> 2) & 3], acc[u], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * THREADS + tid] = s;
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void kbf(const half8* frag, float* out, int iters) {
+    const int tid = threadIdx.x;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8, frag[(tid * 8 + i) & 4095]);
+        b[i] = __builtin_bit_cast(bf16x8, frag[(tid * 8 + 4 + i) & 4095]);
+    }
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            acc[u % 8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 3], b[(u >> 2) & 3], acc[u % 8], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * THREADS + tid] = s;
+}
+
 int main() {
     half8* frag;
     float* out;
@@ -85,6 +137,8 @@ int main() {
         run(k<512, 8, 1>, 512, "2 waves/SIMD, 8 acc each, barrier per 16 MFMAs, lock-step");
         run(k<512, 8, 2>, 512, "2 waves/SIMD, 8 acc each, alternating halves (2 barriers)");
         run(k<256, 16, 1>, 256, "1 wave/SIMD, 16 acc, barrier per 16 MFMAs");
+        run(k16<512>, 512, "2 waves/SIMD, 16x16x32 f16 (32 per trip = same flops)");
+        run(kbf<512>, 512, "2 waves/SIMD, 32x32x16 bf16 (same bit patterns)");
     }
     return 0;
 }

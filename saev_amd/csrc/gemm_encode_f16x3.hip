@@ -11,7 +11,7 @@
 //
 // Inputs are the pre-split operands produced by split.hip, already in LDS image order: for every block of
 // 256 rows (batch rows of x; latents of W_enc^T) and every 16-wide k-step one contiguous 16 KB image
-//   [row 0..255][4 chunks of 8 halfs: (hi|lo) x (k 0-7 | k 8-15), chunk c of row r at position c ^ ((r>>2)&3)]
+//   [row 0..255][4 chunks of 8 halfs: (hi|lo) x (k 0-7 | k 8-15), chunk c of row r at position c ^ ((4 - ((r>>2)&3)) & 3)]
 // so a k-step slot is filled by straight 1 KB-per-wave copies (every global_load_lds touches 8 full lines)
 // and every MFMA fragment is one conflict-free ds_read_b128.
 //
@@ -19,8 +19,8 @@
 // (4 x 2 MFMA blocks, 128 accumulator registers).  LDS is a ring of four 32 KB k-step slots filled by
 // global_load_lds three k-steps ahead; the loop never drains the load queue (counted s_waitcnt vmcnt + raw
 // s_barrier, one per k-step).  Rows of a slot are 64 bytes = 4 chunks of 16 B (hi/lo x lane-half); chunk c of
-// row r sits at position c ^ ((r >> 2) & 3) (applied on the global source address), which makes the fragment
-// reads conflict-free.  Orientation and the TopK epilogue are those of gemm_encode.hip (lanes own batch rows).
+// row r sits at position c ^ ((4 - ((r >> 2) & 3)) & 3) (applied on the global source address), which makes the fragment
+// reads conflict-free for both instruction shapes (encode_m16_kernel below).  Orientation and the TopK epilogue are those of gemm_encode.hip (lanes own batch rows).
 #include "common.h"
 #include "kernels.h"
 
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     // fragment rows of this lane and their chunk swizzles
     const int arow0 = ws * 128 + l31;             // + 32*sb
     const int brow0 = wb * 64 + l31;              // + 32*jb
-    const int asw = (l31 >> 2) & 3;               // ((arow0 + 32*sb) >> 2) & 3 is independent of sb, ws
-    const int bsw = (l31 >> 2) & 3;
+    const int asw = (4 - ((l31 >> 2) & 3)) & 3;   // swizzle of row r: (4 - ((r >> 2) & 3)) & 3, independent of sb, ws
+    const int bsw = asw;
 
     // k-steps 0 and 1 of a tile are requested by the previous tile's epilogue (or here for the first tile)
     if (st_begin < st_end) {
@@ -642,6 +642,309 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------------
+// The single-product TopK kernel (AR = 1 bf16 / AR = 2 fp16 first pass; 32 groups, guaranteed bounds) on
+// v_mfma_f32_16x16x32_{bf16,f16} instead of 32x32x16.  Same tile, ring, staging, images and LDS bytes per k-step (twelve
+// ds_read_b128 per wave); the instruction has a quarter of the accumulator registers per flop to read and write back, and
+// on real operands the matrix pipes -- which are clock-limited by power, not by issue -- sustain 1.93 PFLOP/s with it
+// against 1.66 (tools/ubench/mfma_issue.hip, profiles/r02_mfma_issue.txt).  What changes is who owns what:
+//   wave tile 128 latents x 64 rows = 8 x 4 blocks of 16 x 16; lane = 16 * kg + l15 holds, of block (sb, jb), batch row
+//   wb*64 + jb*16 + l15 and latents ws*128 + sb*16 + 4*kg + e (e = 0..3) -- four lanes and four blocks per row where the
+//   32 x 32 layout has two and two.  A/B fragment of a lane: its row's chunk kg (k 8kg .. 8kg+7 of the k-step's 32),
+//   one ds_read_b128; with the image swizzle (position c ^ ((4 - (r >> 2)) & 3)) each of the instruction's four service
+//   groups touches all 64 banks once.
+// Group of a latent (for the 32 shared group maxima): its position modulo 32.
+template <int AR>
+__device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
+    if constexpr (AR == 1)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int AR>
+__global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    HSmem& sm = *reinterpret_cast<HSmem*>(smem_raw);
+
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wid & 1;   // wave position along s (128 latents each)
+    const int wb = wid >> 1;  // wave position along b (64 rows each)
+    const int l15 = lane & 15;
+    const int kg = lane >> 4;
+
+    const int Dp = a.Dp, S = a.S, B = a.n_rows;
+    const int n_stiles = (S + HTS - 1) / HTS;
+    int bb, sp;
+    {
+        const int id = blockIdx.x;
+        const int nbb = (B + HTB - 1) / HTB;
+        const int full = (nbb / 8) * 8 * a.s_splits;
+        if (id < full) {
+            const int xcd = id & 7, j = id >> 3;
+            sp = j % a.s_splits;
+            bb = (j / a.s_splits) * 8 + xcd;
+        } else {
+            const int r = id - full;
+            bb = (nbb / 8) * 8 + r / a.s_splits;
+            sp = r % a.s_splits;
+        }
+    }
+    const int st_begin = (int)((long)n_stiles * sp / a.s_splits);
+    const int st_end = (int)((long)n_stiles * (sp + 1) / a.s_splits);
+    const int b0 = bb * HTB;
+
+    const int nks = Dp / 32;  // k-steps per tile
+    const int rot = (bb & 7) % nks;  // see encode_f16x3_kernel
+    auto kmap = [&](int t) { const int k = t + rot; return k >= nks ? k - nks : k; };
+
+    const uint32_t g_off = (uint32_t)(wid * 2048 + lane * 16);
+    const size_t img = (size_t)256 * 32;  // halfs per image
+    const int blk_imgs = a.blk_imgs > 0 ? a.blk_imgs : nks;
+    const _Float16* x_imgs = a.xs + (size_t)bb * blk_imgs * img;
+    auto stage_kstep = [&](int slot, int s0, int ks) {
+        KSlot& st = sm.slot[slot];
+        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * blk_imgs + ks) * img) + g_off;
+        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + g_off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16h(wsrc + 1024 * j, &st.a[wid * 32 + 16 * j][0]);
+            glds16h(xsrc + 1024 * j, &st.b[wid * 32 + 16 * j][0]);
+        }
+    };
+
+    const int arow0 = ws * 128 + l15;  // + 16 * sb
+    const int brow0 = wb * 64 + l15;   // + 16 * jb
+    const int coff = 8 * (kg ^ ((4 - (l15 >> 2)) & 3));  // this lane's chunk within its rows (halfs)
+
+    if (st_begin < st_end) {
+        stage_kstep(0, st_begin * HTS, kmap(0));
+        if (nks > 1) stage_kstep(1, st_begin * HTS, kmap(1));
+    }
+
+    for (int st = st_begin; st < st_end; ++st) {
+        const int s0 = st * HTS;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        float* const bias_t = sm.bias[st & 1];
+        if (tid < HTS) bias_t[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : NEG_INF;
+        __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
+        if (nks > 2) stage_kstep(2, s0, kmap(2));
+
+        for (int t = 0; t < nks; ++t) {
+            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));
+            const KSlot& cs = sm.slot[t & 3];
+            // 8 groups of 4 MFMAs (latent block sb); the A fragment of group sb + 2 is requested after the first MFMA of
+            // group sb
+            half8 fa[3], fb[4];
+            auto load_a = [&](int set, int sb) { fa[set] = *reinterpret_cast<const half8*>(&cs.a[arow0 + 16 * sb][coff]); };
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) fb[jb] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 16 * jb][coff]);
+            load_a(0, 0);
+            load_a(1, 1);
+            __builtin_amdgcn_s_setprio(1);
+            static_for<8>([&](auto G) {
+                constexpr int sb = decltype(G)::value;
+                constexpr int as = sb % 3;
+                acc[sb][0] = mfma16<AR>(fa[as], fb[0], acc[sb][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (sb + 2 < 8) load_a((sb + 2) % 3, sb + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[sb][1] = mfma16<AR>(fa[as], fb[1], acc[sb][1]);
+                acc[sb][2] = mfma16<AR>(fa[as], fb[2], acc[sb][2]);
+                acc[sb][3] = mfma16<AR>(fa[as], fb[3], acc[sb][3]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __builtin_amdgcn_s_setprio(0);
+            if (t + 3 < nks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (t + 2 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const bool prefetched = st + 1 < st_end;
+        if (prefetched) {
+            stage_kstep(0, s0 + HTS, kmap(0));
+            if (nks > 1) stage_kstep(1, s0 + HTS, kmap(1));
+        }
+
+        // ---------------- epilogue (the 32-group TopK epilogue of encode_f16x3_kernel in this kernel's ownership) -------
+        // lane owns batch rows bl(jb) = wb*64 + jb*16 + l15; latent of acc[sb][jb][e]: sl = ws*128 + sb*16 + 4*kg + e
+        const float unscale = a.scale_dev != nullptr ? 1.0f / (a.w_scale * a.scale_dev[0] * a.scale_dev[1]) : 1.0f / a.w_scale;
+        const int tile_no = st - st_begin;
+        const bool refresh = tile_no < a.refresh_first || (tile_no & (a.refresh_every - 1)) == a.refresh_every - 1;
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_t[ws * 128 + sb * 16 + 4 * kg]);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[sb][jb][e] = fmaf(acc[sb][jb][e], unscale, bq[e]);
+        }
+        if (refresh) {
+            // group maxima of this tile: group = (sb & 1) * 16 + 4 * kg + e
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int bl_ = wb * 64 + jb * 16 + l15;
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float m = fmaxf(fmaxf(acc[p][jb][e], acc[p + 2][jb][e]), fmaxf(acc[p + 4][jb][e], acc[p + 6][jb][e]));
+                        sm.e32.slots32[ws][p * 16 + 4 * kg + e][bl_] = f2key(m);
+                    }
+            }
+            __syncthreads();
+            if (tid < HTB) sm.tau_key[tid] = INT32_MAX;
+            __syncthreads();
+            {
+                const int row = tid % HTB;
+                const int part = __builtin_amdgcn_readfirstlane(tid / HTB);
+                constexpr int GPT = 16;  // groups per thread
+                const int b = b0 + row;
+                const bool share = b < B;
+                const uint32_t boff = (uint32_t)b * 4u;
+                int32_t m = INT32_MAX;
+                int32_t old[GPT];
+#pragma unroll
+                for (int i = 0; i < GPT; ++i) {
+                    old[i] = INT32_MIN;
+                    if (share)
+                        old[i] = __hip_atomic_load(
+                            reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)(part * GPT + i) * a.gmax_stride) + boff),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int i = 0; i < GPT; ++i) {
+                    const int g = part * GPT + i;
+                    const int32_t v = max(sm.e32.slots32[0][g][row], sm.e32.slots32[1][g][row]);
+                    if (share && v > old[i])
+                        atomicMax(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + (size_t)g * a.gmax_stride) + boff), v);
+                    m = min(m, max(v, old[i]));
+                }
+                atomicMin(&sm.tau_key[row], m);
+            }
+            __syncthreads();
+        }
+        if (st == st_begin && a.top_k <= HTS / 4) {
+            // first tile: the largest of three thresholds between the group bound and the row maximum that top_k values of
+            // this tile reach (see encode_f16x3_kernel)
+            if (tid < HTB) { sm.ref[0][tid] = INT32_MIN; sm.ref[1][tid] = 0; sm.ref[2][tid] = 0; sm.ref[3][tid] = 0; }
+            __syncthreads();
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                float m = NEG_INF;
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m = fmaxf(m, acc[sb][jb][e]);
+                atomicMax(&sm.ref[0][wb * 64 + jb * 16 + l15], f2key(m));
+            }
+            __syncthreads();
+            float tg[4][3];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int row = wb * 64 + jb * 16 + l15;
+                const float t0 = key2f(sm.tau_key[row]), M = key2f(sm.ref[0][row]);
+                const bool usable = t0 > -3.0e38f && M > t0;
+                const float span = usable ? (M - t0) : 0.f;
+                tg[jb][0] = t0 + 0.25f * span; tg[jb][1] = t0 + 0.40f * span; tg[jb][2] = t0 + 0.55f * span;
+                int c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[sb][jb][e];
+                        c0 += (v >= tg[jb][0]) ? 1 : 0; c1 += (v >= tg[jb][1]) ? 1 : 0; c2 += (v >= tg[jb][2]) ? 1 : 0;
+                    }
+                if (usable) { atomicAdd(&sm.ref[1][row], c0); atomicAdd(&sm.ref[2][row], c1); atomicAdd(&sm.ref[3][row], c2); }
+            }
+            __syncthreads();
+            if (ws == 0 && kg == 0) {  // one lane per row writes the refined bound back
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int row = wb * 64 + jb * 16 + l15;
+                    float best = key2f(sm.tau_key[row]);
+                    if (sm.ref[1][row] >= a.top_k) best = fmaxf(best, tg[jb][0]);
+                    if (sm.ref[2][row] >= a.top_k) best = fmaxf(best, tg[jb][1]);
+                    if (sm.ref[3][row] >= a.top_k) best = fmaxf(best, tg[jb][2]);
+                    sm.tau_key[row] = f2key(best);
+                }
+            }
+            __syncthreads();
+        }
+        // Count, reserve, store.  The four lanes that share a row (kg = 0..3, 16 lanes apart) add their counts up with two
+        // lane-row swaps (v_permlane16_swap / v_permlane32_swap: VALU, no LDS) and reserve the row's list space with ONE
+        // atomic, issued by the kg = 0 lane as soon as that row block's count is known, so the first three round trips
+        // overlap the counting of the following blocks.
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        int npass[4], pos[4], rowtot[4], base[4];
+        float tau4[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int b = b0 + wb * 64 + jb * 16 + l15;
+            float tau = fmaxf(key2f(sm.tau_key[wb * 64 + jb * 16 + l15]), -3.0e38f);
+            if (a.row_margin != nullptr) tau -= (b < B) ? a.row_margin[b] : 0.f;
+            tau4[jb] = tau;
+            int n = 0;
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n += (acc[sb][jb][e] >= tau) ? 1 : 0;
+            n = (b < B) ? n : 0;
+            npass[jb] = n;
+            const u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)n, (unsigned)n, false, false);  // {even, odd row} of my row pair
+            const unsigned pair = r[0] + r[1];
+            const u32x2 q = __builtin_amdgcn_permlane32_swap(pair, pair, false, false);                // {rows 0+1, rows 2+3}
+            rowtot[jb] = (int)(q[0] + q[1]);
+            pos[jb] = (int)(((kg & 1) ? r[0] : 0u) + ((kg & 2) ? q[0] : 0u));  // lanes of the row before this one
+            base[jb] = 0;
+            if (kg == 0 && rowtot[jb] > 0) base[jb] = atomicAdd(&a.cand_cnt[b], rowtot[jb]);
+        }
+        // wait for the counters once, here: otherwise every conditionally executed store block below gets its own
+        // s_waitcnt vmcnt(0), which also serialises the stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(base[0]), "+v"(base[1]), "+v"(base[2]), "+v"(base[3]));
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            // kg = 0 lanes -> all four lanes of the row
+            const u32x2 h = __builtin_amdgcn_permlane32_swap((unsigned)base[jb], (unsigned)base[jb], false, false);
+            const u32x2 f = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);
+            const int row_base = (int)f[0];
+            // a row whose list would overflow is not written at all: its counter already says so, and the step then
+            // re-runs on the exact dense route (overflow_check)
+            if (npass[jb] > 0 && row_base + rowtot[jb] <= a.cand_cap) {
+                const int bl_ = wb * 64 + jb * 16 + l15;
+                const float tau = tau4[jb];
+                uint32_t off = ((uint32_t)(b0 + bl_) * (uint32_t)a.cand_stride + (uint32_t)(row_base + pos[jb])) * 4u;
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[sb][jb][e];
+                        if (v >= tau) {
+                            *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;
+                            *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = s0 + ws * 128 + sb * 16 + 4 * kg + e;
+                            off += 4u;
+                        }
+                    }
+            }
+        }
+        if (!prefetched && st + 1 < st_end) {  // (never: kept for symmetry with encode_f16x3_kernel)
+            __syncthreads();
+            stage_kstep(0, s0 + HTS, kmap(0));
+            if (nks > 1) stage_kstep(1, s0 + HTS, kmap(1));
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream) {
@@ -649,8 +952,13 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
     dim3 grid(n_bblocks * a.s_splits, (epi == EPI_DENSE && a.n_batches > 1) ? a.n_batches : 1), block(HTHREADS);
     const size_t smem = sizeof(HSmem);
     static bool attr_set = false;
+    static bool use_m16 = true;
     if (!attr_set) {
-        const void* fns[12] = {reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 0, true>),
+        const char* shape = getenv("SAEV_AMD_ENC_MFMA");
+        use_m16 = !(shape != nullptr && atoi(shape) == 32);
+        const void* fns[14] = {reinterpret_cast<const void*>(&encode_m16_kernel<1>),
+                              reinterpret_cast<const void*>(&encode_m16_kernel<2>),
+                              reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 0, true>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 1, true>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 2, true>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_DENSE, 32, 0>),
@@ -680,6 +988,10 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
         if (a.arith == 1) hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 1, true>), grid, block, smem, stream, a);
         else if (a.arith == 2) hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 2, true>), grid, block, smem, stream, a);
         else hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 0, true>), grid, block, smem, stream, a);
+    } else if (a.ngroups <= 32 && a.arith != 0 && use_m16) {
+        // single-product modes: the 16x16x32 kernel (SAEV_AMD_ENC_MFMA=32 brings the 32x32x16 one back for A/B runs)
+        if (a.arith == 1) hipLaunchKernelGGL((encode_m16_kernel<1>), grid, block, smem, stream, a);
+        else hipLaunchKernelGGL((encode_m16_kernel<2>), grid, block, smem, stream, a);
     } else if (a.ngroups <= 32) LAUNCH_AR(EPI_TOPK, 32);
     else LAUNCH_AR(EPI_TOPK, 64);
 #undef LAUNCH_AR

@@ -5,7 +5,7 @@
 //       image(blk, ks) at  ((blk * nks + ks) * 256 * 32) halfs,   nks = Dp / 16
 //       inside: row rl (0..255) owns 32 halfs = 4 chunks of 8; logical chunk c = 2*part + h
 //               (part 0 = hi, 1 = lo; h = which half of the k-step: k%16 < 8 or >= 8)
-//               is stored at position c ^ ((rl >> 2) & 3)   <- the bank-conflict swizzle of the fragment reads
+//               is stored at position c ^ ((4 - ((rl >> 2) & 3)) & 3)   <- the bank-conflict swizzle of the fragment reads
 //
 //   split_rows_kernel : x (n, D) fp32 (* scale)  -> xs images (rows padded to 256)
 //   split_wT_kernel   : W_enc (D, S) fp32, i.e. k-major -> ws images of W_enc^T * scale (rows = latents)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
     const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
     const int i = threadIdx.x;           // chunk index inside the image
     const int rl = i >> 2, p = i & 3;
-    const int c = p ^ ((rl >> 2) & 3);
+    const int c = p ^ ((4 - ((rl >> 2) & 3)) & 3);
     const int part = c >> 1, h = c & 1;
     const int r = blk * 256 + rl, k = MODE != 0 ? ks * 32 + c * 8 : ks * 16 + h * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
     __syncthreads();
     const int i = threadIdx.x;
     const int rl = i >> 2, p = i & 3;
-    const int c = p ^ ((rl >> 2) & 3);
+    const int c = p ^ ((4 - ((rl >> 2) & 3)) & 3);
     const int part = c >> 1, h = c & 1;
     float v[8];
 #pragma unroll

@@ -3,7 +3,7 @@
     python tools/ablate_encoder.py            # writes build/abl/lib_<VARIANT>.so
     SAEV_AMD_LIB=build/abl/lib_NOEPI.so python tools/time_encoder.py
 
-Variants: NOEPI (no TopK epilogue), NOSTAGE (no in-loop operand staging), NOLDS (fragments from registers), NOMFMA (no matrix
+Variants: MFMA16, NOIDX, NOSTORE (see below), NOEPI (no TopK epilogue), NOSTAGE (no in-loop operand staging), NOLDS (fragments from registers), NOMFMA (no matrix
 instructions), NOBAR (no k-loop barrier), NOCAND (no candidate count/reserve/store), and combinations.  The patches are textual and applied to a temporary copy of the kernel source.
 """
 import pathlib
@@ -60,6 +60,13 @@ def patched(text: str) -> str:
     sub("                    acc[sb][1] = mfma1<AR>(fa[as][0], fb[1][0], acc[sb][1]);", "                    acc[sb][1] = MF(0, fa[as][0], fb[1][0], acc[sb][1]);")
     sub("                    acc[sb][0] = mfma1<AR>(fa[as][1], fb[0][1], acc[sb][0]);", "                    acc[sb][0] = MF(1, fa[as][1], fb[0][1], acc[sb][0]);")
     sub("                    acc[sb][1] = mfma1<AR>(fa[as][1], fb[1][1], acc[sb][1]);", "                    acc[sb][1] = MF(1, fa[as][1], fb[1][1], acc[sb][1]);")
+    # NOIDX: candidate values are stored, their indices are not (one store and the index arithmetic less per candidate);
+    # NOSTORE: neither (compare / exec mask / offset bookkeeping stay)
+    sub("                                *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;\n",
+        "#ifndef ABL_NOSTORE\n                                *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;\n#endif\n"
+        "#if !defined(ABL_NOSTORE) && !defined(ABL_NOIDX)\n")
+    sub("                                    s0 + ws * 128 + sb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);\n",
+        "                                    s0 + ws * 128 + sb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);\n#endif\n")
     sub("            int npass[2], pos[2];\n",
         "#ifdef ABL_NOCAND\n            if (sm.tau_key[0] == 12345) a.cand_cnt[0] = (int)acc[0][0][0] + (int)acc[1][1][1] + (int)acc[2][0][2] + (int)acc[3][1][3];\n"
         "            if (sm.tau_key[1] != 777777) goto tile_done;\n#endif\n            int npass[2], pos[2];\n")

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -105,10 +106,16 @@ int main() {
     hipMalloc(&frag, 4096 * sizeof(half8));
     hipMalloc(&out, 256 * 512 * 4);
     const int iters = 20000;
-    for (int zero = 0; zero < 2; ++zero) {
+    // zero = 0: random fp16; 1: zeros; 2..4: random with the low 3 / 5 / 7 mantissa bits cleared (does the power the
+    // multipliers draw -- and with it the sustained clock -- follow the number of significant bits?)
+    for (int zero = 0; zero < 5; ++zero) {
         std::vector<_Float16> h(4096 * 8);
         srand(1);
-        for (auto& v : h) v = zero ? (_Float16)0.f : (_Float16)((rand() / (float)RAND_MAX * 2.f - 1.f) * 3.0f);
+        for (auto& v : h) v = zero == 1 ? (_Float16)0.f : (_Float16)((rand() / (float)RAND_MAX * 2.f - 1.f) * 3.0f);
+        if (zero >= 2) {
+            const unsigned short mask = (unsigned short)(0xFFFFu << (zero == 2 ? 3 : zero == 3 ? 5 : 7));
+            for (auto& v : h) { unsigned short u; memcpy(&u, &v, 2); u &= mask; memcpy(&v, &u, 2); }
+        }
         hipMemcpy(frag, h.data(), h.size() * 2, hipMemcpyHostToDevice);
         auto run = [&](auto kern, int threads, const char* name) {
             hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, frag, out, 200);
@@ -128,7 +135,7 @@ int main() {
             }
             const double flops = 256.0 * (threads / 64) * iters * 16 * 32768.0;
             const double per_simd = (double)(threads / 256) * iters * 16;  // MFMAs per SIMD
-            printf("%-58s %s  %7.1f TFLOP/s  %6.1f ns/MFMA/SIMD (%.1f clk at 2.4 GHz)\n", name, zero ? "zeros " : "random",
+            printf("%-58s %s  %7.1f TFLOP/s  %6.1f ns/MFMA/SIMD (%.1f clk at 2.4 GHz)\n", name, zero == 0 ? "random" : zero == 1 ? "zeros " : zero == 2 ? "7 bits" : zero == 3 ? "5 bits" : "3 bits",
                    flops / (best * 1e-3) / 1e12, best * 1e6 / per_simd, best * 1e6 / per_simd * 2.4);
         };
         run(k<256, 8, 0>, 256, "1 wave/SIMD, 8 acc (128 regs), no barrier");

@@ -306,8 +306,8 @@ def main():
         f16x3 = eng.cfg.encoder == "f16x3"
         peak = F32_MFMA_PEAK_TFLOPS if eng.cfg.encoder == "f32" else F16_MFMA_PEAK_TFLOPS
         kernel_name = {"f16x3": "encode_f16x3_kernel<EPI_TOPK,32,3> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)",
-                       "bf16": "encode_f16x3_kernel<EPI_TOPK,32,1> (v_mfma_f32_32x32x16_bf16)",
-                       "f16r": "encode_f16x3_kernel<EPI_TOPK,32,2> (v_mfma_f32_32x32x16_f16 first pass; exact fp32 refinement in select)",
+                       "bf16": "encode_m16_kernel<1> (v_mfma_f32_16x16x32_bf16; k > 32: encode_f16x3_kernel<EPI_TOPK,64,1>)",
+                       "f16r": "encode_m16_kernel<2> (v_mfma_f32_16x16x32_f16 first pass; exact fp32 refinement in select)",
                        "f32": "encode_gemm_kernel<EPI_TOPK> (v_mfma_f32_32x32x2_f32)"}[eng.cfg.encoder]
         dtype_name = {"f16x3": "f32 (encoder products as 3 x f16 MFMA on fp16 hi/lo splits, fp32 accumulate; all else fp32)",
                       "bf16": "bf16 encoder operands, fp32 accumulate; all else fp32 (NOT the headline precision)",
@@ -325,7 +325,7 @@ def main():
             tfile = ROOT / "profiles" / "r01_g_encoder_traffic.json"
         # what a register-resident loop of the same MFMA sustains on random fp16 operands (tools/ubench/mfma_issue.hip,
         # profiles/r02_mfma_issue.txt): the matrix pipes are clock-limited by power on real data
-        roof["power_limited_mfma_ceiling_tflops"] = 1690.0
+        roof["power_limited_mfma_ceiling_tflops"] = 1930.0 if eng.cfg.encoder in ("f16r", "bf16") else 1690.0  # 16x16x32 / 32x32x16
         if tfile is not None and B == BATCH and tfile.exists():
             tj = json.loads(tfile.read_text())
             roof["traffic"] = tj["traffic_bytes_per_launch"]

@@ -22,4 +22,6 @@ for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     torch.cuda.synchronize()
     ts.append(eng.encoder_ms())
 ts = ts[4:]
+st = eng.read_stats()
+print("cand_max", st.cand_max, "overflow rows", st.n_overflow_rows, "dense route", st.dense_route)
 print("encoder ms:", " ".join(f"{t:.3f}" for t in ts[:8]), " median %.3f min %.3f" % (sorted(ts)[len(ts) // 2], min(ts)))

@@ -1137,6 +1137,9 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
         HIPCHK(c, hipEventSynchronize(c->dead_ev[s0 % DEAD_RING]));
         const volatile DeadRecord* r = c->rec_host + s0 % DEAD_RING;
         if (r->step == s0 && c->tokens_seen - r->cum_tokens <= r->horizon_tokens && r->n_near <= small_max) {
+            // nobody was within reach of the threshold then: nothing can be dead now, the auxiliary term is exactly zero
+            // and its dozen count-predicated launches (each ~5 us of an empty grid) are not enqueued at all
+            if (r->n_near == 0) return SAEV_OK;
             c->aux_route = AUX_SMALL_DEVICE;
             return auxk_small_forward(c, s);
         }

@@ -609,9 +609,10 @@ def test_steady_state_needs_no_readback_of_n_dead(n_dead):
             # (an Adam update of a gradient element near eps = 1e-8 magnifies its last-bit differences: isolated elements)
             bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6)
             assert bad.float().mean() <= 1e-4, f"step {i} {key}: {bad.sum().item()} of {bad.numel()} elements off"
-    # steps 1-4 have no record of their own tracker yet (the host wrote it): exact read-backs; from step 5 on none
+    # steps 1-4 have no record of their own tracker yet (the host wrote it): exact read-backs; from step 5 on none (and
+    # with nobody near the threshold in the record, no AuxK launch at all: route 0)
     first = 2 if n_dead else 0
-    assert routes == [first] * 4 + [1] * 5, routes
+    assert routes == [first] * 4 + [1 if n_dead else 0] * 5, routes
     assert eng.dead_readbacks() == 4
 
 
@@ -649,8 +650,9 @@ def test_growing_dead_set_switches_to_the_dense_route_in_time():
             torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6, msg=lambda m: f"step {i} {key}: {m}")
     assert deads == [0] * 5 + [60] * 4, deads
     # steps 1-4: read-backs (no record yet, nothing dead); step 5: the record of step 1 has nobody within four steps of
-    # the threshold -> no read-back; step 6 on: the record of step 2 counts the 60 as near-dead -> read-back -> dense
-    assert routes == [0, 0, 0, 0, 1, 3, 3, 3, 3], routes
+    # the threshold -> no read-back, no AuxK launch; step 6 on: the record of step 2 counts the 60 as near-dead ->
+    # read-back -> dense
+    assert routes == [0, 0, 0, 0, 0, 3, 3, 3, 3], routes
 
 
 def test_failed_bound_prediction_is_caught_and_repeated(encoder_mode):

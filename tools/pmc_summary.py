@@ -47,7 +47,9 @@ def main():
     ]
     for k, f, w in rows[:26]:
         lines.append(f"{k[:66]:66s} {f:10.0f} {2 * f * 1024 / 1e6:12.1f} {w * 1024 / 1e6:10.1f}")
-    enc = next((k for k in fetch if "encode_f16x3_kernel" in k and "1, 32, 2" in k.replace("ELi", ", ")), None)
+    enc = next((k for k in fetch if "encode_m16_kernel" in k), None)  # the shipped f16r / bf16 first pass
+    if enc is None:
+        enc = next((k for k in fetch if "encode_f16x3_kernel" in k and "1, 32, 2" in k.replace("ELi", ", ")), None)
     if enc is None:
         enc = next((k for k in fetch if "encode_f16x3_kernel" in k), None)
     if enc is not None:
@@ -67,7 +69,7 @@ def main():
                 lines.append(f"  SQ_VALU_MFMA_BUSY_CYCLES {mf:.3e} -> MFMA pipe busy {100 * mf / (gui / 8 * 1024):.1f} % of SIMD cycles")
         json.dump({
             "source": f"profiles/{tag}_pmc.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes)",
-            "kernel": "encode_f16x3_kernel<EPI_TOPK,32,2>", "encoder": "f16r",
+            "kernel": "encode_m16_kernel<2>" if "m16" in enc else "encode_f16x3_kernel<EPI_TOPK,32,2>", "encoder": "f16r",
             "fetch_size_kb_reported": f, "write_size_kb_reported": w,
             "traffic_bytes_per_launch": 2 * f * 1024 + w * 1024,
             "note": "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; WRITE_SIZE as reported",

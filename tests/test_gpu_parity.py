@@ -767,3 +767,30 @@ def test_teacher_forced_matryoshka_steps_match_oracle(tag):
                 assert bad.float().mean() <= 1e-4, f"step {i} {key}: {bad.sum().item()} of {bad.numel()} elements off"
         lr = sched.step()
     assert flips <= 3 and dead_max > 0 and routes & {1, 2, 3}, (flips, dead_max, routes)
+
+
+def test_32x32_first_pass_kernel_still_selectable():
+    """SAEV_AMD_ENC_MFMA=32 brings the 32x32x16 first-pass kernel back (the A/B switch of the 16x16x32 one; read once per
+    process, hence the subprocess): same codes as the default kernel on the same input."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import torch, math, sys\n"
+        "from saev_amd.engine import EngineConfig, SaeEngine\n"
+        "d, s, k, b = 256, 4096, 16, 700\n"
+        "eng = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, max_batch=b, k_aux=0, encoder='f16r'))\n"
+        "g = torch.Generator(device='cuda').manual_seed(3)\n"
+        "W = (torch.rand(s, d, device='cuda', generator=g) * 2 - 1) * math.sqrt(6.0 / d)\n"
+        "eng.view('W_dec').copy_(W); eng.view('W_enc').copy_(W.t())\n"
+        "x = torch.randn(b, d, device='cuda', generator=g)\n"
+        "idx, val = eng.encode_topk(x)\n"
+        "torch.save((idx.cpu(), val.cpu()), sys.argv[1])\n")
+    outs = []
+    for shape in ("16", "32"):
+        path = f"/tmp/saev_amd_mfma{shape}.pt"
+        env = dict(os.environ, SAEV_AMD_ENC_MFMA=shape, PYTHONPATH=os.pathsep.join(sys.path))
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+        outs.append(torch.load(path))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -675,7 +675,7 @@ __device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int AR, int EMIT = 1>
+template <int AR>
 __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     HSmem& sm = *reinterpret_cast<HSmem*>(smem_raw);
@@ -903,65 +903,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
         // atomic, issued by the kg = 0 lane as soon as that row block's count is known, so the first three round trips
         // overlap the counting of the following blocks.
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        if constexpr (EMIT == 0) {
-        int npass[4], pos[4], rowtot[4], base[4];
-        float tau4[4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            const int b = b0 + wb * 64 + jb * 16 + l15;
-            float tau = fmaxf(key2f(sm.tau_key[wb * 64 + jb * 16 + l15]), -3.0e38f);
-            if (a.row_margin != nullptr) tau -= (b < B) ? a.row_margin[b] : 0.f;
-            tau4[jb] = tau;
-            int n = 0;
-#pragma unroll
-            for (int sb = 0; sb < 8; ++sb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) n += (acc[sb][jb][e] >= tau) ? 1 : 0;
-            n = (b < B) ? n : 0;
-            npass[jb] = n;
-            const u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)n, (unsigned)n, false, false);  // {even, odd row} of my row pair
-            const unsigned pair = r[0] + r[1];
-            const u32x2 q = __builtin_amdgcn_permlane32_swap(pair, pair, false, false);                // {rows 0+1, rows 2+3}
-            rowtot[jb] = (int)(q[0] + q[1]);
-            pos[jb] = (int)(((kg & 1) ? r[0] : 0u) + ((kg & 2) ? q[0] : 0u));  // lanes of the row before this one
-            base[jb] = 0;
-            if (kg == 0 && rowtot[jb] > 0) base[jb] = atomicAdd(&a.cand_cnt[b], rowtot[jb]);
-        }
-        // wait for the counters once, here: otherwise every conditionally executed store block below gets its own
-        // s_waitcnt vmcnt(0), which also serialises the stores
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" : "+v"(base[0]), "+v"(base[1]), "+v"(base[2]), "+v"(base[3]));
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            // kg = 0 lanes -> all four lanes of the row
-            const u32x2 h = __builtin_amdgcn_permlane32_swap((unsigned)base[jb], (unsigned)base[jb], false, false);
-            const u32x2 f = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);
-            const int row_base = (int)f[0];
-            // a row whose list would overflow is not written at all: its counter already says so, and the step then
-            // re-runs on the exact dense route (overflow_check)
-            if (npass[jb] > 0 && row_base + rowtot[jb] <= a.cand_cap) {
-                const int bl_ = wb * 64 + jb * 16 + l15;
-                const float tau = tau4[jb];
-                uint32_t off = ((uint32_t)(b0 + bl_) * (uint32_t)a.cand_stride + (uint32_t)(row_base + pos[jb])) * 4u;
-#pragma unroll
-                for (int sb = 0; sb < 8; ++sb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[sb][jb][e];
-                        if (v >= tau) {
-                            *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;
-                            *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = s0 + ws * 128 + sb * 16 + 4 * kg + e;
-                            off += 4u;
-                        }
-                    }
-            }
-        }
-        } else {
-        // EMIT == 1.  About one value in 70 passes, so a per-value store block (compare, exec mask, branch, two stores)
+        // About one value in 70 passes, so a per-value store block (compare, exec mask, branch, two stores)
         // finds some lane of the wave active at nearly every one of a lane's 128 positions and the wave pays for all of
-        // them: 0.175 of this kernel's 1.18 ms.  Here the compare pass leaves a 32-bit hit mask per lane and row block
+        // them: 0.175 of this kernel's 1.18 ms (the first version of this kernel).  Here the compare pass leaves a 32-bit hit mask per lane and row block
         // instead of a count (same two instructions per value: v_cmp + v_addc "m = 2m + hit"); the lanes that have a hit
-        // park the block's 32 values in LDS (the tile scratch, 128 B per lane, chunks XOR-swizzled) and walk their own
+        // park the block's 32 values in LDS (the tile scratch, 8 KB per wave) and walk their own
         // mask: leading-zero count -> value index -> ds_read -> two stores.  The wave loops as often as its busiest lane has
         // hits (three or four times), not 32 times.
         uint32_t hit[4];
@@ -990,8 +936,8 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(base[0]), "+v"(base[1]), "+v"(base[2]), "+v"(base[3]));
-        float* const park = reinterpret_cast<float*>(&sm.e32.slots32[0][0][0]) + wid * 2048 + lane * 32;  // 8 KB per wave
-        const int l7 = lane & 7;
+        // 8 KB per wave, [quad sb][lane][4]: a parked quad is one ds_write_b128 at an immediate offset, conflict-free
+        float* const park = reinterpret_cast<float*>(&sm.e32.slots32[0][0][0]) + wid * 2048 + lane * 4;
         const int lat0 = s0 + ws * 128 + 4 * kg;
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
@@ -1003,7 +949,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
             if (__ballot(mm != 0u) == 0ull) continue;
             if (mm != 0u) {
 #pragma unroll
-                for (int sb = 0; sb < 8; ++sb) *reinterpret_cast<f32x4*>(park + 4 * (sb ^ l7)) = acc[sb][jb];
+                for (int sb = 0; sb < 8; ++sb) *reinterpret_cast<f32x4*>(park + 256 * sb) = acc[sb][jb];
             }
             uint32_t off = ((uint32_t)(b0 + wb * 64 + jb * 16 + l15) * (uint32_t)a.cand_stride + (uint32_t)(row_base + pos[jb])) * 4u;
             int i0 = 0;
@@ -1013,12 +959,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
                 mm = (mm << p) << 1;
                 i0 = i + 1;
                 const int c = i >> 2, e = i & 3;
-                const float v = park[4 * (c ^ l7) + e];
+                const float v = park[256 * c + e];
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;
                 *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = lat0 + 16 * c + e;
                 off += 4u;
             }
-        }
         }
         if (!prefetched && st + 1 < st_end) {  // (never: kept for symmetry with encode_f16x3_kernel)
             __syncthreads();
@@ -1035,16 +980,12 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
     dim3 grid(n_bblocks * a.s_splits, (epi == EPI_DENSE && a.n_batches > 1) ? a.n_batches : 1), block(HTHREADS);
     const size_t smem = sizeof(HSmem);
     static bool attr_set = false;
-    static bool use_m16 = true, use_emit0 = false;
+    static bool use_m16 = true;
     if (!attr_set) {
         const char* shape = getenv("SAEV_AMD_ENC_MFMA");
         use_m16 = !(shape != nullptr && atoi(shape) == 32);
 
-        const char* emit = getenv("SAEV_AMD_ENC_EMIT");
-        use_emit0 = emit != nullptr && atoi(emit) == 0;
-        const void* fns[16] = {reinterpret_cast<const void*>(&encode_m16_kernel<1, 0>),
-                              reinterpret_cast<const void*>(&encode_m16_kernel<2, 0>),
-                              reinterpret_cast<const void*>(&encode_m16_kernel<1>),
+        const void* fns[14] = {reinterpret_cast<const void*>(&encode_m16_kernel<1>),
                               reinterpret_cast<const void*>(&encode_m16_kernel<2>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 0, true>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 1, true>),
@@ -1078,10 +1019,7 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
         else hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 0, true>), grid, block, smem, stream, a);
     } else if (a.ngroups <= 32 && a.arith != 0 && use_m16) {
         // single-product modes: the 16x16x32 kernel (SAEV_AMD_ENC_MFMA=32 brings the 32x32x16 one back for A/B runs)
-        if (use_emit0) {
-            if (a.arith == 1) hipLaunchKernelGGL((encode_m16_kernel<1, 0>), grid, block, smem, stream, a);
-            else hipLaunchKernelGGL((encode_m16_kernel<2, 0>), grid, block, smem, stream, a);
-        } else if (a.arith == 1) hipLaunchKernelGGL((encode_m16_kernel<1>), grid, block, smem, stream, a);
+        if (a.arith == 1) hipLaunchKernelGGL((encode_m16_kernel<1>), grid, block, smem, stream, a);
         else hipLaunchKernelGGL((encode_m16_kernel<2>), grid, block, smem, stream, a);
     } else if (a.ngroups <= 32) LAUNCH_AR(EPI_TOPK, 32);
     else LAUNCH_AR(EPI_TOPK, 64);

@@ -69,16 +69,22 @@ def patched(text: str) -> str:
         "                                    s0 + ws * 128 + sb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);\n#endif\n")
     # NOATOM (16x16x32 kernel): list space is not reserved (no global atomic; positions are made up)
     sub("            if (kg == 0 && rowtot[jb] > 0) base[jb] = atomicAdd(&a.cand_cnt[b], rowtot[jb]);",
-        "#ifdef ABL_NOATOM\n            base[jb] = tile_no * 24;\n#else\n            if (kg == 0 && rowtot[jb] > 0) base[jb] = atomicAdd(&a.cand_cnt[b], rowtot[jb]);\n#endif")
-    # NOEPI16 / NOSTORE16: the 16x16x32 kernel without its epilogue / without the candidate stores
+        "#ifdef ABL_NOATOM\n            base[jb] = tile_no * 24;\n#else\n            if (kg == 0 && rowtot[jb] > 0) base[jb] = atomicAdd(&a.cand_cnt[b],  rowtot[jb]);\n#endif")
+    # NOST: the mask walk runs (park, ds_read, index arithmetic) but nothing is stored to the lists
+    sub("                *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;\n"
+        "                *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = lat0 + 16 * c + e;\n",
+        "#ifdef ABL_NOST\n                asm volatile(\"\" :: \"v\"(v), \"v\"(lat0 + 16 * c + e), \"v\"(off));\n#else\n"
+        "                *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;\n"
+        "                *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = lat0 + 16 * c + e;\n#endif\n")
+    # NOEMIT: hit masks are formed and space is reserved, nothing is parked or stored
+    sub("            uint32_t mm = (row_base + rowtot[jb] <= a.cand_cap) ? hit[jb] : 0u;",
+        "#ifdef ABL_NOEMIT\n            uint32_t mm = (sm.tau_key[1] == 777777 && row_base + rowtot[jb] <= a.cand_cap) ? hit[jb] : 0u;\n#else\n"
+        "            uint32_t mm = (row_base + rowtot[jb] <= a.cand_cap) ? hit[jb] : 0u;\n#endif")
+    # NOEPI16: the 16x16x32 kernel without its epilogue (NOST / NOEMIT below: without the list stores / the whole mask walk)
     sub("        // lane owns batch rows bl(jb) = wb*64 + jb*16 + l15; latent of acc[sb][jb][e]: sl = ws*128 + sb*16 + 4*kg + e\n",
         "#ifdef ABL_NOEPI16\n        { float chk = 0.f;\n          for (int sb = 0; sb < 8; ++sb) for (int jb = 0; jb < 4; ++jb) for (int e = 0; e < 4; ++e) chk += acc[sb][jb][e];\n"
         "          if (chk == 12345.f) a.cand_cnt[0] = 1; }\n        if (sm.tau_key[1] == 777777)\n#endif\n        {\n")
     sub("        if (!prefetched && st + 1 < st_end) {  // (never", "        }\n        if (!prefetched && st + 1 < st_end) {  // (never")
-    sub("                            *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = s0 + ws * 128 + sb * 16 + 4 * kg + e;\n",
-        "#ifndef ABL_NOSTORE16\n                            *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = s0 + ws * 128 + sb * 16 + 4 * kg + e;\n#endif\n")
-    sub("                        if (v >= tau) {\n                            *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;\n#ifndef ABL_NOSTORE16",
-        "                        if (v >= tau) {\n#ifndef ABL_NOSTORE16\n                            *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;\n#endif\n#ifndef ABL_NOSTORE16")
     sub("            int npass[2], pos[2];\n",
         "#ifdef ABL_NOCAND\n            if (sm.tau_key[0] == 12345) a.cand_cnt[0] = (int)acc[0][0][0] + (int)acc[1][1][1] + (int)acc[2][0][2] + (int)acc[3][1][3];\n"
         "            if (sm.tau_key[1] != 777777) goto tile_done;\n#endif\n            int npass[2], pos[2];\n")

@@ -64,6 +64,9 @@ struct saev_ctx {
     int2* pairs = nullptr;
     float* colsum_partials = nullptr;
     double *sumsq_partials = nullptr, *sumsq_total = nullptr;
+    // squares of the W_enc gradient, taken by the transpose that ends the backward: valid until the gradient buffer may
+    // have been touched from outside (wenc_sq_valid), used by the tail only inside saev_train_step (wenc_sq_trusted)
+    bool wenc_sq_valid = false, wenc_sq_trusted = false;
     int64_t* toks = nullptr;
     int32_t *fired = nullptr, *dead = nullptr;
     int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use [6,7,8] dead_update scratch
@@ -277,7 +280,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(chunk_starts, S + 1); A(part_starts, S); A(work_latent, c->max_work);
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part);
     A(colsum_partials, ((MB + 63) / 64) * D);
-    A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8); A(sumsq_total, 1);
+    A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32 || KA > 0) {  // (the f32 encoder needs the image geometry for AuxK only)
         c->Dp = (int)((D + 31) / 32 * 32);
         c->S_pad = (int)((S + 255) / 256 * 256);
@@ -1224,7 +1227,10 @@ int saev_bind_w_enc_t(saev_ctx* c, float* scratch) {
 int saev_backward_end(saev_ctx* c, void* stream) {
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, c->grads, SAEV_NOT_BOUND, "gradient buffer not bound");
-    HIPCHK(c, launch_transpose(c->dW_encT, c->grads + c->off_W_enc, c->cfg.d_sae, c->cfg.d_model, (hipStream_t)stream));
+    // (the per-tile squares land behind the tail's other partial sums: [2 nb + ceil(S / 4), ...))
+    double* sq = c->sumsq_partials + 2 * sumsq_blocks() + (c->cfg.d_sae + 3) / 4;
+    HIPCHK(c, launch_transpose(c->dW_encT, c->grads + c->off_W_enc, c->cfg.d_sae, c->cfg.d_model, (hipStream_t)stream, sq));
+    c->wenc_sq_valid = true;
     return SAEV_OK;
 }
 
@@ -1282,6 +1288,15 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
                          c->cfg.remove_parallel_grads ? 1 : 0));
     const long rest_lo = std::max(r.a_lo, S * D);
     HIPCHK(c, launch_sumsq_partials(c->grads + rest_lo, std::max(0L, r.a_hi - rest_lo), part, s));
+    // encoder half: inside saev_train_step nothing has touched the gradient since the backward's transpose left the
+    // squares of dW_enc tile by tile -- only b_enc's remain to be summed (one pass over 128 MB less)
+    const bool fused = c->wenc_sq_trusted && c->wenc_sq_valid && shard_rank < 0 && n_rows == (int)S;
+    c->wenc_sq_valid = false;
+    if (fused) {
+        HIPCHK(c, launch_sumsq_partials(c->grads + c->off_b_enc, S, part + nb, s));
+        HIPCHK(c, launch_sumsq_final(part, 2 * nb + (n_rows + 3) / 4 + transpose_blocks((int)S, (int)D), saev_sumsq_device(c), s));
+        return SAEV_OK;
+    }
     HIPCHK(c, launch_sumsq_partials(c->grads + r.b_lo, r.b_hi - r.b_lo, part + nb, s));
     HIPCHK(c, launch_sumsq_final(part, 2 * nb + (n_rows + 3) / 4, saev_sumsq_device(c), s));
     return SAEV_OK;
@@ -1329,7 +1344,10 @@ int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_
     if (rc != SAEV_OK) return rc;
     rc = saev_step_backward(c, stream);
     if (rc != SAEV_OK) return rc;
-    return saev_step_tail(c, lr, max_norm, 1.0f, adam_step, stream);
+    c->wenc_sq_trusted = true;
+    rc = saev_step_tail(c, lr, max_norm, 1.0f, adam_step, stream);
+    c->wenc_sq_trusted = false;
+    return rc;
 }
 
 }  // extern "C"

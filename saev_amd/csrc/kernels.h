@@ -182,7 +182,9 @@ struct DwRowsArgs {
                                   // final range by range)
 };
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream);
-hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream);
+// sq_part: optional, transpose_blocks(S, D) doubles = per-tile sums of squares of `in`
+hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part = nullptr);
+int transpose_blocks(int S, int D);
 
 // out[d] (+)= sum_b m[b][d]; `partials` holds ceil(n_rows/64) * D floats.  k_dev: optional device count -- nothing runs
 // when it is <= 0, and with col_mult > 0 only the first *k_dev * col_mult columns are summed (the rest is not touched)

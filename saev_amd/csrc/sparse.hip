@@ -596,20 +596,30 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
 }
 
 // out (D, S) = in (S, D)^T, 64 x 64 tiles through LDS (padded: conflict-free both ways)
+// sq_part (optional): one double per block = the sum of squares of its tile, block (x, y) at [y * gridDim.x + x] -- the
+// clip norm's share of this matrix without another pass over it
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int S,
-                                                        int D) {
+                                                        int D, double* __restrict__ sq_part) {
     // 64 x 64 tile; both sides move 16 bytes per lane (S % 4 == 0 and D % 4 == 0)
     __shared__ float tile[64][65];
+    __shared__ double sh[4];
     const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
     const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
     for (int r = r0; r < 64; r += 16) {
         const int s = s0 + r, d = d0 + c4;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (s < S && d < D) v = *reinterpret_cast<const f32x4*>(in + (size_t)s * D + d);
         tile[r][c4] = v[0]; tile[r][c4 + 1] = v[1]; tile[r][c4 + 2] = v[2]; tile[r][c4 + 3] = v[3];
+        q0 += v[0] * v[0]; q1 += v[1] * v[1]; q2 += v[2] * v[2]; q3 += v[3] * v[3];
+    }
+    if (sq_part != nullptr) {
+        const double q = wave_sum_d((double)q0 + (double)q1 + (double)q2 + (double)q3);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = q;
     }
     __syncthreads();
+    if (sq_part != nullptr && threadIdx.x == 0) sq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 #pragma unroll
     for (int r = r0; r < 64; r += 16) {
         const int d = d0 + r, s = s0 + c4;
@@ -738,10 +748,11 @@ hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream)
         hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.lat_hi - a.lat_lo + 3) / 4), dim3(256), 0, stream, a);
     });
 }
-hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((S + 63) / 64, (D + 63) / 64), dim3(256), 0, stream, in, out, S, D);
+hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((S + 63) / 64, (D + 63) / 64), dim3(256), 0, stream, in, out, S, D, sq_part);
     return hipGetLastError();
 }
+int transpose_blocks(int S, int D) { return ((S + 63) / 64) * ((D + 63) / 64); }
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
                          const int32_t* k_dev, hipStream_t stream, long row_stride, float out_scale, int col_mult) {
     const int nb = (n_rows + 63) / 64;

@@ -223,7 +223,17 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
             int c = 0;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(key[e] >= trial));
-            if (c >= k) t = trial;
+            if (c == k) {
+                // exactly k keys reach the trial value: they are the top k, and the k-th largest is the smallest of them --
+                // no need to resolve the remaining bits (on real lists this happens about half way down)
+                uint32_t m = 0xffffffffu;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) m = min(m, key[e] >= trial ? key[e] : 0xffffffffu);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+                return m;
+            }
+            if (c > k) t = trial;
         }
         return t;
     };

@@ -794,3 +794,29 @@ def test_32x32_first_pass_kernel_still_selectable():
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
         outs.append(torch.load(path))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fused_train_step_and_phase_by_phase_agree(encoder_mode):
+    """saev_train_step takes the squares of dW_enc from the transpose that ends the backward; the phase-by-phase entry
+    points (what a data-parallel caller uses, with its exchange between backward and tail) re-read the gradient.  Same
+    clip norm to fp32 rounding, same parameters, step after step -- with the clip active (max_norm below the norm)."""
+    d, s, k, n = 128, 1024, 8, 300
+    p = rand_params(d, s, seed=120)
+    gen = torch.Generator().manual_seed(121)
+    a = make_engine(d, s, k, k_aux=0, max_batch=n, encoder=encoder_mode)
+    b = make_engine(d, s, k, k_aux=0, max_batch=n, encoder=encoder_mode)
+    a.load_params(p)
+    b.load_params(p)
+    for i in range(4):
+        x = torch.randn(n, d, generator=gen).cuda()
+        a.train_step(x, 1e-3, 0.05)
+        b.step_forward(x, training=True, n_rows_global=n)
+        b.step_dead(n)
+        b.step_backward()
+        b.step_tail(1e-3, 0.05)
+        sa, sb = a.read_stats(), b.read_stats()
+        assert sa.grad_norm > 0.05, "the clip is meant to be active"
+        assert math.isclose(sa.grad_norm, sb.grad_norm, rel_tol=2e-6), (i, sa.grad_norm, sb.grad_norm)
+        assert math.isclose(sa.mse, sb.mse, rel_tol=1e-6)
+        for key in R.PARAM_ORDER:
+            torch.testing.assert_close(a.view(key), b.view(key), rtol=1e-5, atol=1e-7, msg=lambda m: f"step {i} {key}: {m}")

@@ -752,8 +752,12 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
         __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
         if (nks > 2) stage_kstep(2, s0, kmap(2));
 
-        for (int t = 0; t < nks; ++t) {
-            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));
+        // one k-step; WAIT = loads that may stay in flight behind the one the next step needs (8: the steady state, this
+        // step staged k-step t + 3; 4 and 0: the ring runs empty at the end of the tile).  Three instantiations instead of a
+        // branch chain per step.
+        auto kstep = [&](int t, auto WAIT_) {
+            constexpr int WAIT = decltype(WAIT_)::value;
+            if constexpr (WAIT == 8) stage_kstep((t + 3) & 3, s0, kmap(t + 3));
             const KSlot& cs = sm.slot[t & 3];
             // 8 groups of 4 MFMAs (latent block sb); the A fragment of group sb + 2 is requested after the first MFMA of
             // group sb
@@ -777,10 +781,16 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
                 __builtin_amdgcn_sched_barrier(0);
             });
             __builtin_amdgcn_s_setprio(0);
-            if (t + 3 < nks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (t + 2 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (WAIT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        };
+        {
+            int t = 0;
+            for (; t + 3 < nks; ++t) kstep(t, std::integral_constant<int, 8>());
+            if (t + 2 < nks) { kstep(t, std::integral_constant<int, 4>()); ++t; }
+            for (; t < nks; ++t) kstep(t, std::integral_constant<int, 0>());
         }
         const bool prefetched = st + 1 < st_end;
         if (prefetched) {

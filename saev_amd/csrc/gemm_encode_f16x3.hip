@@ -715,19 +715,26 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
     const int rot = (bb & 7) % nks;  // see encode_f16x3_kernel
     auto kmap = [&](int t) { const int k = t + rot; return k >= nks ? k - nks : k; };
 
-    const uint32_t g_off = (uint32_t)(wid * 2048 + lane * 16);
     const size_t img = (size_t)256 * 32;  // halfs per image
     const int blk_imgs = a.blk_imgs > 0 ? a.blk_imgs : nks;
     const _Float16* x_imgs = a.xs + (size_t)bb * blk_imgs * img;
+    // Staging in its "uniform base + 32-bit lane offset" form, written out: what hipcc makes of the builtin is a 64-bit
+    // VALU add per request (four per k-step, in the middle of the MFMA stream).  Wave w copies bytes [2 KB * w, + 2 KB)
+    // of each 16 KB image with two 1 KB requests; the instruction offset moves the global and the LDS address alike, so
+    // the second request of an image needs no address of its own.
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)&sm.slot[0].a[wid * 32][0];
     auto stage_kstep = [&](int slot, int s0, int ks) {
-        KSlot& st = sm.slot[slot];
-        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * blk_imgs + ks) * img) + g_off;
-        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + g_off;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            glds16h(wsrc + 1024 * j, &st.a[wid * 32 + 16 * j][0]);
-            glds16h(xsrc + 1024 * j, &st.b[wid * 32 + 16 * j][0]);
-        }
+        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * blk_imgs + ks) * img) + wid * 2048;
+        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + wid * 2048;
+        const uint32_t lds_a = lds_w + (uint32_t)slot * (uint32_t)sizeof(KSlot);
+        asm volatile(
+            "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+            "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
+            ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(wsrc), "s"(xsrc)
+            : "memory", "m0");
     };
 
     const int arow0 = ws * 128 + l15;  // + 16 * sb
@@ -755,10 +762,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
         // one k-step; WAIT = loads that may stay in flight behind the one the next step needs (8: the steady state, this
         // step staged k-step t + 3; 4 and 0: the ring runs empty at the end of the tile).  Three instantiations instead of a
         // branch chain per step.
-        auto kstep = [&](int t, auto WAIT_) {
+        auto kstep = [&](int t, auto WAIT_, auto SLOT_) {
             constexpr int WAIT = decltype(WAIT_)::value;
-            if constexpr (WAIT == 8) stage_kstep((t + 3) & 3, s0, kmap(t + 3));
-            const KSlot& cs = sm.slot[t & 3];
+            constexpr int SLOT = decltype(SLOT_)::value;  // t & 3, or -1: not known at compile time
+            if constexpr (WAIT == 8) stage_kstep(SLOT >= 0 ? (SLOT + 3) & 3 : (t + 3) & 3, s0, kmap(t + 3));
+            const KSlot& cs = sm.slot[SLOT >= 0 ? SLOT : t & 3];
             // 8 groups of 4 MFMAs (latent block sb); the A fragment of group sb + 2 is requested after the first MFMA of
             // group sb
             half8 fa[3], fb[4];
@@ -787,10 +795,20 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
             __builtin_amdgcn_s_barrier();
         };
         {
+            // the steady state four steps at a time: the ring slot of every step is a constant, so the fragment reads and
+            // the staging destinations are immediate offsets from loop-invariant bases
+            using IC8 = std::integral_constant<int, 8>;
+            using NOSLOT = std::integral_constant<int, -1>;
             int t = 0;
-            for (; t + 3 < nks; ++t) kstep(t, std::integral_constant<int, 8>());
-            if (t + 2 < nks) { kstep(t, std::integral_constant<int, 4>()); ++t; }
-            for (; t < nks; ++t) kstep(t, std::integral_constant<int, 0>());
+            for (; t + 6 < nks; t += 4) {
+                kstep(t, IC8(), std::integral_constant<int, 0>());
+                kstep(t + 1, IC8(), std::integral_constant<int, 1>());
+                kstep(t + 2, IC8(), std::integral_constant<int, 2>());
+                kstep(t + 3, IC8(), std::integral_constant<int, 3>());
+            }
+            for (; t + 3 < nks; ++t) kstep(t, IC8(), NOSLOT());
+            if (t + 2 < nks) { kstep(t, std::integral_constant<int, 4>(), NOSLOT()); ++t; }
+            for (; t < nks; ++t) kstep(t, std::integral_constant<int, 0>(), NOSLOT());
         }
         const bool prefetched = st + 1 < st_end;
         if (prefetched) {

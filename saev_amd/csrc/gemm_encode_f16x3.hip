@@ -70,11 +70,6 @@ __device__ __forceinline__ f32x16 mfma1(half8 a, half8 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void glds16h(const char* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // AR = 0: the split-fp16 scheme above (three products).  AR = 1 / 2: single product on bf16 / fp16 operands: the same
 // 16 KB images hold 32 consecutive k of the rounded x / W^T per row, chunk pairs (0,1) and (2,3) feed two
 // v_mfma_f32_32x32x16_{bf16,f16} per block, fp32 accumulate; everything after the contraction is identical.  AR = 2
@@ -130,20 +125,24 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     auto kmap = [&](int t) { const int k = t + rot; return k >= nks ? k - nks : k; };
 
     // a slot image is 16 KB per operand; wave w copies bytes [2 KB * w, +2 KB) of each with two 1 KB calls
-    const uint32_t g_off = (uint32_t)(wid * 2048 + lane * 16);
     const size_t img = (size_t)256 * 32;  // halfs per image
     const int blk_imgs = a.blk_imgs > 0 ? a.blk_imgs : nks;  // images per row block in memory
     const int k_first = (EPI == EPI_DENSE) ? (int)blockIdx.y * nks : 0;  // contraction slice of this batch
     const _Float16* x_imgs = a.xs + ((size_t)bb * blk_imgs + k_first) * img;
+    // (staging written out as "uniform base + 32-bit lane offset" global_load_lds: see encode_m16_kernel)
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)&sm.slot[0].a[wid * 32][0];
     auto stage_kstep = [&](int slot, int s0, int ks) {
-        KSlot& st = sm.slot[slot];
-        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * blk_imgs + k_first + ks) * img) + g_off;
-        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + g_off;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            glds16h(wsrc + 1024 * j, &st.a[wid * 32 + 16 * j][0]);
-            glds16h(xsrc + 1024 * j, &st.b[wid * 32 + 16 * j][0]);
-        }
+        const char* wsrc = reinterpret_cast<const char*>(a.ws + ((size_t)(s0 / HTS) * blk_imgs + k_first + ks) * img) + wid * 2048;
+        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + wid * 2048;
+        const uint32_t lds_a = lds_w + (uint32_t)slot * (uint32_t)sizeof(KSlot);
+        asm volatile(
+            "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+            "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
+            ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(wsrc), "s"(xsrc)
+            : "memory", "m0");
     };
 
     // fragment rows of this lane and their chunk swizzles
@@ -172,11 +171,17 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
         // (latents past d_sae get a bias of -inf: their pre-activation is -inf without a select per accumulator; the dense
         // epilogue never stores them)
         if (tid < HTS) bias_t[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : NEG_INF;
-        __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
+        // k-steps 0,1 must have landed in every wave (the staging is inline asm: the compiler does not know of these loads
+        // and would only wait in the waves that also loaded a bias value)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // bias visible
         if (nks > 2) stage_kstep(2, s0, kmap(2));
 
-        for (int t = 0; t < nks; ++t) {
-            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));
+        // one k-step; WAIT = loads that may stay in flight behind the one the next step needs (8: steady state, this step
+        // staged k-step t + 3; 4 and 0: the ring runs empty at the end of the tile): three instantiations, no branch chain
+        auto kstep = [&](int t, auto WAIT_) {
+            constexpr int WAIT = decltype(WAIT_)::value;
+            if constexpr (WAIT == 8) stage_kstep((t + 3) & 3, s0, kmap(t + 3));
             const KSlot& cs = sm.slot[t & 3];
             // 4 groups of 6 MFMAs (latent block sb).  The fragments of group sb+1 are requested right after the
             // first MFMA of group sb, so their LDS latency hides behind the other five.
@@ -223,10 +228,16 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             __builtin_amdgcn_s_setprio(0);
             // k-step t+1 must have landed (this wave's part) before the barrier publishes it; newer requests
             // (t+2, t+3: 4 loads each) stay in flight.  Raw barrier: __syncthreads() would drain the queue.
-            if (t + 3 < nks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (t + 2 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (WAIT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        };
+        {
+            int t = 0;
+            for (; t + 3 < nks; ++t) kstep(t, std::integral_constant<int, 8>());
+            if (t + 2 < nks) { kstep(t, std::integral_constant<int, 4>()); ++t; }
+            for (; t < nks; ++t) kstep(t, std::integral_constant<int, 0>());
         }
         // all slots are free.  Request the next tile's first two k-steps so they land during the epilogue
         // (the NG == 32 scratch only uses slots 2,3).
@@ -756,7 +767,10 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
 
         float* const bias_t = sm.bias[st & 1];
         if (tid < HTS) bias_t[tid] = (s0 + tid < S) ? a.b_enc[s0 + tid] : NEG_INF;
-        __syncthreads();  // (drains the queue) k-steps 0,1 have landed; bias visible
+        // k-steps 0,1 must have landed in every wave (the staging is inline asm: the compiler does not know of these loads
+        // and would only wait in the waves that also loaded a bias value)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // bias visible
         if (nks > 2) stage_kstep(2, s0, kmap(2));
 
         // one k-step; WAIT = loads that may stay in flight behind the one the next step needs (8: the steady state, this

@@ -772,6 +772,24 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // bias visible
         if (nks > 2) stage_kstep(2, s0, kmap(2));
+        // the in-loop staging walks the images of this tile by a running byte offset (k index (t + 3 + rot) mod nks) from two
+        // uniform bases: two scalar add-with-carry per request pair instead of the whole index arithmetic
+        const char* const w_tile = reinterpret_cast<const char*>(a.ws + (size_t)(s0 / HTS) * blk_imgs * img) + wid * 2048;
+        const char* const x_blk = reinterpret_cast<const char*>(x_imgs) + wid * 2048;
+        const uint32_t run_bytes = (uint32_t)nks * (uint32_t)(img * sizeof(_Float16));
+        uint32_t koff = (uint32_t)kmap(nks > 3 ? 3 : 0) * (uint32_t)(img * sizeof(_Float16));
+        auto stage_next = [&](int slot) {
+            const uint32_t lds_a = lds_w + (uint32_t)slot * (uint32_t)sizeof(KSlot);
+            asm volatile(
+                "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
+                ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(w_tile + koff), "s"(x_blk + koff)
+                : "memory", "m0");
+            koff += (uint32_t)(img * sizeof(_Float16));
+            koff = koff == run_bytes ? 0u : koff;
+        };
 
         // one k-step; WAIT = loads that may stay in flight behind the one the next step needs (8: the steady state, this
         // step staged k-step t + 3; 4 and 0: the ring runs empty at the end of the tile).  Three instantiations instead of a
@@ -779,7 +797,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
         auto kstep = [&](int t, auto WAIT_, auto SLOT_) {
             constexpr int WAIT = decltype(WAIT_)::value;
             constexpr int SLOT = decltype(SLOT_)::value;  // t & 3, or -1: not known at compile time
-            if constexpr (WAIT == 8) stage_kstep(SLOT >= 0 ? (SLOT + 3) & 3 : (t + 3) & 3, s0, kmap(t + 3));
+            if constexpr (WAIT == 8) stage_next(SLOT >= 0 ? (SLOT + 3) & 3 : (t + 3) & 3);
             const KSlot& cs = sm.slot[SLOT >= 0 ? SLOT : t & 3];
             // 8 groups of 4 MFMAs (latent block sb); the A fragment of group sb + 2 is requested after the first MFMA of
             // group sb

@@ -22,8 +22,8 @@ def patched(text: str) -> str:
         assert old in text, old[:60]
         text = text.replace(old, new, 1)
 
-    sub("            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));",
-        "#ifndef ABL_NOSTAGE\n            if (t + 3 < nks) stage_kstep((t + 3) & 3, s0, kmap(t + 3));\n#endif")
+    sub("            if constexpr (WAIT == 8) stage_kstep((t + 3) & 3, s0, kmap(t + 3));",
+        "#ifndef ABL_NOSTAGE\n            if constexpr (WAIT == 8) stage_kstep((t + 3) & 3, s0, kmap(t + 3));\n#endif")
     sub("        const float unscale = a.scale_dev != nullptr",
         "        bool skip_epi = false;\n        const float unscale = a.scale_dev != nullptr")
     # NOLDS: fragments come from registers instead of LDS

@@ -76,6 +76,11 @@ def patched(text: str) -> str:
         "#ifdef ABL_NOST\n                asm volatile(\"\" :: \"v\"(v), \"v\"(lat0 + 16 * c + e), \"v\"(off));\n#else\n"
         "                *reinterpret_cast<float*>(reinterpret_cast<char*>(a.cand_val) + off) = v;\n"
         "                *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = lat0 + 16 * c + e;\n#endif\n")
+    # SLEEP1 / SLEEP2: ~1 / ~2 us of s_sleep after the candidate stores of every tile -- if the kernel does not get slower by
+    # 32 x that, the time was already being spent waiting for the stores' acknowledgements
+    sub("        if (!prefetched && st + 1 < st_end) {  // (never",
+        "#ifdef ABL_SLEEP1\n        __builtin_amdgcn_s_sleep(30);\n#endif\n#ifdef ABL_SLEEP2\n        __builtin_amdgcn_s_sleep(60);\n#endif\n"
+        "        if (!prefetched && st + 1 < st_end) {  // (never")
     # NOEMIT: hit masks are formed and space is reserved, nothing is parked or stored
     sub("            uint32_t mm = (row_base + rowtot[jb] <= a.cand_cap) ? hit[jb] : 0u;",
         "#ifdef ABL_NOEMIT\n            uint32_t mm = (sm.tau_key[1] == 777777 && row_base + rowtot[jb] <= a.cand_cap) ? hit[jb] : 0u;\n#else\n"

@@ -306,7 +306,7 @@ def main():
         f16x3 = eng.cfg.encoder == "f16x3"
         peak = F32_MFMA_PEAK_TFLOPS if eng.cfg.encoder == "f32" else F16_MFMA_PEAK_TFLOPS
         kernel_name = {"f16x3": "encode_f16x3_kernel<EPI_TOPK,32,3> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)",
-                       "bf16": "encode_m16_kernel<1> (v_mfma_f32_16x16x32_bf16; k > 32: encode_f16x3_kernel<EPI_TOPK,64,1>)",
+                       "bf16": "encode_m16_kernel<1> (v_mfma_f32_16x16x32_bf16)",
                        "f16r": "encode_m16_kernel<2> (v_mfma_f32_16x16x32_f16 first pass; exact fp32 refinement in select)",
                        "f32": "encode_gemm_kernel<EPI_TOPK> (v_mfma_f32_32x32x2_f32)"}[eng.cfg.encoder]
         dtype_name = {"f16x3": "f32 (encoder products as 3 x f16 MFMA on fp16 hi/lo splits, fp32 accumulate; all else fp32)",

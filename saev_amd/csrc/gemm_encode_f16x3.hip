@@ -668,7 +668,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
 
 
 // -------------------------------------------------------------------------------------------------------------------------
-// The single-product TopK kernel (AR = 1 bf16 / AR = 2 fp16 first pass; 32 groups, guaranteed bounds) on
+// The single-product TopK kernel (AR = 1 bf16 / AR = 2 fp16 first pass; 32 or 64 groups, guaranteed bounds) on
 // v_mfma_f32_16x16x32_{bf16,f16} instead of 32x32x16.  Same tile, ring, staging, images and LDS bytes per k-step (twelve
 // ds_read_b128 per wave); the instruction has a quarter of the accumulator registers per flop to read and write back, and
 // on real operands the matrix pipes -- which are clock-limited by power, not by issue -- sustain 1.93 PFLOP/s with it
@@ -686,7 +686,7 @@ __device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int AR>
+template <int AR, int NG = 32>
 __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     HSmem& sm = *reinterpret_cast<HSmem*>(smem_raw);
@@ -866,7 +866,97 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
                 acc[sb][jb] = f32x4{lo[0], lo[1], hi[0], hi[1]};
             }
         }
-        if (refresh) {
+        if constexpr (NG == 64) {
+            // 64 groups (top_k up to 64): bound = top_k-th largest of the 64 merged group maxima, as in encode_f16x3_kernel's
+            // 64-group variant -- the same LDS words (two 16-bit keys each) and the same bound phase; only who supplies
+            // which word differs.  Group of a latent: its position modulo 64 = (sb & 3) * 16 + 4 * kg + e; word = group / 2.
+            if (refresh) {
+                typedef short short2v __attribute__((ext_vector_type(2)));
+                const int trow = wid * 32 + (lane & 31);
+                const int tpart = lane >> 5;
+                const int tb = b0 + trow;
+                const bool share = tb < B;
+                const uint32_t boff = (uint32_t)tb * 4u;
+                // (group bases are wave-uniform -> SGPR pairs; the lane's half and row go into one 32-bit offset)
+                const uint32_t voff = ((uint32_t)(32 * tpart) * (uint32_t)a.gmax_stride + (uint32_t)min(tb, B - 1)) * 4u;
+                // (the empty asm makes each group's element offset an opaque uniform value: otherwise the compiler sees an
+                // arithmetic progression, turns the 32 addresses into 64-bit VGPR pairs, hoists them out of the tile loop and
+                // spills them; like this every access is "SGPR base + 32-bit lane offset")
+#define GPTR(i)                                                                          \
+    ({                                                                                   \
+        size_t go_ = (size_t)(i) * (size_t)a.gmax_stride;                                \
+        asm("" : "+s"(go_));                                                             \
+        reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + go_) + voff);        \
+    })
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int bl_ = wb * 64 + jb * 16 + l15;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float m0 = fmaxf(acc[q][jb][2 * h], acc[q + 4][jb][2 * h]);
+                            const float m1 = fmaxf(acc[q][jb][2 * h + 1], acc[q + 4][jb][2 * h + 1]);
+                            sm.e32.slots32[ws][q * 8 + 2 * kg + h][bl_] =
+                                (int32_t)__builtin_amdgcn_perm((uint32_t)f2key(m1), (uint32_t)f2key(m0), 0x07060302u);  // {hi16(m1), hi16(m0)}
+                        }
+                }
+                __syncthreads();
+                {
+                    int32_t old[32];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {  // all global reads of this lane in flight together
+                        old[i] = __hip_atomic_load(GPTR(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (row clamped)
+                    }
+                    short2v mp[16];  // merged maxima, two 16-bit keys per register
+                    uint32_t improved = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int gp = 16 * tpart + j;
+                        const short2v w0 = __builtin_bit_cast(short2v, sm.e32.slots32[0][gp][trow]);
+                        const short2v w1 = __builtin_bit_cast(short2v, sm.e32.slots32[1][gp][trow]);
+                        const short2v wm = __builtin_elementwise_max(w0, w1);
+                        // the published halves of the two groups, packed like the tile's own
+                        const short2v o = __builtin_bit_cast(
+                            short2v, __builtin_amdgcn_perm((uint32_t)old[2 * j + 1], (uint32_t)old[2 * j], 0x07060302u));
+                        mp[j] = __builtin_elementwise_max(wm, o);
+                        improved |= __builtin_bit_cast(uint32_t, mp[j]) ^ __builtin_bit_cast(uint32_t, o);
+                    }
+                    if (share && improved != 0) {  // publish what this tile raised (late tiles: rarely anything)
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int32_t a0 = (int32_t)mp[j][0], a1 = (int32_t)mp[j][1];
+                            if (a0 > (old[2 * j] >> 16)) atomicMax(GPTR(2 * j), a0 << 16);
+                            if (a1 > (old[2 * j + 1] >> 16)) atomicMax(GPTR(2 * j + 1), a1 << 16);
+                        }
+                    }
+                    short2v mn = mp[0], mx = mp[0];
+#pragma unroll
+                    for (int j = 1; j < 16; ++j) { mn = __builtin_elementwise_min(mn, mp[j]); mx = __builtin_elementwise_max(mx, mp[j]); }
+                    int32_t lo = min((int32_t)mn[0], (int32_t)mn[1]), hi = max((int32_t)mx[0], (int32_t)mx[1]);
+                    lo = min(lo, __shfl_xor(lo, 32, 64));
+                    hi = max(hi, __shfl_xor(hi, 32, 64));
+                    // largest key T (to the resolution of four halvings of [lo, hi]) with at least top_k of the 64 maxima
+                    // >= T; lo always satisfies it (all 64 are >= the minimum, and top_k <= 64)
+                    const int K = a.top_k;
+#pragma unroll 1
+                    for (int it = 0; it < 4 && lo < hi && K < 64; ++it) {  // (K = 64: the minimum is the answer)
+                        const int32_t mid = lo + ((hi - lo + 1) >> 1);
+                        const short2v midp = {(short)mid, (short)mid};
+                        uint32_t lt = 0;  // packed counters of (m < mid): low half / high half of the words
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            lt += (__builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mp[j], midp)) >> 15) & 0x00010001u;
+                        int c = 32 - (int)((lt & 0xffffu) + (lt >> 16));
+                        c += __shfl_xor(c, 32, 64);
+                        if (c >= K) lo = mid; else hi = mid - 1;
+                    }
+                    if (tpart == 0) sm.tau_key[trow] = (int32_t)((uint32_t)lo << 16);
+                }
+#undef GPTR
+                __syncthreads();
+            }
+        } else if (refresh) {
             // group maxima of this tile: group = (sb & 1) * 16 + 4 * kg + e
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
@@ -911,7 +1001,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
             }
             __syncthreads();
         }
-        if (st == st_begin && a.top_k <= HTS / 4) {
+        if (NG == 32 && st == st_begin && a.top_k <= HTS / 4) {
             // first tile: the largest of three thresholds between the group bound and the row maximum that top_k values of
             // this tile reach (see encode_f16x3_kernel)
             if (tid < HTB) { sm.ref[0][tid] = INT32_MIN; sm.ref[1][tid] = 0; sm.ref[2][tid] = 0; sm.ref[3][tid] = 0; }
@@ -1045,8 +1135,10 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
         const char* shape = getenv("SAEV_AMD_ENC_MFMA");
         use_m16 = !(shape != nullptr && atoi(shape) == 32);
 
-        const void* fns[14] = {reinterpret_cast<const void*>(&encode_m16_kernel<1>),
+        const void* fns[16] = {reinterpret_cast<const void*>(&encode_m16_kernel<1>),
                               reinterpret_cast<const void*>(&encode_m16_kernel<2>),
+                              reinterpret_cast<const void*>(&encode_m16_kernel<1, 64>),
+                              reinterpret_cast<const void*>(&encode_m16_kernel<2, 64>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 0, true>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 1, true>),
                               reinterpret_cast<const void*>(&encode_f16x3_kernel<EPI_TOPK, 32, 2, true>),
@@ -1082,6 +1174,10 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
         if (a.arith == 1) hipLaunchKernelGGL((encode_m16_kernel<1>), grid, block, smem, stream, a);
         else hipLaunchKernelGGL((encode_m16_kernel<2>), grid, block, smem, stream, a);
     } else if (a.ngroups <= 32) LAUNCH_AR(EPI_TOPK, 32);
+    else if (a.arith != 0 && use_m16) {
+        if (a.arith == 1) hipLaunchKernelGGL((encode_m16_kernel<1, 64>), grid, block, smem, stream, a);
+        else hipLaunchKernelGGL((encode_m16_kernel<2, 64>), grid, block, smem, stream, a);
+    }
     else LAUNCH_AR(EPI_TOPK, 64);
 #undef LAUNCH_AR
 #undef LAUNCH_ENC

@@ -807,7 +807,6 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
             for (int jb = 0; jb < 4; ++jb) fb[jb] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 16 * jb][coff]);
             load_a(0, 0);
             load_a(1, 1);
-            __builtin_amdgcn_s_setprio(1);
             static_for<8>([&](auto G) {
                 constexpr int sb = decltype(G)::value;
                 constexpr int as = sb % 3;
@@ -820,7 +819,6 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
                 acc[sb][3] = mfma16<AR>(fa[as], fb[3], acc[sb][3]);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            __builtin_amdgcn_s_setprio(0);
             if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (WAIT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

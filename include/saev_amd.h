@@ -219,6 +219,12 @@ int saev_step_backward(saev_ctx* ctx, void* stream);
  * uses it as W_enc^T scratch during the forward. */
 int saev_backward_begin(saev_ctx* ctx, void* stream);
 int saev_backward_rows(saev_ctx* ctx, int32_t lat_lo, int32_t lat_hi, void* stream);
+/* The same in two passes over the latents' (row, latent) pairs: part 1 forms the decoder gradient (rows of dL/dx_hat) and
+ * keeps the per-pair dot products, part 2 the encoder gradient and db_enc (rows of x).  part 0 = saev_backward_rows.  A
+ * data-parallel caller runs part 1, starts the exchange of the decoder half [W_dec | b_dec] -- final at that point -- and
+ * lets it travel while part 2 and saev_backward_end run.  Both parts must cover the same latent ranges before
+ * saev_backward_end. */
+int saev_backward_rows_part(saev_ctx* ctx, int32_t lat_lo, int32_t lat_hi, int32_t part, void* stream);
 int saev_backward_end(saev_ctx* ctx, void* stream);
 float* saev_grad_w_enc_t(saev_ctx* ctx);
 int saev_bind_w_enc_t(saev_ctx* ctx, float* scratch);

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "saev_step_backward": (C.c_int, [P, P]),
     "saev_backward_begin": (C.c_int, [P, P]),
     "saev_backward_rows": (C.c_int, [P, C.c_int32, C.c_int32, P]),
+    "saev_backward_rows_part": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, P]),
     "saev_backward_end": (C.c_int, [P, P]),
     "saev_grad_w_enc_t": (P, [P]),
     "saev_bind_w_enc_t": (C.c_int, [P, P]),

@@ -354,7 +354,8 @@ __global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
 __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl, int nd, int D, const float* dWd,
                                                                const float* dWe, const float* dbe, float* gW_dec,
                                                                float* gW_encT, float* gb_enc, int lat_lo, int lat_hi,
-                                                               const int32_t* nd_dev) {
+                                                               const int32_t* nd_dev, int part) {
+    // part: 0 = all three gradients; 1 = the decoder rows only; 2 = the encoder rows and bias only (saev_backward_rows_part)
     if (nd_dev != nullptr) nd = min(nd, *nd_dev);
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -366,10 +367,10 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
     f32x4* oa = reinterpret_cast<f32x4*>(gW_dec + (size_t)i * D);
     f32x4* oe = reinterpret_cast<f32x4*>(gW_encT + (size_t)i * D);
     for (int q = lane; q < (D >> 2); q += 64) {
-        oa[q] = oa[q] + a[q];
-        oe[q] = oe[q] + e[q];
+        if (part != 2) oa[q] = oa[q] + a[q];
+        if (part != 1) oe[q] = oe[q] + e[q];
     }
-    if (lane == 0) gb_enc[i] += dbe[j];
+    if (lane == 0 && part != 1) gb_enc[i] += dbe[j];
 }
 
 int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
@@ -457,9 +458,9 @@ hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStre
 }
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
-                                   const int32_t* nd_dev) {
+                                   const int32_t* nd_dev, int part) {
     if (nd <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_add_dead_kernel, dim3((nd + 3) / 4), dim3(256), 0, s, dl, nd, D, dWd, dWe, dbe, gW_dec,
-                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev);
+                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev, part);
     return hipGetLastError();
 }

@@ -63,6 +63,7 @@ struct saev_ctx {
     int32_t *counts = nullptr, *starts = nullptr;
     int2* pairs = nullptr;
     float* colsum_partials = nullptr;
+    float* dval_pairs = nullptr;  // <g row, W_dec[latent]> per (row, latent) pair in CSC order (saev_backward_rows_part 1 -> 2)
     double *sumsq_partials = nullptr, *sumsq_total = nullptr;
     // squares of the W_enc gradient, taken by the transpose that ends the backward: valid until the gradient buffer may
     // have been touched from outside (wenc_sq_valid), used by the tail only inside saev_train_step (wenc_sq_trusted)
@@ -271,7 +272,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(bitmap, S * c->bitmap_words);
     A(grp_prefix, S * (c->bitmap_words / 8));
     A(scan_totals, ((S + 1023) / 1024) * 3);
-    A(counts, S); A(starts, S + 1); A(pairs, MB * K);
+    A(counts, S); A(starts, S + 1); A(pairs, MB * K); A(dval_pairs, MB * (size_t)cfg->top_k);
     {
         const long max_pairs = MB * K;
         c->max_work = (int)(S + (max_pairs + DW_CHUNK - 1) / DW_CHUNK);
@@ -1188,7 +1189,12 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
 }
 
 int saev_backward_rows(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, void* stream) {
+    return saev_backward_rows_part(c, lat_lo, lat_hi, 0, stream);
+}
+
+int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t part, void* stream) {
     if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, part >= 0 && part <= 2, SAEV_INVALID_ARG, "saev_backward_rows_part: part must be 0 (both), 1 (decoder) or 2 (encoder)");
     REQUIRE(c, c->x_last && c->training_last && c->grads, SAEV_INVALID_ARG, "saev_backward_rows: call saev_backward_begin first");
     const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
     REQUIRE(c, 0 <= lat_lo && lat_lo < lat_hi && lat_hi <= S, SAEV_INVALID_ARG, "saev_backward_rows: bad latent range");
@@ -1204,15 +1210,16 @@ int saev_backward_rows(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, void* stream
     a.dW_dec = c->grads + c->off_W_dec; a.dW_encT = c->dW_encT; a.db_enc = c->grads + c->off_b_enc;
     a.partials = c->partials; a.db_partials = c->db_partials;
     a.lat_lo = lat_lo; a.lat_hi = lat_hi;
+    a.part = part; a.dval = c->dval_pairs;
     // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
     const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
     HIPCHK(c, launch_dw_rows(a, max_work, s));
     if (c->aux_route == AUX_DENSE)
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
-                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s));
+                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, nullptr, part));
     else if (c->aux_route != AUX_NONE)  // few dead latents: the device knows how many
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
-                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4));
+                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part));
     return SAEV_OK;
 }
 

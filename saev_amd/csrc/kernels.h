@@ -180,6 +180,8 @@ struct DwRowsArgs {
     float* db_partials;           // (max_part)
     int lat_lo, lat_hi;           // only latents in [lat_lo, lat_hi) are processed (data-parallel overlap: rows become
                                   // final range by range)
+    int part;                     // 0: both gradients; 1: dW_dec only (dval stored); 2: dW_encT + db_enc only (dval loaded)
+    float* dval;                  // (n_rows * k) dot products <g row, W_dec[latent]> in pair order (part 1 -> part 2)
 };
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream);
 // sq_part: optional, transpose_blocks(S, D) doubles = per-tile sums of squares of `in`
@@ -342,4 +344,4 @@ hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStre
 // nd rows are scattered; with nd_dev the count is *nd_dev (<= nd, which then only sizes the grid)
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
-                                   const int32_t* nd_dev = nullptr);
+                                   const int32_t* nd_dev = nullptr, int part = 0);

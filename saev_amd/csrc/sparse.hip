@@ -440,21 +440,28 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
         for (int n = 0; n < NV; ++n) {
             accd[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             acce[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[n] = (a.part != 2 && lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};  // (pass 2 has dval already)
         }
     }
     int my_b = 0;
-    float my_v = 0.f;
+    float my_v = 0.f, my_dv = 0.f;
     const int cnt = end - beg;  // 0..64
+    // a.part: 0 = both gradients in one pass; 1 = the decoder's only (g rows; the dot products dval go to a.dval);
+    // 2 = the encoder's only (x rows, weighted with the stored dval).  Two passes move the same bytes as one; a
+    // data-parallel caller starts exchanging the decoder half while the second pass runs (framework/ddp.py).
+    const int part = a.part;
     if (lane < cnt) {
         const int2 pr = a.pairs[beg + lane];
         my_b = pr.x;
         my_v = a.val[pr.y];
+        if (part == 2) my_dv = a.dval[beg + lane];
     }
     float dbs = 0.f;  // sum of dval over this chunk (wave-uniform)
     for (int j0 = 0; j0 < cnt; j0 += 8) {
         // (1) eight rows of g: dW_dec accumulation + per-lane shares of the eight dot products
         float p[8];
+        float r = 0.f;
+        if (part != 2) {
 #pragma unroll
         for (int t = 0; t < 8; t += 2) {
             p[t] = 0.f; p[t + 1] = 0.f;
@@ -481,13 +488,19 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
             }
             if (!two) p[t + 1] = 0.f;
         }
-        const float r = wave_reduce_scatter<8>(p, lane);  // lane l holds the dot product of entry j0 + ((l >> 3) & 7)
+        r = wave_reduce_scatter<8>(p, lane);  // lane l holds the dot product of entry j0 + ((l >> 3) & 7)
+        if (part == 1) {
+            if ((lane & 7) == 0 && j0 + (lane >> 3) < cnt) a.dval[beg + j0 + (lane >> 3)] = r;
+            continue;
+        }
+        }
         // (2) the same eight rows of x, weighted with the dot products just formed
 #pragma unroll
         for (int t = 0; t < 8; t += 2) {
             if (j0 + t >= cnt) continue;
             const bool two = j0 + t + 1 < cnt;
-            const float e0 = __shfl(r, t << 3, 64), e1 = two ? __shfl(r, (t + 1) << 3, 64) : 0.f;
+            const float e0 = part == 2 ? __shfl(my_dv, j0 + t, 64) : __shfl(r, t << 3, 64);
+            const float e1 = !two ? 0.f : part == 2 ? __shfl(my_dv, min(j0 + t + 1, 63), 64) : __shfl(r, (t + 1) << 3, 64);
             dbs += e0 + e1;
             const int b0 = __shfl(my_b, j0 + t, 64), b1 = __shfl(my_b, min(j0 + t + 1, 63), 64);
             const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);
@@ -523,11 +536,11 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
         if (q < D4) {
             f32x4* pd = reinterpret_cast<f32x4*>(od) + q;
             f32x4* pe = reinterpret_cast<f32x4*>(oe) + q;
-            if (direct && a.accumulate) { *pd = *pd + accd[n]; *pe = *pe + acce[n]; }
-            else { *pd = accd[n]; *pe = acce[n]; }
+            if (part != 2) { if (direct && a.accumulate) *pd = *pd + accd[n]; else *pd = accd[n]; }
+            if (part != 1) { if (direct && a.accumulate) *pe = *pe + acce[n]; else *pe = acce[n]; }
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && part != 1) {
         if (direct) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
         else a.db_partials[a.part_starts[i] + c] = dbs;
     }
@@ -584,15 +597,16 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
     }
     f32x4* od = reinterpret_cast<f32x4*>(a.dW_dec + (size_t)i * D);
     f32x4* oe = reinterpret_cast<f32x4*>(a.dW_encT + (size_t)i * D);
+    // (a.part = 1 / 2: only the decoder / the encoder rows of this pass are valid in the partial slots and are written)
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int q = lane + 64 * n;
         if (q < D4) {
-            if (a.accumulate) { od[q] = od[q] + accd[n]; oe[q] = oe[q] + acce[n]; }
-            else { od[q] = accd[n]; oe[q] = acce[n]; }
+            if (a.part != 2) od[q] = a.accumulate ? od[q] + accd[n] : accd[n];
+            if (a.part != 1) oe[q] = a.accumulate ? oe[q] + acce[n] : acce[n];
         }
     }
-    if (lane == 0) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
+    if (lane == 0 && a.part != 1) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
 }
 
 // out (D, S) = in (S, D)^T, 64 x 64 tiles through LDS (padded: conflict-free both ways)

@@ -270,8 +270,10 @@ class SaeEngine:
     def backward_begin(self):
         self._chk(self.lib.saev_backward_begin(self.ctx, _stream()), "saev_backward_begin")
 
-    def backward_rows(self, lo: int, hi: int):
-        self._chk(self.lib.saev_backward_rows(self.ctx, lo, hi, _stream()), "saev_backward_rows")
+    def backward_rows(self, lo: int, hi: int, part: int = 0):
+        """Gradient rows of the latents [lo, hi).  part 0: both matrices in one pass; 1: the decoder's only (after it the
+        decoder half of the gradient -- W_dec and b_dec -- is final); 2: the encoder's (needs part 1 first)."""
+        self._chk(self.lib.saev_backward_rows_part(self.ctx, lo, hi, part, _stream()), "saev_backward_rows_part")
 
     def backward_end(self):
         self._chk(self.lib.saev_backward_end(self.ctx, _stream()), "saev_backward_end")

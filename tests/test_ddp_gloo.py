@@ -103,11 +103,13 @@ class OracleEngine:
                    for k in R.PARAM_ORDER}
         self.view("b_dec").copy_(self._g["b_dec"])
 
-    def backward_rows(self, lo, hi):
-        self.calls.append(f"rows[{lo}:{hi}]")
-        self.view("W_dec")[lo:hi] = self._g["W_dec"][lo:hi]
-        self.grad_w_enc_t()[lo:hi] = self._g["W_enc"].T[lo:hi]
-        self.view("b_enc")[lo:hi] = self._g["b_enc"][lo:hi]
+    def backward_rows(self, lo, hi, part=0):
+        self.calls.append(f"rows[{lo}:{hi}]" + (f"/{part}" if part else ""))
+        if part != 2:
+            self.view("W_dec")[lo:hi] = self._g["W_dec"][lo:hi]
+        if part != 1:
+            self.grad_w_enc_t()[lo:hi] = self._g["W_enc"].T[lo:hi]
+            self.view("b_enc")[lo:hi] = self._g["b_enc"][lo:hi]
 
     def backward_end(self):
         self.calls.append("backward_end")
@@ -195,7 +197,9 @@ def _worker(rank, world, port, out, overlap=False, tail="replicated"):
             assert eng.calls[:7] == ["forward", "dead", "backward_begin", "rows[0:85]", "rows[85:170]", "rows[170:256]",
                                      "backward_end"] and eng.calls[7] == "tail"
         elif tail == "sharded":
-            assert eng.calls[:5] == ["forward", "dead", "backward", "prepare[0]", "apply[0]"] and "tail" not in eng.calls
+            # (backward in two passes: the decoder half is exchanged while the encoder pass runs)
+            assert eng.calls[:8] == ["forward", "dead", "backward_begin", "rows[0:256]/1", "rows[0:256]/2", "backward_end",
+                                     "prepare[0]", "apply[0]"] and "tail" not in eng.calls
         else:
             assert eng.calls[:4] == ["forward", "dead", "backward", "tail"]
     # padding of a sharded layout stays zero

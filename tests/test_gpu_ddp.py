@@ -212,3 +212,41 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
     for k in R.PARAM_ORDER:
         bad = ~torch.isclose(eng.view(k).cpu(), r0["params"][k], rtol=2e-4, atol=2e-6)
         assert bad.float().mean() <= 1e-4, f"{k}: {bad.sum().item()} of {bad.numel()} elements off"
+
+
+@pytest.mark.parametrize("n_dead", [0, 5, 80])
+def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead):
+    """saev_backward_rows_part: decoder pass (dval kept per pair), then encoder pass = the one-pass backward, bit for bit --
+    with no dead latents, a few (the count-predicated AuxK kernels) and many (dense AuxK route)."""
+    import sae_ref as R
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    d, s, k, n, thr = 256, 2048, 16, 700, 1000
+    g = torch.Generator().manual_seed(50 + n_dead)
+    p = R.init_params(R.RefConfig(d_model=d, d_sae=s), g)
+    p["b_enc"] = 0.05 * torch.randn(s, generator=g)
+    toks = torch.zeros(s, dtype=torch.int64)
+    dead = torch.randperm(s, generator=g)[:n_dead]
+    toks[dead] = thr
+    p["b_enc"][dead] = -100.0
+    x = (torch.randn(n, d, generator=g) + torch.randn(d, generator=g)).cuda()
+    grads = []
+    for two_pass in (False, True):
+        eng = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, k_aux=64, dead_threshold_tokens=thr, max_batch=n))
+        eng.load_params(p)
+        eng.set_tracker(toks)
+        eng.step_forward(x, training=True, n_rows_global=n)
+        eng.step_dead(n)
+        if two_pass:
+            eng.backward_begin()
+            eng.backward_rows(0, s, 1)
+            dec_after_pass_1 = eng.halves(eng.grads)[0].clone()
+            eng.backward_rows(0, s, 2)
+            eng.backward_end()
+            assert torch.equal(dec_after_pass_1, eng.halves(eng.grads)[0]), "the decoder half must be final after pass 1"
+        else:
+            eng.step_backward()
+        assert eng.read_stats().n_dead == n_dead
+        grads.append(eng.grads.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert grads[0].abs().sum() > 0

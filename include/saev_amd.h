@@ -250,6 +250,10 @@ int saev_bind_sumsq(saev_ctx* ctx, double* sumsq);
  * renormalises W_dec there instead of at its top -- for a caller whose decoder half of the parameter all-gather is
  * still running on another stream.  NULL cancels. */
 int saev_wdec_ready_event(saev_ctx* ctx, void* event);
+/* One-shot, the encoder half's counterpart: the next forward (saev_step_forward / saev_encode_topk) enqueues what depends
+ * on the batch alone -- statistics, centring, fp16 images of x -- and waits for this hipEvent_t only before it first reads
+ * W_enc or b_enc.  NULL cancels. */
+int saev_wenc_ready_event(saev_ctx* ctx, void* event);
 
 /* Phases 1-4 back to back for the single-GPU case. */
 int saev_train_step(saev_ctx* ctx, const float* x, int32_t n_rows, float lr, float max_norm,

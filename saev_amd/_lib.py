@@ -83,6 +83,7 @@ _SIGNATURES = {
     "saev_sumsq_device": (P, [P]),
     "saev_bind_sumsq": (C.c_int, [P, P]),
     "saev_wdec_ready_event": (C.c_int, [P, P]),
+    "saev_wenc_ready_event": (C.c_int, [P, P]),
     "saev_train_step": (C.c_int, [P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
     "saev_last_idx": (P, [P]),
     "saev_last_val": (P, [P]),

@@ -45,6 +45,7 @@ struct saev_ctx {
     long chunk_a = 0, chunk_b = 0;  // floats per rank of the [W_dec | b_dec] half and of the [W_enc | b_enc] half
     double* sumsq_bound = nullptr;  // caller-owned replacement of sumsq_total (so that a collective can reach it)
     hipEvent_t wdec_ready = nullptr;  // one-shot: the next forward waits for it before it touches W_dec
+    hipEvent_t wenc_ready = nullptr;  // one-shot: ... before it touches W_enc / b_enc (the x-only preparation runs ahead of it)
     // scratch
     std::vector<void*> allocs;
     int cuts_last[MAX_PREFIXES] = {0};  // the cut points the forward in flight used (the backward must see the same)
@@ -533,6 +534,17 @@ static bool bind_x_sources(saev_ctx* c, const float* x, int n, bool allow_borrow
     return borrow;
 }
 
+// saev_wenc_ready_event: the encoder half of the parameters may still be arriving on another stream; everything that
+// depends on x alone has been enqueued by the time this is called
+static int wait_wenc(saev_ctx* c, hipStream_t s) {
+    if (c->wenc_ready != nullptr) {
+        hipEvent_t ev = c->wenc_ready;
+        c->wenc_ready = nullptr;
+        HIPCHK(c, hipStreamWaitEvent(s, ev, 0));
+    }
+    return SAEV_OK;
+}
+
 // operand preparation for the f16 encoders: x and W_enc^T rewritten as fp16 / bf16 images (no-op for the f32 encoder).
 // `xmax_dev` = device scalar max|x| when the caller has it already (the step computes it for the MSE), else NULL.
 static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag, hipStream_t s,
@@ -546,6 +558,7 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // comes from the previous step's largest column norm; f16r_check sends the step down the dense route if the
         // current parameters do not fit that scale.  Only the first use needs a pass of its own for the norm.
         if (!c->wmax_known) {
+            { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }
             HIPCHK(c, launch_transpose(c->params + c->off_W_enc, c->dW_encT, D, S, s));
             HIPCHK(c, launch_wnorm_max(c->dW_encT, S, D, c->wnorm_scratch, c->wmax_prev, s));
             c->wmax_known = true;
@@ -562,6 +575,7 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // to its own W scale)
         HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
         if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
+        { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }  // x is prepared; from here on W_enc / b_enc are read
         HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
                                   c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
@@ -571,6 +585,7 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         return SAEV_OK;
     }
     if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
+    { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }
     HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, bf ? 1.0f : 256.0f, c->ws, bf ? 1 : 0, s));
     return SAEV_OK;
 }
@@ -664,6 +679,8 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     int32_t* need_dense = c->flags + 1;
     {
         int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev, x_borrowed);
+        if (rc0 != SAEV_OK) return rc0;
+        rc0 = wait_wenc(c, s);  // (the f32 encoder has no preparation: it reads W_enc from here on)
         if (rc0 != SAEV_OK) return rc0;
     }
     if (fused_supported(c->cfg)) {
@@ -1269,6 +1286,12 @@ double* saev_sumsq_device(saev_ctx* c) { return c ? (c->sumsq_bound ? c->sumsq_b
 int saev_bind_sumsq(saev_ctx* c, double* sumsq) {
     if (!c) return SAEV_INVALID_ARG;
     c->sumsq_bound = sumsq;
+    return SAEV_OK;
+}
+
+int saev_wenc_ready_event(saev_ctx* c, void* event) {
+    if (!c) return SAEV_INVALID_ARG;
+    c->wenc_ready = (hipEvent_t)event;
     return SAEV_OK;
 }
 

@@ -302,6 +302,12 @@ class SaeEngine:
         self._chk(self.lib.saev_wdec_ready_event(self.ctx, C.c_void_p(event.cuda_event) if event is not None else None),
                   "saev_wdec_ready_event")
 
+    def wenc_ready_after(self, event: "torch.cuda.Event | None"):
+        """The next forward prepares x first and waits for ``event`` only before it reads W_enc / b_enc."""
+        self._wenc_event = event
+        self._chk(self.lib.saev_wenc_ready_event(self.ctx, C.c_void_p(event.cuda_event) if event is not None else None),
+                  "saev_wenc_ready_event")
+
     def train_step(self, x: torch.Tensor, lr: float, max_norm: float = 1.0):
         """Phases 1-4 on one GPU (reference train.py:332-460 loop body for one SAE)."""
         x = self._check_x(x)

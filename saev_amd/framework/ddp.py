@@ -99,21 +99,35 @@ class DataParallelStepper:
         eng.tail_apply(lr, max_norm, 1.0 / self.world, r)     # Adam on my chunks
         p_a, p_b = eng.halves(eng.params)
         cb = p_b.numel() // self.world
-        dist.all_gather_into_tensor(p_b, p_b[r * cb : (r + 1) * cb])  # encoder half: the next forward starts with it
         ca = p_a.numel() // self.world
         if p_a.is_cuda:
             import torch
 
+            # both gathers on a side stream: the next forward prepares its batch meanwhile and waits for the encoder half
+            # only before it reads W_enc, for the decoder half only before its decode
             if self._side is None:
                 self._side = torch.cuda.Stream(device=p_a.device)
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
+                dist.all_gather_into_tensor(p_b, p_b[r * cb : (r + 1) * cb])
+                ev_b = torch.cuda.Event()
+                ev_b.record(self._side)
                 dist.all_gather_into_tensor(p_a, p_a[r * ca : (r + 1) * ca])
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-            eng.wdec_ready_after(ev)                          # the next forward waits for it right before its decode
+                ev_a = torch.cuda.Event()
+                ev_a.record(self._side)
+            eng.wenc_ready_after(ev_b)
+            eng.wdec_ready_after(ev_a)
         else:
+            dist.all_gather_into_tensor(p_b, p_b[r * cb : (r + 1) * cb])
             dist.all_gather_into_tensor(p_a, p_a[r * ca : (r + 1) * ca])
+
+    def sync_params(self) -> None:
+        """Make the current stream wait for parameter halves still arriving on the side stream (sharded tail): call before
+        reading the parameters outside the train step -- checkpoints, evaluation, tests."""
+        if self._side is not None:
+            import torch
+
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def _exchange_overlapped(self) -> None:
         eng, dist = self.engine, self.dist

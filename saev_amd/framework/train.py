@@ -242,6 +242,8 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
             logger.info("step %d: %s", global_step, ", ".join(f"{k}: {v:.5f}" for k, v in metrics[0].items()
                                                                 if k.startswith("loss/") and isinstance(v, float)))
         global_step += 1
+    for st in steppers:
+        st.sync_params()  # (sharded tail: the last step's parameter gathers run on a side stream)
     logger.info("trained %d steps in %.1fs", global_step, time.time() - t_start)
     return saes, objs, run, global_step
 

@@ -148,6 +148,9 @@ class OracleEngine:
             R.adam_update(self.params[lo:hi], self.grads[lo:hi] * (grad_scale * coef), self.adam_m[lo:hi], self.adam_v[lo:hi],
                           self.state.adam_steps, lr)
 
+    def wenc_ready_after(self, event):
+        self.calls.append("wenc_ready_after")
+
     def wdec_ready_after(self, event):
         self.calls.append("wdec_ready_after")
 

@@ -81,6 +81,9 @@ def patched(text: str) -> str:
     sub("        if (!prefetched && st + 1 < st_end) {  // (never",
         "#ifdef ABL_SLEEP1\n        __builtin_amdgcn_s_sleep(30);\n#endif\n#ifdef ABL_SLEEP2\n        __builtin_amdgcn_s_sleep(60);\n#endif\n"
         "        if (!prefetched && st + 1 < st_end) {  // (never")
+    # NOIDX16: the mask walk stores the values only (half the list bytes): is the cost of the stores their bytes?
+    sub("                *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = lat0 + 16 * c + e;\n#endif\n",
+        "#ifndef ABL_NOIDX16\n                *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.cand_idx) + off) = lat0 + 16 * c + e;\n#endif\n#endif\n")
     # NOEMIT: hit masks are formed and space is reserved, nothing is parked or stored
     sub("            uint32_t mm = (row_base + rowtot[jb] <= a.cand_cap) ? hit[jb] : 0u;",
         "#ifdef ABL_NOEMIT\n            uint32_t mm = (sm.tau_key[1] == 777777 && row_base + rowtot[jb] <= a.cand_cap) ? hit[jb] : 0u;\n#else\n"

@@ -214,8 +214,9 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
         assert bad.float().mean() <= 1e-4, f"{k}: {bad.sum().item()} of {bad.numel()} elements off"
 
 
+@pytest.mark.parametrize("prefixes", [None, (300, 900, 2048)])
 @pytest.mark.parametrize("n_dead", [0, 5, 80])
-def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead):
+def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes):
     """saev_backward_rows_part: decoder pass (dval kept per pair), then encoder pass = the one-pass backward, bit for bit --
     with no dead latents, a few (the count-predicated AuxK kernels) and many (dense AuxK route)."""
     import sae_ref as R
@@ -235,6 +236,8 @@ def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead):
         eng = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, k_aux=64, dead_threshold_tokens=thr, max_batch=n))
         eng.load_params(p)
         eng.set_tracker(toks)
+        if prefixes is not None:  # Matryoshka: latents receive the suffix-summed gradient of their prefix block
+            eng.set_prefixes(list(prefixes))
         eng.step_forward(x, training=True, n_rows_global=n)
         eng.step_dead(n)
         if two_pass:

@@ -35,6 +35,7 @@ import dataclasses
 import io
 import json
 import math
+import os
 import pathlib
 import sys
 
@@ -45,7 +46,7 @@ HERE = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE))
 import _refshim  # noqa: E402
 
-OUT = HERE.parent / "tests" / "golden"
+OUT = pathlib.Path(os.environ["SAEV_GOLDEN_OUT"]) if os.environ.get("SAEV_GOLDEN_OUT") else HERE.parent / "tests" / "golden"
 
 
 def npz(name, **arrays):
@@ -293,6 +294,8 @@ def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm, gr
 
     sd.ShuffledDataLoader = fake_loader
     # the monitor/entropy helpers are loader-observability, not part of the path: stub to {}
+    # (both are put back after the run: g16_batch_entropy needs the real calc_batch_entropy of the same module)
+    orig_monitor, orig_entropy = T.DataloaderMonitor, T.statistics.calc_batch_entropy
     T.DataloaderMonitor = lambda dl: type("M", (), {"compute": lambda self, now=None: {}})()
     T.statistics.calc_batch_entropy = lambda *a, **kw: {}
 
@@ -315,12 +318,16 @@ def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm, gr
 
     T.make_saes = make_and_record
     torch.manual_seed(cfg.seed)
-    saes, objs, _, steps = T.train([cfg])
-    T.make_saes = orig_make
-    final = {k: v.detach().clone() for k, v in saes[0].state_dict().items()}
-    toks = objs[0].toks_since_active.clone()
-    state["which"] = "val"
-    ev = T.evaluate([cfg], saes, objs)[0]
+    try:
+        saes, objs, _, steps = T.train([cfg])
+        T.make_saes = orig_make
+        final = {k: v.detach().clone() for k, v in saes[0].state_dict().items()}
+        toks = objs[0].toks_since_active.clone()
+        state["which"] = "val"
+        ev = T.evaluate([cfg], saes, objs)[0]
+    finally:
+        T.make_saes = orig_make
+        T.DataloaderMonitor, T.statistics.calc_batch_entropy = orig_monitor, orig_entropy
 
     keys = ["loss/mse", "loss/aux", "loss/l0", "loss/l1", "loss/n_dead", "loss/loss", "metrics/grad_norm",
             "progress/learning_rate", "metrics/normalized_mse", "metrics/sse_sae", "metrics/sse_baseline",

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const int32_t* dead,
 // Wenc_dead (D, ndp) = W_enc[:, dl] (zero columns beyond nd);  Wdec_dead (ndp, D) = W_dec[dl, :] (zero rows beyond nd)
 __global__ __launch_bounds__(256) void gather_dead_kernel(const float* W_enc, const float* W_dec, const int32_t* dl,
                                                           int nd, int ndp, int D, int S, float* Wenc_dead,
-                                                          float* Wdec_dead) {
+                                                          float* Wdec_dead, const int32_t* nd_dev) {
+    if (nd_dev != nullptr) nd = min(nd, *nd_dev);  // the host sized the launch by a bound; the list holds *nd_dev entries
     const long n1 = (long)D * ndp;
     const long n2 = (long)ndp * (D >> 2);
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n1 + n2; q += (long)gridDim.x * 256) {
@@ -69,14 +70,17 @@ __global__ __launch_bounds__(256) void gather_dead_kernel(const float* W_enc, co
 }
 
 // compact bias of the dead set for the fused dense contraction: out[j] = b_enc[dl[j]], -inf on the padding columns
-__global__ void dead_bias_vec_kernel(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, float pad) {
+__global__ void dead_bias_vec_kernel(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, float pad,
+                                     const int32_t* nd_dev) {
+    if (nd_dev != nullptr) nd = min(nd, *nd_dev);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < ndp) out[j] = (j < nd) ? b_enc[dl[j]] : pad;
 }
 
 // A[b][idx] = val, mask[b][idx] = 1 for the selected codes (A and mask are zeroed by the caller)
 __global__ __launch_bounds__(256) void aux_scatter_kernel(const int32_t* idx, const float* val, long n_rows, int k,
-                                                          int stride, int ndp, float* A, uint8_t* mask) {
+                                                          int stride, int ndp, float* A, uint8_t* mask, const int32_t* k_dev) {
+    if (k_dev != nullptr) k = min(k, *k_dev);  // (0: nothing was selected, idx / val are stale)
     const long total = n_rows * k;
     for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
         const long b = p / k;
@@ -92,12 +96,20 @@ __global__ __launch_bounds__(256) void aux_scatter_kernel(const int32_t* idx, co
 // E holds A @ W_dec[dl]; in place: g_aux = gscale * (E + b_dec - (x - x_hat)); per-row sum of squared differences
 template <int NV>
 __global__ __launch_bounds__(256) void aux_resid_kernel(float* E, const float* x, const float* x_hat, const float* b_dec,
-                                                        int n_rows, int D, float gscale, RowStats* rowstats) {
+                                                        int n_rows, int D, float gscale, RowStats* rowstats,
+                                                        const int32_t* nd_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     const int D4 = D >> 2;
     f32x4* er = reinterpret_cast<f32x4*>(E + (size_t)row * D);
+    if (nd_dev != nullptr && *nd_dev <= 0) {  // sized by a bound, but nothing is dead: the auxiliary term is exactly zero (modeling.py:92-94)
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+            if (lane + 64 * n < D4) er[lane + 64 * n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane == 0) rowstats[row].aux_sse = 0.f;
+        return;
+    }
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
     const f32x4* hr = reinterpret_cast<const f32x4*>(x_hat + (size_t)row * D);
     const f32x4* br = reinterpret_cast<const f32x4*>(b_dec);
@@ -354,7 +366,8 @@ __global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
 __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl, int nd, int D, const float* dWd,
                                                                const float* dWe, const float* dbe, float* gW_dec,
                                                                float* gW_encT, float* gb_enc, int lat_lo, int lat_hi,
-                                                               const int32_t* nd_dev, int part) {
+                                                               const int32_t* nd_dev, int part, float2* row_proj,
+                                                               const float* W_dec, int project) {
     // part: 0 = all three gradients; 1 = the decoder rows only; 2 = the encoder rows and bias only (saev_backward_rows_part)
     if (nd_dev != nullptr) nd = min(nd, *nd_dev);
     const int lane = threadIdx.x & 63;
@@ -366,11 +379,33 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
     const f32x4* e = reinterpret_cast<const f32x4*>(dWe + (size_t)j * D);
     f32x4* oa = reinterpret_cast<f32x4*>(gW_dec + (size_t)i * D);
     f32x4* oe = reinterpret_cast<f32x4*>(gW_encT + (size_t)i * D);
+    float dot = 0.f, nsq = 0.f;
     for (int q = lane; q < (D >> 2); q += 64) {
-        if (part != 2) oa[q] = oa[q] + a[q];
+        if (part != 2) {
+            const f32x4 g = oa[q] + a[q];
+            oa[q] = g;
+            if (row_proj != nullptr) {  // the row changed: refresh its projection coefficient / projected squares (DwRowsArgs::row_proj)
+                const f32x4 w = project ? reinterpret_cast<const f32x4*>(W_dec + (size_t)i * D)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { dot = __builtin_fmaf(g[c], w[c], dot); nsq = __builtin_fmaf(w[c], w[c], nsq); }
+            }
+        }
         if (part != 1) oe[q] = oe[q] + e[q];
     }
     if (lane == 0 && part != 1) gb_enc[i] += dbe[j];
+    if (row_proj != nullptr && part != 2) {  // same arithmetic, in the same order, as rpg_row_stats (common.h)
+        dot = wave_sum(dot); nsq = wave_sum(nsq);
+        const float sc = (project && nsq > 0.f) ? dot / nsq : 0.f;
+        float sq = 0.f;
+        for (int q = lane; q < (D >> 2); q += 64) {
+            const f32x4 g = oa[q];  // (this lane's own stores)
+            const f32x4 w = project ? reinterpret_cast<const f32x4*>(W_dec + (size_t)i * D)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = rpg_apply(g[c], sc, w[c]); sq = __builtin_fmaf(t, t, sq); }
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) row_proj[i] = float2{sc, sq};
+    }
 }
 
 int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
@@ -400,27 +435,28 @@ hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStr
     return hipGetLastError();
 }
 hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int32_t* dl, int nd, int ndp, int D, int S,
-                              float* Wenc_dead, float* Wdec_dead, hipStream_t s) {
+                              float* Wenc_dead, float* Wdec_dead, hipStream_t s, const int32_t* nd_dev) {
     hipLaunchKernelGGL(gather_dead_kernel, dim3(grid_for((long)D * ndp + (long)ndp * (D >> 2))), dim3(256), 0, s, W_enc,
-                       W_dec, dl, nd, ndp, D, S, Wenc_dead, Wdec_dead);
+                       W_dec, dl, nd, ndp, D, S, Wenc_dead, Wdec_dead, nd_dev);
     return hipGetLastError();
 }
-hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s, bool pad_zero) {
+hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s, bool pad_zero,
+                                const int32_t* nd_dev) {
     hipLaunchKernelGGL(dead_bias_vec_kernel, dim3((ndp + 255) / 256), dim3(256), 0, s, b_enc, dl, nd, ndp, out,
-                       pad_zero ? 0.f : NEG_INF);
+                       pad_zero ? 0.f : NEG_INF, nd_dev);
     return hipGetLastError();
 }
 hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, int k, int stride, int ndp, float* A,
-                              uint8_t* mask, hipStream_t s) {
+                              uint8_t* mask, hipStream_t s, const int32_t* k_dev) {
     hipLaunchKernelGGL(aux_scatter_kernel, dim3(grid_for((long)n_rows * k)), dim3(256), 0, s, idx, val, (long)n_rows, k,
-                       stride, ndp, A, mask);
+                       stride, ndp, A, mask, k_dev);
     return hipGetLastError();
 }
 hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const float* b_dec, int n_rows, int D,
-                            float gscale, RowStats* rowstats, hipStream_t s) {
+                            float gscale, RowStats* rowstats, hipStream_t s, const int32_t* nd_dev) {
     return dispatch_nv(D, [&](auto nv) {
         hipLaunchKernelGGL(aux_resid_kernel<decltype(nv)::value>, dim3((n_rows + 3) / 4), dim3(256), 0, s, E, x, x_hat,
-                           b_dec, n_rows, D, gscale, rowstats);
+                           b_dec, n_rows, D, gscale, rowstats, nd_dev);
     });
 }
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s) {
@@ -458,9 +494,9 @@ hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStre
 }
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
-                                   const int32_t* nd_dev, int part) {
+                                   const int32_t* nd_dev, int part, float2* row_proj, const float* W_dec, int project) {
     if (nd <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_add_dead_kernel, dim3((nd + 3) / 4), dim3(256), 0, s, dl, nd, D, dWd, dWe, dbe, gW_dec,
-                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev, part);
+                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev, part, row_proj, W_dec, project);
     return hipGetLastError();
 }

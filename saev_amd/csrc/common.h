@@ -47,3 +47,27 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 #define NEG_INF (-__builtin_huge_valf())
+
+// remove_parallel_grads on one decoder-gradient row held across a wave (NV float4 per lane, zeros past the row's end):
+// sc = <g, w> / ||w||^2 (0 when the projection is off or w = 0) and the sum of squares of the projected row g - sc w.
+// The rpg pass (tail.hip), the backward kernels that leave {sc, sq} behind for a tail that projects inside Adam
+// (sparse.hip, auxk.hip) and that Adam all use these explicit fmas, so the two routes give bit-identical updates.
+__device__ __forceinline__ float rpg_apply(float g, float sc, float w) { return __builtin_fmaf(-sc, w, g); }
+template <int NV>
+__device__ __forceinline__ float rpg_row_stats(const f32x4 (&g)[NV], const f32x4 (&w)[NV], int project, float* sc_out) {
+    float dot = 0.f, nsq = 0.f;
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dot = __builtin_fmaf(g[n][e], w[n][e], dot); nsq = __builtin_fmaf(w[n][e], w[n][e], nsq); }
+    dot = wave_sum(dot);
+    nsq = wave_sum(nsq);
+    const float sc = (project && nsq > 0.f) ? dot / nsq : 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = rpg_apply(g[n][e], sc, w[n][e]); sq = __builtin_fmaf(t, t, sq); }
+    *sc_out = sc;
+    return wave_sum(sq);
+}

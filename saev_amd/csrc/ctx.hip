@@ -61,6 +61,9 @@ struct saev_ctx {
     int32_t* grp_prefix = nullptr;
     int32_t* scan_totals = nullptr;
     int bitmap_words = 0;
+    int bitmap_words_last = 0;
+    bool bitmap_clean = false;  // every word the next csc build will use is zero (the last full backward cleared behind itself)
+    int bitmap_clean_words = 0; // ... for row pitches up to this many words
     int32_t *counts = nullptr, *starts = nullptr;
     int2* pairs = nullptr;
     float* colsum_partials = nullptr;
@@ -69,6 +72,10 @@ struct saev_ctx {
     // squares of the W_enc gradient, taken by the transpose that ends the backward: valid until the gradient buffer may
     // have been touched from outside (wenc_sq_valid), used by the tail only inside saev_train_step (wenc_sq_trusted)
     bool wenc_sq_valid = false, wenc_sq_trusted = false;
+    // {projection coefficient, projected squares} of every decoder-gradient row, left by the kernels that wrote the rows
+    // (DwRowsArgs::row_proj); valid after a one-pass backward over all latents, trusted like wenc_sq
+    float2* row_proj = nullptr;
+    bool row_proj_valid = false, tail_proj_in_adam = false;
     int64_t* toks = nullptr;
     int32_t *fired = nullptr, *dead = nullptr;
     int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use [6,7,8] dead_update scratch
@@ -97,6 +104,7 @@ struct saev_ctx {
     int32_t* dead_list = nullptr;
     float *Wenc_dead = nullptr, *Wdec_dead = nullptr, *H_dead = nullptr, *A_dead = nullptr, *dWd = nullptr, *dWe = nullptr,
           *dbe = nullptr, *aux_partials = nullptr, *WencT_dead = nullptr, *aux_small_part = nullptr, *aux_small_part2 = nullptr;
+    bool aux_dev_count = false;  // dense branch sized by a host-side BOUND of the dead count; the count itself stays on the device
     bool aux_small = false;  // this step's AuxK ran on the few-dead-latents path
     bool aux_all = false;    // dense branch with every dead latent selected (n_dead <= k_aux): no select, no mask
     uint8_t* A_mask = nullptr;
@@ -121,6 +129,7 @@ struct saev_ctx {
     float *upper_c = nullptr, *mu_c = nullptr, *xnorm_c = nullptr, *xabs_c = nullptr;
     _Float16* xs_c = nullptr;
     saev_ctx* leader = nullptr;
+    std::vector<saev_ctx*> followers;  // contexts whose `leader` is this one (saev_destroy / a new link clears them)
     const float* xprep_x = nullptr;  // what this context's own x-derived buffers currently describe
     int xprep_n = 0;
     int64_t xprep_serial = 0;        // bumped every time they are rebuilt
@@ -131,6 +140,8 @@ struct saev_ctx {
     int max_work = 0, max_part = 0;
     float* upper = nullptr;
     saev_step_stats* stats = nullptr;
+    double* stats_scratch = nullptr;  // per-workgroup partial sums + ticket of stats_reduce_kernel
+    int* tickets = nullptr;           // arrival counters of "last workgroup finishes" kernels (zero between launches)
     // state of the step in flight
     const float* x_last = nullptr;
     int n_last = 0;
@@ -280,7 +291,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         c->max_part = (int)(2 * ((max_pairs + DW_CHUNK - 1) / DW_CHUNK) + 2);
     }
     A(chunk_starts, S + 1); A(part_starts, S); A(work_latent, c->max_work);
-    A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part);
+    A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part); A(row_proj, S);
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32 || KA > 0) {  // (the f32 encoder needs the image geometry for AuxK only)
@@ -298,7 +309,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
-    A(tau_max, MB); A(heur_state, 8);
+    A(tau_max, MB); A(heur_state, 8); A(stats_scratch, STATS_SCRATCH_DOUBLES); A(tickets, 8);
 #undef A
     if (rc != SAEV_OK) {
         // keep the context so the caller can read the message, but report failure
@@ -311,6 +322,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     hipMemset(c->dead, 0, S * sizeof(int32_t));
     hipMemset(c->flags, 0, 16 * sizeof(int32_t));
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
+    hipMemset(c->stats_scratch, 0, STATS_SCRATCH_DOUBLES * sizeof(double));
+    hipMemset(c->tickets, 0, 8 * sizeof(int));
     {
         const float init[8] = {2.6f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // z starts where a Gaussian row of 32 k latents has ~8 k values above its bound
         hipMemcpy(c->heur_state, init, sizeof(init), hipMemcpyHostToDevice);
@@ -350,8 +363,20 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     return SAEV_OK;
 }
 
+static void unlink_from_leader(saev_ctx* c) {
+    if (c->leader != nullptr) {
+        auto& f = c->leader->followers;
+        f.erase(std::remove(f.begin(), f.end(), c), f.end());
+        c->leader = nullptr;
+    }
+}
+
 void saev_destroy(saev_ctx* c) {
     if (!c) return;
+    // no dangling links either way: followers fall back to their own x-derived buffers, the leader forgets this context
+    for (saev_ctx* f : c->followers) f->leader = nullptr;
+    c->followers.clear();
+    unlink_from_leader(c);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (void* p : c->allocs) hipFree(p);
@@ -430,11 +455,14 @@ int saev_tracker_touched(saev_ctx* c) {
 
 int saev_share_x(saev_ctx* c, saev_ctx* leader) {
     if (!c) return SAEV_INVALID_ARG;
-    if (leader == nullptr || leader == c) { c->leader = nullptr; return SAEV_OK; }
+    if (leader == nullptr || leader == c) { unlink_from_leader(c); return SAEV_OK; }
     REQUIRE(c, leader->device == c->device && leader->cfg.d_model == c->cfg.d_model && leader->cfg.encoder_mode == c->cfg.encoder_mode,
             SAEV_INVALID_ARG, "saev_share_x: both contexts must live on one device with the same d_model and encoder mode");
     REQUIRE(c, leader->leader == nullptr, SAEV_INVALID_ARG, "saev_share_x: the leader must build its own x-derived buffers");
+    REQUIRE(c, c->followers.empty(), SAEV_INVALID_ARG, "saev_share_x: a context that lends its buffers cannot borrow");
+    unlink_from_leader(c);
     c->leader = leader;
+    leader->followers.push_back(c);
     c->leader_serial_seen = leader->xprep_serial;  // nothing built before this call is borrowed
     return SAEV_OK;
 }
@@ -548,7 +576,7 @@ static int wait_wenc(saev_ctx* c, hipStream_t s) {
 // operand preparation for the f16 encoders: x and W_enc^T rewritten as fp16 / bf16 images (no-op for the f32 encoder).
 // `xmax_dev` = device scalar max|x| when the caller has it already (the step computes it for the MSE), else NULL.
 static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag, hipStream_t s,
-                           const float* xmax_dev = nullptr, bool x_borrowed = false) {
+                           const float* xmax_dev = nullptr, bool x_borrowed = false, bool defer_margins = false) {
     if (c->cfg.encoder_mode == SAEV_ENCODER_F32) return SAEV_OK;
     const int D = c->cfg.d_model, S = c->cfg.d_sae;
     const bool bf = c->cfg.encoder_mode == SAEV_ENCODER_BF16;
@@ -568,20 +596,23 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // (mu = column sums / n, scaled in the same kernel so that every consumer sees the same fp32 values)
         if (!x_borrowed) {
             if (!c->mu_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n));
-            HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s));
+            // (its last workgroup writes the scales: the x scale from the maxima it just formed, the W scale from wmax_prev)
+            HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s, c->tickets, c->wmax_prev, c->f16r_scales));
         }
         c->mu_ready = false;
         // (the x scale depends on x alone: a borrowing context recomputes the same value from the leader's maxima, next
         // to its own W scale)
-        HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
+        if (x_borrowed) HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
         if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
         { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }  // x is prepared; from here on W_enc / b_enc are read
         HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
                                   c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
                                      c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
-        HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales + 1, pre_flag,
-                                     c->wmax_prev, c->row_margin, s));
+        // (defer_margins: the caller's launch_pre_encode forms the margins together with the encoder's per-launch state)
+        if (!defer_margins)
+            HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales + 1, pre_flag,
+                                         c->wmax_prev, c->row_margin, s));
         return SAEV_OK;
     }
     if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
@@ -677,8 +708,12 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                             const int32_t* pre_flag, hipStream_t s, const float* xmax_dev = nullptr, bool x_borrowed = false) {
     const int K = c->cfg.top_k;
     int32_t* need_dense = c->flags + 1;
+    const bool f16r_mode = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
+    const bool predict_mode = fused_supported(c->cfg) && c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 &&
+                              f16_ngroups(c->cfg) == 32;
+    const bool one_launch_pre = fused_supported(c->cfg) && !predict_mode;  // margins + encoder state + list flags in one launch
     {
-        int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev, x_borrowed);
+        int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev, x_borrowed, one_launch_pre);
         if (rc0 != SAEV_OK) return rc0;
         rc0 = wait_wenc(c, s);  // (the f32 encoder has no preparation: it reads W_enc from here on)
         if (rc0 != SAEV_OK) return rc0;
@@ -687,20 +722,31 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         const int ng = c->cfg.encoder_mode == SAEV_ENCODER_F32 ? (c->cfg.top_k <= 32 ? 32 : 64) : f16_ngroups(c->cfg);
         const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
         // select -> (f16r: exact refinement -> select) on the candidate lists, predicated on `flag == when`
-        auto select_stage = [&](const int32_t* flag, int when, int32_t* bad, const int32_t* tau_max) -> int {
+        auto select_stage = [&](const int32_t* flag, int when, int32_t* bad, const int32_t* tau_max, int32_t* ovf = nullptr,
+                                const int32_t* first_flag = nullptr) -> int {
+            // ovf / first_flag: the first select of the stage also does what overflow_check_kernel did (it is predicated on
+            // first_flag, the flag known before the encoder ran; the kernels after it on `flag`, which it may raise)
             SelectCandArgs sc{};
             sc.cand_cnt = c->cand_cnt; sc.cand_val = c->cand_val; sc.cand_idx = c->cand_idx;
             sc.cand_cap = CAND_CAP; sc.cand_stride = CAND_STRIDE; sc.n_rows = n; sc.k = K;
             sc.idx_out = idx_out; sc.val_out = val_out; sc.out_stride = K;
-            sc.enable_flag = flag; sc.enable_when = when;
-            sc.tau_max = tau_max; sc.invalid = bad;
+            sc.enable_flag = first_flag ? first_flag : flag; sc.enable_when = when;
+            sc.tau_max = tau_max; sc.invalid = bad; sc.ovf = ovf;
             if (f16r) {
                 // approximate values: (1) survivors of the cut lowered by the row margin, (2) their exact fp32 values,
                 // (3) the final cut on exact values.  A row with more than REFINE_CAP survivors raises `bad`.
                 sc.row_margin = c->row_margin; sc.x = x; sc.W_encT = c->dW_encT; sc.b_enc = c->params + c->off_b_enc;
                 sc.D = c->cfg.d_model; sc.refine_overflow = bad;
                 sc.surv_idx = c->surv_idx; sc.surv_val = c->surv_val; sc.surv_cnt = c->surv_cnt;
+                static const bool chain_fused = [] { const char* e = getenv("SAEV_AMD_FUSED_CHAIN"); return e == nullptr || atoi(e) != 0; }();
+                if (chain_fused && tau_max == nullptr && first_flag != nullptr) {
+                    // survivors, their exact values and the final cut in one launch; a survivor overflow raises `bad`
+                    // (= need_dense) like a list overflow does, and the dense route that follows redoes the step exactly
+                    HIPCHK(c, launch_select_refine(sc, s));
+                    return SAEV_OK;
+                }
                 HIPCHK(c, launch_select_cand(sc, s));
+                sc.enable_flag = flag; sc.ovf = nullptr;
                 HIPCHK(c, launch_refine_exact(sc, s));
                 sc.row_margin = nullptr; sc.tau_max = nullptr;
                 sc.cand_cnt = c->surv_cnt; sc.cand_val = c->surv_val; sc.cand_idx = c->surv_idx; sc.cand_cap = REFINE_CAP; sc.cand_stride = REFINE_CAP;
@@ -734,13 +780,15 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
             rc = select_stage(run2, 1, need_dense, nullptr);
             if (rc != SAEV_OK) return rc;
         } else {
-            HIPCHK(c, launch_encoder_init(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, s));
+            const int S_ = c->cfg.d_sae;
+            HIPCHK(c, launch_pre_encode(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, f16r_mode ? c->xnorm_c : nullptr, c->cfg.d_model,
+                                        c->wnorm_scratch, (S_ + 255) / 256, f16r_mode ? c->f16r_scales + 1 : nullptr, const_cast<int32_t*>(pre_flag),
+                                        c->wmax_prev, c->row_margin, c->flags + 1, s));
             timing_begin(c, s);  // the events bracket the encoder kernel alone
             int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
             if (rc != SAEV_OK) return rc;
             timing_end(c, s);
-            HIPCHK(c, launch_overflow_check(c->cand_cnt, n, CAND_CAP, pre_flag, need_dense, c->flags + 2, c->flags + 3, s));
-            rc = select_stage(need_dense, 0, need_dense, nullptr);
+            rc = select_stage(need_dense, 0, need_dense, nullptr, c->flags + 1, pre_flag);
             if (rc != SAEV_OK) return rc;
         }
     } else {
@@ -852,16 +900,19 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     // only there -- the encoder hides the transfer.
     hipEvent_t wdec_ev = c->wdec_ready;
     c->wdec_ready = nullptr;
-    HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));  // flags[0]: force-dense flag, unused by the step
     // everything that depends on x alone comes from the context this one shares its batches with, if that one has just
     // built it for this very batch (saev_share_x); otherwise it is built here
     const bool borrowed = bind_x_sources(c, x, n, true);
-    if (!borrowed) {
+    if (!borrowed && c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
+        // one pass: max|x| for the MSE and the column sums the encoder centres on; the launch that finishes them also clears
+        // the step's statistics and the force-dense flag (flags[0])
         c->xprep_x = nullptr;
-        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) {  // one pass: max|x| for the MSE and the column sums the encoder centres on
-            HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s, 1.0f / (float)n));
-            c->mu_ready = true;
-        } else {
+        HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s, 1.0f / (float)n, c->stats, c->flags));
+        c->mu_ready = true;
+    } else {
+        HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));
+        if (!borrowed) {
+            c->xprep_x = nullptr;
             HIPCHK(c, launch_absmax(x, (long)n * D, c->upper, s));
         }
     }
@@ -894,7 +945,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     }
     c->P_last = c->P;
     for (int p = 0; p < c->P; ++p) c->cuts_last[p] = c->cuts[p];  // a later saev_set_prefixes must not reach this step's backward
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper_c, c->flags + 2, c->stats, s));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper_c, c->flags + 2, c->stats, s, nullptr, c->stats_scratch));
     return SAEV_OK;
 }
 
@@ -1004,7 +1055,7 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s) {
     HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                    c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
                                    c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, c->flags + 2, c->stats, s, nd_dev));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, c->flags + 2, c->stats, s, nd_dev, c->stats_scratch));
     return SAEV_OK;
 }
 
@@ -1020,9 +1071,15 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     // the exact pre-activations (the bf16 mode's oracle does the same).  Only the f16x3 mode already has hi/lo x images.
     const bool own_images = c->cfg.encoder_mode != SAEV_ENCODER_F16X3;
     const int ndp256 = (ndp + 255) / 256 * 256, Dp2 = (ndp + 31) / 32 * 32;
+    // aux_dev_count: nd / ku are upper bounds (the tracker record of a few steps ago, saev_step_dead); the true count and
+    // min(k_aux, count) are flags[4] / flags[5].  Columns of the dead set past the true count are padding -- zero weights,
+    // bias -inf (never selected) or 0 (all-selected mode) -- exactly like the columns that pad nd to a multiple of four,
+    // so every product below has its usual shape and nothing is read back.
+    const int32_t* nd_dev = c->aux_dev_count ? c->flags + 4 : nullptr;
+    const int32_t* ku_dev = c->aux_dev_count ? c->flags + 5 : nullptr;
     HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
     HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
-                                 c->Wenc_dead, c->Wdec_dead, s));
+                                 c->Wenc_dead, c->Wdec_dead, s, nd_dev));
     c->aux_small = false;
     c->aux_all = false;
     // n_dead <= k_aux: every dead latent is selected, the codes are H itself (padding columns zero) and there is no mask
@@ -1030,7 +1087,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     {
         // H = x W_enc[:, dl] + b_enc[dl]: in f16x3 mode the x images of this step are already there (prepare_encoder)
         HIPCHK(c, launch_split_wT(c->Wenc_dead, D, ndp, ndp256, c->Dp, 256.0f, c->aux_ws1, 0, s));
-        HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s, c->aux_all));
+        HIPCHK(c, launch_dead_bias_vec(c->params + c->off_b_enc, c->dead_list, nd, ndp, c->bias_dead, s, c->aux_all, nd_dev));
         const _Float16* xs_hl = c->xs_c;
         if (own_images) {  // the step's x images are single fp16 / bf16 or absent: make the hi/lo ones (the buffer is free until the backward)
             // (with the step's power-of-two x scale, so that no activation magnitude can overflow fp16)
@@ -1044,12 +1101,12 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     }
     if (!c->aux_all) {
         SelectDenseArgs sd{};
-        sd.h = c->H_dead; sd.n_rows = n; sd.S = ndp; sd.k = ku;
+        sd.h = c->H_dead; sd.n_rows = n; sd.S = ndp; sd.k = ku; sd.k_dev = ku_dev;
         sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
         HIPCHK(c, launch_select_dense(sd, s));
         HIPCHK(c, hipMemsetAsync(c->A_dead, 0, (size_t)n * ndp * sizeof(float), s));
         HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
-        HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s));
+        HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s, ku_dev));
     }
     {
         // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
@@ -1063,8 +1120,9 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     }
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
-                               c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper_c, c->flags + 2, c->stats, s));
+                               c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s, nd_dev));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper_c, c->flags + 2, c->stats, s, nullptr,
+                                  c->stats_scratch));
     return SAEV_OK;
 }
 
@@ -1138,6 +1196,7 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     c->k_use_host = 0;
     c->aux_route = AUX_NONE;
     c->aux_small = false;
+    c->aux_dev_count = false;
     if (c->cfg.k_aux <= 0) return SAEV_OK;
     HIPCHK(c, hipEventRecord(c->dead_ev[step % DEAD_RING], s));
     // A latent can only be dead once `threshold` tokens went by since the tracker was last known to be all-zero.
@@ -1149,15 +1208,27 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     // steps in the past; it only ever blocks a host that has run further ahead than that, and never drains the queue.
     const int small_max = std::min(AUX_SMALL_MAX, c->cfg.k_aux);
     const int64_t s0 = step - DEAD_LAG;
-    if (s0 >= c->rec_valid_from && c->cfg.d_model <= 2048) {
+    if (s0 >= c->rec_valid_from) {
         HIPCHK(c, hipEventSynchronize(c->dead_ev[s0 % DEAD_RING]));
         const volatile DeadRecord* r = c->rec_host + s0 % DEAD_RING;
-        if (r->step == s0 && c->tokens_seen - r->cum_tokens <= r->horizon_tokens && r->n_near <= small_max) {
+        if (r->step == s0 && c->tokens_seen - r->cum_tokens <= r->horizon_tokens) {
+            const int bound = r->n_near;  // >= the dead count of this step
             // nobody was within reach of the threshold then: nothing can be dead now, the auxiliary term is exactly zero
             // and its dozen count-predicated launches (each ~5 us of an empty grid) are not enqueued at all
-            if (r->n_near == 0) return SAEV_OK;
-            c->aux_route = AUX_SMALL_DEVICE;
-            return auxk_small_forward(c, s);
+            if (bound == 0) return SAEV_OK;
+            if (bound <= small_max && c->cfg.d_model <= 2048) {
+                c->aux_route = AUX_SMALL_DEVICE;
+                return auxk_small_forward(c, s);
+            }
+            // A larger dead set: the dense algebra, sized by the bound, with the count left on the device (round 2 read it
+            // back here: one blocking read per step whenever more than a few dozen latents were dead -- configs[2]'s regime)
+            if ((bound + 3) / 4 * 4 <= c->nd_cap) {
+                c->aux_route = AUX_DENSE;
+                c->aux_dev_count = true;
+                c->n_dead_host = bound;
+                c->k_use_host = std::min(c->cfg.k_aux, bound);
+                return auxk_forward(c, s);
+            }
         }
     }
     int32_t host[2] = {0, 0};
@@ -1184,12 +1255,16 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
     const int words = ((n + 31) / 32 + 7) / 8 * 8;
+    c->row_proj_valid = false;
     CscArgs a{};
     a.idx = c->idx; a.code_stride = K; a.k = K; a.k_dev = nullptr; a.n_rows = n; a.S = S;
     a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals;
     a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
     a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
-    HIPCHK(c, launch_csc_build(a, s));
+    // (the bit map row pitch depends on the batch: a map cleaned for a pitch covers every shorter one, S * words <= before)
+    HIPCHK(c, launch_csc_build(a, s, c->bitmap_clean && words <= c->bitmap_clean_words));
+    c->bitmap_clean = false;
+    c->bitmap_words_last = words;
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0); the AuxK contractions add theirs
     const float* gmat = c->P_last > 1 ? c->G : c->g;
     HIPCHK(c, launch_colsum(gmat, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s, (long)c->P_last * D));
@@ -1223,15 +1298,24 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     a.partials = c->partials; a.db_partials = c->db_partials;
     a.lat_lo = lat_lo; a.lat_hi = lat_hi;
     a.part = part; a.dval = c->dval_pairs;
+    const bool all_rows = part == 0 && lat_lo == 0 && lat_hi == S;
+    // a pass over all latents also clears the CSC bit map behind itself (nothing reads it after the build)
+    const bool clears = part != 2 && lat_lo == 0 && lat_hi == S && c->bitmap_words_last > 0;
+    if (clears) { a.clear_bitmap = c->bitmap; a.clear_words = c->bitmap_words_last; }
+    a.row_proj = all_rows ? c->row_proj : nullptr; a.project = c->cfg.remove_parallel_grads ? 1 : 0;
     // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
     const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
     HIPCHK(c, launch_dw_rows(a, max_work, s));
-    if (c->aux_route == AUX_DENSE)
+    if (c->aux_route == AUX_DENSE)  // (the count on the device when the host only had a bound of it: aux_dev_count)
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
-                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, nullptr, part));
+                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s,
+                                          c->aux_dev_count ? c->flags + 4 : nullptr, part, a.row_proj, a.W_dec, a.project));
     else if (c->aux_route != AUX_NONE)  // few dead latents: the device knows how many
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
-                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part));
+                                          c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part,
+                                          a.row_proj, a.W_dec, a.project));
+    c->row_proj_valid = all_rows;
+    if (clears) { c->bitmap_clean = true; c->bitmap_clean_words = c->bitmap_words_last; }
     return SAEV_OK;
 }
 
@@ -1304,6 +1388,20 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
     if (rc != SAEV_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const long S = c->cfg.d_sae, D = c->cfg.d_model;
+    c->tail_proj_in_adam = false;
+    if (c->wenc_sq_trusted && c->wenc_sq_valid && c->row_proj_valid && shard_rank < 0) {
+        // Inside saev_train_step nothing has touched the gradient since the backward: the kernels that wrote the decoder
+        // rows left each row's projection coefficient and projected squares (row_proj), the transpose the squares of dW_enc
+        // tile by tile.  One small reduction gives the clip norm, and Adam applies the projection to the rows as it reads
+        // them: the gradient is streamed once by the whole tail instead of three times (rpg read + write, Adam read).
+        c->wenc_sq_valid = false; c->row_proj_valid = false;
+        const double* tsq = c->sumsq_partials + 2 * sumsq_blocks() + (S + 3) / 4;
+        HIPCHK(c, launch_sumsq_final_ex(tsq, transpose_blocks((int)S, (int)D), c->row_proj, (int)S, c->grads + S * D, r.a_hi - S * D,
+                                        c->grads + c->off_b_enc, r.b_hi - c->off_b_enc, saev_sumsq_device(c), s));
+        c->tail_proj_in_adam = true;
+        return SAEV_OK;
+    }
+    c->row_proj_valid = false;
     // decoder rows of the range: projection (modeling.py:419-445) and their squares in one pass over the gradient
     const long row_lo = std::min(r.a_lo / D, S), row_hi = std::min(r.a_hi / D, S);
     const int n_rows = (int)(row_hi - row_lo);
@@ -1343,6 +1441,16 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, (double)adam_step));
     a.grad_scale = grad_scale; a.max_norm = max_norm; a.sumsq = saev_sumsq_device(c); a.stats = c->stats;
     const long lo[2] = {r.a_lo, r.b_lo}, hi[2] = {r.a_hi, r.b_hi};
+    if (shard_rank < 0 && c->tail_proj_in_adam) {  // decoder rows with the projection applied on the way in, then the rest
+        c->tail_proj_in_adam = false;
+        const long S = c->cfg.d_sae, D = c->cfg.d_model;
+        a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = S * D;
+        HIPCHK(c, launch_adam_rows(a, c->row_proj, (int)S, (int)D, s));
+        a.p += S * D; a.g += S * D; a.m += S * D; a.v += S * D; a.n = c->n_params - S * D;
+        HIPCHK(c, launch_adam(a, s));
+        return SAEV_OK;
+    }
+    c->tail_proj_in_adam = false;
     if (shard_rank < 0) {  // one contiguous stream over everything
         a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = c->n_params;
         HIPCHK(c, launch_adam(a, s));

@@ -74,13 +74,23 @@ struct SelectCandArgs {
     // top-k iff the k-th largest entry found is >= the largest bound used for the row.  Rows that fail raise *invalid.
     const int32_t* tau_max;   // (n_rows) ordered-int keys or NULL (guaranteed bounds: nothing to verify)
     int32_t* invalid;         // device flag
+    // optional, first select after the encoder: ovf[0] |= any list longer than cand_cap (the step's dense-route flag),
+    // ovf[1] += such rows, ovf[2] = max list length (zeroed by launch_pre_encode)
+    int32_t* ovf;
 };
 hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream);
+// survivors -> exact values -> final cut in one launch (f16r with guaranteed bounds); a.row_margin, x, W_encT, b_enc set
+hipError_t launch_select_refine(const SelectCandArgs& a, hipStream_t stream);
 constexpr int REFINE_CAP = 512;
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream,
                                int32_t* tau_max = nullptr, const int32_t* enable_flag = nullptr, int enable_when = 0);
+// encoder_init + (xnorm != NULL: row margins and scale check of launch_row_margins) + the list flags flags1[0..2] =
+// {need_dense = *pre_flag, n_overflow = 0, cand_max = 0} in one launch
+hipError_t launch_pre_encode(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, const float* xnorm, int D,
+                             const float* wg_part, int n_part, const float* w_scale, int32_t* pre_flag, float* wmax_prev,
+                             float* margin, int32_t* flags1, hipStream_t stream);
 hipError_t launch_heur_gate(float* state, const int32_t* pre_flag, int32_t* gate, hipStream_t stream);
 hipError_t launch_heur_update(float* state, const int32_t* bad, const float* cand_mean, int k, const int32_t* gate,
                               hipStream_t stream);
@@ -88,8 +98,10 @@ hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0
 hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream);
 hipError_t launch_f16r_scales(const float* xmax_part, int n_part, const float* wmax, float* scales, hipStream_t stream);
 hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream);
+// ||x_b - mu|| per row, max |x - mu| per workgroup of 4 rows; with `ticket` (an int, zero between launches) the last
+// workgroup also writes the scales launch_f16r_scales would
 hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
-                               hipStream_t stream);  // ||x_b - mu|| per row, max |x - mu| per workgroup of 4 rows
+                               hipStream_t stream, int* ticket = nullptr, const float* wmax = nullptr, float* scales = nullptr);
 hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
                               int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream);
 // see overflow_check_kernel (select.hip) for the two-stage use
@@ -154,7 +166,8 @@ struct CscArgs {
     int32_t* part_starts;   // (S) partial-sum slot of each multi-chunk latent (with chunk_starts)
     int32_t* work_latent;   // (max_work) or NULL
 };
-hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream);
+// bitmap_clean: the whole bit map is known to be zero (dw_combine_kernel cleared it after the previous build)
+hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean = false);
 
 constexpr int DW_CHUNK = 64;   // pairs per work item of the weight-gradient kernels
 
@@ -182,6 +195,15 @@ struct DwRowsArgs {
                                   // final range by range)
     int part;                     // 0: both gradients; 1: dW_dec only (dval stored); 2: dW_encT + db_enc only (dval loaded)
     float* dval;                  // (n_rows * k) dot products <g row, W_dec[latent]> in pair order (part 1 -> part 2)
+    // optional (part != 2): per latent {sc, q} of the decoder-gradient row as written: sc = <g_i, w_i> / ||w_i||^2 (0 when
+    // project == 0 or w_i == 0), q = ||g_i||^2 - sc <g_i, w_i> = the squares of the projected row (modeling.py:419-445) --
+    // the tail then applies the projection inside Adam and never streams the gradient for it (saev_train_step only)
+    float2* row_proj;
+    int project;
+    // optional: dw_combine_kernel zeroes the CSC bit map rows of its latents (clear_words uint32 per latent) once the pairs
+    // have been placed, so that the next step's csc build starts from a clean map without a pass of its own
+    uint32_t* clear_bitmap;
+    int clear_words;
 };
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream);
 // sq_part: optional, transpose_blocks(S, D) doubles = per-tile sums of squares of `in`
@@ -193,8 +215,11 @@ int transpose_blocks(int S, int D);
 hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, float* out, int accumulate,
                          const int32_t* k_dev, hipStream_t stream, long row_stride = 0, float out_scale = 1.0f,
                          int col_mult = 0);
+// + max |m| from the same pass; with `zero_stats` the finishing launch also clears the step's statistics block and the
+// force-dense flag (launch_step_zero's job)
 hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partials, float* out, float* wg_scratch,
-                                float* absmax_out, hipStream_t stream, float out_scale = 1.0f);  // + max |m|, same pass
+                                float* absmax_out, hipStream_t stream, float out_scale = 1.0f,
+                                saev_step_stats* zero_stats = nullptr, int32_t* zero_flag = nullptr);
 
 // ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
 hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream);
@@ -217,6 +242,11 @@ struct AdamArgs {
     saev_step_stats* stats; // grad_norm written here by block 0
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
+// the decoder rows [0, S) of a.p / a.g / a.m / a.v with the projection coefficient row_proj[i].x applied to the gradient
+hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream);
+// total = sum(partials[0..nb)) + sum_i row_proj[i].y + |e1|^2 + |e2|^2 (see sumsq_final_ex_kernel)
+hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
+                                 const float* e2, long n2, double* total, hipStream_t stream);
 
 // what the host learns about the dead set of a step without waiting for it (saev_step_dead reads the record of an
 // earlier step): n_near bounds the dead count of any later step by which at most horizon_tokens more tokens went by
@@ -252,7 +282,8 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
 // with_aux: 0 no auxiliary term, 1 add it, 2 add it iff *n_dead_dev > 0 (and do nothing at all otherwise)
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
                                const int32_t* n_overflow_and_max, saev_step_stats* stats, hipStream_t stream,
-                               const int32_t* n_dead_dev = nullptr);
+                               const int32_t* n_dead_dev, double* scratch);  // scratch: STATS_SCRATCH_DOUBLES doubles, zeroed once
+constexpr int STATS_SCRATCH_DOUBLES = 16 * 6 + 1;
 
 // ---- f16x3 encoder (fp32-accurate split-fp16 MFMA) -------------------------------------------------
 struct EncodeF16Args {
@@ -318,13 +349,16 @@ hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stre
 hipError_t launch_dead_compact(const int32_t* dead, int S, int32_t* list, hipStream_t s,
                                const int32_t* n_dead_dev = nullptr);  // exits at once when *n_dead_dev == 0
 hipError_t launch_gather_dead(const float* W_enc, const float* W_dec, const int32_t* dl, int nd, int ndp, int D, int S,
-                              float* Wenc_dead, float* Wdec_dead, hipStream_t s);
+                              float* Wenc_dead, float* Wdec_dead, hipStream_t s,
+                              const int32_t* nd_dev = nullptr);  // nd_dev: the list holds min(nd, *nd_dev) entries, the rest is padding
 hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, int ndp, float* out, hipStream_t s,
-                                bool pad_zero = false);  // padding columns: -inf (never selected) or 0 (all-selected mode)
+                                bool pad_zero = false,  // padding columns: -inf (never selected) or 0 (all-selected mode)
+                                const int32_t* nd_dev = nullptr);
 hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, int k, int stride, int ndp, float* A,
-                              uint8_t* mask, hipStream_t s);
+                              uint8_t* mask, hipStream_t s, const int32_t* k_dev = nullptr);  // k_dev: min(k, *k_dev) codes per row
 hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const float* b_dec, int n_rows, int D,
-                            float gscale, RowStats* rowstats, hipStream_t s);
+                            float gscale, RowStats* rowstats, hipStream_t s,
+                            const int32_t* nd_dev = nullptr);  // *nd_dev <= 0: zero gradient, zero loss
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 // a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
 constexpr int AUX_SMALL_MAX = 48;
@@ -344,4 +378,6 @@ hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStre
 // nd rows are scattered; with nd_dev the count is *nd_dev (<= nd, which then only sizes the grid)
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
-                                   const int32_t* nd_dev = nullptr, int part = 0);
+                                   const int32_t* nd_dev = nullptr, int part = 0,
+                                   // optional: refresh row_proj of the rows touched (W_dec = the parameter rows)
+                                   float2* row_proj = nullptr, const float* W_dec = nullptr, int project = 1);

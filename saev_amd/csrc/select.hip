@@ -199,12 +199,10 @@ __device__ __forceinline__ void sort_by_idx_and_store(const SelectCandArgs& a, i
 
 template <int EPL>  // elements per lane: handles lists of up to 64*EPL candidates
 __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row, int n, int32_t (&s_idx)[4][64],
-                                                float (&s_val)[4][64]) {
+                                                float (&s_val)[4][64], const float* cv, const int32_t* ci) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int k = min(a.k, n);
-    const float* cv = a.cand_val + (size_t)row * a.cand_stride;
-    const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
 
     uint32_t key[EPL];
     int32_t idx[EPL];
@@ -296,14 +294,14 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
 // Lists of at most 64 entries (the second, exact pass of the f16r encoder: ~45 survivors per row): one entry per lane
 // and a 64-lane bitonic sort by (value descending, index ascending) instead of the 32-step bit search -- the first k lanes
 // are the winners, ties at the cut resolved towards the smaller index exactly as in select_cand_row.
-__device__ __forceinline__ void select_small_row(const SelectCandArgs& a, int row, int n) {
+__device__ __forceinline__ void select_small_row(const SelectCandArgs& a, int row, int n, const float* cv, const int32_t* ci) {
     const int lane = threadIdx.x & 63;
     const int k = min(a.k, n);
     uint32_t key = 0u;            // sorts below every real float key
     int32_t idx = 0x7fffffff;
     if (lane < n) {
-        key = f2ukey(a.cand_val[(size_t)row * a.cand_stride + lane]);
-        idx = a.cand_idx[(size_t)row * a.cand_stride + lane];
+        key = f2ukey(cv[lane]);
+        idx = ci[lane];
     }
 #pragma unroll
     for (int size = 2; size <= 64; size <<= 1) {
@@ -333,12 +331,137 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     __shared__ float s_val[4][64];
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.n_rows) return;
-    const int n = min(a.cand_cnt[row], a.cand_cap);  // wave-uniform
-    if (n <= 64 && a.row_margin == nullptr) select_small_row(a, row, n);
-    else if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val);
-    else if (n <= 1024) select_cand_row<16>(a, row, n, s_idx, s_val);
-    else if (n <= 2048) select_cand_row<32>(a, row, n, s_idx, s_val);
-    else select_cand_row<64>(a, row, n, s_idx, s_val);
+    const int cnt = a.cand_cnt[row];
+    if (a.ovf != nullptr && (threadIdx.x & 63) == 0) {
+        // the list statistics the step reports, and the overflow flag: a row whose list did not fit sends the whole launch
+        // down the exact dense route (the kernels in between run on its truncated list and are overwritten there).  This
+        // used to be a launch of its own between the encoder and the select.
+        if (cnt > a.cand_cap) { atomicOr(&a.ovf[0], 1); atomicAdd(&a.ovf[1], 1); }
+        if (cnt > __hip_atomic_load(&a.ovf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.ovf[2], cnt);
+    }
+    const int n = min(cnt, a.cand_cap);  // wave-uniform
+    const float* cv = a.cand_val + (size_t)row * a.cand_stride;
+    const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
+    if (n <= 64 && a.row_margin == nullptr) select_small_row(a, row, n, cv, ci);
+    else if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val, cv, ci);
+    else if (n <= 1024) select_cand_row<16>(a, row, n, s_idx, s_val, cv, ci);
+    else if (n <= 2048) select_cand_row<32>(a, row, n, s_idx, s_val, cv, ci);
+    else select_cand_row<64>(a, row, n, s_idx, s_val, cv, ci);
+}
+
+// ---- the f16r exactness chain in ONE launch -------------------------------------------------------------------------
+// select_cand_kernel (survivors) -> refine_exact_kernel -> select_cand_kernel (final cut) as one kernel, one wave per row:
+// the survivor list and its exact values live in LDS instead of making two global round trips, the two relaunches are gone,
+// and the bit search of one wave (issue-bound) overlaps the row gathers of its neighbours (memory-bound) on the same CU.
+// Same arithmetic in the same order as the three kernels: bit-identical codes.
+
+// survivors of the approximate cut of one row -> lds_idx[0..ns); returns ns (wave-uniform), -1 when more than REFINE_CAP
+template <int EPL>
+__device__ __forceinline__ int survivors_to_lds(const SelectCandArgs& a, int row, int n, const float* cv, const int32_t* ci,
+                                                int32_t* lds_idx) {
+    const int lane = threadIdx.x & 63;
+    const int k = min(a.k, n);
+    uint32_t key[EPL];
+    int32_t idx[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int p = e * 64 + lane;
+        if (p < n) { key[e] = f2ukey(cv[p]); idx[e] = ci[p]; }
+        else { key[e] = 0u; idx[e] = 0x7fffffff; }
+    }
+    uint32_t t = 0;
+    bool done = false;
+    for (int bit = 31; bit >= 0 && !done; --bit) {
+        const uint32_t trial = t | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(key[e] >= trial));
+        if (c == k) {  // exactly k keys reach the trial value: the k-th largest is the smallest of them
+            uint32_t m = 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) m = min(m, key[e] >= trial ? key[e] : 0xffffffffu);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+            t = m;
+            done = true;
+        } else if (c > k) {
+            t = trial;
+        }
+    }
+    const uint32_t key_lo = f2ukey(ukey2f(t) - a.row_margin[row]);
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const bool sv = key[e] >= key_lo && idx[e] != 0x7fffffff;
+        const unsigned long long m = __ballot(sv);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (sv && pos < REFINE_CAP) lds_idx[pos] = idx[e];
+        base += __popcll(m);
+    }
+    return base > REFINE_CAP ? -1 : base;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void select_refine_kernel(SelectCandArgs a) {
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+    __shared__ int32_t l_idx[4][REFINE_CAP];
+    __shared__ float l_val[4][REFINE_CAP];
+    __shared__ int32_t s_idx[4][64];
+    __shared__ float s_val[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= a.n_rows) return;
+    const int cnt = a.cand_cnt[row];
+    if (a.ovf != nullptr && lane == 0) {
+        if (cnt > a.cand_cap) { atomicOr(&a.ovf[0], 1); atomicAdd(&a.ovf[1], 1); }
+        if (cnt > __hip_atomic_load(&a.ovf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.ovf[2], cnt);
+    }
+    const int n = min(cnt, a.cand_cap);
+    const float* cv = a.cand_val + (size_t)row * a.cand_stride;
+    const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
+    int ns;
+    if (n <= 512) ns = survivors_to_lds<8>(a, row, n, cv, ci, l_idx[w]);
+    else if (n <= 1024) ns = survivors_to_lds<16>(a, row, n, cv, ci, l_idx[w]);
+    else if (n <= 2048) ns = survivors_to_lds<32>(a, row, n, cv, ci, l_idx[w]);
+    else ns = survivors_to_lds<64>(a, row, n, cv, ci, l_idx[w]);
+    if (ns < 0) {  // the caller's dense route redoes the launch exactly
+        if (lane == 0) *a.refine_overflow = 1;
+        ns = REFINE_CAP;
+    }
+    // exact pre-activations of the survivors (refine_exact_kernel's loop, lists in LDS)
+    const int D4 = a.D >> 2;
+    f32x4 xv[NV];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(a.x + (size_t)row * a.D);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) xv[q] = (lane + 64 * q < D4) ? xr[lane + 64 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < ns; j0 += 8) {
+        const int32_t my = l_idx[w][min(j0 + (lane & 7), ns - 1)];
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int32_t li = __shfl(my, t, 64);
+            const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_encT + (size_t)li * a.D);
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (lane + 64 * q < D4) {
+                    const f32x4 wv = wr[lane + 64 * q];
+                    acc += xv[q][0] * wv[0] + xv[q][1] * wv[1] + xv[q][2] * wv[2] + xv[q][3] * wv[3];
+                }
+            }
+            p[t] = acc;
+        }
+        const float r = wave_reduce_scatter8(p, lane);  // lane l holds the sum of slot (l >> 3) & 7
+        if ((lane & 7) == 0) {
+            const int t = lane >> 3;
+            if (j0 + t < ns) l_val[w][j0 + t] = r + a.b_enc[l_idx[w][j0 + t]];
+        }
+    }
+    // the final cut on the exact values (select_cand_kernel without a margin, lists in LDS)
+    SelectCandArgs b = a;
+    b.row_margin = nullptr; b.tau_max = nullptr;
+    if (ns <= 64) select_small_row(b, row, ns, l_val[w], l_idx[w]);
+    else select_cand_row<8>(b, row, ns, s_idx, s_val, l_val[w], l_idx[w]);
 }
 
 __global__ void init_i32_kernel(int32_t* p, int32_t v, int n) {
@@ -444,8 +567,10 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n,
 //
 // per row: ||x_b - mu||; per workgroup: max |x - mu| (thousands of same-address atomics would serialise: two stages)
 __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const float* mu, int n, int D,
-                                                           float* xnorm, float* wg_max) {
+                                                           float* xnorm, float* wg_max, int* ticket, const float* wmax,
+                                                           float* scales) {
     __shared__ float sh[4];
+    __shared__ int last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
     float s = 0.f, m = 0.f;
@@ -473,6 +598,29 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
     if (lane == 0) sh[w] = m;
     __syncthreads();
     if (threadIdx.x == 0) wg_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    if (ticket == nullptr) return;
+    // The last workgroup to arrive turns the per-workgroup maxima into the step's power-of-two scales (f16r_scales_kernel's
+    // job, one launch less): release by the one lane that wrote, ticket, acquire by one lane of the last workgroup.
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+        if (last) { __threadfence(); *ticket = 0; }
+    }
+    __syncthreads();
+    if (!last) return;
+    float mm = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) mm = fmaxf(mm, wg_max[i]);
+    mm = wave_max(mm);
+    __syncthreads();
+    if (lane == 0) sh[w] = mm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float xm = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])), wm = *wmax;
+        scales[0] = (xm > 0.f && xm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(xm))) : 1.0f;
+        scales[1] = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
+        scales[2] = scales[0];
+        scales[3] = 1.0f;
+    }
 }
 // margin[b] = 2 E_b, E_b = 1.05 * (2^-10 + D * 2^-22) * ||x_b - mu|| * max_s ||W_enc[:, s]|| + 2^-23 max |b_shift|: an
 // upper bound of the error of a pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products;
@@ -509,6 +657,42 @@ __global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int
     if (r >= n) return;
     const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
     margin[r] = coef * xnorm[r] * wmax + 2.0f * 1.1920929e-07f * bmax;
+}
+// Everything the fused encoder launch needs zeroed or derived right before it, in one pass (three launches before):
+//   * the per-launch state of the encoder: candidate counters 0, shared group maxima "-inf";
+//   * f16r (xnorm != NULL): the row margins and the scale check of row_margin_kernel above;
+//   * the step's list flags: flags1[0] need_dense = the force-dense flag *pre_flag as it stands after the scale check,
+//     flags1[1] n_overflow = 0, flags1[2] cand_max = 0 (select_cand_kernel raises them).
+__global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax,
+                                                         const float* xnorm, int D, const float* wg_part, int n_part,
+                                                         const float* w_scale, int32_t* pre_flag, float* wmax_prev,
+                                                         float* margin, int32_t* flags1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_rows) cand_cnt[i] = 0;
+    if (i < n_gmax) gmax[i] = INT32_MIN;
+    if (xnorm == nullptr) {
+        if (i == 0) { flags1[0] = (pre_flag != nullptr && *pre_flag != 0) ? 1 : 0; flags1[1] = 0; flags1[2] = 0; }
+        return;
+    }
+    if ((int)blockIdx.x * 256 >= n_rows && blockIdx.x != 0) return;  // (blocks past the rows only initialise)
+    __shared__ float sh[2][4];
+    float bm = 0.f, wm = 0.f;
+    for (int j = threadIdx.x; j < n_part; j += 256) { bm = fmaxf(bm, wg_part[j]); wm = fmaxf(wm, wg_part[n_part + j]); }
+    bm = wave_max(bm); wm = wave_max(wm);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = bm; sh[1][threadIdx.x >> 6] = wm; }
+    __syncthreads();
+    const float bmax = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
+    const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
+    if (i == 0) {
+        const float t = wmax * (*w_scale);
+        int pre = *pre_flag != 0 ? 1 : 0;
+        if (!(t < 60000.0f && (t >= 2048.0f || wmax == 0.f))) { pre = 1; *pre_flag = 1; }  // (an all-zero W_enc has exact images)
+        *wmax_prev = wmax;
+        flags1[0] = pre; flags1[1] = 0; flags1[2] = 0;
+    }
+    if (i >= n_rows) return;
+    const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
+    margin[i] = coef * xnorm[i] * wmax + 2.0f * 1.1920929e-07f * bmax;
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)
@@ -636,6 +820,14 @@ hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int
                        enable_flag, enable_when);
     return hipGetLastError();
 }
+hipError_t launch_pre_encode(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, const float* xnorm, int D,
+                             const float* wg_part, int n_part, const float* w_scale, int32_t* pre_flag, float* wmax_prev,
+                             float* margin, int32_t* flags1, hipStream_t stream) {
+    const int n = std::max(1, n_rows > n_gmax ? n_rows : n_gmax);
+    hipLaunchKernelGGL(pre_encode_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cand_cnt, n_rows, gmax, n_gmax, xnorm, D,
+                       wg_part, n_part, w_scale, pre_flag, wmax_prev, margin, flags1);
+    return hipGetLastError();
+}
 hipError_t launch_heur_gate(float* state, const int32_t* pre_flag, int32_t* gate, hipStream_t stream) {
     hipLaunchKernelGGL(heur_gate_kernel, dim3(1), dim3(64), 0, stream, state, pre_flag, gate);
     return hipGetLastError();
@@ -665,8 +857,9 @@ hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t strea
     return hipGetLastError();
 }
 hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
-                               hipStream_t stream) {
-    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_absmax);
+                               hipStream_t stream, int* ticket, const float* wmax, float* scales) {
+    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_absmax, ticket, wmax,
+                       scales);
     return hipGetLastError();
 }
 hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream) {
@@ -685,6 +878,19 @@ hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream) {
     const dim3 grid((a.n_rows + 3) / 4), block(256);
     const int nv = (a.D / 4 + 63) / 64;
 #define RF(N) hipLaunchKernelGGL(refine_exact_kernel<N>, grid, block, 0, stream, a)
+    if (nv <= 1) RF(1); else if (nv <= 2) RF(2); else if (nv <= 3) RF(3); else if (nv <= 4) RF(4);
+    else if (nv <= 6) RF(6); else if (nv <= 8) RF(8); else if (nv <= 12) RF(12); else if (nv <= 16) RF(16);
+    else return hipErrorInvalidValue;
+#undef RF
+    return hipGetLastError();
+}
+
+hipError_t launch_select_refine(const SelectCandArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    if (a.cand_cap > 4096 || a.row_margin == nullptr) return hipErrorInvalidValue;
+    const dim3 grid((a.n_rows + 3) / 4), block(256);
+    const int nv = (a.D / 4 + 63) / 64;
+#define RF(N) hipLaunchKernelGGL(select_refine_kernel<N>, grid, block, 0, stream, a)
     if (nv <= 1) RF(1); else if (nv <= 2) RF(2); else if (nv <= 3) RF(3); else if (nv <= 4) RF(4);
     else if (nv <= 6) RF(6); else if (nv <= 8) RF(8); else if (nv <= 12) RF(12); else if (nv <= 16) RF(16);
     else return hipErrorInvalidValue;

@@ -411,6 +411,15 @@ __global__ void csc_place_kernel(CscArgs a) {
 // Single-chunk latents write their rows directly; multi-chunk latents write per-chunk partials that
 // dw_combine_kernel adds up in chunk order (deterministic).
 
+// {sc, sq} of a decoder-gradient row g held across a wave (DwRowsArgs::row_proj), exactly as rpg_kernel would form them
+template <int NV>
+__device__ __forceinline__ void write_row_proj(float2* row_proj, int i, const f32x4 (&g)[NV], const f32x4 (&w)[NV], int project,
+                                               int lane) {
+    float sc;
+    const float sq = rpg_row_stats<NV>(g, w, project, &sc);
+    if (lane == 0) row_proj[i] = float2{sc, sq};
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
@@ -544,6 +553,8 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
         if (direct) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
         else a.db_partials[a.part_starts[i] + c] = dbs;
     }
+    // the row just written is final (single-chunk latent): its projection coefficient and projected squares for the tail
+    if (a.row_proj != nullptr && direct && part != 2 && !a.accumulate) write_row_proj<NV>(a.row_proj, i, accd, wv, a.project, lane);
 }
 
 template <int NV>
@@ -552,6 +563,10 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
     const int lane = threadIdx.x & 63;
     const int i = a.lat_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.lat_hi) return;
+    if (a.clear_bitmap != nullptr) {  // (clear_words is a multiple of 8: whole uint4s)
+        uint4* row = reinterpret_cast<uint4*>(a.clear_bitmap + (size_t)i * a.clear_words);
+        for (int q = lane; q < (a.clear_words >> 2); q += 64) row[q] = uint4{0, 0, 0, 0};
+    }
     const int nch = a.chunk_starts[i + 1] - a.chunk_starts[i];
     if (nch <= 1) return;
     const int c0 = a.part_starts[i], c1 = c0 + nch;
@@ -607,6 +622,13 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
         }
     }
     if (lane == 0 && a.part != 1) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
+    if (a.row_proj != nullptr && a.part != 2 && !a.accumulate) {
+        f32x4 wv[NV];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+        write_row_proj<NV>(a.row_proj, i, accd, wv, a.project, lane);
+    }
 }
 
 // out (D, S) = in (S, D)^T, 64 x 64 tiles through LDS (padded: conflict-free both ways)
@@ -686,8 +708,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* m, int
 // 64 columns per workgroup, 4 threads per column each summing every 4th partial row with independent loads in
 // flight, then a fixed-order LDS combine (deterministic).
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partials, int n_blocks, int D, float* out,
-                                                           int accumulate, const int32_t* k_dev, float out_scale, int col_mult) {
+                                                           int accumulate, const int32_t* k_dev, float out_scale, int col_mult,
+                                                           const float* wg_absmax, float* absmax_out,
+                                                           saev_step_stats* zero_stats, int32_t* zero_flag) {
     if (k_dev && *k_dev <= 0) return;
+    if (blockIdx.x == 0 && absmax_out != nullptr) {  // the maximum behind colsum_partial_kernel<true>, and the step's zeroing
+        __shared__ float shm[4];
+        float m = 0.f;
+        for (int i = threadIdx.x; i < n_blocks; i += 256) m = fmaxf(m, wg_absmax[i]);
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *absmax_out = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+            if (zero_stats != nullptr) *zero_stats = saev_step_stats{};
+            if (zero_flag != nullptr) *zero_flag = 0;
+        }
+    }
     if (k_dev && col_mult > 0 && (int)blockIdx.x * 64 >= *k_dev * col_mult) return;  // columns past the live ones
     __shared__ float part[4][64];
     const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -743,12 +780,12 @@ hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStrea
         hipLaunchKernelGGL(decode_matry_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a, m);
     });
 }
-hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream) {
+hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean) {
     if (a.n_rows <= 0) return hipSuccess;
     const long n = (long)a.n_rows * a.k;
     const int blocks = (int)std::min<long>((n + 255) / 256, 4096);
     const int place_blocks = (int)std::min<long>((std::max<long>(n, a.S) + 255) / 256, 8192);
-    hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
+    if (!bitmap_clean) hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(csc_count_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(csc_scan_block_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);
@@ -774,17 +811,19 @@ hipError_t launch_colsum(const float* m, int n_rows, int D, float* partials, flo
     hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials, k_dev,
                        row_stride > 0 ? row_stride : (long)D, (float*)nullptr, col_mult);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out,
-                       accumulate, k_dev, out_scale, col_mult);
+                       accumulate, k_dev, out_scale, col_mult, (const float*)nullptr, (float*)nullptr, (saev_step_stats*)nullptr,
+                       (int32_t*)nullptr);
     return hipGetLastError();
 }
 // column sums and max |m| from one pass over m; wg_scratch holds ceil(n_rows / 64) floats
 hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partials, float* out, float* wg_scratch,
-                                float* absmax_out, hipStream_t stream, float out_scale) {
+                                float* absmax_out, hipStream_t stream, float out_scale, saev_step_stats* zero_stats,
+                                int32_t* zero_flag) {
     const int nb = (n_rows + 63) / 64;
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(nb), dim3(256), 0, stream, m, n_rows, D, partials,
                        (const int32_t*)nullptr, (long)D, wg_scratch, 0);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, nb, D, out, 0,
-                       (const int32_t*)nullptr, out_scale, 0);
-    return launch_max_reduce(wg_scratch, nb, absmax_out, stream);
+                       (const int32_t*)nullptr, out_scale, 0, (const float*)wg_scratch, absmax_out, zero_stats, zero_flag);
+    return hipGetLastError();
 }

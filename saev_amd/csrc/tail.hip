@@ -50,33 +50,22 @@ __global__ __launch_bounds__(256) void rpg_kernel(float* gW, const float* W, int
         f32x4* gr = reinterpret_cast<f32x4*>(gW + (size_t)i * D);
         const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
         f32x4 g[NV], w[NV];
-        float dot = 0.f, nsq = 0.f;
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
             const int q = lane + 64 * n;
             const bool ok = q < D4;
             g[n] = ok ? gr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
             w[n] = (ok && project) ? wr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { dot += g[n][e] * w[n][e]; nsq += w[n][e] * w[n][e]; }
         }
-        dot = wave_sum(dot);
-        nsq = wave_sum(nsq);
-        if (project && nsq > 0.f) {
-            const float sc = dot / nsq;
+        float sc;
+        sq = rpg_row_stats<NV>(g, w, project, &sc);
+        if (sc != 0.f) {
 #pragma unroll
             for (int n = 0; n < NV; ++n) {
                 const int q = lane + 64 * n;
-                g[n] = g[n] - sc * w[n];
-                if (q < D4) gr[q] = g[n];
+                if (q < D4) gr[q] = f32x4{rpg_apply(g[n][0], sc, w[n][0]), rpg_apply(g[n][1], sc, w[n][1]),
+                                          rpg_apply(g[n][2], sc, w[n][2]), rpg_apply(g[n][3], sc, w[n][3])};
             }
-        }
-        if (sq_partials != nullptr) {
-#pragma unroll
-            for (int n = 0; n < NV; ++n)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sq += g[n][e] * g[n][e];
-            sq = wave_sum(sq);
         }
     }
     if (sq_partials != nullptr) {
@@ -119,6 +108,100 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* partial
     }
 }
 
+// The clip norm of a step whose decoder-gradient rows were never projected in memory (saev_train_step): total = sum of
+//   * `partials` (nb doubles: per-tile squares of dW_enc left by the backward's transpose),
+//   * row_proj[i].y for the S decoder rows (||g_i||^2 - <g_i, w_i>^2 / ||w_i||^2: what the projected row's squares sum to,
+//     formed by the kernels that wrote the row -- dw_rows / dw_combine / scatter_add_dead),
+//   * the squares of two short fp32 ranges (b_dec and b_enc, padding included),
+// every thread adding its strided share in index order, then a fixed tree: deterministic.
+__global__ __launch_bounds__(1024) void sumsq_final_ex_kernel(const double* partials, int nb, const float2* row_proj, int n_rows,
+                                                              const float* e1, long n1, const float* e2, long n2, double* total) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 1024) s += partials[i];
+    for (int i = threadIdx.x; i < n_rows; i += 1024) s += (double)row_proj[i].y;
+    for (long i = threadIdx.x; i < n1; i += 1024) s += (double)e1[i] * (double)e1[i];
+    for (long i = threadIdx.x; i < n2; i += 1024) s += (double)e2[i] * (double)e2[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += sh[i];
+        *total = t;
+    }
+}
+
+// One element of torch's fused Adam (train.py:294, 444-446) with every rounding spelled out -- no contraction left to the
+// compiler -- so that the flat kernel and the row kernel (and any future variant) update bit-identically.
+struct AdamElem { float p, m, v; };
+__device__ __forceinline__ AdamElem adam_elem(float p, float ge, float m, float v, const AdamArgs& a, float step_size) {
+#pragma clang fp contract(off)
+    const float d = ge - m;
+    m = __builtin_fmaf(d, 1.f - a.beta1, m);
+    const float g2 = (1.f - a.beta2) * ge;
+    const float g3 = g2 * ge;
+    v = __builtin_fmaf(a.beta2, v, g3);
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    const float upd = m / denom;
+    p = __builtin_fmaf(-step_size, upd, p);
+    return AdamElem{p, m, v};
+}
+__device__ __forceinline__ float scaled_grad(float g, float gs) {
+#pragma clang fp contract(off)
+    return g * gs;
+}
+
+__device__ __forceinline__ float clip_coef(const AdamArgs& a, float* norm_out) {
+    const float norm = a.grad_scale * (float)sqrt(*a.sumsq);
+    *norm_out = norm;
+    return a.max_norm >= 0.f ? fminf(a.max_norm / (norm + 1e-6f), 1.f) : 1.f;
+}
+
+// Adam over the S decoder rows with remove_parallel_grads applied on the way in: g' = g - sc_i * W_dec[i] with sc_i =
+// row_proj[i].x (= <g_i, w_i> / ||w_i||^2 of the rows the backward wrote; 0 when the projection is off) -- the parameter
+// row is being read anyway, so the projected gradient never has to be written (rpg_kernel: 0.4 GB of traffic per step).
+// One wave per row, 16-byte non-temporal accesses, 4 * NV loads in flight per lane.
+template <int NV>
+__global__ __launch_bounds__(256) void adam_rows_kernel(AdamArgs a, const float2* __restrict__ row_proj, int S, int D) {
+    float norm;
+    const float coef = clip_coef(a, &norm);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.stats) a.stats->grad_norm = norm;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= S) return;
+    const float gs = a.grad_scale * coef;
+    const float step_size = a.lr / a.bc1;
+    const float sc = row_proj[i].x;
+    const int D4 = D >> 2;
+    const size_t base = (size_t)i * D4;
+    f32x4 p[NV], g[NV], m[NV], v[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        if (q < D4) {
+            p[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + base + q);
+            g[n] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
+            m[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + base + q);
+            v[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + base + q);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int q = lane + 64 * n;
+        if (q >= D4) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = scaled_grad(rpg_apply(g[n][e], sc, p[n][e]), gs);
+            const AdamElem r = adam_elem(p[n][e], ge, m[n][e], v[n][e], a, step_size);
+            p[n][e] = r.p; m[n][e] = r.m; v[n][e] = r.v;
+        }
+        __builtin_nontemporal_store(p[n], reinterpret_cast<f32x4*>(a.p) + base + q);
+        __builtin_nontemporal_store(m[n], reinterpret_cast<f32x4*>(a.m) + base + q);
+        __builtin_nontemporal_store(v[n], reinterpret_cast<f32x4*>(a.v) + base + q);
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     // clip coefficient from the global norm of the (scaled) gradient; torch semantics
     const float norm = a.grad_scale * (float)sqrt(*a.sumsq);
@@ -152,11 +235,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
             if (q >= n4) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float ge = g[u][e] * gs;
-                m[u][e] = m[u][e] + (ge - m[u][e]) * (1.f - a.beta1);
-                v[u][e] = a.beta2 * v[u][e] + (1.f - a.beta2) * ge * ge;
-                const float denom = sqrtf(v[u][e]) / a.bc2_sqrt + a.eps;
-                p[u][e] -= step_size * (m[u][e] / denom);
+                const float ge = scaled_grad(g[u][e], gs);
+                const AdamElem r = adam_elem(p[u][e], ge, m[u][e], v[u][e], a, step_size);
+                p[u][e] = r.p; m[u][e] = r.m; v[u][e] = r.v;
             }
             __builtin_nontemporal_store(p[u], reinterpret_cast<f32x4*>(a.p) + q);
             __builtin_nontemporal_store(m[u], reinterpret_cast<f32x4*>(a.m) + q);
@@ -165,11 +246,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
     if (blockIdx.x == 0) {
         for (long i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) {
-            const float ge = a.g[i] * gs;
-            const float m = a.m[i] + (ge - a.m[i]) * (1.f - a.beta1);
-            const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * ge * ge;
-            a.m[i] = m; a.v[i] = v;
-            a.p[i] -= step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+            const AdamElem r = adam_elem(a.p[i], scaled_grad(a.g[i], gs), a.m[i], a.v[i], a, step_size);
+            a.p[i] = r.p; a.m[i] = r.m; a.v[i] = r.v;
         }
     }
 }
@@ -252,16 +330,22 @@ __global__ __launch_bounds__(256) void scatter_dense_kernel(const int32_t* idx, 
     if (i >= 0 && i < S) f[(size_t)b * S + i] = val[(size_t)b * stride + j];
 }
 
+// Up to 16 workgroups each reduce a contiguous slice of the rows (one workgroup alone took 15 us for 16 384 rows: latency,
+// not bytes); the last one to finish -- a ticket -- adds the slices in index order and writes the step's statistics.
+// scratch: 16 x 6 doubles followed by the ticket counter (an int, zero between launches).
 __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, int n_rows, int D, int P, float alpha,
                                                             int with_aux, const float* upper,
                                                             const int32_t* n_overflow, saev_step_stats* stats,
-                                                            const int32_t* n_dead_dev) {
+                                                            const int32_t* n_dead_dev, double* scratch) {
     // with_aux == 2: the AuxK pass of a step whose dead count only the device knows -- nothing to add when it is zero
     // (the forward's call has already written every other field)
     if (with_aux == 2 && *n_dead_dev <= 0) return;
     __shared__ double sh[16][6];
+    __shared__ int last;
     double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int r = threadIdx.x; r < n_rows; r += 1024) {
+    const int per = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
         const RowStats v = rs[r];
         s[0] += v.sse_scaled; s[1] += v.l0; s[2] += v.l1; s[3] += with_aux ? v.aux_sse : 0.f;
         s[4] += v.sse64; s[5] += v.sumsq64;
@@ -271,10 +355,23 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
     if ((threadIdx.x & 63) == 0)
         for (int i = 0; i < 6; ++i) sh[threadIdx.x >> 6][i] = s[i];
     __syncthreads();
+    int* ticket = reinterpret_cast<int*>(scratch + 16 * 6);
     if (threadIdx.x == 0) {
         double t[6] = {0, 0, 0, 0, 0, 0};
         for (int w = 0; w < 16; ++w)
             for (int i = 0; i < 6; ++i) t[i] += sh[w][i];
+        for (int i = 0; i < 6; ++i) __hip_atomic_store(&scratch[blockIdx.x * 6 + i], t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    {
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < (int)gridDim.x; ++b)
+            for (int i = 0; i < 6; ++i) t[i] += __hip_atomic_load(&scratch[b * 6 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ticket = 0;
         const double nd = (double)n_rows * (double)D;
         stats->mse = (float)(t[0] / (nd * (double)P));  // mean over rows x prefixes x d_model
         stats->l0 = (float)(t[1] / n_rows);
@@ -333,6 +430,17 @@ hipError_t launch_sumsq(const float* g, long n, double* partials, double* total,
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, stream, partials, SUMSQ_BLOCKS, total);
     return hipGetLastError();
 }
+hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
+                                 const float* e2, long n2, double* total, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_final_ex_kernel, dim3(1), dim3(1024), 0, stream, partials, nb, row_proj, n_rows, e1, n1, e2, n2, total);
+    return hipGetLastError();
+}
+hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream) {
+    if (S <= 0) return hipSuccess;
+    return dispatch_nv(D, [&](auto nv) {
+        hipLaunchKernelGGL(adam_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, a, row_proj, S, D);
+    });
+}
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {
     const long n4 = a.n >> 2;
     const int blocks = (int)std::max<long>(1, std::min<long>((n4 + 1023) / 1024, 256 * 8));
@@ -363,8 +471,9 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
 }
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
                                const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream,
-                               const int32_t* n_dead_dev) {
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, rs, n_rows, D, P, alpha, with_aux, upper,
-                       n_overflow, stats, n_dead_dev);
+                               const int32_t* n_dead_dev, double* scratch) {
+    const int nb = std::max(1, std::min(16, (n_rows + 1023) / 1024));
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(nb), dim3(1024), 0, stream, rs, n_rows, D, P, alpha, with_aux, upper,
+                       n_overflow, stats, n_dead_dev, scratch);
     return hipGetLastError();
 }

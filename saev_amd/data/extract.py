@@ -104,7 +104,10 @@ class DeviceReservoir:
 
     def put(self, act: torch.Tensor, example_idx: torch.Tensor, token_idx: torch.Tensor) -> None:
         n = act.shape[0]
-        assert n <= self._n_free, "reservoir overflow: check room() before put()"
+        if n > self.capacity:
+            raise ValueError(f"a block of {n} rows cannot enter a reservoir of {self.capacity}: raise buffer_size")
+        if n > self._n_free:
+            raise ValueError(f"reservoir overflow: {n} rows offered, room for {self._n_free} (check room() before put())")
         slots = self._free[self._n_free - n : self._n_free].copy()
         self._n_free -= n
         self._filled[self._n_filled : self._n_filled + n] = slots
@@ -226,6 +229,11 @@ class ExtractionFeed:
                     raise ValueError("one forward pass produces more rows than the reservoir holds: raise buffer_size")
             if res._n_filled == 0:
                 if not more:
+                    # the images ran out before this rank delivered its share: under data parallelism the other ranks would
+                    # wait in the step's collectives forever -- fail loudly instead of ending the epoch early
+                    if self.world > 1:
+                        raise RuntimeError(f"rank {self.rank}: images exhausted with {left} of {self.n_epoch} rows of the epoch "
+                                           "still to deliver; every rank must be given examples for n_examples / world_size")
                     return
                 if res.room() < self._block_rows:
                     raise RuntimeError("reservoir cannot take another block and holds nothing to draw")

@@ -99,6 +99,10 @@ class SaeEngine:
         self.chunk_a, self.chunk_b = lay.chunk_a, lay.chunk_b
         self.offsets = {"W_dec": lay.off_W_dec, "b_dec": lay.off_b_dec, "W_enc": lay.off_W_enc, "b_enc": lay.off_b_enc}
         self.shapes = {"W_dec": (S, D), "b_dec": (D,), "W_enc": (D, S), "b_enc": (S,)}
+        if cfg.bounds not in ("guaranteed", "predicted"):
+            raise ValueError(f"EngineConfig.bounds (SAEV_AMD_BOUNDS) must be 'guaranteed' or 'predicted', got {cfg.bounds!r}")
+        if cfg.encoder not in ("f32", "f16x3", "bf16", "f16r"):
+            raise ValueError(f"EngineConfig.encoder (SAEV_AMD_ENCODER) must be one of f32, f16x3, bf16, f16r, got {cfg.encoder!r}")
         with torch.cuda.device(self.device):
             self.params = torch.zeros(self.n_params, device=self.device, dtype=torch.float32)
             self.grads = torch.zeros_like(self.params) if with_optim else None

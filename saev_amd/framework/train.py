@@ -192,7 +192,10 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
     dataloader = train_feed if train_feed is not None else _make_loader(cfg.train_data, device, rank, world, train_pool)
     limiter = scheduling.BatchLimiter(dataloader, cfg.n_train, rows_scale=world)
     torch.manual_seed(cfg.seed)
-    saes, objs, _ = make_saes([(c.sae, c.objective) for c in cfgs], limiter, device)
+    # (datapoint init reads local rows: under data parallelism it gets a limiter that counts them as such -- the step
+    # limiter ends a pass after n_train GLOBAL rows, i.e. n_train / world local ones, which can be fewer than the init needs)
+    init_dl = limiter if world == 1 else scheduling.BatchLimiter(dataloader, cfg.n_train)
+    saes, objs, _ = make_saes([(c.sae, c.objective) for c in cfgs], init_dl, device)
     run = RunLog(cfgs, len(cfgs))
 
     saes.train()

@@ -261,8 +261,10 @@ class SparseAutoencoder(torch.nn.Module):
             eng.load_params(values)
             if old is not None and old.device == dev:
                 eng.set_tracker(old.toks_since_active)
-                eng.adam_m.copy_(old.adam_m)
-                eng.adam_v.copy_(old.adam_v)
+                # per tensor: the padded layout of a sharded tail (shard_world > 1) has other offsets and another length
+                for n in eng.offsets:
+                    eng.view(n, eng.adam_m).copy_(old.view(n, old.adam_m))
+                    eng.view(n, eng.adam_v).copy_(old.view(n, old.adam_v))
                 eng.adam_steps = old.adam_steps
                 old.close()
             for n in eng.offsets:

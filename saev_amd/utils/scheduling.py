@@ -21,7 +21,35 @@ import math
 from collections.abc import Mapping, Sized
 
 
-class WarmupCosine:
+class Scheduler:
+    """Base of the schedules (reference utils/scheduling.py:9-17): ``step()`` yields the next value."""
+
+    def step(self) -> float:
+        raise NotImplementedError(f"{self.__class__.__name__} must implement step().")
+
+    def __repr__(self) -> str:
+        raise NotImplementedError(f"{self.__class__.__name__} must implement __repr__().")
+
+
+class Warmup(Scheduler):
+    """Linear ramp from ``init`` to ``final`` over ``n_steps`` calls, ``final`` from then on (reference
+    utils/scheduling.py:20-39)."""
+
+    def __init__(self, init: float, final: float, n_steps: int):
+        self.init, self.final, self.n_steps = init, final, n_steps
+        self.n_calls = 0
+
+    def step(self) -> float:
+        self.n_calls += 1
+        if self.n_calls < self.n_steps:
+            return self.init + (self.final - self.init) * (self.n_calls / self.n_steps)
+        return self.final
+
+    def __repr__(self) -> str:
+        return f"Warmup(init={self.init}, final={self.final}, n_steps={self.n_steps})"
+
+
+class WarmupCosine(Scheduler):
     def __init__(self, init: float, n_warmup: int, peak: float, n_steps: int, final: float):
         self.init, self.n_warmup, self.peak, self.n_steps, self.final = init, n_warmup, peak, n_steps, final
         self.n_calls = 0

@@ -655,6 +655,55 @@ def test_growing_dead_set_switches_to_the_dense_route_in_time():
     assert routes == [0, 0, 0, 0, 0, 3, 3, 3, 3], routes
 
 
+@pytest.mark.parametrize("n_dead,n_near", [(80, 100), (0, 600), (55, 0)])
+def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near):
+    """A dead set too large for the few-dead-latents kernels used to cost one blocking read of n_dead per step (round 2:
+    configs[2]'s regime).  Now the dense algebra is sized by the BOUND the tracker record of four steps earlier gives
+    (latents dead or within four steps of the threshold then) and the true count stays on the device: columns past it are
+    padding.  `n_near` latents sit two steps short of the threshold and mostly fire again, so the bound exceeds the count
+    -- by a lot in the (0, 600) case, where next to nothing is dead and the auxiliary term must come out (nearly) zero;
+    (55, 0) is the every-dead-latent-selected mode (48 < n_dead <= k_aux).  Teacher-forced against the oracle on every step."""
+    d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
+    p = rand_params(d, s, seed=180 + n_dead)
+    gen = torch.Generator().manual_seed(181 + n_dead)
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
+    toks = torch.zeros(s, dtype=torch.int64)
+    order = torch.randperm(s, generator=torch.Generator().manual_seed(182))
+    dead, near = order[:n_dead], order[n_dead:n_dead + n_near]
+    toks[dead] = thr
+    toks[near] = thr - 2 * n
+    p["b_enc"][dead] = -100.0  # never selected: they stay dead
+    eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)
+    eng.load_params(p)
+    eng.set_tracker(toks)
+    routes, deads = [], []
+    for i in range(9):
+        x = torch.randn(n, d, generator=gen)
+        state = R.TrainState(
+            params={k_: v.cpu().clone() for k_, v in eng.param_views().items()},
+            m={k_: eng.view(k_, eng.adam_m).cpu().clone() for k_ in R.PARAM_ORDER},
+            v={k_: eng.view(k_, eng.adam_v).cpu().clone() for k_ in R.PARAM_ORDER},
+            toks_since_active=eng.toks_since_active.cpu().clone(), adam_steps=eng.adam_steps, lr=1e-3)
+        ref = R.train_step(state, x, cfg)
+        eng.train_step(x.cuda(), 1e-3, 1.0)
+        routes.append(eng.aux_route())
+        st = eng.read_stats()
+        deads.append(st.n_dead)
+        assert st.n_dead == ref["n_dead"], (i, st.n_dead, ref["n_dead"])
+        assert math.isclose(st.mse, ref["mse"], rel_tol=1e-4)
+        assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-12), (i, st.aux, ref["aux"])
+        assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-4)
+        for key in R.PARAM_ORDER:
+            bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6)
+            assert bad.float().mean() <= 1e-4, f"step {i} {key}: {bad.sum().item()} of {bad.numel()} elements off"
+    assert eng.dead_readbacks() == 4, eng.dead_readbacks()  # steps 1-4 only (the host wrote the tracker)
+    # dense algebra from the first record on, nothing read back (without forced dead latents the later records count fewer
+    # and fewer near-dead latents, and the step goes back to the few-dead-latents kernels or to nothing)
+    assert routes[4] == 3 and (n_dead == 0 or routes[4:] == [3] * 5), (routes, deads)
+    if n_near:
+        assert min(deads[4:]) < n_dead + n_near - 10, deads   # the bound really was above the count
+
+
 def test_failed_bound_prediction_is_caught_and_repeated(encoder_mode):
     """Predicted TopK bounds (mean + z sigma of a sample of the row's pre-activations) are verified, not trusted: here
     the first 256 latents -- the sample of the first latent range -- have encoder columns a hundred times larger than the

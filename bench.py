@@ -88,6 +88,57 @@ def mse_vs_oracle(eng, x, n_rows: int = 2048):
     return {"rows": n_rows, "mse_hip": got, "mse_oracle": ref, "mse_rel_err_vs_oracle": abs(got - ref) / ref}
 
 
+def other_config_record(dev, *, name, d, s, k, b, encoder, n_prefixes=1, steps=10, warmup=5):
+    """One of BASELINE.json's other configurations at its own shape on this GPU: ms per step and the encoder kernel's
+    share of its MFMA peak (same measurement as the headline: HIP events on the launch stream).  Synthetic N(mu, 1)
+    activations, random-init weights, pool of 8 batches, lr ramp as in the headline."""
+    import dataclasses
+
+    from saev_amd.engine import EngineConfig, SaeEngine
+    from saev_amd.nn.objectives import sample_prefixes
+
+    ecfg = EngineConfig(d_model=d, d_sae=s, top_k=k, max_batch=b, aux_dead_cap=4096)
+    if encoder:
+        ecfg = dataclasses.replace(ecfg, encoder=encoder)
+    eng = SaeEngine(ecfg, dev)
+    g = torch.Generator(device=dev).manual_seed(42)
+    W = (torch.rand(s, d, device=dev, generator=g) * 2 - 1) * math.sqrt(6.0 / d)
+    W /= W.norm(dim=1, keepdim=True)
+    eng.view("W_dec").copy_(W)
+    eng.view("W_enc").copy_(W.t())
+    del W
+    mu = torch.randn(d, device=dev, generator=g)
+    pool = torch.randn(8 * b, d, device=dev, generator=g) + mu
+    torch.manual_seed(7)  # the Matryoshka cut points come from torch's global CPU generator, as in the reference
+
+    def one(i):
+        if n_prefixes > 1:
+            eng.set_prefixes(sample_prefixes(s, n_prefixes))
+        eng.train_step(pool[(i % 8) * b:(i % 8 + 1) * b], 4e-4 * min(1.0, i / 500), 1.0)
+
+    for i in range(warmup):
+        one(i)
+    eng.enable_kernel_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    enc_ms = eng.encoder_ms()
+    st = eng.read_stats()
+    peak = F32_MFMA_PEAK_TFLOPS if eng.cfg.encoder == "f32" else F16_MFMA_PEAK_TFLOPS
+    rec = {"config": name, "d_model": d, "d_sae": s, "top_k": k, "batch": b, "encoder": eng.cfg.encoder, "n_prefixes": n_prefixes,
+           "steps": steps, "ms_per_step": dt / steps * 1e3, "activations_per_sec": b * steps / dt,
+           "encoder_kernel_ms": enc_ms, "encoder_tflops": 2.0 * b * d * s / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else None,
+           "encoder_frac_of_peak": (2.0 * b * d * s / (enc_ms * 1e-3) / 1e12 / peak) if enc_ms > 0 else None,
+           "mse_last": st.mse, "n_overflow_rows": st.n_overflow_rows, "cand_max": st.cand_max, "dense_route": st.dense_route}
+    eng.close()
+    del eng, pool
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +163,11 @@ def main():
                          "--sustained-after further steps, past the (lowered) dead-latent threshold")
     ap.add_argument("--sustained-after", type=int, default=625)
     ap.add_argument("--no-auxk-probe", action="store_true", help="skip the AuxK-active sub-records (forced dead sets)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` sub-records (configs[0], configs[3] in bf16, configs[1] with 10 Matryoshka prefixes)")
+    ap.add_argument("--extract-e2e", action="store_true",
+                    help="add the `extract_e2e` sub-record: configs[4] on one GPU -- ViT-L/14-shaped transformer forward (random init, "
+                         "bf16 autocast) -> hooks -> device reservoir -> SAE train steps, no disk in between")
     ap.add_argument("--n-saes", type=int, default=1,
                     help="train this many SAEs on every batch (the reference's parallel groups); the extra ones differ in "
                          "parameters only and share the first one's x statistics / operand images.  value still counts each batch once")
@@ -300,6 +356,22 @@ def main():
             auxk_active.append({"n_dead_forced": nd, "n_dead": st_a.n_dead, "ms_per_step": t_a / 30 * 1e3, "steps": 30,
                                 "aux": st_a.aux, "aux_route": eng.aux_route(), "n_dead_readbacks": eng.dead_readbacks() - rb0})
 
+    # ---- the other BASELINE configurations at their own shapes (single GPU; extra keys, the headline stays configs[1]) ----
+    other_configs = None
+    if world == 1 and not args.no_other_configs and B == BATCH:
+        other_configs = [
+            other_config_record(dev, name="configs[0]: d_in=768, 8x, k=32, batch=4096", d=768, s=6144, k=32, b=4096, encoder=args.encoder),
+            other_config_record(dev, name="configs[3] (one GPU's share): d_in=1280, 64x (81 920 latents), k=64, bf16, batch=16384",
+                                d=1280, s=81920, k=64, b=16384, encoder="bf16"),
+            other_config_record(dev, name="configs[1] with the reference's default objective: 10 Matryoshka prefixes sampled per step",
+                                d=D_MODEL, s=D_SAE, k=TOP_K, b=BATCH, encoder=args.encoder, n_prefixes=10),
+        ]
+    extract_e2e = None
+    if world == 1 and args.extract_e2e:
+        from tools.bench_extract_e2e import run as extract_run
+
+        extract_e2e = extract_run(dev)
+
     if rank == 0:
         flops = 2.0 * B * D_MODEL * D_SAE
         achieved = flops / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else None
@@ -369,6 +441,10 @@ def main():
             out["sustained"] = sustained
         if auxk_active is not None:
             out["auxk_active"] = auxk_active
+        if other_configs is not None:
+            out["other_configs"] = other_configs
+        if extract_e2e is not None:
+            out["extract_e2e"] = extract_e2e
         if world == 1 and not args.no_cpu_baseline:
             out.update(mse_vs_oracle(eng, x))
             out["cpu_baseline"] = cpu_baseline()

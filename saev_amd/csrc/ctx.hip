@@ -596,13 +596,13 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // (mu = column sums / n, scaled in the same kernel so that every consumer sees the same fp32 values)
         if (!x_borrowed) {
             if (!c->mu_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n));
-            // (its last workgroup writes the scales: the x scale from the maxima it just formed, the W scale from wmax_prev)
-            HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s, c->tickets, c->wmax_prev, c->f16r_scales));
+            HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s));
         }
         c->mu_ready = false;
         // (the x scale depends on x alone: a borrowing context recomputes the same value from the leader's maxima, next
-        // to its own W scale)
-        if (x_borrowed) HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
+        // to its own W scale.  Folding this reduction into center_stats_kernel's last workgroup was tried: a release fence
+        // per workgroup of four rows took that kernel from 12 to 115 us)
+        HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
         if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
         { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }  // x is prepared; from here on W_enc / b_enc are read
         HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
@@ -738,10 +738,14 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 sc.row_margin = c->row_margin; sc.x = x; sc.W_encT = c->dW_encT; sc.b_enc = c->params + c->off_b_enc;
                 sc.D = c->cfg.d_model; sc.refine_overflow = bad;
                 sc.surv_idx = c->surv_idx; sc.surv_val = c->surv_val; sc.surv_cnt = c->surv_cnt;
-                static const bool chain_fused = [] { const char* e = getenv("SAEV_AMD_FUSED_CHAIN"); return e == nullptr || atoi(e) != 0; }();
+                // SAEV_AMD_FUSED_CHAIN=1: survivors, their exact values and the final cut in ONE launch (select_refine_kernel).
+                // Opt-in: measured 335 us against 351 for the three kernels when all of them run at seven waves per SIMD,
+                // and slower than them (+0.03 ms per step) once lists of 1 025-2 048 entries stay in registers, which the
+                // survivor select needs (tools/experiments/README.md); a survivor overflow raises `bad` (= need_dense) like
+                // a list overflow does, and the dense route that follows redoes the step exactly
+                const char* fe = getenv("SAEV_AMD_FUSED_CHAIN");
+                const bool chain_fused = fe != nullptr && atoi(fe) != 0;
                 if (chain_fused && tau_max == nullptr && first_flag != nullptr) {
-                    // survivors, their exact values and the final cut in one launch; a survivor overflow raises `bad`
-                    // (= need_dense) like a list overflow does, and the dense route that follows redoes the step exactly
                     HIPCHK(c, launch_select_refine(sc, s));
                     return SAEV_OK;
                 }
@@ -945,7 +949,11 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     }
     c->P_last = c->P;
     for (int p = 0; p < c->P; ++p) c->cuts_last[p] = c->cuts[p];  // a later saev_set_prefixes must not reach this step's backward
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper_c, c->flags + 2, c->stats, s, nullptr, c->stats_scratch));
+    // (list statistics from the candidate counters themselves unless the fused encoder is out of play or predicts bounds,
+    // where overflow_check_kernel leaves them in flags[2..3])
+    const bool lists = fused_supported(c->cfg) && !(c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 && f16_ngroups(c->cfg) == 32);
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper_c, c->flags + 2, c->stats, s, nullptr, c->stats_scratch,
+                                  lists ? c->cand_cnt : nullptr, CAND_CAP));
     return SAEV_OK;
 }
 
@@ -1055,7 +1063,7 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s) {
     HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                    c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
                                    c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, c->flags + 2, c->stats, s, nd_dev, c->stats_scratch));
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, nullptr, c->stats, s, nd_dev, c->stats_scratch));
     return SAEV_OK;
 }
 
@@ -1121,7 +1129,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     if (rc != SAEV_OK) return rc;
     HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
                                c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s, nd_dev));
-    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper_c, c->flags + 2, c->stats, s, nullptr,
+    HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper_c, nullptr, c->stats, s, nullptr,
                                   c->stats_scratch));
     return SAEV_OK;
 }
@@ -1397,7 +1405,8 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
         c->wenc_sq_valid = false; c->row_proj_valid = false;
         const double* tsq = c->sumsq_partials + 2 * sumsq_blocks() + (S + 3) / 4;
         HIPCHK(c, launch_sumsq_final_ex(tsq, transpose_blocks((int)S, (int)D), c->row_proj, (int)S, c->grads + S * D, r.a_hi - S * D,
-                                        c->grads + c->off_b_enc, r.b_hi - c->off_b_enc, saev_sumsq_device(c), s));
+                                        c->grads + c->off_b_enc, r.b_hi - c->off_b_enc, saev_sumsq_device(c), c->sumsq_partials,
+                                        c->tickets + 1, s));
         c->tail_proj_in_adam = true;
         return SAEV_OK;
     }

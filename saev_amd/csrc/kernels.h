@@ -74,8 +74,8 @@ struct SelectCandArgs {
     // top-k iff the k-th largest entry found is >= the largest bound used for the row.  Rows that fail raise *invalid.
     const int32_t* tau_max;   // (n_rows) ordered-int keys or NULL (guaranteed bounds: nothing to verify)
     int32_t* invalid;         // device flag
-    // optional, first select after the encoder: ovf[0] |= any list longer than cand_cap (the step's dense-route flag),
-    // ovf[1] += such rows, ovf[2] = max list length (zeroed by launch_pre_encode)
+    // optional, first select after the encoder: ovf[0] |= any list longer than cand_cap (the step's dense-route flag;
+    // the list statistics of the step come from stats_reduce)
     int32_t* ovf;
 };
 hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream);
@@ -98,10 +98,8 @@ hipError_t launch_step_zero(saev_step_stats* stats, float* upper, int32_t* flag0
 hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch, float* wmax, hipStream_t stream);
 hipError_t launch_f16r_scales(const float* xmax_part, int n_part, const float* wmax, float* scales, hipStream_t stream);
 hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream);
-// ||x_b - mu|| per row, max |x - mu| per workgroup of 4 rows; with `ticket` (an int, zero between launches) the last
-// workgroup also writes the scales launch_f16r_scales would
 hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
-                               hipStream_t stream, int* ticket = nullptr, const float* wmax = nullptr, float* scales = nullptr);
+                               hipStream_t stream);  // ||x_b - mu|| per row, max |x - mu| per workgroup of 4 rows
 hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
                               int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream);
 // see overflow_check_kernel (select.hip) for the two-stage use
@@ -200,8 +198,8 @@ struct DwRowsArgs {
     // the tail then applies the projection inside Adam and never streams the gradient for it (saev_train_step only)
     float2* row_proj;
     int project;
-    // optional: dw_combine_kernel zeroes the CSC bit map rows of its latents (clear_words uint32 per latent) once the pairs
-    // have been placed, so that the next step's csc build starts from a clean map without a pass of its own
+    // optional: dw_rows_kernel zeroes the CSC bit map words of its pairs (row pitch clear_words uint32 per latent) -- the
+    // pairs have been placed by then -- so that the next step's csc build starts from a clean map without a pass of its own
     uint32_t* clear_bitmap;
     int clear_words;
 };
@@ -246,7 +244,8 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
 hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream);
 // total = sum(partials[0..nb)) + sum_i row_proj[i].y + |e1|^2 + |e2|^2 (see sumsq_final_ex_kernel)
 hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
-                                 const float* e2, long n2, double* total, hipStream_t stream);
+                                 const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream);
+constexpr int SUMSQ_EX_BLOCKS = 32;  // blk_part: this many doubles of scratch; ticket: an int, zero between launches
 
 // what the host learns about the dead set of a step without waiting for it (saev_step_dead reads the record of an
 // earlier step): n_near bounds the dead count of any later step by which at most horizon_tokens more tokens went by
@@ -282,8 +281,10 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
 // with_aux: 0 no auxiliary term, 1 add it, 2 add it iff *n_dead_dev > 0 (and do nothing at all otherwise)
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
                                const int32_t* n_overflow_and_max, saev_step_stats* stats, hipStream_t stream,
-                               const int32_t* n_dead_dev, double* scratch);  // scratch: STATS_SCRATCH_DOUBLES doubles, zeroed once
-constexpr int STATS_SCRATCH_DOUBLES = 16 * 6 + 1;
+                               const int32_t* n_dead_dev, double* scratch,  // scratch: STATS_SCRATCH_DOUBLES doubles, zeroed once
+                               // optional: take n_overflow_rows / cand_max from the candidate lists themselves
+                               const int32_t* cand_cnt = nullptr, int cand_cap = 0);
+constexpr int STATS_SCRATCH_DOUBLES = 16 * 8 + 1;
 
 // ---- f16x3 encoder (fp32-accurate split-fp16 MFMA) -------------------------------------------------
 struct EncodeF16Args {

@@ -291,6 +291,104 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
     sort_by_idx_and_store(a, row, k, s_idx[w][lane], s_val[w][lane], lane);
 }
 
+// ---- lists too long for registers (more than 2 048 candidates: a few rows of a launch at most) ---------------------------
+// The same selection with the list left where it is (L2): every step of the threshold search is a pass over it.  Keeping
+// 4 096 entries per row in registers for these rows cost every row of the kernel its occupancy (151 VGPRs, three waves
+// per SIMD); this path is ~10 us for the wave that takes it.  (Lists of 1 025 .. 2 048 entries are common -- the mean is
+// ~900 at configs[1] -- and stay in registers: streaming them made the survivor select 100 us instead of 70.)
+__device__ __forceinline__ int stream_count(const float* cv, const int32_t* ci, int n, uint32_t lo_key, int mode, uint32_t T,
+                                            int32_t idx_lt, int lane) {
+    // mode 0: key >= lo_key;  1: key > T;  2: key == T;  3: key == T && idx < idx_lt
+    int c = 0;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        const int p = p0 + lane;
+        bool hit = false;
+        if (p < n) {
+            const uint32_t key = f2ukey(cv[p]);
+            hit = mode == 0 ? key >= lo_key : mode == 1 ? key > T : mode == 2 ? key == T : (key == T && ci[p] < idx_lt);
+        }
+        c += __popcll(__ballot(hit));
+    }
+    return c;
+}
+__device__ __forceinline__ uint32_t stream_kth_largest(const float* cv, const int32_t* ci, int n, int k, int lane) {
+    uint32_t t = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = t | (1u << bit);
+        const int c = stream_count(cv, ci, n, trial, 0, 0u, 0, lane);
+        if (c == k) {  // the k-th largest is the smallest key that reaches the trial value
+            uint32_t m = 0xffffffffu;
+            for (int p = lane; p < n; p += 64) { const uint32_t key = f2ukey(cv[p]); if (key >= trial) m = min(m, key); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+            return m;
+        }
+        if (c > k) t = trial;
+    }
+    return t;
+}
+// survivors of the approximate cut -> out[0..), returns their number (may exceed REFINE_CAP: only the first REFINE_CAP are stored)
+__device__ __forceinline__ int stream_survivors(const SelectCandArgs& a, int row, int n, const float* cv, const int32_t* ci,
+                                                int32_t* out, uint32_t* T_out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t T = stream_kth_largest(cv, ci, n, min(a.k, n), lane);
+    *T_out = T;
+    const uint32_t key_lo = f2ukey(ukey2f(T) - a.row_margin[row]);
+    int base = 0;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        const int p = p0 + lane;
+        const bool sv = p < n && f2ukey(cv[p]) >= key_lo;
+        const unsigned long long m = __ballot(sv);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (sv && pos < REFINE_CAP) out[pos] = ci[p];
+        base += __popcll(m);
+    }
+    return base;
+}
+__device__ __forceinline__ void select_cand_row_stream(const SelectCandArgs& a, int row, int n, int32_t (&s_idx)[4][64],
+                                                       float (&s_val)[4][64], const float* cv, const int32_t* ci) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = min(a.k, n);
+    if (a.row_margin != nullptr) {
+        uint32_t T;
+        const int base = stream_survivors(a, row, n, cv, ci, a.surv_idx + (size_t)row * REFINE_CAP, &T);
+        if (a.tau_max != nullptr && lane == 0 && (n < a.k || ukey2f(T) < key2f(a.tau_max[row]))) *a.invalid = 1;
+        if (lane == 0) {
+            a.surv_cnt[row] = min(base, REFINE_CAP);
+            if (base > REFINE_CAP) *a.refine_overflow = 1;
+        }
+        return;
+    }
+    const uint32_t T = stream_kth_largest(cv, ci, n, k, lane);
+    if (a.tau_max != nullptr && lane == 0 && (n < a.k || ukey2f(T) < key2f(a.tau_max[row]))) *a.invalid = 1;
+    const int cgt = stream_count(cv, ci, n, 0u, 1, T, 0, lane), ceq = stream_count(cv, ci, n, 0u, 2, T, 0, lane);
+    const int need = k - cgt;
+    int32_t idx_cut = 0x7fffffff;
+    if (ceq > need) {
+        int32_t X = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+            const int32_t trial = X | (1 << bit);
+            if (stream_count(cv, ci, n, 0u, 3, T, trial, lane) < need) X = trial;
+        }
+        idx_cut = X;
+    }
+    s_idx[w][lane] = 0x7fffffff;
+    s_val[w][lane] = 0.f;
+    int base = 0;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        const int p = p0 + lane;
+        uint32_t key = 0u;
+        int32_t idx = 0x7fffffff;
+        if (p < n) { key = f2ukey(cv[p]); idx = ci[p]; }
+        const bool sel = p < n && ((key > T) || (key == T && idx <= idx_cut));
+        const unsigned long long m = __ballot(sel);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (sel && pos < 64) { s_idx[w][pos] = idx; s_val[w][pos] = ukey2f(key); }
+        base += __popcll(m);
+    }
+    sort_by_idx_and_store(a, row, k, s_idx[w][lane], s_val[w][lane], lane);
+}
+
 // Lists of at most 64 entries (the second, exact pass of the f16r encoder: ~45 survivors per row): one entry per lane
 // and a 64-lane bitonic sort by (value descending, index ascending) instead of the 32-step bit search -- the first k lanes
 // are the winners, ties at the cut resolved towards the smaller index exactly as in select_cand_row.
@@ -332,13 +430,10 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.n_rows) return;
     const int cnt = a.cand_cnt[row];
-    if (a.ovf != nullptr && (threadIdx.x & 63) == 0) {
-        // the list statistics the step reports, and the overflow flag: a row whose list did not fit sends the whole launch
-        // down the exact dense route (the kernels in between run on its truncated list and are overwritten there).  This
-        // used to be a launch of its own between the encoder and the select.
-        if (cnt > a.cand_cap) { atomicOr(&a.ovf[0], 1); atomicAdd(&a.ovf[1], 1); }
-        if (cnt > __hip_atomic_load(&a.ovf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.ovf[2], cnt);
-    }
+    // a row whose list did not fit sends the whole launch down the exact dense route (the kernels in between run on its
+    // truncated list and are overwritten there); this check used to be a launch of its own between the encoder and the
+    // select.  (The list statistics come from stats_reduce: a per-row atomic here cost 30 us.)
+    if (a.ovf != nullptr && (threadIdx.x & 63) == 0 && cnt > a.cand_cap) atomicOr(&a.ovf[0], 1);
     const int n = min(cnt, a.cand_cap);  // wave-uniform
     const float* cv = a.cand_val + (size_t)row * a.cand_stride;
     const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
@@ -346,7 +441,7 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     else if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val, cv, ci);
     else if (n <= 1024) select_cand_row<16>(a, row, n, s_idx, s_val, cv, ci);
     else if (n <= 2048) select_cand_row<32>(a, row, n, s_idx, s_val, cv, ci);
-    else select_cand_row<64>(a, row, n, s_idx, s_val, cv, ci);
+    else select_cand_row_stream(a, row, n, s_idx, s_val, cv, ci);
 }
 
 // ---- the f16r exactness chain in ONE launch -------------------------------------------------------------------------
@@ -412,10 +507,7 @@ __global__ __launch_bounds__(256) void select_refine_kernel(SelectCandArgs a) {
     const int row = blockIdx.x * 4 + w;
     if (row >= a.n_rows) return;
     const int cnt = a.cand_cnt[row];
-    if (a.ovf != nullptr && lane == 0) {
-        if (cnt > a.cand_cap) { atomicOr(&a.ovf[0], 1); atomicAdd(&a.ovf[1], 1); }
-        if (cnt > __hip_atomic_load(&a.ovf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.ovf[2], cnt);
-    }
+    if (a.ovf != nullptr && lane == 0 && cnt > a.cand_cap) atomicOr(&a.ovf[0], 1);
     const int n = min(cnt, a.cand_cap);
     const float* cv = a.cand_val + (size_t)row * a.cand_stride;
     const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
@@ -423,7 +515,11 @@ __global__ __launch_bounds__(256) void select_refine_kernel(SelectCandArgs a) {
     if (n <= 512) ns = survivors_to_lds<8>(a, row, n, cv, ci, l_idx[w]);
     else if (n <= 1024) ns = survivors_to_lds<16>(a, row, n, cv, ci, l_idx[w]);
     else if (n <= 2048) ns = survivors_to_lds<32>(a, row, n, cv, ci, l_idx[w]);
-    else ns = survivors_to_lds<64>(a, row, n, cv, ci, l_idx[w]);
+    else {
+        uint32_t T;
+        ns = stream_survivors(a, row, n, cv, ci, l_idx[w], &T);
+        if (ns > REFINE_CAP) ns = -1;
+    }
     if (ns < 0) {  // the caller's dense route redoes the launch exactly
         if (lane == 0) *a.refine_overflow = 1;
         ns = REFINE_CAP;
@@ -567,10 +663,8 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n,
 //
 // per row: ||x_b - mu||; per workgroup: max |x - mu| (thousands of same-address atomics would serialise: two stages)
 __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const float* mu, int n, int D,
-                                                           float* xnorm, float* wg_max, int* ticket, const float* wmax,
-                                                           float* scales) {
+                                                           float* xnorm, float* wg_max) {
     __shared__ float sh[4];
-    __shared__ int last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
     float s = 0.f, m = 0.f;
@@ -598,29 +692,6 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
     if (lane == 0) sh[w] = m;
     __syncthreads();
     if (threadIdx.x == 0) wg_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-    if (ticket == nullptr) return;
-    // The last workgroup to arrive turns the per-workgroup maxima into the step's power-of-two scales (f16r_scales_kernel's
-    // job, one launch less): release by the one lane that wrote, ticket, acquire by one lane of the last workgroup.
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-        if (last) { __threadfence(); *ticket = 0; }
-    }
-    __syncthreads();
-    if (!last) return;
-    float mm = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) mm = fmaxf(mm, wg_max[i]);
-    mm = wave_max(mm);
-    __syncthreads();
-    if (lane == 0) sh[w] = mm;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float xm = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])), wm = *wmax;
-        scales[0] = (xm > 0.f && xm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(xm))) : 1.0f;
-        scales[1] = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
-        scales[2] = scales[0];
-        scales[3] = 1.0f;
-    }
 }
 // margin[b] = 2 E_b, E_b = 1.05 * (2^-10 + D * 2^-22) * ||x_b - mu|| * max_s ||W_enc[:, s]|| + 2^-23 max |b_shift|: an
 // upper bound of the error of a pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products;
@@ -857,9 +928,8 @@ hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t strea
     return hipGetLastError();
 }
 hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
-                               hipStream_t stream, int* ticket, const float* wmax, float* scales) {
-    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_absmax, ticket, wmax,
-                       scales);
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_absmax);
     return hipGetLastError();
 }
 hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream) {

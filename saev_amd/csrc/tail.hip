@@ -115,20 +115,46 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* partial
 //   * the squares of two short fp32 ranges (b_dec and b_enc, padding included),
 // every thread adding its strided share in index order, then a fixed tree: deterministic.
 __global__ __launch_bounds__(1024) void sumsq_final_ex_kernel(const double* partials, int nb, const float2* row_proj, int n_rows,
-                                                              const float* e1, long n1, const float* e2, long n2, double* total) {
+                                                              const float* e1, long n1, const float* e2, long n2, double* total,
+                                                              double* blk_part, int* ticket) {
+    // (one workgroup alone needed 32 us for the 0.4 MB: latency.  gridDim.x workgroups take contiguous slices of each
+    // range, the last one to arrive -- a ticket -- adds the slices in index order)
     __shared__ double sh[16];
+    __shared__ int last;
+    const int nblk = gridDim.x, blk = blockIdx.x;
+    auto slice = [&](long n, long& lo, long& hi) { const long per = (n + nblk - 1) / nblk; lo = min(n, blk * per); hi = min(n, lo + per); };
     double s = 0.0;
-    for (int i = threadIdx.x; i < nb; i += 1024) s += partials[i];
-    for (int i = threadIdx.x; i < n_rows; i += 1024) s += (double)row_proj[i].y;
-    for (long i = threadIdx.x; i < n1; i += 1024) s += (double)e1[i] * (double)e1[i];
-    for (long i = threadIdx.x; i < n2; i += 1024) s += (double)e2[i] * (double)e2[i];
+    long lo, hi;
+    slice(nb, lo, hi);
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) s += partials[i];
+    slice(n_rows, lo, hi);
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)row_proj[i].y;
+    slice(n1, lo, hi);
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)e1[i] * (double)e1[i];
+    slice(n2, lo, hi);
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)e2[i] * (double)e2[i];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < 16; ++i) t += sh[i];
-        *total = t;
+        __hip_atomic_store(&blk_part[blk], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (atomicAdd(ticket, 1) == nblk - 1) ? 1 : 0;
+        if (last) __threadfence();
+    }
+    __syncthreads();
+    if (!last) return;
+    __shared__ double part[64];
+    if ((int)threadIdx.x < nblk && threadIdx.x < 64)  // all slices in flight together, then a fixed-order sum
+        part[threadIdx.x] = __hip_atomic_load(&blk_part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tt = 0.0;
+        for (int i = 0; i < nblk; ++i) tt += part[i];
+        *total = tt;
+        *ticket = 0;
     }
 }
 
@@ -332,45 +358,70 @@ __global__ __launch_bounds__(256) void scatter_dense_kernel(const int32_t* idx, 
 
 // Up to 16 workgroups each reduce a contiguous slice of the rows (one workgroup alone took 15 us for 16 384 rows: latency,
 // not bytes); the last one to finish -- a ticket -- adds the slices in index order and writes the step's statistics.
-// scratch: 16 x 6 doubles followed by the ticket counter (an int, zero between launches).
+// scratch: 16 x 8 doubles followed by the ticket counter (an int, zero between launches).  With cand_cnt the same pass
+// also gives the list statistics of the fused encoder (rows whose list overflowed, longest list).
 __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, int n_rows, int D, int P, float alpha,
                                                             int with_aux, const float* upper,
                                                             const int32_t* n_overflow, saev_step_stats* stats,
-                                                            const int32_t* n_dead_dev, double* scratch) {
+                                                            const int32_t* n_dead_dev, double* scratch,
+                                                            const int32_t* cand_cnt, int cand_cap) {
     // with_aux == 2: the AuxK pass of a step whose dead count only the device knows -- nothing to add when it is zero
     // (the forward's call has already written every other field)
     if (with_aux == 2 && *n_dead_dev <= 0) return;
-    __shared__ double sh[16][6];
+    constexpr int NS = 8;
+    __shared__ double sh[16][NS];
     __shared__ int last;
-    double s[6] = {0, 0, 0, 0, 0, 0};
+    double s[NS] = {0, 0, 0, 0, 0, 0, 0, 0};  // [6] rows with cand_cnt > cap, [7] max cand_cnt
     const int per = (n_rows + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * per, r1 = min(n_rows, r0 + per);
     for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
         const RowStats v = rs[r];
         s[0] += v.sse_scaled; s[1] += v.l0; s[2] += v.l1; s[3] += with_aux ? v.aux_sse : 0.f;
         s[4] += v.sse64; s[5] += v.sumsq64;
+        if (cand_cnt != nullptr) {
+            const int c = cand_cnt[r];
+            s[6] += c > cand_cap ? 1.0 : 0.0;
+            s[7] = fmax(s[7], (double)c);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) s[i] = wave_sum_d(s[i]);
+    for (int i = 0; i < 7; ++i) s[i] = wave_sum_d(s[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[7] = fmax(s[7], __shfl_xor(s[7], o, 64));
     if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 6; ++i) sh[threadIdx.x >> 6][i] = s[i];
+        for (int i = 0; i < NS; ++i) sh[threadIdx.x >> 6][i] = s[i];
     __syncthreads();
-    int* ticket = reinterpret_cast<int*>(scratch + 16 * 6);
+    int* ticket = reinterpret_cast<int*>(scratch + 16 * NS);
+    if (threadIdx.x < NS) {  // one lane per statistic: the slice's value, written through to where the last workgroup reads it
+        const int i = threadIdx.x;
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t = i < 7 ? t + sh[w][i] : fmax(t, sh[w][i]);
+        __hip_atomic_store(&scratch[blockIdx.x * NS + i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double t[6] = {0, 0, 0, 0, 0, 0};
-        for (int w = 0; w < 16; ++w)
-            for (int i = 0; i < 6; ++i) t[i] += sh[w][i];
-        for (int i = 0; i < 6; ++i) __hip_atomic_store(&scratch[blockIdx.x * 6 + i], t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+        if (last) __threadfence();
     }
     __syncthreads();
-    if (!last || threadIdx.x != 0) return;
-    __threadfence();
+    if (!last) return;
+    // the last workgroup: all slices' values in flight together (one thread alone paid 128 L2 round trips here), then a
+    // fixed-order sum per statistic
+    __shared__ double part[16][NS];
+    if (threadIdx.x < 16 * NS) {
+        const int b = threadIdx.x / NS, i = threadIdx.x % NS;
+        part[b][i] = b < (int)gridDim.x ? __hip_atomic_load(&scratch[b * NS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     {
-        double t[6] = {0, 0, 0, 0, 0, 0};
-        for (int b = 0; b < (int)gridDim.x; ++b)
-            for (int i = 0; i < 6; ++i) t[i] += __hip_atomic_load(&scratch[b * 6 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double t[NS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < (int)gridDim.x; ++b) {
+            for (int i = 0; i < 7; ++i) t[i] += part[b][i];
+            t[7] = fmax(t[7], part[b][7]);
+        }
         *ticket = 0;
         const double nd = (double)n_rows * (double)D;
         stats->mse = (float)(t[0] / (nd * (double)P));  // mean over rows x prefixes x d_model
@@ -380,7 +431,9 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
         stats->sse = t[4];
         stats->sum_sq = t[5];
         if (upper) stats->upper = *upper;
-        if (n_overflow) { stats->n_overflow_rows = n_overflow[0]; stats->cand_max = n_overflow[1]; stats->dense_route = n_overflow[-1]; }  // ctx flags: [1] need_dense [2] n_overflow [3] cand_max
+        // ctx flags: [1] need_dense [2] n_overflow [3] cand_max (the last two from the lists themselves when given)
+        if (n_overflow) { stats->n_overflow_rows = n_overflow[0]; stats->cand_max = n_overflow[1]; stats->dense_route = n_overflow[-1]; }
+        if (cand_cnt != nullptr) { stats->n_overflow_rows = (int32_t)t[6]; stats->cand_max = (int32_t)t[7]; }
     }
 }
 
@@ -431,8 +484,9 @@ hipError_t launch_sumsq(const float* g, long n, double* partials, double* total,
     return hipGetLastError();
 }
 hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
-                                 const float* e2, long n2, double* total, hipStream_t stream) {
-    hipLaunchKernelGGL(sumsq_final_ex_kernel, dim3(1), dim3(1024), 0, stream, partials, nb, row_proj, n_rows, e1, n1, e2, n2, total);
+                                 const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_final_ex_kernel, dim3(SUMSQ_EX_BLOCKS), dim3(1024), 0, stream, partials, nb, row_proj, n_rows, e1, n1, e2,
+                       n2, total, blk_part, ticket);
     return hipGetLastError();
 }
 hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream) {
@@ -471,9 +525,9 @@ hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows
 }
 hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, float alpha, int with_aux, const float* upper,
                                const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream,
-                               const int32_t* n_dead_dev, double* scratch) {
+                               const int32_t* n_dead_dev, double* scratch, const int32_t* cand_cnt, int cand_cap) {
     const int nb = std::max(1, std::min(16, (n_rows + 1023) / 1024));
     hipLaunchKernelGGL(stats_reduce_kernel, dim3(nb), dim3(1024), 0, stream, rs, n_rows, D, P, alpha, with_aux, upper,
-                       n_overflow, stats, n_dead_dev, scratch);
+                       n_overflow, stats, n_dead_dev, scratch, cand_cnt, cand_cap);
     return hipGetLastError();
 }

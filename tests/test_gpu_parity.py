@@ -664,8 +664,8 @@ def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near):
     -- by a lot in the (0, 600) case, where next to nothing is dead and the auxiliary term must come out (nearly) zero;
     (55, 0) is the every-dead-latent-selected mode (48 < n_dead <= k_aux).  Teacher-forced against the oracle on every step."""
     d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
-    p = rand_params(d, s, seed=180 + n_dead)
-    gen = torch.Generator().manual_seed(181 + n_dead)
+    p = rand_params(d, s, seed=380 + n_dead)
+    gen = torch.Generator().manual_seed(381 + n_dead)
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
     toks = torch.zeros(s, dtype=torch.int64)
     order = torch.randperm(s, generator=torch.Generator().manual_seed(182))
@@ -692,7 +692,10 @@ def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near):
         assert st.n_dead == ref["n_dead"], (i, st.n_dead, ref["n_dead"])
         assert math.isclose(st.mse, ref["mse"], rel_tol=1e-4)
         assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-12), (i, st.aux, ref["aux"])
-        assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-4)
+        # (the seeds are chosen free of near-ties at a row's k-th place: one resolved the other way moves the gradient by
+        # ~1 / (n k) -- with seed 180 step 6 of the (0, 600) case had one, 1.6e-4 on the norm, while every device-side quantity
+        # recomputed by hand agreed with the HIP path; tools/experiments/r3_aux_debug.py)
+        assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-4), (i, st.grad_norm, ref["grad_norm"])
         for key in R.PARAM_ORDER:
             bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6)
             assert bad.float().mean() <= 1e-4, f"step {i} {key}: {bad.sum().item()} of {bad.numel()} elements off"
@@ -869,3 +872,25 @@ def test_fused_train_step_and_phase_by_phase_agree(encoder_mode):
         assert math.isclose(sa.mse, sb.mse, rel_tol=1e-6)
         for key in R.PARAM_ORDER:
             torch.testing.assert_close(a.view(key), b.view(key), rtol=1e-5, atol=1e-7, msg=lambda m: f"step {i} {key}: {m}")
+
+
+def test_one_launch_exactness_chain_gives_the_same_codes(monkeypatch):
+    """SAEV_AMD_FUSED_CHAIN=1 runs survivor select -> exact refinement -> final select of the f16r encoder as one kernel
+    (lists in LDS).  Same arithmetic in the same order: the codes must be bit-identical to the three-kernel chain, also on
+    rows whose candidate lists are long (a batch with a strong common direction) and on near-ties."""
+    d, s, k, n = 256, 4096, 32, 600
+    p = rand_params(d, s, seed=300)
+    g = torch.Generator().manual_seed(301)
+    x = torch.randn(n, d, generator=g) + 3.0 * torch.randn(d, generator=g)
+    x[::7] = x[::7] * 0.01  # rows of a very different scale: other margins, other list lengths
+    eng = make_engine(d, s, k, max_batch=n, encoder="f16r")
+    eng.load_params(p)
+    monkeypatch.delenv("SAEV_AMD_FUSED_CHAIN", raising=False)
+    idx0, val0 = eng.encode_topk(x.cuda())
+    torch.cuda.synchronize()
+    monkeypatch.setenv("SAEV_AMD_FUSED_CHAIN", "1")
+    idx1, val1 = eng.encode_topk(x.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(idx0, idx1) and torch.equal(val0, val1)
+    h = x.double() @ p["W_enc"].double() + p["b_enc"].double()
+    torch.testing.assert_close(h.gather(1, idx1.cpu().long()).float(), val1.cpu(), rtol=1e-5, atol=1e-5)

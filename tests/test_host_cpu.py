@@ -517,5 +517,8 @@ def test_batch_entropy_equals_the_reference_values():
     for tag in "abc":
         n_ex, n_tok = g[f"{tag}_support"].tolist()
         got = batch_entropy(g[f"{tag}_example_idx"], g[f"{tag}_token_idx"], n_ex, n_tok)
+        # (a whole-script run of oracle/gen_golden.py once wrote this fixture with EMPTY keys: g9_train had left a stub of
+        # calc_batch_entropy behind; the recipe restores it now and the fixture must carry the six values)
+        assert len(g[f"{tag}_keys"]) == 6 and len(g[f"{tag}_vals"]) == 6
         assert sorted(got) == g[f"{tag}_keys"].tolist()
         np.testing.assert_allclose([got[k] for k in sorted(got)], g[f"{tag}_vals"].numpy(), rtol=1e-12, atol=0)

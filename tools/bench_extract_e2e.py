@@ -3,28 +3,24 @@ network for checkpoints) -> forward hooks -> HBM reservoir -> configs[1]-shaped 
 
     python tools/bench_extract_e2e.py [--images 4096] [--img-batch 64] [--autocast bf16|none]
 
-Prints activations/s of the whole pipeline and the split between the transformer forward and the SAE steps."""
+Prints activations/s of the whole pipeline and the split between the transformer forward and the SAE steps; `run()` is also
+what `bench.py --extract-e2e` puts on its line as the `extract_e2e` sub-record."""
 import argparse
+import pathlib
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 from saev_amd import data, nn  # noqa: E402
 from saev_amd.data.vit import VisionTransformer  # noqa: E402
 from saev_amd.framework import train as T  # noqa: E402
 from saev_amd.nn import objectives  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--images", type=int, default=4096)
-    ap.add_argument("--img-batch", type=int, default=64)
-    ap.add_argument("--autocast", default="bf16")
-    ap.add_argument("--layer", type=int, default=23)
-    args = ap.parse_args()
-    dev = torch.device("cuda", 0)
+def run(dev, images: int = 4096, img_batch: int = 64, autocast: str = "bf16", layer: int = 23) -> dict:
+    args = argparse.Namespace(images=images, img_batch=img_batch, autocast=autocast, layer=layer)
     torch.manual_seed(0)
     vit = VisionTransformer.vit_l14().to(dev).eval()
     rec = data.ActivationRecorder(vit, vit.blocks, layers=(args.layer,), content_tokens_per_example=256, cls_token=True)
@@ -66,9 +62,28 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = args.images * 256
-    print(f"{steps} SAE steps on {n} activations in {dt:.2f} s = {n / dt / 1e6:.3f} M activations/s end to end; "
-          f"transformer forward {t_fwd[0]:.2f} s ({100 * t_fwd[0] / dt:.0f} %, {args.autocast}), "
-          f"everything else (hand-off + SAE steps + init) {dt - t_fwd[0]:.2f} s = {(dt - t_fwd[0]) / steps * 1e3:.2f} ms per step")
+    return {"workload": "configs[4] on one GPU: ViT-L/14-shaped transformer (24 blocks, d_model 1024, 257 tokens, random init, "
+                        f"{args.autocast} forward, stock PyTorch-ROCm) -> hooks on block {args.layer} -> device reservoir -> "
+                        "d_sae=32768 k=32 SAE train steps of 16384 rows, no disk in between",
+            "images": args.images, "image_batch": args.img_batch, "activations": n, "sae_steps": steps, "seconds": dt,
+            "activations_per_sec_end_to_end": n / dt, "transformer_forward_seconds": t_fwd[0],
+            "transformer_forward_share": t_fwd[0] / dt,
+            "handoff_plus_sae_ms_per_step": (dt - t_fwd[0]) / steps * 1e3,
+            "note": "the transformer forward is PyTorch's, not this package's; what is ours is everything after the hooks"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=4096)
+    ap.add_argument("--img-batch", type=int, default=64)
+    ap.add_argument("--autocast", default="bf16")
+    ap.add_argument("--layer", type=int, default=23)
+    args = ap.parse_args()
+    r = run(torch.device("cuda", 0), args.images, args.img_batch, args.autocast, args.layer)
+    print(f"{r['sae_steps']} SAE steps on {r['activations']} activations in {r['seconds']:.2f} s = "
+          f"{r['activations_per_sec_end_to_end'] / 1e6:.3f} M activations/s end to end; transformer forward "
+          f"{r['transformer_forward_seconds']:.2f} s ({100 * r['transformer_forward_share']:.0f} %, {args.autocast}), everything else "
+          f"(hand-off + SAE steps + init) = {r['handoff_plus_sae_ms_per_step']:.2f} ms per step")
 
 
 if __name__ == "__main__":

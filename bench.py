@@ -158,6 +158,13 @@ def main():
                     help="data-parallel optimizer tail: every rank all of it after an all-reduce, or reduce-scatter -> 1/N of "
                          "the tail per rank -> all-gather (framework/ddp.py).  auto: sharded when a start-up self-check on a "
                          "small problem reproduces the all-reduce path on every rank, else replicated")
+    ap.add_argument("--exchange", choices=["dense", "sparse"], default="dense",
+                    help="what the ranks exchange per step: the gradient (all-reduce, or reduce-scatter / all-gather with --tail "
+                         "sharded), or the sparse step state -- x, dL/dx_hat, codes all-gathered, every rank runs the backward "
+                         "over the global batch (framework/ddp.py; for small per-rank batches, i.e. strong scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: this many rows per step in total, split evenly over the ranks (overrides --batch; "
+                         "configs[2] at BASELINE's global batch: 16384)")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="length of the steady-state segment timed after the headline steps (0 = skip); it starts after "
                          "--sustained-after further steps, past the (lowered) dead-latent threshold")
@@ -228,16 +235,22 @@ def main():
         return bool(flag.item())
 
     tail_mode = "replicated"
-    if dist is not None and not args.overlap:
+    if dist is not None and not args.overlap and args.exchange == "dense":
         if args.tail == "sharded" or (args.tail == "auto" and sharded_tail_ok()):
             tail_mode = "sharded"
 
     B = args.batch
+    strong = args.global_batch > 0
+    if strong:
+        assert args.global_batch % world == 0, "--global-batch must divide evenly over the ranks"
+        B = args.global_batch // world
+    sparse = dist is not None and args.exchange == "sparse"
     # The reference's dead-latent threshold, 10 M tokens (objectives.py:24), is 611 of these steps: the sustained segment
     # below starts after it, so it runs in the regime a real run spends its life in (tracker consulted every step, AuxK on
     # whatever is dead).
     dead_thr = 10_000_000
-    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B, dead_threshold_tokens=dead_thr,
+    # (the sparse-state exchange runs the backward over every rank's rows: scratch for the global batch)
+    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B * (world if sparse else 1), dead_threshold_tokens=dead_thr,
                         shard_world=world if tail_mode == "sharded" else 1)
     if args.encoder:
         import dataclasses
@@ -257,7 +270,8 @@ def main():
     pool = torch.randn(POOL_BATCHES * B, D_MODEL, device=dev, generator=g) + mu
     perm = torch.randperm(pool.shape[0], device=dev, generator=g)
     x = torch.empty(B, D_MODEL, device=dev)
-    stepper = DataParallelStepper(eng, dist, world, force=args.force_dist, overlap=args.overlap, tail=tail_mode)
+    stepper = DataParallelStepper(eng, dist, world, force=args.force_dist, overlap=args.overlap, tail=tail_mode,
+                                  exchange="sparse" if sparse else "dense")
     extra = []  # further SAEs of the group (--n-saes): same batches, their own parameters
     for j in range(1, args.n_saes):
         import dataclasses as _dc
@@ -265,7 +279,8 @@ def main():
         e2 = SaeEngine(ecfg, dev)
         e2.params.copy_(eng.params)
         e2.share_x(eng)
-        extra.append(DataParallelStepper(e2, dist, world, force=args.force_dist, overlap=args.overlap, tail=tail_mode))
+        extra.append(DataParallelStepper(e2, dist, world, force=args.force_dist, overlap=args.overlap, tail=tail_mode,
+                                         exchange="sparse" if sparse else "dense"))
     lr_sched = lambda i: 4e-4 * min(1.0, i / 500)  # noqa: E731  warm-up region of the reference schedule
 
     def one_step(i):
@@ -417,14 +432,17 @@ def main():
             "unit": "activations/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": dtype_name,
             "data": "synthetic",
             "config": {"workload": f"configs[1]: d_in={D_MODEL}, d_sae={D_SAE} (32x), k={TOP_K}, batch={B}/GPU, "
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder, "n_saes": args.n_saes,
                        "grad_exchange": ("none" if stepper.dist is None else
-                                         ("bucketed all-reduce overlapped with the backward" if stepper.overlap else
+                                         ("no gradient crosses ranks: all-gather of x, dL/dx_hat and the codes ((8 D + 8 k) bytes per row), "
+                                          "backward over the global batch on every rank, the auxiliary term's compact rows all-reduced, "
+                                          "replicated tail" if stepper.exchange == "sparse" else
+                                          "bucketed all-reduce overlapped with the backward" if stepper.overlap else
                                           ("reduce-scatter of the two gradient halves, tail on 1/N of the elements per rank, all-gather of "
                                            "the parameter halves (decoder half on a side stream); verified at start-up against the "
                                            "all-reduce path" if stepper.tail == "sharded" else "one flat all-reduce, replicated tail")))},

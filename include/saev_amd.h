@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 4
+#define SAEV_AMD_ABI_VERSION 5
 
 typedef enum {
     SAEV_OK = 0,
@@ -226,6 +226,29 @@ int saev_backward_rows(saev_ctx* ctx, int32_t lat_lo, int32_t lat_hi, void* stre
  * saev_backward_end. */
 int saev_backward_rows_part(saev_ctx* ctx, int32_t lat_lo, int32_t lat_hi, int32_t part, void* stream);
 int saev_backward_end(saev_ctx* ctx, void* stream);
+/* Gathered backward -- the low-traffic exchange for strong scaling ("all-gather the sparse step state"; the
+ * reference has no distributed training, framework/train.py:760-769).  Instead of summing the 4 N_p-byte gradient over
+ * the ranks, every rank all-gathers what the backward consumes -- x, dL/dx_hat, the codes: (8 D + 8 k) bytes per row --
+ * and forms the FULL gradient of the global batch itself, redundantly and bit-identically on every rank:
+ *   saev_copy_step_state     this rank's rows of dL/dx_hat and of the codes into caller buffers (the rank's slice of the
+ *                            all-gather outputs); n_rows = the rows of the training forward in flight;
+ *   saev_backward_override   the gathered buffers (n_all <= max_batch rows of all ranks, rank-major) for the NEXT
+ *                            saev_backward_begin / _rows: pairs, db_dec and both weight gradients then cover all n_all
+ *                            rows.  One-shot (the next forward cancels it); NULL cancels.  No Matryoshka prefixes.
+ * The auxiliary loss stays local to a rank's rows; its gradient is a few rows: saev_aux_compact_rows rows of
+ * [dW_dec | dW_enc^T] for the dead latents, their db_enc and the term's share of db_dec.  Between saev_backward_begin and
+ * saev_backward_rows the caller exports them (rows * (2 d_model + 1) + d_model floats), sums over ranks, imports:
+ *   saev_aux_compact_rows / _export / _import.
+ * Gradients carry the local 1/(n_local d_model) factor as in every data-parallel mode: tail with grad_scale = 1/world.
+ * saev_trust_gradients(1) lets saev_step_tail use what the backward left behind (row statistics, tile squares) as
+ * saev_train_step does -- the caller vouches that nothing writes the gradient between saev_backward_end and the tail. */
+int saev_copy_step_state(saev_ctx* ctx, int32_t n_rows, float* g_out, int32_t* idx_out, float* val_out, void* stream);
+int saev_backward_override(saev_ctx* ctx, const float* x_all, const float* g_all, const int32_t* idx_all,
+                           const float* val_all, int32_t n_all);
+int32_t saev_aux_compact_rows(const saev_ctx* ctx);
+int saev_aux_compact_export(saev_ctx* ctx, float* buf, void* stream);
+int saev_aux_compact_import(saev_ctx* ctx, const float* buf, void* stream);
+int saev_trust_gradients(saev_ctx* ctx, int32_t on);
 float* saev_grad_w_enc_t(saev_ctx* ctx);
 int saev_bind_w_enc_t(saev_ctx* ctx, float* scratch);
 /* Phase 4: grads *= grad_scale (1/world_size after a sum all-reduce), remove_parallel_grads

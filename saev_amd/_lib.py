@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SaevCfg(C.Structure):
@@ -75,6 +75,12 @@ _SIGNATURES = {
     "saev_backward_rows": (C.c_int, [P, C.c_int32, C.c_int32, P]),
     "saev_backward_rows_part": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, P]),
     "saev_backward_end": (C.c_int, [P, P]),
+    "saev_copy_step_state": (C.c_int, [P, C.c_int32, P, P, P, P]),
+    "saev_backward_override": (C.c_int, [P, P, P, P, P, C.c_int32]),
+    "saev_aux_compact_rows": (C.c_int32, [P]),
+    "saev_aux_compact_export": (C.c_int, [P, P, P]),
+    "saev_aux_compact_import": (C.c_int, [P, P, P]),
+    "saev_trust_gradients": (C.c_int, [P, C.c_int32]),
     "saev_grad_w_enc_t": (P, [P]),
     "saev_bind_w_enc_t": (C.c_int, [P, P]),
     "saev_step_tail": (C.c_int, [P, C.c_float, C.c_float, C.c_float, C.c_int64, P]),

@@ -142,6 +142,12 @@ struct saev_ctx {
     saev_step_stats* stats = nullptr;
     double* stats_scratch = nullptr;  // per-workgroup partial sums + ticket of stats_reduce_kernel
     int* tickets = nullptr;           // arrival counters of "last workgroup finishes" kernels (zero between launches)
+    // gathered backward (saev_backward_override): the (row, latent) pairs of ALL ranks' rows, set for one backward
+    const float *ov_x = nullptr, *ov_g = nullptr, *ov_val = nullptr;
+    const int32_t* ov_idx = nullptr;
+    int ov_n = 0;
+    float* db_aux = nullptr;       // the auxiliary term's share of db_dec, kept apart while an override is active
+    bool trust_grads = false;      // the caller vouches that nothing touches the gradient between backward and tail
     // state of the step in flight
     const float* x_last = nullptr;
     int n_last = 0;
@@ -309,7 +315,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
-    A(tau_max, MB); A(heur_state, 8); A(stats_scratch, STATS_SCRATCH_DOUBLES); A(tickets, 8);
+    A(tau_max, MB); A(heur_state, 8); A(stats_scratch, STATS_SCRATCH_DOUBLES); A(tickets, 8); A(db_aux, D);
 #undef A
     if (rc != SAEV_OK) {
         // keep the context so the caller can read the message, but report failure
@@ -897,6 +903,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     c->x_last = x;
     c->n_last = n;
     c->training_last = training;
+    c->ov_x = nullptr; c->ov_n = 0;  // an override serves one backward
     // The reference renormalises the rows of W_dec at the top of a training step (train.py:334-335).  Nothing before the
     // decode reads W_dec, so it is done right in front of the decode instead: the rows it has just written are what the
     // decode gathers next (3.053 -> 3.034 ms per step against doing it first), and a caller whose decoder half of the
@@ -1150,7 +1157,12 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         HIPCHK(c, launch_colsum(c->aux_small_part + (size_t)L * D, nb, L * D, c->aux_small_part2, c->dWe, 0, nd_dev, s,
                                 (long)2 * L * D, 1.0f, D));
         HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
-        HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nd_dev, s));
+        if (c->ov_x != nullptr) {  // gathered backward: the local share travels with the compact rows (saev_aux_compact_export)
+            HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));  // (the count may be zero on the device)
+            HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->db_aux, 0, nd_dev, s));
+        } else {
+            HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nd_dev, s));
+        }
         return SAEV_OK;
     }
     {
@@ -1178,7 +1190,8 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         if (rc != SAEV_OK) return rc;
     }
     HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));
-    HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
+    HIPCHK(c, launch_colsum(c->g_aux, n, D, c->colsum_partials, c->ov_x != nullptr ? c->db_aux : c->grads + c->off_b_dec,
+                            c->ov_x != nullptr ? 0 : 1, nullptr, s));
     // the compact rows dWd / dWe / dbe are added into the gradient rows of the dead latents by saev_backward_rows
     return SAEV_OK;
 }
@@ -1261,11 +1274,14 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_backward_begin: no training forward in flight");
     REQUIRE(c, c->grads, SAEV_NOT_BOUND, "gradient buffer not bound");
     hipStream_t s = (hipStream_t)stream;
-    const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k;
+    const bool ov = c->ov_x != nullptr;
+    REQUIRE(c, !ov || c->P_last == 1, SAEV_UNSUPPORTED, "gathered backward: Matryoshka prefixes are not supported");
+    const int n = ov ? c->ov_n : c->n_last;  // rows whose (row, latent) pairs this backward covers
     const int words = ((n + 31) / 32 + 7) / 8 * 8;
     c->row_proj_valid = false;
     CscArgs a{};
-    a.idx = c->idx; a.code_stride = K; a.k = K; a.k_dev = nullptr; a.n_rows = n; a.S = S;
+    a.idx = ov ? c->ov_idx : c->idx; a.code_stride = K; a.k = K; a.k_dev = nullptr; a.n_rows = n; a.S = S;
     a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals;
     a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
     a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
@@ -1274,7 +1290,7 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     c->bitmap_clean = false;
     c->bitmap_words_last = words;
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0); the AuxK contractions add theirs
-    const float* gmat = c->P_last > 1 ? c->G : c->g;
+    const float* gmat = ov ? c->ov_g : (c->P_last > 1 ? c->G : c->g);
     HIPCHK(c, launch_colsum(gmat, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s, (long)c->P_last * D));
     if (c->aux_route != AUX_NONE) {
         int rc = auxk_backward(c, s);
@@ -1291,14 +1307,16 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, part >= 0 && part <= 2, SAEV_INVALID_ARG, "saev_backward_rows_part: part must be 0 (both), 1 (decoder) or 2 (encoder)");
     REQUIRE(c, c->x_last && c->training_last && c->grads, SAEV_INVALID_ARG, "saev_backward_rows: call saev_backward_begin first");
-    const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k, n = c->n_last;
+    const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k;
+    const bool ov = c->ov_x != nullptr;
+    const int n = ov ? c->ov_n : c->n_last;
     REQUIRE(c, 0 <= lat_lo && lat_lo < lat_hi && lat_hi <= S, SAEV_INVALID_ARG, "saev_backward_rows: bad latent range");
     hipStream_t s = (hipStream_t)stream;
     DwRowsArgs a{};
     a.starts = c->starts; a.chunk_starts = c->chunk_starts; a.work_latent = c->work_latent;
-    a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = c->val; a.W_dec = c->params + c->off_W_dec;
-    a.g = c->P_last > 1 ? c->G : c->g;  // Matryoshka: rows receive the suffix-summed gradients C_p
-    a.x = c->x_last;
+    a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = ov ? c->ov_val : c->val; a.W_dec = c->params + c->off_W_dec;
+    a.g = ov ? c->ov_g : (c->P_last > 1 ? c->G : c->g);  // Matryoshka: rows receive the suffix-summed gradients C_p
+    a.x = ov ? c->ov_x : c->x_last;
     a.D = D; a.S = S; a.k_dev = nullptr; a.accumulate = 0;
     a.P = c->P_last;
     for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts_last[p];
@@ -1322,6 +1340,9 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part,
                                           a.row_proj, a.W_dec, a.project));
+    // gathered backward: the auxiliary term's share of db_dec (summed over the ranks by the caller, like the compact rows)
+    if (ov && c->aux_route != AUX_NONE && part != 2 && lat_lo == 0)
+        HIPCHK(c, launch_colsum(c->db_aux, 1, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
     c->row_proj_valid = all_rows;
     if (clears) { c->bitmap_clean = true; c->bitmap_clean_words = c->bitmap_words_last; }
     return SAEV_OK;
@@ -1332,6 +1353,67 @@ float* saev_grad_w_enc_t(saev_ctx* c) { return c ? c->dW_encT : nullptr; }
 int saev_bind_w_enc_t(saev_ctx* c, float* scratch) {
     if (!c || !scratch) return SAEV_INVALID_ARG;
     c->dW_encT = scratch;
+    return SAEV_OK;
+}
+
+int saev_copy_step_state(saev_ctx* c, int32_t n_rows, float* g_out, int32_t* idx_out, float* val_out, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->n_last > 0 && c->training_last && n_rows == c->n_last, SAEV_INVALID_ARG,
+            "saev_copy_step_state: n_rows must be the row count of the training forward in flight");
+    REQUIRE(c, c->P_last == 1, SAEV_UNSUPPORTED, "saev_copy_step_state: Matryoshka prefixes are not supported");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nk = (size_t)n_rows * c->cfg.top_k, nd = (size_t)n_rows * c->cfg.d_model;
+    if (g_out) HIPCHK(c, hipMemcpyAsync(g_out, c->g, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (idx_out) HIPCHK(c, hipMemcpyAsync(idx_out, c->idx, nk * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (val_out) HIPCHK(c, hipMemcpyAsync(val_out, c->val, nk * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SAEV_OK;
+}
+
+int saev_backward_override(saev_ctx* c, const float* x_all, const float* g_all, const int32_t* idx_all, const float* val_all,
+                           int32_t n_all) {
+    if (!c) return SAEV_INVALID_ARG;
+    if (x_all == nullptr) { c->ov_x = nullptr; c->ov_n = 0; return SAEV_OK; }
+    REQUIRE(c, g_all && idx_all && val_all && n_all > 0, SAEV_INVALID_ARG, "saev_backward_override: NULL buffer");
+    REQUIRE(c, n_all <= c->cfg.max_batch, SAEV_INVALID_ARG,
+            "saev_backward_override: the gathered row count exceeds max_batch (create the context for the GLOBAL batch)");
+    REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_backward_override: no training forward in flight");
+    REQUIRE(c, ((uintptr_t)x_all % 16) == 0 && ((uintptr_t)g_all % 16) == 0, SAEV_INVALID_ARG, "x_all / g_all must be 16-byte aligned");
+    c->ov_x = x_all; c->ov_g = g_all; c->ov_idx = idx_all; c->ov_val = val_all; c->ov_n = n_all;
+    return SAEV_OK;
+}
+
+int32_t saev_aux_compact_rows(const saev_ctx* c) {
+    if (!c || c->aux_route == AUX_NONE) return 0;
+    return c->aux_route == AUX_DENSE ? (c->n_dead_host + 3) / 4 * 4 : AUX_SMALL_MAX;
+}
+
+// [dWd rows x D | dWe rows x D | dbe rows | db_aux D]
+static int aux_compact_copy(saev_ctx* c, float* buf, bool out, hipStream_t s) {
+    const size_t rows = (size_t)saev_aux_compact_rows(c), D = c->cfg.d_model;
+    if (rows == 0) return SAEV_OK;
+    REQUIRE(c, buf != nullptr, SAEV_INVALID_ARG, "saev_aux_compact_*: NULL buffer");
+    float* seg[4] = {c->dWd, c->dWe, c->dbe, c->db_aux};
+    const size_t len[4] = {rows * D, rows * D, rows, D};
+    size_t off = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (out) HIPCHK(c, hipMemcpyAsync(buf + off, seg[i], len[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+        else HIPCHK(c, hipMemcpyAsync(seg[i], buf + off, len[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+        off += len[i];
+    }
+    return SAEV_OK;
+}
+int saev_aux_compact_export(saev_ctx* c, float* buf, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    return aux_compact_copy(c, buf, true, (hipStream_t)stream);
+}
+int saev_aux_compact_import(saev_ctx* c, const float* buf, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    return aux_compact_copy(c, const_cast<float*>(buf), false, (hipStream_t)stream);
+}
+
+int saev_trust_gradients(saev_ctx* c, int32_t on) {
+    if (!c) return SAEV_INVALID_ARG;
+    c->trust_grads = on != 0;
     return SAEV_OK;
 }
 
@@ -1397,7 +1479,7 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const long S = c->cfg.d_sae, D = c->cfg.d_model;
     c->tail_proj_in_adam = false;
-    if (c->wenc_sq_trusted && c->wenc_sq_valid && c->row_proj_valid && shard_rank < 0) {
+    if ((c->wenc_sq_trusted || c->trust_grads) && c->wenc_sq_valid && c->row_proj_valid && shard_rank < 0) {
         // Inside saev_train_step nothing has touched the gradient since the backward: the kernels that wrote the decoder
         // rows left each row's projection coefficient and projected squares (row_proj), the transpose the squares of dW_enc
         // tile by tile.  One small reduction gives the clip norm, and Adam applies the projection to the rows as it reads

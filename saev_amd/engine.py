@@ -282,9 +282,56 @@ class SaeEngine:
     def backward_end(self):
         self._chk(self.lib.saev_backward_end(self.ctx, _stream()), "saev_backward_end")
 
-    def step_tail(self, lr: float, max_norm: float = 1.0, grad_scale: float = 1.0):
+    def step_tail(self, lr: float, max_norm: float = 1.0, grad_scale: float = 1.0, *, trusted: bool = False):
+        """``trusted``: nothing wrote the gradient buffer since ``backward_end`` -- the tail may use the row statistics the
+        backward left behind (projection inside Adam, no rpg pass), as ``train_step`` does."""
         self.adam_steps += 1
-        self._chk(self.lib.saev_step_tail(self.ctx, lr, max_norm, grad_scale, self.adam_steps, _stream()), "saev_step_tail")
+        if trusted:
+            self._chk(self.lib.saev_trust_gradients(self.ctx, 1), "saev_trust_gradients")
+        try:
+            self._chk(self.lib.saev_step_tail(self.ctx, lr, max_norm, grad_scale, self.adam_steps, _stream()), "saev_step_tail")
+        finally:
+            if trusted:
+                self.lib.saev_trust_gradients(self.ctx, 0)
+
+    # ---- gathered backward (data-parallel runs that exchange the sparse step state instead of the gradient) -------------
+    def gather_buffers(self, world: int, n_local: int):
+        """(x_all, g_all, idx_all, val_all) for ``world`` ranks of ``n_local`` rows each, allocated once per shape."""
+        key = (world, n_local)
+        if getattr(self, "_gather_key", None) != key:
+            n, D, K = world * n_local, self.cfg.d_model, min(self.cfg.top_k, self.cfg.d_sae)
+            if n > self.cfg.max_batch:
+                raise _lib.SaevError(f"gathered backward over {n} rows needs an engine with max_batch >= {n} (the GLOBAL batch), "
+                                     f"got {self.cfg.max_batch}")
+            self._gather_bufs = (torch.empty(n, D, device=self.device), torch.empty(n, D, device=self.device),
+                                 torch.empty(n, K, device=self.device, dtype=torch.int32), torch.empty(n, K, device=self.device))
+            self._gather_key = key
+        return self._gather_bufs
+
+    def copy_step_state(self, n_rows: int, g_out: torch.Tensor, idx_out: torch.Tensor, val_out: torch.Tensor):
+        """This rank's rows of dL/dx_hat and of the codes of the training forward in flight, into caller tensors."""
+        self._chk(self.lib.saev_copy_step_state(self.ctx, n_rows, _ptr(g_out), _ptr(idx_out), _ptr(val_out), _stream()), "saev_copy_step_state")
+
+    def backward_begin_gathered(self, x_all: torch.Tensor, g_all: torch.Tensor, idx_all: torch.Tensor, val_all: torch.Tensor):
+        """``backward_begin`` over the rows of ALL ranks (rank-major); the following ``backward_rows`` cover them too."""
+        assert x_all.is_contiguous() and g_all.is_contiguous() and idx_all.is_contiguous() and val_all.is_contiguous()
+        self._gather_keepalive = (x_all, g_all, idx_all, val_all)
+        self._chk(self.lib.saev_backward_override(self.ctx, _ptr(x_all), _ptr(g_all), _ptr(idx_all), _ptr(val_all), x_all.shape[0]),
+                  "saev_backward_override")
+        self.backward_begin()
+
+    def aux_compact_export(self) -> torch.Tensor | None:
+        """The auxiliary term's local gradient -- the dead latents' rows of dW_dec and dW_enc^T, their db_enc, its share of
+        db_dec -- packed into one tensor (None when the step has no auxiliary work); sum it over ranks, then import."""
+        rows = int(self.lib.saev_aux_compact_rows(self.ctx))
+        if rows == 0:
+            return None
+        buf = torch.empty(rows * (2 * self.cfg.d_model + 1) + self.cfg.d_model, device=self.device)
+        self._chk(self.lib.saev_aux_compact_export(self.ctx, _ptr(buf), _stream()), "saev_aux_compact_export")
+        return buf
+
+    def aux_compact_import(self, buf: torch.Tensor):
+        self._chk(self.lib.saev_aux_compact_import(self.ctx, _ptr(buf), _stream()), "saev_aux_compact_import")
 
     # tail in two parts over this rank's chunks (data-parallel runs with a sharded tail, framework/ddp.py)
     def halves(self, flat: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:

@@ -33,6 +33,17 @@ Tail, two ways (``tail=``, ``SAEV_AMD_DDP_TAIL``):
     half on a side stream, waited for only right before the next step's decode (``saev_wdec_ready_event``), so the
     encoder hides it.  Same bytes on the wire as the all-reduce, less tail, part of the gather off the critical path.
 
+Strong scaling (``exchange="sparse"``, ``SAEV_AMD_DDP_EXCHANGE=sparse``): when the GLOBAL batch is fixed and the ranks
+split it, a rank's compute shrinks with 1/world while the 268 MB gradient exchange does not -- at configs[2]'s 2 048 rows
+per rank the all-reduce (>= 0.66 ms over seven xGMI links) is longer than the rank's forward.  This mode exchanges what the
+backward CONSUMES instead of what it produces: every rank all-gathers x, dL/dx_hat and the codes of its rows
+((8 D + 8 k) bytes per row: 17 MB per rank at D = 1024, k = 32, 2 048 rows) and forms the full gradient of the global
+batch itself -- redundantly, with deterministic kernels, hence bit-identically on every rank.  The auxiliary loss stays
+local to a rank's rows; its gradient is a few compact rows (the dead latents'), summed with one small all-reduce.  No
+gradient buffer crosses ranks, every rank runs the whole tail (and may use the fused one: nothing touches the gradient
+between backward and tail).  What it costs: the sparse backward over the global batch on every rank (0.8 ms at 16 384
+rows) -- worth it when that is less than the dense exchange, i.e. for small per-rank batches; weak scaling keeps "dense".
+
 `dist` may be any object with torch.distributed's collectives / ReduceOp API (gloo on CPU in tests).
 """
 
@@ -45,8 +56,12 @@ import torch
 
 class DataParallelStepper:
     def __init__(self, engine, dist=None, world_size: int = 1, force: bool = False, overlap: bool | None = None,
-                 n_buckets: int = 2, tail: str | None = None, rank: int | None = None):
+                 n_buckets: int = 2, tail: str | None = None, rank: int | None = None, exchange: str | None = None):
         """``force`` keeps the collective path even for one rank (exercises RCCL on a single-GPU box)."""
+        if exchange is None:
+            exchange = os.environ.get("SAEV_AMD_DDP_EXCHANGE", "dense")
+        if exchange not in ("dense", "sparse"):
+            raise ValueError(f"exchange must be 'dense' or 'sparse', got {exchange!r}")
         self.engine = engine
         self.dist = dist if (world_size > 1 or force) else None
         self.world = world_size
@@ -61,6 +76,12 @@ class DataParallelStepper:
         self.tail = tail if self.dist is not None else "replicated"
         self.rank = rank if rank is not None else (self.dist.get_rank() if self.dist is not None else 0)
         self._side = None
+        self.exchange = exchange if self.dist is not None else "dense"
+        if self.exchange == "sparse":
+            if self.overlap or self.tail == "sharded":
+                raise ValueError("exchange='sparse' moves no gradient between ranks: it goes with the replicated tail and no overlap")
+            if not hasattr(engine, "backward_begin_gathered"):
+                raise ValueError("exchange='sparse' needs an engine with the gathered backward")
         self.two_pass = os.environ.get("SAEV_AMD_DDP_TWO_PASS", "1") != "0"
         if self.tail == "sharded":
             if self.overlap:
@@ -150,6 +171,35 @@ class DataParallelStepper:
             w.wait()
         eng.backward_end()  # reduced transposed gradient -> W_enc segment of the flat buffer
 
+    def _step_sparse(self, x_local: torch.Tensor, lr: float, max_norm: float, pre_tail) -> None:
+        """The sparse-state exchange (module docstring): forward on this rank's rows, all-gather of x / dL/dx_hat / codes,
+        backward over every rank's rows, the auxiliary term's compact rows summed, replicated tail."""
+        eng, dist, r, w = self.engine, self.dist, self.rank, self.world
+        n = x_local.shape[0]
+        n_global = n * w
+        eng.step_forward(x_local, training=True, n_rows_global=n_global)
+        dist.all_reduce(eng.fired, op=dist.ReduceOp.MAX)
+        eng.step_dead(n_global)
+        x_all, g_all, idx_all, val_all = eng.gather_buffers(w, n)
+        sl = slice(r * n, (r + 1) * n)
+        x_all[sl].copy_(x_local)
+        eng.copy_step_state(n, g_all[sl], idx_all[sl], val_all[sl])
+        # (RCCL gathers in place; other backends -- gloo in the tests -- get an input that does not alias the output)
+        in_place = getattr(dist, "get_backend", lambda: "nccl")() == "nccl"
+        for buf in (x_all, g_all, idx_all, val_all):  # rank-major row order on every rank: identical pair lists, identical sums
+            dist.all_gather_into_tensor(buf, buf[sl] if in_place else buf[sl].clone())
+        eng.backward_begin_gathered(x_all, g_all, idx_all, val_all)
+        aux = eng.aux_compact_export()
+        if aux is not None:
+            dist.all_reduce(aux, op=dist.ReduceOp.SUM)
+            eng.aux_compact_import(aux)
+        eng.backward_rows(0, eng.cfg.d_sae)
+        eng.backward_end()
+        if pre_tail is not None:
+            pre_tail()
+        # (with a log-step callback in between the caller may look at -- not write -- the gradient: still trusted)
+        eng.step_tail(lr, max_norm, grad_scale=1.0 / w, trusted=True)
+
     def train_step(self, x_local: torch.Tensor, lr: float, max_norm: float = 1.0, pre_tail=None) -> None:
         """One optimizer step.  ``pre_tail`` (log steps) is called after the backward and before rpg / clip / Adam --
         the point where the reference's log block looks at the parameters (train.py:365-442 sits between
@@ -165,6 +215,9 @@ class DataParallelStepper:
             eng.step_backward()
             pre_tail()
             eng.step_tail(lr, max_norm)
+            return
+        if self.exchange == "sparse":
+            self._step_sparse(x_local, lr, max_norm, pre_tail)
             return
         n_global = x_local.shape[0] * self.world  # equal shards by construction (data.ShuffledDataLoader.n_epoch)
         eng.step_forward(x_local, training=True, n_rows_global=n_global)

@@ -204,15 +204,19 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
     steppers, scheds, lrs = [], [], []
     # how the optimizer tail is spread over data-parallel ranks (framework/ddp.py): every rank all of it, or 1/world each
     tail_mode = os.environ.get("SAEV_AMD_DDP_TAIL", "replicated") if world > 1 else "replicated"
+    # how the ranks exchange a step (framework/ddp.py): the gradient ("dense"), or -- small per-rank batches, strong scaling
+    # -- the sparse step state, every rank running the backward over the global batch ("sparse")
+    exchange = os.environ.get("SAEV_AMD_DDP_EXCHANGE", "dense") if world > 1 else "dense"
     for sae, obj, c in zip(saes, objs, cfgs):
         if tail_mode == "sharded":
             sae._shard_world = world  # the engine lays its flat buffers out in `world` equal chunks per half
-        eng = obj._bind(sae, dataloader.local_batch)
+        # (the gathered backward covers every rank's rows: its scratch is sized for the global batch)
+        eng = obj._bind(sae, dataloader.local_batch * (world if exchange == "sparse" else 1))
         if world > 1:  # identical replicas: rank 0's initial parameters everywhere
             dist.broadcast(eng.params, src=0)
         if steppers:  # one batch feeds every SAE of the group (train.py:334-348): the first engine's x statistics,
             eng.share_x(steppers[0].engine)  # centring and operand images serve the others
-        steppers.append(DataParallelStepper(eng, dist, world, tail=tail_mode))
+        steppers.append(DataParallelStepper(eng, dist, world, tail=tail_mode, exchange=exchange))
         scheds.append(scheduling.WarmupCosine(0.0, c.n_lr_warmup, c.lr, len(limiter), 0.0))
         lrs.append(0.0)  # first optimizer step is pure warm-up (train.py:118)
     dataloader.engine = steppers[0].engine

@@ -67,10 +67,60 @@ class OracleEngine:
         self.fired.zero_()
         dead = t >= self.cfg.dead_threshold_tokens
         x_hats = R.decode(self.f, self.leaves["W_dec"], self.leaves["b_dec"])
+        x_hats.retain_grad()
         mse = R.mean_squared_err(x_hats, self.x[:, None, :]).mean()
         aux = R.auxk_loss(x=self.x, h=self.h, x_hat_last=x_hats[:, -1], dead_mask=dead, W_dec=self.leaves["W_dec"],
                           b_dec=self.leaves["b_dec"], k_aux=self.cfg.k_aux, alpha=self.cfg.alpha)
         self.loss, self.mse, self.n_dead = mse + aux, mse.item(), int(dead.sum())
+        self._mse_t, self._aux_t, self._x_hats, self._dead = mse, aux, x_hats, dead
+
+    # ---- gathered backward (exchange="sparse"): what crosses ranks is x, dL/dx_hat and the codes; every rank forms the main
+    # path's gradient of ALL rows from them with plain algebra, the auxiliary term's gradient stays local and travels as
+    # the dead latents' compact rows ----
+    def gather_buffers(self, world, n_local):
+        n, D, K = world * n_local, self.cfg.d_model, self.cfg.top_k
+        return torch.empty(n, D), torch.empty(n, D), torch.empty(n, K, dtype=torch.int32), torch.empty(n, K)
+
+    def copy_step_state(self, n_rows, g_out, idx_out, val_out):
+        self.calls.append("copy_state")
+        (g,) = torch.autograd.grad(self._mse_t, self._x_hats, retain_graph=True)
+        idx = torch.topk(self.h.detach(), self.cfg.top_k, dim=-1).indices.sort(dim=-1).values
+        g_out.copy_(g[:, -1])
+        idx_out.copy_(idx.to(torch.int32))
+        val_out.copy_(self.h.detach().gather(1, idx))
+
+    def backward_begin_gathered(self, x_all, g_all, idx_all, val_all):
+        self.calls.append("backward_begin_gathered")
+        S = self.cfg.d_sae
+        W_dec = self.leaves["W_dec"].detach()
+        idx = idx_all.long()
+        F = torch.zeros(x_all.shape[0], S).scatter_(1, idx, val_all)
+        mask = torch.zeros(x_all.shape[0], S).scatter_(1, idx, 1.0)
+        dF = (g_all @ W_dec.T) * mask  # straight through the kept entries
+        self._g = {"W_dec": F.T @ g_all, "b_dec": g_all.sum(dim=0), "W_enc": x_all.T @ dF, "b_enc": dF.sum(dim=0)}
+        self._aux_local = None
+        if self.n_dead > 0:
+            ga = torch.autograd.grad(self._aux_t, [self.leaves[k] for k in R.PARAM_ORDER], allow_unused=True)
+            ga = {k: (torch.zeros_like(self.leaves[k]) if v is None else v) for k, v in zip(R.PARAM_ORDER, ga)}
+            dl = self._dead.nonzero().flatten()
+            # (only the dead latents' rows / columns and b_dec receive anything from the auxiliary term)
+            live = torch.ones(S, dtype=torch.bool); live[dl] = False
+            assert ga["W_dec"][live].abs().max() == 0 and ga["W_enc"][:, live].abs().max() == 0 and ga["b_enc"][live].abs().max() == 0
+            self._aux_local = (dl, torch.cat([ga["W_dec"][dl].reshape(-1), ga["W_enc"][:, dl].T.reshape(-1), ga["b_enc"][dl], ga["b_dec"]]))
+        self.view("b_dec").copy_(self._g["b_dec"])
+
+    def aux_compact_export(self):
+        return None if self._aux_local is None else self._aux_local[1].clone()
+
+    def aux_compact_import(self, buf):
+        self.calls.append("aux_import")
+        dl, D = self._aux_local[0], self.cfg.d_model
+        nd = len(dl)
+        self._g["W_dec"][dl] += buf[: nd * D].view(nd, D)
+        self._g["W_enc"][:, dl] += buf[nd * D : 2 * nd * D].view(nd, D).T
+        self._g["b_enc"][dl] += buf[2 * nd * D : 2 * nd * D + nd]
+        self._g["b_dec"] += buf[2 * nd * D + nd :]
+        self.view("b_dec").copy_(self._g["b_dec"])
 
     def step_backward(self):
         self.calls.append("backward")
@@ -154,7 +204,7 @@ class OracleEngine:
     def wdec_ready_after(self, event):
         self.calls.append("wdec_ready_after")
 
-    def step_tail(self, lr, max_norm=1.0, grad_scale=1.0):
+    def step_tail(self, lr, max_norm=1.0, grad_scale=1.0, trusted=False):
         self.calls.append("tail")
         self.tail_prepare(-1)
         self.tail_apply(lr, max_norm, grad_scale, -1)
@@ -181,13 +231,13 @@ def _problem():
     return cfg, params, batches
 
 
-def _worker(rank, world, port, out, overlap=False, tail="replicated"):
+def _worker(rank, world, port, out, overlap=False, tail="replicated", exchange="dense"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     cfg, params, batches = _problem()
     eng = OracleEngine(params, cfg, shard_world=world if tail == "sharded" else 1)
-    stepper = DataParallelStepper(eng, dist, world, overlap=overlap, n_buckets=3, tail=tail)
+    stepper = DataParallelStepper(eng, dist, world, overlap=overlap, n_buckets=3, tail=tail, exchange=exchange)
     sched = R.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, len(batches), 0.0)
     lr, dead_counts = 0.0, []
     for x in batches:
@@ -196,7 +246,13 @@ def _worker(rank, world, port, out, overlap=False, tail="replicated"):
         dead_counts.append(eng.n_dead)
         lr = sched.step()
     if rank == 0:
-        if overlap:
+        if exchange == "sparse":
+            # (no gradient crosses ranks: state gathered, backward over all rows, compact auxiliary rows summed, whole tail)
+            first = eng.calls[: eng.calls.index("tail") + 1]
+            assert first in (["forward", "dead", "copy_state", "backward_begin_gathered", "rows[0:256]", "backward_end", "tail"],
+                             ["forward", "dead", "copy_state", "backward_begin_gathered", "aux_import", "rows[0:256]", "backward_end", "tail"])
+            assert "aux_import" in eng.calls and "backward" not in eng.calls
+        elif overlap:
             assert eng.calls[:7] == ["forward", "dead", "backward_begin", "rows[0:85]", "rows[85:170]", "rows[170:256]",
                                      "backward_end"] and eng.calls[7] == "tail"
         elif tail == "sharded":
@@ -222,13 +278,16 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,overlap,tail", [(2, False, "replicated"), (2, True, "replicated"), (2, False, "sharded"),
-                                                (4, False, "sharded"), (4, False, "replicated")])
-def test_ranks_reproduce_single_process_step(tmp_path, world, overlap, tail):
-    """2 (4) ranks x B/2 (B/4) rows == one process on B rows, for the all-reduce exchange (flat and bucketed / overlapped)
-    and for the sharded tail (reduce-scatter -> tail on 1/world of the elements -> all-gather)."""
+@pytest.mark.parametrize("world,overlap,tail,exchange", [(2, False, "replicated", "dense"), (2, True, "replicated", "dense"),
+                                                         (2, False, "sharded", "dense"), (4, False, "sharded", "dense"),
+                                                         (4, False, "replicated", "dense"), (2, False, "replicated", "sparse"),
+                                                         (4, False, "replicated", "sparse")])
+def test_ranks_reproduce_single_process_step(tmp_path, world, overlap, tail, exchange):
+    """2 (4) ranks x B/2 (B/4) rows == one process on B rows, for the all-reduce exchange (flat and bucketed / overlapped),
+    for the sharded tail (reduce-scatter -> tail on 1/world of the elements -> all-gather) and for the sparse-state exchange
+    (all-gather of x / dL/dx_hat / codes, full backward on every rank, the auxiliary term's compact rows summed)."""
     out = str(tmp_path / "rank{rank}.pt")
-    mp.spawn(_worker, args=(world, _free_port(), out, overlap, tail), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, overlap, tail, exchange), nprocs=world, join=True)
     rs = [torch.load(out.format(rank=r)) for r in range(world)]
     r0 = rs[0]
     # replicas stay bit-identical

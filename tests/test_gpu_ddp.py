@@ -154,7 +154,7 @@ def test_chunked_tail_covers_the_padded_layout_exactly(world, encoder_mode):
         assert (flat[pad] == 0).all()
 
 
-def _two_rank_worker(rank, world, port, out, tail):
+def _two_rank_worker(rank, world, port, out, tail, exchange="dense"):
     import os
 
     import torch.distributed as dist
@@ -167,7 +167,7 @@ def _two_rank_worker(rank, world, port, out, tail):
         eng, x, s = _setup(shard_world=world if tail == "sharded" else 1)
         g = load_golden("g9_train_b")
         bsz = int(g["bsz"])
-        stepper = DataParallelStepper(eng, dist, world, tail=tail)
+        stepper = DataParallelStepper(eng, dist, world, tail=tail, exchange=exchange)
         n_dead = []
         for i, xb in enumerate(g["acts"].split(bsz)[:5]):
             stepper.train_step(xb[rank::world].contiguous().cuda(), 1e-3 * i, 0.05)
@@ -179,19 +179,21 @@ def _two_rank_worker(rank, world, port, out, tail):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tail", ["replicated", "sharded"])
-def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, tail, encoder_mode):
+@pytest.mark.parametrize("tail,exchange", [("replicated", "dense"), ("sharded", "dense"), ("replicated", "sparse")])
+def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, tail, exchange, encoder_mode):
     """The REAL engines under a real two-rank exchange: two processes share the one GPU of the test box and talk over
     gloo (RCCL refuses two ranks on one device; gloo stages device tensors through the host, which is all this needs).
-    Rank r trains on rows r::2 of every batch; both tails must leave both ranks with identical parameters that match one
-    process on the full batches -- fired-flag MAX, 1/world gradient scale, global clip norm, dead tracker, AuxK included."""
+    Rank r trains on rows r::2 of every batch; both tails -- and the sparse-state exchange, where no gradient crosses
+    ranks: x / dL/dx_hat / codes are all-gathered and every rank runs the backward over all rows -- must leave both ranks
+    with identical parameters that match one process on the full batches: fired-flag MAX, 1/world gradient scale, global
+    clip norm, dead tracker, AuxK (its compact rows summed) included."""
     if encoder_mode != "f16r":
         pytest.skip("one encoder mode is enough here")
     import torch.multiprocessing as mp
 
     out = str(tmp_path / "rank{rank}.pt")
     try:
-        mp.spawn(_two_rank_worker, args=(2, _free_port(), out, tail), nprocs=2, join=True)
+        mp.spawn(_two_rank_worker, args=(2, _free_port(), out, tail, exchange), nprocs=2, join=True)
     except Exception as exc:  # a gloo build without device-tensor support for these collectives
         if "gloo" in str(exc).lower() and ("not support" in str(exc).lower() or "unsupported" in str(exc).lower()):
             pytest.skip(f"gloo cannot run this collective on device tensors here: {exc}")
@@ -253,3 +255,64 @@ def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes)
         grads.append(eng.grads.clone())
     assert torch.equal(grads[0], grads[1])
     assert grads[0].abs().sum() > 0
+
+
+def _train_worker(rank, world, port, shards, out, env):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pathlib
+
+        from saev_amd import data, nn
+        from saev_amd.framework import train as T
+        from saev_amd.nn import modeling, objectives
+
+        torch.cuda.set_device(0)
+        cfg = T.Config(
+            train_data=data.ShuffledConfig(shards=pathlib.Path(shards), layer=5, batch_size=256, seed=4),
+            val_data=data.ShuffledConfig(shards=pathlib.Path(shards), layer=5, batch_size=256, seed=4),
+            n_train=256 * 9, sae=nn.SparseAutoencoderConfig(d_model=64, d_sae=512, reinit_blend=0.0,
+                                                            activation=modeling.TopK(top_k=8, aux=modeling.AuxK(k_aux=32))),
+            objective=objectives.Matryoshka(n_prefixes=1, dead_threshold_tokens=600), lr=2e-3, n_lr_warmup=2, log_every=4,
+            track=False, runs_root=pathlib.Path(out).parent / f"runs{rank}")
+        saes, objs, run, steps = T.train([cfg])
+        torch.cuda.synchronize()
+        torch.save({"state": {k: v.detach().cpu().clone() for k, v in saes[0].state_dict().items()}, "steps": steps,
+                    "toks": objs[0].toks_since_active.cpu().clone(),
+                    "mse": [rec["loss/mse"] for _, rec in run.records[0]]}, out.format(rank=rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sharded", "sparse"])
+def test_two_rank_train_on_one_gpu_ends_with_identical_checkpoints(tmp_path, mode, encoder_mode):
+    """framework.train.train() itself under two ranks (two processes on the test box's one GPU, gloo): both ranks take the
+    same number of optimizer steps -- the number one process takes on the same global batches -- log the same global-batch
+    losses and end with bit-identical parameters and trackers, for the replicated tail, the sharded tail and the
+    sparse-state exchange."""
+    if encoder_mode != "f16r":
+        pytest.skip("one encoder mode is enough here")
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    from saev_amd import data
+
+    rng = np.random.default_rng(7)
+    basis = rng.standard_normal((24, 64)).astype(np.float32)
+    acts = (rng.standard_normal((300, 1, 4, 24)).astype(np.float32) ** 3) @ basis + 0.1 * rng.standard_normal((300, 1, 4, 64)).astype(np.float32)
+    shards = data.write_shards(tmp_path / "cache", acts, layers=(5,), cls_token=False, max_tokens_per_shard=4 * 40)
+    env = {"SAEV_AMD_DDP_TAIL": "sharded" if mode == "sharded" else "replicated",
+           "SAEV_AMD_DDP_EXCHANGE": "sparse" if mode == "sparse" else "dense"}
+    out = str(tmp_path / "rank{rank}.pt")
+    mp.spawn(_train_worker, args=(2, _free_port(), str(shards), out, env), nprocs=2, join=True)
+    r0, r1 = (torch.load(out.format(rank=r)) for r in range(2))
+    assert r0["steps"] == r1["steps"] and r0["steps"] >= 9
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), k
+    assert torch.equal(r0["toks"], r1["toks"])
+    # (rank 0 logs, the global-batch block; the others keep no records)
+    assert r1["mse"] == [] and len(r0["mse"]) >= 2 and r0["mse"][-1] < r0["mse"][0]

@@ -75,7 +75,9 @@ struct saev_ctx {
     // {projection coefficient, projected squares} of every decoder-gradient row, left by the kernels that wrote the rows
     // (DwRowsArgs::row_proj); valid after a one-pass backward over all latents, trusted like wenc_sq
     float2* row_proj = nullptr;
+    float* enc_sq = nullptr;  // squares of the rows of the transposed W_enc gradient, from the same kernels
     bool row_proj_valid = false, tail_proj_in_adam = false;
+    bool wenc_t_pending = false;  // saev_train_step: the W_enc gradient is still in dW_encT, the tail's Adam reads it there
     int64_t* toks = nullptr;
     int32_t *fired = nullptr, *dead = nullptr;
     int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use [6,7,8] dead_update scratch
@@ -297,7 +299,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
         c->max_part = (int)(2 * ((max_pairs + DW_CHUNK - 1) / DW_CHUNK) + 2);
     }
     A(chunk_starts, S + 1); A(part_starts, S); A(work_latent, c->max_work);
-    A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part); A(row_proj, S);
+    A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part); A(row_proj, S); A(enc_sq, S);
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32 || KA > 0) {  // (the f32 encoder needs the image geometry for AuxK only)
@@ -1329,17 +1331,18 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     const bool clears = part != 2 && lat_lo == 0 && lat_hi == S && c->bitmap_words_last > 0;
     if (clears) { a.clear_bitmap = c->bitmap; a.clear_words = c->bitmap_words_last; }
     a.row_proj = all_rows ? c->row_proj : nullptr; a.project = c->cfg.remove_parallel_grads ? 1 : 0;
+    a.enc_sq = all_rows ? c->enc_sq : nullptr;
     // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
     const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
     HIPCHK(c, launch_dw_rows(a, max_work, s));
     if (c->aux_route == AUX_DENSE)  // (the count on the device when the host only had a bound of it: aux_dev_count)
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s,
-                                          c->aux_dev_count ? c->flags + 4 : nullptr, part, a.row_proj, a.W_dec, a.project));
+                                          c->aux_dev_count ? c->flags + 4 : nullptr, part, a.row_proj, a.W_dec, a.project, a.enc_sq));
     else if (c->aux_route != AUX_NONE)  // few dead latents: the device knows how many
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part,
-                                          a.row_proj, a.W_dec, a.project));
+                                          a.row_proj, a.W_dec, a.project, a.enc_sq));
     // gathered backward: the auxiliary term's share of db_dec (summed over the ranks by the caller, like the compact rows)
     if (ov && c->aux_route != AUX_NONE && part != 2 && lat_lo == 0)
         HIPCHK(c, launch_colsum(c->db_aux, 1, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
@@ -1479,6 +1482,17 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const long S = c->cfg.d_sae, D = c->cfg.d_model;
     c->tail_proj_in_adam = false;
+    if (c->wenc_t_pending) {
+        // saev_train_step left the W_enc gradient in the transposed scratch: its squares come from the rows' statistics too
+        // (enc_sq), and the one Adam launch reads it from there (adam_fused_kernel) -- no transpose pass at all
+        REQUIRE(c, c->row_proj_valid && shard_rank < 0, SAEV_INVALID_ARG, "saev_tail_prepare: pending transposed gradient without a full backward");
+        c->row_proj_valid = false;
+        HIPCHK(c, launch_sumsq_final_ex(nullptr, 0, c->row_proj, (int)S, c->grads + S * D, r.a_hi - S * D,
+                                        c->grads + c->off_b_enc, r.b_hi - c->off_b_enc, saev_sumsq_device(c), c->sumsq_partials,
+                                        c->tickets + 1, s, c->enc_sq));
+        c->tail_proj_in_adam = true;
+        return SAEV_OK;
+    }
     if ((c->wenc_sq_trusted || c->trust_grads) && c->wenc_sq_valid && c->row_proj_valid && shard_rank < 0) {
         // Inside saev_train_step nothing has touched the gradient since the backward: the kernels that wrote the decoder
         // rows left each row's projection coefficient and projected squares (row_proj), the transpose the squares of dW_enc
@@ -1532,6 +1546,14 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, (double)adam_step));
     a.grad_scale = grad_scale; a.max_norm = max_norm; a.sumsq = saev_sumsq_device(c); a.stats = c->stats;
     const long lo[2] = {r.a_lo, r.b_lo}, hi[2] = {r.a_hi, r.b_hi};
+    if (shard_rank < 0 && c->tail_proj_in_adam && c->wenc_t_pending) {  // everything in one launch (adam_fused_kernel)
+        c->tail_proj_in_adam = false; c->wenc_t_pending = false;
+        const long S = c->cfg.d_sae, D = c->cfg.d_model;
+        a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = c->n_params;
+        HIPCHK(c, launch_adam_fused(a, c->row_proj, c->dW_encT, (int)S, (int)D, S * D, c->off_W_enc - S * D, c->off_W_enc,
+                                    c->off_b_enc, c->n_params - c->off_b_enc, s));
+        return SAEV_OK;
+    }
     if (shard_rank < 0 && c->tail_proj_in_adam) {  // decoder rows with the projection applied on the way in, then the rest
         c->tail_proj_in_adam = false;
         const long S = c->cfg.d_sae, D = c->cfg.d_model;
@@ -1566,11 +1588,16 @@ int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_
     if (rc != SAEV_OK) return rc;
     rc = saev_step_dead(c, n, stream);
     if (rc != SAEV_OK) return rc;
-    rc = saev_step_backward(c, stream);
+    // (no saev_backward_end: the W_enc gradient stays in the transposed scratch the backward writes; the tail's single Adam
+    // launch reads it there through LDS tiles.  The W_enc segment of the gradient buffer is NOT updated by this entry point
+    // -- callers that want to look at gradients use the phases)
+    rc = saev_backward_begin(c, stream);
     if (rc != SAEV_OK) return rc;
-    c->wenc_sq_trusted = true;
+    rc = saev_backward_rows(c, 0, c->cfg.d_sae, stream);
+    if (rc != SAEV_OK) return rc;
+    c->wenc_t_pending = true;
     rc = saev_step_tail(c, lr, max_norm, 1.0f, adam_step, stream);
-    c->wenc_sq_trusted = false;
+    c->wenc_t_pending = false;
     return rc;
 }
 

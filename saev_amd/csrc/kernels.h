@@ -198,6 +198,7 @@ struct DwRowsArgs {
     // the tail then applies the projection inside Adam and never streams the gradient for it (saev_train_step only)
     float2* row_proj;
     int project;
+    float* enc_sq;                // optional (part != 1): per latent the sum of squares of its dW_enc^T row as written
     // optional: dw_rows_kernel zeroes the CSC bit map words of its pairs (row pitch clear_words uint32 per latent) -- the
     // pairs have been placed by then -- so that the next step's csc build starts from a clean map without a pass of its own
     uint32_t* clear_bitmap;
@@ -244,7 +245,13 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
 hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream);
 // total = sum(partials[0..nb)) + sum_i row_proj[i].y + |e1|^2 + |e2|^2 (see sumsq_final_ex_kernel)
 hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
-                                 const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream);
+                                 const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream,
+                                 const float* enc_sq = nullptr);  // + sum_i enc_sq[i] (squares of the rows of the transposed dW_enc)
+// Adam over everything in one launch with the gradients where the backward left them: a.{p,g,m,v} = the flat buffers, the
+// decoder rows projected through row_proj, W_enc's gradient read from the transposed scratch gT (S, D) through LDS tiles,
+// the two bias segments [off, off + n) element-wise (adam_fused_kernel)
+hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
+                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream);
 constexpr int SUMSQ_EX_BLOCKS = 32;  // blk_part: this many doubles of scratch; ticket: an int, zero between launches
 
 // what the host learns about the dead set of a step without waiting for it (saev_step_dead reads the record of an
@@ -381,4 +388,5 @@ hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
                                    const int32_t* nd_dev = nullptr, int part = 0,
                                    // optional: refresh row_proj of the rows touched (W_dec = the parameter rows)
-                                   float2* row_proj = nullptr, const float* W_dec = nullptr, int project = 1);
+                                   float2* row_proj = nullptr, const float* W_dec = nullptr, int project = 1,
+                                   float* enc_sq = nullptr);

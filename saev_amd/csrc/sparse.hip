@@ -420,6 +420,17 @@ __device__ __forceinline__ void write_row_proj(float2* row_proj, int i, const f3
     if (lane == 0) row_proj[i] = float2{sc, sq};
 }
 
+// sum of squares of a row held across a wave (DwRowsArgs::enc_sq)
+template <int NV>
+__device__ __forceinline__ float row_sumsq(const f32x4 (&g)[NV]) {
+    float sq = 0.f;
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq = __builtin_fmaf(g[n][e], g[n][e], sq);
+    return wave_sum(sq);
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
@@ -558,75 +569,80 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
     }
     // the row just written is final (single-chunk latent): its projection coefficient and projected squares for the tail
     if (a.row_proj != nullptr && direct && part != 2 && !a.accumulate) write_row_proj<NV>(a.row_proj, i, accd, wv, a.project, lane);
+    if (a.enc_sq != nullptr && direct && part != 1 && !a.accumulate) {
+        const float sq = row_sumsq<NV>(acce);
+        if (lane == 0) a.enc_sq[i] = sq;
+    }
 }
 
+// One wave sums the per-chunk partials of ONE of a latent's two gradient rows (blockIdx.y: 0 decoder row, 1 encoder row +
+// db_enc): a latent that fires on most rows has hundreds of chunks (the batch-mean direction of a trained dictionary fires
+// on every row: 256 chunks at 16 384 rows), and one wave walking all of its 8 KB partial pairs was a 90 us serial tail of the
+// sustained step.  Half the bytes per wave and eight partial rows in flight per trip; the summation order is fixed (chunk
+// order inside a trip, trips in order), so the result does not depend on scheduling.
 template <int NV>
 __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
     const int lane = threadIdx.x & 63;
     const int i = a.lat_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.lat_hi) return;
+    const int enc = blockIdx.y;  // 0: dW_dec row, 1: dW_enc^T row and db_enc
+    if ((enc == 0 && a.part == 2) || (enc == 1 && a.part == 1)) return;  // (the other pass of a two-pass backward owns that row)
     const int nch = a.chunk_starts[i + 1] - a.chunk_starts[i];
     if (nch <= 1) return;
     const int c0 = a.part_starts[i], c1 = c0 + nch;
     const int D = a.D, D4 = D >> 2;
-    f32x4 accd[NV], acce[NV];
+    const float* base = a.partials + (enc ? D : 0);
+    f32x4 acc[NV];
 #pragma unroll
-    for (int n = 0; n < NV; ++n) { accd[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acce[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int n = 0; n < NV; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbs = 0.f;
     int c = c0;
-    // four partial rows per trip: their loads are independent, so a latent with hundreds of chunks is bound by
-    // bandwidth rather than by one load latency per chunk; the summation order is fixed (chunk order inside a trip,
-    // trips in order)
-    if constexpr (NV <= 8)  // (wider rows keep to one partial row per trip: 8 * NV float4 temporaries would spill)
-    for (; c + 4 <= c1; c += 4) {
-        f32x4 td[4][NV], te[4][NV];
+    constexpr int TRIP = NV <= 4 ? 8 : (NV <= 8 ? 4 : 2);  // partial rows in flight (TRIP * NV float4 temporaries)
+    for (; c + TRIP <= c1; c += TRIP) {
+        f32x4 t[TRIP][NV];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4* pd = reinterpret_cast<const f32x4*>(a.partials + (size_t)(c + t) * 2 * D);
-            const f32x4* pe = pd + D4;
+        for (int u = 0; u < TRIP; ++u) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(base + (size_t)(c + u) * 2 * D);
 #pragma unroll
-            for (int n = 0; n < NV; ++n) {
-                const int q = lane + 64 * n;
-                td[t][n] = (q < D4) ? pd[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-                te[t][n] = (q < D4) ? pe[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int n = 0; n < NV; ++n) t[u][n] = (lane + 64 * n < D4) ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
-            accd[n] += (td[0][n] + td[1][n]) + (td[2][n] + td[3][n]);
-            acce[n] += (te[0][n] + te[1][n]) + (te[2][n] + te[3][n]);
+            if constexpr (TRIP == 8) acc[n] += ((t[0][n] + t[1][n]) + (t[2][n] + t[3][n])) + ((t[4][n] + t[5][n]) + (t[6][n] + t[7][n]));
+            else if constexpr (TRIP == 4) acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
+            else acc[n] += t[0][n] + t[1][n];
         }
-        dbs += (a.db_partials[c] + a.db_partials[c + 1]) + (a.db_partials[c + 2] + a.db_partials[c + 3]);
+        if (enc) {
+#pragma unroll
+            for (int u = 0; u < TRIP; ++u) dbs += a.db_partials[c + u];
+        }
     }
     for (; c < c1; ++c) {
-        const f32x4* pd = reinterpret_cast<const f32x4*>(a.partials + (size_t)c * 2 * D);
-        const f32x4* pe = pd + D4;
+        const f32x4* p = reinterpret_cast<const f32x4*>(base + (size_t)c * 2 * D);
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = lane + 64 * n;
-            if (q < D4) { accd[n] += pd[q]; acce[n] += pe[q]; }
-        }
-        dbs += a.db_partials[c];
+        for (int n = 0; n < NV; ++n)
+            if (lane + 64 * n < D4) acc[n] += p[lane + 64 * n];
+        if (enc) dbs += a.db_partials[c];
     }
-    f32x4* od = reinterpret_cast<f32x4*>(a.dW_dec + (size_t)i * D);
-    f32x4* oe = reinterpret_cast<f32x4*>(a.dW_encT + (size_t)i * D);
-    // (a.part = 1 / 2: only the decoder / the encoder rows of this pass are valid in the partial slots and are written)
+    f32x4* o = reinterpret_cast<f32x4*>((enc ? a.dW_encT : a.dW_dec) + (size_t)i * D);
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int q = lane + 64 * n;
-        if (q < D4) {
-            if (a.part != 2) od[q] = a.accumulate ? od[q] + accd[n] : accd[n];
-            if (a.part != 1) oe[q] = a.accumulate ? oe[q] + acce[n] : acce[n];
-        }
+        if (q < D4) o[q] = a.accumulate ? o[q] + acc[n] : acc[n];
     }
-    if (lane == 0 && a.part != 1) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
-    if (a.row_proj != nullptr && a.part != 2 && !a.accumulate) {
+    if (enc) {
+        if (lane == 0) a.db_enc[i] = a.accumulate ? (a.db_enc[i] + dbs) : dbs;
+        if (a.enc_sq != nullptr && !a.accumulate) {
+            const float sq = row_sumsq<NV>(acc);
+            if (lane == 0) a.enc_sq[i] = sq;
+        }
+    } else if (a.row_proj != nullptr && !a.accumulate) {
         f32x4 wv[NV];
         const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
 #pragma unroll
         for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
-        write_row_proj<NV>(a.row_proj, i, accd, wv, a.project, lane);
+        write_row_proj<NV>(a.row_proj, i, acc, wv, a.project, lane);
     }
 }
 
@@ -795,7 +811,7 @@ hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_cl
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream) {
     return dispatch_nv(a.D, [&](auto nv) {
         hipLaunchKernelGGL(dw_rows_kernel<decltype(nv)::value>, dim3((max_work + 3) / 4), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.lat_hi - a.lat_lo + 3) / 4), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.lat_hi - a.lat_lo + 3) / 4, 2), dim3(256), 0, stream, a);
     });
 }
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part) {

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* partial
 // every thread adding its strided share in index order, then a fixed tree: deterministic.
 __global__ __launch_bounds__(1024) void sumsq_final_ex_kernel(const double* partials, int nb, const float2* row_proj, int n_rows,
                                                               const float* e1, long n1, const float* e2, long n2, double* total,
-                                                              double* blk_part, int* ticket) {
+                                                              double* blk_part, int* ticket, const float* enc_sq) {
     // (one workgroup alone needed 32 us for the 0.4 MB: latency.  gridDim.x workgroups take contiguous slices of each
     // range, the last one to arrive -- a ticket -- adds the slices in index order)
     __shared__ double sh[16];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1024) void sumsq_final_ex_kernel(const double* part
     slice(nb, lo, hi);
     for (long i = lo + threadIdx.x; i < hi; i += 1024) s += partials[i];
     slice(n_rows, lo, hi);
-    for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)row_proj[i].y;
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)row_proj[i].y + (enc_sq != nullptr ? (double)enc_sq[i] : 0.0);
     slice(n1, lo, hi);
     for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)e1[i] * (double)e1[i];
     slice(n2, lo, hi);
@@ -225,6 +225,110 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(AdamArgs a, const float2
         __builtin_nontemporal_store(p[n], reinterpret_cast<f32x4*>(a.p) + base + q);
         __builtin_nontemporal_store(m[n], reinterpret_cast<f32x4*>(a.m) + base + q);
         __builtin_nontemporal_store(v[n], reinterpret_cast<f32x4*>(a.v) + base + q);
+    }
+}
+
+// The whole Adam update of saev_train_step in ONE launch, reading every gradient where the backward left it:
+//   blocks [0, nb_rows)            decoder rows, projection applied on the way in (adam_rows_kernel's body);
+//   blocks [nb_rows, + nb_tiles)   W_enc in 64 x 64 tiles, the gradient taken from the TRANSPOSED (d_sae, d_model) scratch the
+//                                  backward writes and turned through LDS -- the transpose pass that used to write the
+//                                  gradient in W_enc's layout, and Adam's read of it, are gone (268 MB per step);
+//   the rest                       b_dec and b_enc (and the padding of a sharded layout), element-wise.
+// a.p / a.g / a.m / a.v are the flat buffers; off_* / n_* locate the segments.  Same adam_elem arithmetic as the other kernels.
+struct AdamFusedArgs {
+    AdamArgs a;
+    const float2* row_proj;
+    const float* gT;       // (S, D) transposed W_enc gradient
+    int S, D;
+    long off_b_dec, n_b_dec, off_W_enc, off_b_enc, n_b_enc;
+    int nb_rows, nb_tiles, tiles_s;
+};
+template <int NV>
+__global__ __launch_bounds__(256) void adam_fused_kernel(AdamFusedArgs f) {
+    const AdamArgs& a = f.a;
+    float norm;
+    const float coef = clip_coef(a, &norm);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.stats) a.stats->grad_norm = norm;
+    const float gs = a.grad_scale * coef;
+    const float step_size = a.lr / a.bc1;
+    const int S = f.S, D = f.D;
+    if ((int)blockIdx.x < f.nb_rows) {
+        const int lane = threadIdx.x & 63;
+        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (i >= S) return;
+        const float sc = f.row_proj[i].x;
+        const int D4 = D >> 2;
+        const size_t base = (size_t)i * D4;
+        f32x4 p[NV], g[NV], m[NV], v[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) {
+                p[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + base + q);
+                g[n] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
+                m[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + base + q);
+                v[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + base + q);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q >= D4) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const AdamElem r = adam_elem(p[n][e], scaled_grad(rpg_apply(g[n][e], sc, p[n][e]), gs), m[n][e], v[n][e], a, step_size);
+                p[n][e] = r.p; m[n][e] = r.m; v[n][e] = r.v;
+            }
+            __builtin_nontemporal_store(p[n], reinterpret_cast<f32x4*>(a.p) + base + q);
+            __builtin_nontemporal_store(m[n], reinterpret_cast<f32x4*>(a.m) + base + q);
+            __builtin_nontemporal_store(v[n], reinterpret_cast<f32x4*>(a.v) + base + q);
+        }
+        return;
+    }
+    if ((int)blockIdx.x < f.nb_rows + f.nb_tiles) {
+        __shared__ float tile[64][65];
+        const int t = blockIdx.x - f.nb_rows;
+        const int s0 = (t % f.tiles_s) * 64, d0 = (t / f.tiles_s) * 64;
+        const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+        for (int r = r0; r < 64; r += 16) {
+            const int sidx = s0 + r, d = d0 + c4;
+            f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (sidx < S && d < D) g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.gT + (size_t)sidx * D + d));
+            tile[r][c4] = g[0]; tile[r][c4 + 1] = g[1]; tile[r][c4 + 2] = g[2]; tile[r][c4 + 3] = g[3];
+        }
+        __syncthreads();
+        float* const P = a.p + f.off_W_enc;
+        float* const M = a.m + f.off_W_enc;
+        float* const V = a.v + f.off_W_enc;
+#pragma unroll
+        for (int r = r0; r < 64; r += 16) {
+            const int d = d0 + r, sidx = s0 + c4;
+            if (d >= D || sidx >= S) continue;
+            const size_t o = (size_t)d * S + sidx;
+            f32x4 p = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(P + o));
+            f32x4 m = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(M + o));
+            f32x4 v = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(V + o));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const AdamElem q = adam_elem(p[e], scaled_grad(tile[c4 + e][r], gs), m[e], v[e], a, step_size);
+                p[e] = q.p; m[e] = q.m; v[e] = q.v;
+            }
+            __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(P + o));
+            __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(M + o));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(V + o));
+        }
+        return;
+    }
+    // the two bias segments
+    const long nb = gridDim.x - f.nb_rows - f.nb_tiles;
+    const long bi = blockIdx.x - f.nb_rows - f.nb_tiles;
+    for (int seg = 0; seg < 2; ++seg) {
+        const long off = seg ? f.off_b_enc : f.off_b_dec, n = seg ? f.n_b_enc : f.n_b_dec;
+        for (long i = bi * 256 + threadIdx.x; i < n; i += nb * 256) {
+            const AdamElem r = adam_elem(a.p[off + i], scaled_grad(a.g[off + i], gs), a.m[off + i], a.v[off + i], a, step_size);
+            a.p[off + i] = r.p; a.m[off + i] = r.m; a.v[off + i] = r.v;
+        }
     }
 }
 
@@ -484,15 +588,29 @@ hipError_t launch_sumsq(const float* g, long n, double* partials, double* total,
     return hipGetLastError();
 }
 hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
-                                 const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream) {
+                                 const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream,
+                                 const float* enc_sq) {
     hipLaunchKernelGGL(sumsq_final_ex_kernel, dim3(SUMSQ_EX_BLOCKS), dim3(1024), 0, stream, partials, nb, row_proj, n_rows, e1, n1, e2,
-                       n2, total, blk_part, ticket);
+                       n2, total, blk_part, ticket, enc_sq);
     return hipGetLastError();
 }
 hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream) {
     if (S <= 0) return hipSuccess;
     return dispatch_nv(D, [&](auto nv) {
         hipLaunchKernelGGL(adam_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, a, row_proj, S, D);
+    });
+}
+hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
+                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream) {
+    AdamFusedArgs f{};
+    f.a = a; f.row_proj = row_proj; f.gT = gT; f.S = S; f.D = D;
+    f.off_b_dec = off_b_dec; f.n_b_dec = n_b_dec; f.off_W_enc = off_W_enc; f.off_b_enc = off_b_enc; f.n_b_enc = n_b_enc;
+    f.nb_rows = (S + 3) / 4;
+    f.tiles_s = (S + 63) / 64;
+    f.nb_tiles = f.tiles_s * ((D + 63) / 64);
+    const int nb_bias = 32;
+    return dispatch_nv(D, [&](auto nv) {
+        hipLaunchKernelGGL(adam_fused_kernel<decltype(nv)::value>, dim3(f.nb_rows + f.nb_tiles + nb_bias), dim3(256), 0, stream, f);
     });
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(AdamArgs a, const float2
 
 // The whole Adam update of saev_train_step in ONE launch, reading every gradient where the backward left it:
 //   blocks [0, nb_rows)            decoder rows, projection applied on the way in (adam_rows_kernel's body);
-//   blocks [nb_rows, + nb_tiles)   W_enc in 64 x 64 tiles, the gradient taken from the TRANSPOSED (d_sae, d_model) scratch the
+//   blocks [nb_rows, + nb_tiles)   W_enc in 32 x 256 tiles, the gradient taken from the TRANSPOSED (d_sae, d_model) scratch the
 //                                  backward writes and turned through LDS -- the transpose pass that used to write the
 //                                  gradient in W_enc's layout, and Adam's read of it, are gone (268 MB per step);
 //   the rest                       b_dec and b_enc (and the padding of a sharded layout), element-wise.
@@ -286,32 +286,41 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFusedArgs f) {
         return;
     }
     if ((int)blockIdx.x < f.nb_rows + f.nb_tiles) {
-        __shared__ float tile[64][65];
+        // tile = 32 (d) x 256 (s): the transposed gradient comes in as 128-byte row segments (whole lines), and p / m / v --
+        // six of the seven streams -- move as 1 KB runs along s (a 64 x 64 tile moved them in 256-byte runs: 0.32 ms for
+        // this launch instead of 0.27)
+        constexpr int TD = 32, TS = 256, LDT = TS + 4;
+        __shared__ float tile[TD][LDT];
         const int t = blockIdx.x - f.nb_rows;
-        const int s0 = (t % f.tiles_s) * 64, d0 = (t / f.tiles_s) * 64;
-        const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+        const int s0 = (t % f.tiles_s) * TS, d0 = (t / f.tiles_s) * TD;
 #pragma unroll
-        for (int r = r0; r < 64; r += 16) {
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = idx >> 3, c4 = (idx & 7) * 4;
             const int sidx = s0 + r, d = d0 + c4;
             f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
             if (sidx < S && d < D) g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.gT + (size_t)sidx * D + d));
-            tile[r][c4] = g[0]; tile[r][c4 + 1] = g[1]; tile[r][c4 + 2] = g[2]; tile[r][c4 + 3] = g[3];
+            tile[c4][r] = g[0]; tile[c4 + 1][r] = g[1]; tile[c4 + 2][r] = g[2]; tile[c4 + 3][r] = g[3];
         }
         __syncthreads();
         float* const P = a.p + f.off_W_enc;
         float* const M = a.m + f.off_W_enc;
         float* const V = a.v + f.off_W_enc;
+        const int sl = (threadIdx.x & 63) * 4, dr = threadIdx.x >> 6;
+        const int sidx = s0 + sl;
+        if (sidx >= S) return;
 #pragma unroll
-        for (int r = r0; r < 64; r += 16) {
-            const int d = d0 + r, sidx = s0 + c4;
-            if (d >= D || sidx >= S) continue;
+        for (int i = 0; i < 8; ++i) {
+            const int dl = dr + 4 * i, d = d0 + dl;
+            if (d >= D) continue;
             const size_t o = (size_t)d * S + sidx;
             f32x4 p = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(P + o));
             f32x4 m = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(M + o));
             f32x4 v = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(V + o));
+            const f32x4 g = *reinterpret_cast<const f32x4*>(&tile[dl][sl]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const AdamElem q = adam_elem(p[e], scaled_grad(tile[c4 + e][r], gs), m[e], v[e], a, step_size);
+                const AdamElem q = adam_elem(p[e], scaled_grad(g[e], gs), m[e], v[e], a, step_size);
                 p[e] = q.p; m[e] = q.m; v[e] = q.v;
             }
             __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(P + o));
@@ -606,8 +615,8 @@ hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const fl
     f.a = a; f.row_proj = row_proj; f.gT = gT; f.S = S; f.D = D;
     f.off_b_dec = off_b_dec; f.n_b_dec = n_b_dec; f.off_W_enc = off_W_enc; f.off_b_enc = off_b_enc; f.n_b_enc = n_b_enc;
     f.nb_rows = (S + 3) / 4;
-    f.tiles_s = (S + 63) / 64;
-    f.nb_tiles = f.tiles_s * ((D + 63) / 64);
+    f.tiles_s = (S + 255) / 256;
+    f.nb_tiles = f.tiles_s * ((D + 31) / 32);
     const int nb_bias = 32;
     return dispatch_nv(D, [&](auto nv) {
         hipLaunchKernelGGL(adam_fused_kernel<decltype(nv)::value>, dim3(f.nb_rows + f.nb_tiles + nb_bias), dim3(256), 0, stream, f);

@@ -554,3 +554,70 @@ def test_extraction_hand_off_equals_the_cache_round_trip_and_trains(tmp_path):
     fills = [rec_["loader/buffer_fill"] for _, rec_ in run.records[0]]
     assert len(mses) == 4 and all(math.isfinite(v) for v in mses) and mses[-1] < mses[0]
     assert all(0.0 <= f <= 1.0 for f in fills)
+
+
+def test_a_destroyed_leader_leaves_no_dangling_link():
+    """a follower kept a raw pointer to its leader's context; rebuilding or closing the leader (a larger
+    batch arrives, the module moves) then made the follower's next forward read freed memory.  saev_destroy now clears the
+    back-links of its followers (and a follower's own destruction takes it off its leader's list): the follower simply builds
+    its own x-derived buffers again."""
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    d, s, n = 64, 512, 128
+    gen = torch.Generator().manual_seed(5)
+    p = R.init_params(R.RefConfig(d_model=d, d_sae=s), gen)
+    x = torch.randn(n, d, generator=gen).cuda()
+    lead, foll, foll2, solo = (SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k_, max_batch=n)) for k_ in (8, 4, 4, 4))
+    for e in (lead, foll, foll2, solo):
+        e.load_params(p)
+    foll.share_x(lead)
+    foll2.share_x(lead)
+
+    def codes(e):
+        e.step_forward(x, training=False)
+        i, v, xh = e.last_codes(n)
+        return i.clone(), v.clone(), xh.clone()
+
+    lead.step_forward(x, training=False)
+    want = codes(solo)
+    assert all(torch.equal(a, b) for a, b in zip(codes(foll), want))  # borrowed
+    foll2.close()            # a follower goes first: the leader must forget it ...
+    lead.step_forward(x, training=False)
+    lead.close()             # ... and the leader's destruction must not touch it, but must unlink the other one
+    torch.cuda.synchronize()
+    for _ in range(3):
+        assert all(torch.equal(a, b) for a, b in zip(codes(foll), want))
+    foll.share_x(None)
+    assert all(torch.equal(a, b) for a, b in zip(codes(foll), want))
+
+
+def test_engine_rebuild_for_a_sharded_tail_keeps_the_optimizer_state_per_tensor():
+    """a module that already owns an engine when a data-parallel run asks for the padded layout of a sharded tail
+    (shard_world > 1: other offsets, another length) must carry Adam's moments over tensor by tensor, not as flat copies."""
+    m = M()
+    sae = m.SparseAutoencoder(m.SparseAutoencoderConfig(d_model=48, d_sae=200, activation=m.TopK(top_k=4), reinit_blend=0.0)).cuda()
+    eng = sae._eng(64)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    eng.adam_m.copy_(torch.randn(eng.n_params, device="cuda", generator=g))
+    eng.adam_v.copy_(torch.rand(eng.n_params, device="cuda", generator=g))
+    eng.adam_steps = 7
+    want = {n: (eng.view(n, eng.adam_m).clone(), eng.view(n, eng.adam_v).clone(), getattr(sae, n).detach().clone()) for n in eng.offsets}
+    sae._shard_world = 8
+    eng2 = sae._eng(64)
+    assert eng2 is not eng and eng2.cfg.shard_world == 8 and eng2.n_params > eng.n_params and eng2.adam_steps == 7
+    for n in eng2.offsets:
+        assert torch.equal(eng2.view(n, eng2.adam_m), want[n][0]) and torch.equal(eng2.view(n, eng2.adam_v), want[n][1])
+        assert torch.equal(getattr(sae, n).detach(), want[n][2])
+    pad = torch.ones(eng2.n_params, dtype=torch.bool, device="cuda")
+    for n in eng2.offsets:
+        pad[eng2.offsets[n] : eng2.offsets[n] + eng2.view(n).numel()] = False
+    assert (eng2.adam_m[pad] == 0).all() and (eng2.adam_v[pad] == 0).all()
+
+
+def test_engine_config_names_are_validated():
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    with pytest.raises(ValueError, match="guaranteed.*predicted"):
+        SaeEngine(EngineConfig(d_model=32, d_sae=64, top_k=4, bounds="predcited"))
+    with pytest.raises(ValueError, match="f16r"):
+        SaeEngine(EngineConfig(d_model=32, d_sae=64, top_k=4, encoder="fp16"))

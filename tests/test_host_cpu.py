@@ -522,3 +522,29 @@ def test_batch_entropy_equals_the_reference_values():
         assert len(g[f"{tag}_keys"]) == 6 and len(g[f"{tag}_vals"]) == 6
         assert sorted(got) == g[f"{tag}_keys"].tolist()
         np.testing.assert_allclose([got[k] for k in sorted(got)], g[f"{tag}_vals"].numpy(), rtol=1e-12, atol=0)
+
+
+def test_warmup_and_scheduler_base_follow_the_reference():
+    """reference utils/scheduling.py:9-39: the Scheduler base raises, Warmup ramps linearly for n_steps calls then stays."""
+    from saev_amd.utils import scheduling as S
+
+    w = S.Warmup(0.0, 1.0, 4)
+    assert [w.step() for _ in range(6)] == [0.25, 0.5, 0.75, 1.0, 1.0, 1.0]
+    assert repr(w) == "Warmup(init=0.0, final=1.0, n_steps=4)"
+    assert isinstance(w, S.Scheduler) and isinstance(S.WarmupCosine(0.0, 2, 1.0, 10, 0.0), S.Scheduler)
+    with pytest.raises(NotImplementedError):
+        S.Scheduler().step()
+
+
+def test_device_reservoir_rejects_oversized_blocks_with_a_value_error():
+    """a block larger than the reservoir (or than its free room) used to hit a bare assert; under -O the negative
+    slice start went on to corrupt the slot bookkeeping."""
+    from saev_amd.data.extract import DeviceReservoir
+
+    r = DeviceReservoir(8, 4, torch.device("cpu"), seed=0)
+    with pytest.raises(ValueError, match="cannot enter a reservoir"):
+        r.put(torch.zeros(9, 4), torch.zeros(9, dtype=torch.int32), torch.zeros(9, dtype=torch.int32))
+    r.put(torch.zeros(6, 4), torch.zeros(6, dtype=torch.int32), torch.zeros(6, dtype=torch.int32))
+    with pytest.raises(ValueError, match="reservoir overflow"):
+        r.put(torch.zeros(3, 4), torch.zeros(3, dtype=torch.int32), torch.zeros(3, dtype=torch.int32))
+    assert r.room() == 2 and r._n_filled == 6

@@ -295,11 +295,13 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
                 // (the empty asm makes each group's element offset an opaque uniform value: otherwise the compiler sees an
                 // arithmetic progression, turns the 32 addresses into 64-bit VGPR pairs, hoists them out of the tile loop and
                 // spills them; like this every access is "SGPR base + 32-bit lane offset")
-#define GPTR(i)                                                                          \
-    ({                                                                                   \
-        size_t go_ = (size_t)(i) * (size_t)a.gmax_stride;                                \
-        asm("" : "+s"(go_));                                                             \
-        reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + go_) + voff);        \
+                // (round 3: one 64-bit base and a 32-bit byte offset per group formed on the vector side -- see encode_m16_kernel)
+                const uint32_t gstride4 = (uint32_t)a.gmax_stride * 4u;
+#define GPTR(i)                                                                                          \
+    ({                                                                                                   \
+        uint32_t vo_ = voff;                                                                             \
+        asm("" : "+v"(vo_));                                                                             \
+        reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax) + (size_t)(vo_ + (uint32_t)(i) * gstride4)); \
     })
                 // pre-activations of the tile (every tile); the bound is refreshed on a subset of tiles only (see the
                 // 32-group variant below)
@@ -880,11 +882,14 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
                 // (the empty asm makes each group's element offset an opaque uniform value: otherwise the compiler sees an
                 // arithmetic progression, turns the 32 addresses into 64-bit VGPR pairs, hoists them out of the tile loop and
                 // spills them; like this every access is "SGPR base + 32-bit lane offset")
-#define GPTR(i)                                                                          \
-    ({                                                                                   \
-        size_t go_ = (size_t)(i) * (size_t)a.gmax_stride;                                \
-        asm("" : "+s"(go_));                                                             \
-        reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax + go_) + voff);        \
+                // (round 3: ONE 64-bit base -- a.gmax -- and a 32-bit byte offset per group formed on the vector side, instead
+                // of a 64-bit uniform base per group: 32 SGPR pairs live across the phase were 64 spilled SGPRs)
+                const uint32_t gstride4 = (uint32_t)a.gmax_stride * 4u;
+#define GPTR(i)                                                                                          \
+    ({                                                                                                   \
+        uint32_t vo_ = voff;                                                                             \
+        asm("" : "+v"(vo_)); /* opaque: the 32 offsets are formed where they are used (one v_mad each) */  \
+        reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.gmax) + (size_t)(vo_ + (uint32_t)(i) * gstride4)); \
     })
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {

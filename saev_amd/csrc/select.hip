@@ -422,7 +422,11 @@ __device__ __forceinline__ void select_small_row(const SelectCandArgs& a, int ro
     sort_by_idx_and_store(a, row, k, win ? idx : 0x7fffffff, win ? ukey2f(key) : 0.f, lane);
 }
 
-// one wave per row; the register footprint of the search is chosen from the row's list length
+// one wave per row; the register footprint of the search is chosen from the row's list length.  BIG: lists of up to 4 096
+// entries in registers as well (151 VGPRs, three waves per SIMD) -- the k > 32 shapes, whose lists average ~2 000 entries
+// (configs[3]: streaming everything above 2 048 made this kernel 0.75 ms there); k <= 32 launches the lean variant, where such
+// lists are a handful of rows and go through the streaming path.
+template <bool BIG>
 __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
     __shared__ int32_t s_idx[4][64];
@@ -441,6 +445,7 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     else if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val, cv, ci);
     else if (n <= 1024) select_cand_row<16>(a, row, n, s_idx, s_val, cv, ci);
     else if (n <= 2048) select_cand_row<32>(a, row, n, s_idx, s_val, cv, ci);
+    else if constexpr (BIG) select_cand_row<64>(a, row, n, s_idx, s_val, cv, ci);
     else select_cand_row_stream(a, row, n, s_idx, s_val, cv, ci);
 }
 
@@ -873,7 +878,8 @@ hipError_t launch_select_dense(const SelectDenseArgs& a, hipStream_t stream) {
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
     if (a.cand_cap > 4096) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(select_cand_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
+    if (a.k > 32) hipLaunchKernelGGL(select_cand_kernel<true>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(select_cand_kernel<false>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -184,48 +184,58 @@ __device__ __forceinline__ float clip_coef(const AdamArgs& a, float* norm_out) {
     return a.max_norm >= 0.f ? fminf(a.max_norm / (norm + 1e-6f), 1.f) : 1.f;
 }
 
+// Adam on one decoder row held across a wave (NV float4 per lane), the projection coefficient applied to the gradient as it is
+// read.  The row is walked in chunks of four float4 per stream (16 loads in flight per lane) with the scheduler fenced
+// between chunks: left alone the compiler interleaves all NV x 4 division / square-root sequences and takes 178 (NV = 4),
+// 256 (NV = 5) or -- spilling thousands of dwords -- more than 256 (NV = 8) VGPRs for a kernel that lives on occupancy.
+template <int NV>
+__device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float sc, float gs, float step_size, int lane) {
+    const int D4 = D >> 2;
+    const size_t base = (size_t)i * D4;
+    constexpr int CH = 4;
+#pragma unroll 1  // (a real loop: unrolled, the address arithmetic of all chunks is hoisted and spills)
+    for (int n0 = 0; n0 < NV; n0 += CH) {
+        f32x4 p[CH], g[CH], m[CH], v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int q = lane + 64 * (n0 + c);
+            if (n0 + c < NV && q < D4) {
+                p[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + base + q);
+                g[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
+                m[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + base + q);
+                v[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + base + q);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int q = lane + 64 * (n0 + c);
+            if (n0 + c >= NV || q >= D4) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const AdamElem r = adam_elem(p[c][e], scaled_grad(rpg_apply(g[c][e], sc, p[c][e]), gs), m[c][e], v[c][e], a, step_size);
+                p[c][e] = r.p; m[c][e] = r.m; v[c][e] = r.v;
+            }
+            __builtin_nontemporal_store(p[c], reinterpret_cast<f32x4*>(a.p) + base + q);
+            __builtin_nontemporal_store(m[c], reinterpret_cast<f32x4*>(a.m) + base + q);
+            __builtin_nontemporal_store(v[c], reinterpret_cast<f32x4*>(a.v) + base + q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Adam over the S decoder rows with remove_parallel_grads applied on the way in: g' = g - sc_i * W_dec[i] with sc_i =
 // row_proj[i].x (= <g_i, w_i> / ||w_i||^2 of the rows the backward wrote; 0 when the projection is off) -- the parameter
 // row is being read anyway, so the projected gradient never has to be written (rpg_kernel: 0.4 GB of traffic per step).
 // One wave per row, 16-byte non-temporal accesses, 4 * NV loads in flight per lane.
 template <int NV>
-__global__ __launch_bounds__(256) void adam_rows_kernel(AdamArgs a, const float2* __restrict__ row_proj, int S, int D) {
+__global__ __launch_bounds__(256, 4) void adam_rows_kernel(AdamArgs a, const float2* __restrict__ row_proj, int S, int D) {
     float norm;
     const float coef = clip_coef(a, &norm);
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.stats) a.stats->grad_norm = norm;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= S) return;
-    const float gs = a.grad_scale * coef;
-    const float step_size = a.lr / a.bc1;
-    const float sc = row_proj[i].x;
-    const int D4 = D >> 2;
-    const size_t base = (size_t)i * D4;
-    f32x4 p[NV], g[NV], m[NV], v[NV];
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const int q = lane + 64 * n;
-        if (q < D4) {
-            p[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + base + q);
-            g[n] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
-            m[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + base + q);
-            v[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + base + q);
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const int q = lane + 64 * n;
-        if (q >= D4) continue;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float ge = scaled_grad(rpg_apply(g[n][e], sc, p[n][e]), gs);
-            const AdamElem r = adam_elem(p[n][e], ge, m[n][e], v[n][e], a, step_size);
-            p[n][e] = r.p; m[n][e] = r.m; v[n][e] = r.v;
-        }
-        __builtin_nontemporal_store(p[n], reinterpret_cast<f32x4*>(a.p) + base + q);
-        __builtin_nontemporal_store(m[n], reinterpret_cast<f32x4*>(a.m) + base + q);
-        __builtin_nontemporal_store(v[n], reinterpret_cast<f32x4*>(a.v) + base + q);
-    }
+    adam_row<NV>(a, i, D, row_proj[i].x, a.grad_scale * coef, a.lr / a.bc1, lane);
 }
 
 // The whole Adam update of saev_train_step in ONE launch, reading every gradient where the backward left it:
@@ -243,55 +253,14 @@ struct AdamFusedArgs {
     long off_b_dec, n_b_dec, off_W_enc, off_b_enc, n_b_enc;
     int nb_rows, nb_tiles, tiles_s;
 };
-template <int NV>
-__global__ __launch_bounds__(256) void adam_fused_kernel(AdamFusedArgs f) {
-    const AdamArgs& a = f.a;
-    float norm;
-    const float coef = clip_coef(a, &norm);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.stats) a.stats->grad_norm = norm;
-    const float gs = a.grad_scale * coef;
-    const float step_size = a.lr / a.bc1;
+__device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const AdamArgs& a, float gs, float step_size, int t) {
     const int S = f.S, D = f.D;
-    if ((int)blockIdx.x < f.nb_rows) {
-        const int lane = threadIdx.x & 63;
-        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (i >= S) return;
-        const float sc = f.row_proj[i].x;
-        const int D4 = D >> 2;
-        const size_t base = (size_t)i * D4;
-        f32x4 p[NV], g[NV], m[NV], v[NV];
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = lane + 64 * n;
-            if (q < D4) {
-                p[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + base + q);
-                g[n] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
-                m[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + base + q);
-                v[n] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + base + q);
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = lane + 64 * n;
-            if (q >= D4) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const AdamElem r = adam_elem(p[n][e], scaled_grad(rpg_apply(g[n][e], sc, p[n][e]), gs), m[n][e], v[n][e], a, step_size);
-                p[n][e] = r.p; m[n][e] = r.m; v[n][e] = r.v;
-            }
-            __builtin_nontemporal_store(p[n], reinterpret_cast<f32x4*>(a.p) + base + q);
-            __builtin_nontemporal_store(m[n], reinterpret_cast<f32x4*>(a.m) + base + q);
-            __builtin_nontemporal_store(v[n], reinterpret_cast<f32x4*>(a.v) + base + q);
-        }
-        return;
-    }
-    if ((int)blockIdx.x < f.nb_rows + f.nb_tiles) {
+    {
         // tile = 32 (d) x 256 (s): the transposed gradient comes in as 128-byte row segments (whole lines), and p / m / v --
         // six of the seven streams -- move as 1 KB runs along s (a 64 x 64 tile moved them in 256-byte runs: 0.32 ms for
         // this launch instead of 0.27)
         constexpr int TD = 32, TS = 256, LDT = TS + 4;
         __shared__ float tile[TD][LDT];
-        const int t = blockIdx.x - f.nb_rows;
         const int s0 = (t % f.tiles_s) * TS, d0 = (t / f.tiles_s) * TD;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -329,9 +298,34 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFusedArgs f) {
         }
         return;
     }
+}
+
+// PART 0: decoder rows + biases (no LDS: full occupancy for the streams); PART 1: the W_enc tiles (33 KB of LDS per
+// workgroup -- in one kernel with the rows it capped THEIR occupancy too: 1.42 ms at configs[3]'s shape against 0.92 for the
+// flat kernel).  Two launches back to back.
+template <int NV, int PART>
+__global__ __launch_bounds__(256, 4) void adam_fused_kernel(AdamFusedArgs f) {
+    const AdamArgs& a = f.a;
+    float norm;
+    const float coef = clip_coef(a, &norm);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.stats) a.stats->grad_norm = norm;
+    const float gs = a.grad_scale * coef;
+    const float step_size = a.lr / a.bc1;
+    const int S = f.S, D = f.D;
+    if constexpr (PART == 1) {
+        adam_wenc_tile(f, a, gs, step_size, (int)blockIdx.x);
+        return;
+    }
+    if ((int)blockIdx.x < f.nb_rows) {
+        const int lane = threadIdx.x & 63;
+        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (i >= S) return;
+        adam_row<NV>(a, i, D, f.row_proj[i].x, gs, step_size, lane);
+        return;
+    }
     // the two bias segments
-    const long nb = gridDim.x - f.nb_rows - f.nb_tiles;
-    const long bi = blockIdx.x - f.nb_rows - f.nb_tiles;
+    const long nb = gridDim.x - f.nb_rows;
+    const long bi = blockIdx.x - f.nb_rows;
     for (int seg = 0; seg < 2; ++seg) {
         const long off = seg ? f.off_b_enc : f.off_b_dec, n = seg ? f.n_b_enc : f.n_b_dec;
         for (long i = bi * 256 + threadIdx.x; i < n; i += nb * 256) {
@@ -619,7 +613,8 @@ hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const fl
     f.nb_tiles = f.tiles_s * ((D + 31) / 32);
     const int nb_bias = 32;
     return dispatch_nv(D, [&](auto nv) {
-        hipLaunchKernelGGL(adam_fused_kernel<decltype(nv)::value>, dim3(f.nb_rows + f.nb_tiles + nb_bias), dim3(256), 0, stream, f);
+        hipLaunchKernelGGL((adam_fused_kernel<decltype(nv)::value, 0>), dim3(f.nb_rows + nb_bias), dim3(256), 0, stream, f);
+        hipLaunchKernelGGL((adam_fused_kernel<1, 1>), dim3(f.nb_tiles), dim3(256), 0, stream, f);
     });
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {

@@ -431,8 +431,14 @@ __device__ __forceinline__ float row_sumsq(const f32x4 (&g)[NV]) {
     return wave_sum(sq);
 }
 
+#ifndef DW_MIN_WAVES
+#define DW_MIN_WAVES 1
+#endif
+#ifndef DW_GROUP
+#define DW_GROUP 8  // (row, latent) pairs whose g / x rows one wave has in flight
+#endif
 template <int NV>
-__global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
+__global__ __launch_bounds__(256, DW_MIN_WAVES) void dw_rows_kernel(DwRowsArgs a) {
     if (a.k_dev && *a.k_dev <= 0) return;
     const int lane = threadIdx.x & 63;
     // work items are latent-major: those of latents [lat_lo, lat_hi) are the contiguous range below
@@ -480,13 +486,14 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
         if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (my_b >> 5)] = 0u;
     }
     float dbs = 0.f;  // sum of dval over this chunk (wave-uniform)
-    for (int j0 = 0; j0 < cnt; j0 += 8) {
-        // (1) eight rows of g: dW_dec accumulation + per-lane shares of the eight dot products
-        float p[8];
+    constexpr int G = DW_GROUP, GS = (G == 8 ? 3 : 4);  // pairs per trip; lanes per slot of the reduce-scatter = 64 / G
+    for (int j0 = 0; j0 < cnt; j0 += G) {
+        // (1) G rows of g: dW_dec accumulation + per-lane shares of the eight dot products
+        float p[G];
         float r = 0.f;
         if (part != 2) {
 #pragma unroll
-        for (int t = 0; t < 8; t += 2) {
+        for (int t = 0; t < G; t += 2) {
             p[t] = 0.f; p[t + 1] = 0.f;
             if (j0 + t >= cnt) continue;  // uniform
             const bool two = j0 + t + 1 < cnt;
@@ -511,19 +518,19 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(DwRowsArgs a) {
             }
             if (!two) p[t + 1] = 0.f;
         }
-        r = wave_reduce_scatter<8>(p, lane);  // lane l holds the dot product of entry j0 + ((l >> 3) & 7)
+        r = wave_reduce_scatter<G>(p, lane);  // lane l holds the dot product of entry j0 + ((l >> GS) & (G - 1))
         if (part == 1) {
-            if ((lane & 7) == 0 && j0 + (lane >> 3) < cnt) a.dval[beg + j0 + (lane >> 3)] = r;
+            if ((lane & ((1 << GS) - 1)) == 0 && j0 + (lane >> GS) < cnt) a.dval[beg + j0 + (lane >> GS)] = r;
             continue;
         }
         }
         // (2) the same eight rows of x, weighted with the dot products just formed
 #pragma unroll
-        for (int t = 0; t < 8; t += 2) {
+        for (int t = 0; t < G; t += 2) {
             if (j0 + t >= cnt) continue;
             const bool two = j0 + t + 1 < cnt;
-            const float e0 = part == 2 ? __shfl(my_dv, j0 + t, 64) : __shfl(r, t << 3, 64);
-            const float e1 = !two ? 0.f : part == 2 ? __shfl(my_dv, min(j0 + t + 1, 63), 64) : __shfl(r, (t + 1) << 3, 64);
+            const float e0 = part == 2 ? __shfl(my_dv, j0 + t, 64) : __shfl(r, t << GS, 64);
+            const float e1 = !two ? 0.f : part == 2 ? __shfl(my_dv, min(j0 + t + 1, 63), 64) : __shfl(r, (t + 1) << GS, 64);
             dbs += e0 + e1;
             const int b0 = __shfl(my_b, j0 + t, 64), b1 = __shfl(my_b, min(j0 + t + 1, 63), 64);
             const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x + (size_t)b0 * D);

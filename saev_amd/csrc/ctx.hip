@@ -611,10 +611,16 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // to its own W scale.  Folding this reduction into center_stats_kernel's last workgroup was tried: a release fence
         // per workgroup of four rows took that kernel from 12 to 115 us)
         HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
-        if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
-        { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }  // x is prepared; from here on W_enc / b_enc are read
-        HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
-                                  c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
+        if (!x_borrowed && c->wenc_ready == nullptr) {
+            // the usual case: nobody's parameter all-gather to wait for in between -- both image passes in one launch
+            HIPCHK(c, launch_split_f16r(x, n, D, c->Dp, c->xs, c->f16r_scales, c->mu, c->params + c->off_W_enc, S, c->S_pad, c->ws,
+                                        reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT, s));
+        } else {
+            if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
+            { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }  // x is prepared; from here on W_enc / b_enc are read
+            HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
+                                      c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
+        }
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
                                      c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
         // (defer_margins: the caller's launch_pre_encode forms the margins together with the encoder's per-launch state)
@@ -1288,12 +1294,13 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
     a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
     // (the bit map row pitch depends on the batch: a map cleaned for a pitch covers every shorter one, S * words <= before)
-    HIPCHK(c, launch_csc_build(a, s, c->bitmap_clean && words <= c->bitmap_clean_words));
+    // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0), formed in the grids of the CSC build's first two
+    // launches; the AuxK contractions add theirs
+    const float* gmat = ov ? c->ov_g : (c->P_last > 1 ? c->G : c->g);
+    HIPCHK(c, launch_csc_build(a, s, c->bitmap_clean && words <= c->bitmap_clean_words, gmat, D, (long)c->P_last * D,
+                               c->colsum_partials, c->grads + c->off_b_dec));
     c->bitmap_clean = false;
     c->bitmap_words_last = words;
-    // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0); the AuxK contractions add theirs
-    const float* gmat = ov ? c->ov_g : (c->P_last > 1 ? c->G : c->g);
-    HIPCHK(c, launch_colsum(gmat, n, D, c->colsum_partials, c->grads + c->off_b_dec, 0, nullptr, s, (long)c->P_last * D));
     if (c->aux_route != AUX_NONE) {
         int rc = auxk_backward(c, s);
         if (rc != SAEV_OK) return rc;

@@ -165,7 +165,11 @@ struct CscArgs {
     int32_t* work_latent;   // (max_work) or NULL
 };
 // bitmap_clean: the whole bit map is known to be zero (dw_combine_kernel cleared it after the previous build)
-hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean = false);
+// colsum_*: optional column sums out[d] = sum_b m[b][d] (b < a.n_rows; partials: ceil(n_rows / 64) * D floats) computed in the
+// grids of the fill / count launches (db_dec of the same backward: two launches instead of four)
+hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean = false, const float* colsum_m = nullptr,
+                            int colsum_D = 0, long colsum_row_stride = 0, float* colsum_partials = nullptr,
+                            float* colsum_out = nullptr);
 
 constexpr int DW_CHUNK = 64;   // pairs per work item of the weight-gradient kernels
 
@@ -346,6 +350,9 @@ hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, floa
                            // ||W*scale||^2 per column, W_T = fp32 transpose of W
                            const float* mu = nullptr, double* dot_part = nullptr, float* sq_part = nullptr,
                            float* W_T = nullptr);
+// launch_split_rows(mode 2, scale_dev = scales, mu) and launch_split_wT(mode 2, scale_dev = scales + 1, mu, ...) in ONE launch
+hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, const float* scales, const float* mu, const float* W,
+                             int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream);
 // f16r: b_shift = float(sum_ks dot_part / *w_scale + b_enc); wg_part[0..nwg) = per-workgroup max |b_shift|,
 // wg_part[nwg..2 nwg) = per-workgroup max column norm of W_enc (nwg = ceil(S/256)); launch_row_margins reduces them and
 // raises *pre_flag when the largest norm times *w_scale is outside the safe fp16 window, then wmax_prev = that norm

@@ -265,24 +265,25 @@ __global__ __launch_bounds__(256) void csc_clear_kernel(CscArgs a) {
 
 // bit (latent i, row b) for every code.  No per-latent counter here: a latent that fires on most rows would
 // serialise tens of thousands of same-address atomics; counts come from the bit map instead.
-__global__ void csc_fill_kernel(CscArgs a) {
+__device__ __forceinline__ void csc_fill_body(const CscArgs& a, int bid, int nblk) {
     const int k = a.k_dev ? min(*a.k_dev, a.k) : a.k;
     if (k <= 0) return;
     const long n = (long)a.n_rows * k;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+    for (long p = (long)bid * blockDim.x + threadIdx.x; p < n; p += (long)nblk * blockDim.x) {
         const int b = (int)(p / k), j = (int)(p % k);
         const int32_t i = a.idx[(size_t)b * a.code_stride + j];
         if (i >= 0 && i < a.S) atomicOr(&a.bitmap[(size_t)i * a.words + (b >> 5)], 1u << (b & 31));
     }
 }
+__global__ void csc_fill_kernel(CscArgs a) { csc_fill_body(a, blockIdx.x, gridDim.x); }
 
 // one wave per latent: counts[i] = number of rows that use latent i, and grp_prefix[i][g] = how many of them lie in
 // row groups (256 rows = 8 bitmap words) before group g -- the rank of a code inside its latent is then one 2-byte
 // and one 32-byte read away (csc_place_kernel).
-__global__ __launch_bounds__(256) void csc_count_kernel(CscArgs a) {
+__device__ __forceinline__ void csc_count_body(const CscArgs& a, int bid) {
     if (a.k_dev && *a.k_dev <= 0) return;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = bid * 4 + (threadIdx.x >> 6);
     if (i >= a.S) return;
     const int groups = a.words >> 3;
     const uint4* bm = reinterpret_cast<const uint4*>(a.bitmap + (size_t)i * a.words);
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(256) void csc_count_kernel(CscArgs a) {
     }
     if (lane == 0) a.counts[i] = base;
 }
+__global__ __launch_bounds__(256) void csc_count_kernel(CscArgs a) { csc_count_body(a, blockIdx.x); }
 
 // exclusive scans over the latents, two small coalesced passes (1024 latents per workgroup, then the block offsets):
 //   starts[i]       pair offset            (sum of counts)
@@ -770,6 +772,53 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partials
     }
 }
 
+// ---- backward begin in two launches instead of four ---------------------------------------------------------------------
+// The column sums of dL/dx_hat (db_dec) are independent of the CSC build that runs next to them: their two passes ride in
+// the grids of csc_fill / csc_count (workgroups past the CSC part), so that the small kernels overlap instead of queueing.
+struct ColsumPlain { const float* m; int n_rows, D; float* partials; long row_stride; float* out; int n_blocks; };
+__device__ __forceinline__ void colsum_partial_plain(const ColsumPlain& c, int bid) {  // = colsum_partial_kernel<false>, k_dev = NULL
+    const int r0 = bid * 64, r1 = min(c.n_rows, r0 + 64);
+    for (int q = threadIdx.x; q < (c.D >> 2); q += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const f32x4*>(c.m + (size_t)(r + u) * c.row_stride)[q];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; r < r1; ++r) s += reinterpret_cast<const f32x4*>(c.m + (size_t)r * c.row_stride)[q];
+        reinterpret_cast<f32x4*>(c.partials + (size_t)bid * c.D)[q] = s;
+    }
+}
+__device__ __forceinline__ void colsum_final_plain(const ColsumPlain& c, int bid, float (&part)[4][64]) {  // = colsum_final_kernel, out = sums
+    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int d = bid * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (d < c.D) {
+        int b = slice;
+        for (; b + 12 < c.n_blocks; b += 16) {
+            s0 += c.partials[(size_t)b * c.D + d];
+            s1 += c.partials[(size_t)(b + 4) * c.D + d];
+            s2 += c.partials[(size_t)(b + 8) * c.D + d];
+            s3 += c.partials[(size_t)(b + 12) * c.D + d];
+        }
+        for (; b < c.n_blocks; b += 4) s0 += c.partials[(size_t)b * c.D + d];
+    }
+    part[slice][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && d < c.D) c.out[d] = ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col])) * 1.0f;
+}
+__global__ __launch_bounds__(256) void csc_fill_colsum_kernel(CscArgs a, int n_fill, ColsumPlain c) {
+    if ((int)blockIdx.x < n_fill) csc_fill_body(a, blockIdx.x, n_fill);
+    else colsum_partial_plain(c, blockIdx.x - n_fill);
+}
+__global__ __launch_bounds__(256) void csc_count_colsum_kernel(CscArgs a, int n_count, ColsumPlain c) {
+    __shared__ float part[4][64];
+    if ((int)blockIdx.x < n_count) csc_count_body(a, blockIdx.x);
+    else colsum_final_plain(c, blockIdx.x - n_count, part);
+}
+
 template <typename F>
 hipError_t dispatch_nv(int D, F&& f) {
     const int nv = (D / 4 + 63) / 64;
@@ -802,14 +851,22 @@ hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStrea
         hipLaunchKernelGGL(decode_matry_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a, m);
     });
 }
-hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean) {
+hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean, const float* colsum_m, int colsum_D,
+                            long colsum_row_stride, float* colsum_partials, float* colsum_out) {
     if (a.n_rows <= 0) return hipSuccess;
     const long n = (long)a.n_rows * a.k;
     const int blocks = (int)std::min<long>((n + 255) / 256, 4096);
     const int place_blocks = (int)std::min<long>((std::max<long>(n, a.S) + 255) / 256, 8192);
     if (!bitmap_clean) hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(csc_count_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+    if (colsum_m != nullptr) {  // out[d] = sum_b m[b][d] over the same n_rows rows, in the same two launches
+        ColsumPlain c{colsum_m, a.n_rows, colsum_D, colsum_partials, colsum_row_stride > 0 ? colsum_row_stride : (long)colsum_D,
+                      colsum_out, (a.n_rows + 63) / 64};
+        hipLaunchKernelGGL(csc_fill_colsum_kernel, dim3(blocks + c.n_blocks), dim3(256), 0, stream, a, blocks, c);
+        hipLaunchKernelGGL(csc_count_colsum_kernel, dim3((a.S + 3) / 4 + (colsum_D + 63) / 64), dim3(256), 0, stream, a, (a.S + 3) / 4, c);
+    } else {
+        hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(csc_count_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
+    }
     hipLaunchKernelGGL(csc_scan_block_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(csc_scan_offset_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);
     hipLaunchKernelGGL(csc_place_kernel, dim3(place_blocks), dim3(256), 0, stream, a);

@@ -49,11 +49,11 @@ __device__ __forceinline__ half8 pack8(const float (&v)[8], int part) {
 
 // one thread = one 16-byte chunk of the image; grid.x = ceil(n/256) * nks images, 1024 threads each
 template <int MODE>
-__global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks, float scale,
-                                                          const float* __restrict__ scale_dev, const float* __restrict__ mu,
-                                                          _Float16* __restrict__ xs) {
+__device__ __forceinline__ void split_rows_body(int bid, const float* __restrict__ x, int n, int D, int nks, float scale,
+                                                const float* __restrict__ scale_dev, const float* __restrict__ mu,
+                                                _Float16* __restrict__ xs) {
     if (scale_dev != nullptr) scale *= *scale_dev;
-    const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
+    const int blk = bid / nks, ks = bid % nks;
     const int i = threadIdx.x;           // chunk index inside the image
     const int rl = i >> 2, p = i & 3;
     const int c = p ^ ((4 - ((rl >> 2) & 3)) & 3);
@@ -70,7 +70,13 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
             v[4] = b[0] * scale; v[5] = b[1] * scale; v[6] = b[2] * scale; v[7] = b[3] * scale;
         }
     }
-    reinterpret_cast<half8*>(xs + (size_t)blockIdx.x * 256 * 32)[i] = pack8<MODE>(v, part);
+    reinterpret_cast<half8*>(xs + (size_t)bid * 256 * 32)[i] = pack8<MODE>(v, part);
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks, float scale,
+                                                          const float* __restrict__ scale_dev, const float* __restrict__ mu,
+                                                          _Float16* __restrict__ xs) {
+    split_rows_body<MODE>(blockIdx.x, x, n, D, nks, scale, scale_dev, mu, xs);
 }
 
 // one workgroup = one image of W_enc^T: 256 latents x 16 k (32 k for bf16).  The k-rows of W_enc (1 KB each) are
@@ -84,15 +90,14 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
 // bias_finish_kernel adds the nks shares in a fixed order.  The tile holds W * scale with a power-of-two scale: exact,
 // undone where it matters.
 template <int MODE>
-__global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict__ W, int D, int S, int nks, float scale,
-                                                        const float* __restrict__ scale_dev, _Float16* __restrict__ ws,
-                                                        const float* __restrict__ mu, double* __restrict__ dot_part,
-                                                        float* __restrict__ sq_part, float* __restrict__ W_T) {
+__device__ __forceinline__ void split_wT_body(int bid, int nblk, float (&tile)[(MODE != 0 ? 32 : 16)][257], float (&mu_s)[(MODE != 0 ? 32 : 16)],
+                                              const float* __restrict__ W, int D, int S, int nks, float scale,
+                                              const float* __restrict__ scale_dev, _Float16* __restrict__ ws,
+                                              const float* __restrict__ mu, double* __restrict__ dot_part,
+                                              float* __restrict__ sq_part, float* __restrict__ W_T) {
     if (scale_dev != nullptr) scale *= *scale_dev;
     constexpr int KS = MODE != 0 ? 32 : 16;
-    __shared__ float tile[KS][257];
-    __shared__ float mu_s[KS];
-    const int blk = blockIdx.x / nks, ks = blockIdx.x % nks;
+    const int blk = bid / nks, ks = bid % nks;
     const int s0 = blk * 256, k0 = ks * KS;
     if (MODE == 2 && mu != nullptr && threadIdx.x < KS) mu_s[threadIdx.x] = (k0 + threadIdx.x < D) ? mu[k0 + threadIdx.x] : 0.f;
     for (int q = threadIdx.x; q < KS * 64; q += 1024) {  // 16 bytes per lane (S % 4 == 0)
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[(MODE != 0 ? c : h) * 8 + e][rl];
-    reinterpret_cast<half8*>(ws + (size_t)blockIdx.x * 256 * 32)[i] = pack8<MODE>(v, part);
+    reinterpret_cast<half8*>(ws + (size_t)bid * 256 * 32)[i] = pack8<MODE>(v, part);
     if constexpr (MODE == 2) {
         if (mu != nullptr) {  // the four threads of a latent hold its 32 k of this image
             double acc = 0.0;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
             sq += __shfl_xor(sq, 1, 64);
             sq += __shfl_xor(sq, 2, 64);
             if (p == 0) {
-                const size_t o = (size_t)ks * ((size_t)gridDim.x / nks * 256) + s0 + rl;
+                const size_t o = (size_t)ks * ((size_t)nblk / nks * 256) + s0 + rl;
                 dot_part[o] = acc;
                 sq_part[o] = sq;
             }
@@ -138,6 +143,31 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
             }
         }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict__ W, int D, int S, int nks, float scale,
+                                                        const float* __restrict__ scale_dev, _Float16* __restrict__ ws,
+                                                        const float* __restrict__ mu, double* __restrict__ dot_part,
+                                                        float* __restrict__ sq_part, float* __restrict__ W_T) {
+    constexpr int KS = MODE != 0 ? 32 : 16;
+    __shared__ float tile[KS][257];
+    __shared__ float mu_s[KS];
+    split_wT_body<MODE>(blockIdx.x, gridDim.x, tile, mu_s, W, D, S, nks, scale, scale_dev, ws, mu, dot_part, sq_part, W_T);
+}
+// The f16r step's two image passes in one launch (they depend on the same scales and on nothing of each other): workgroups
+// [0, n_x) write the centred x images, the rest the W_enc^T images with everything else that pass produces.
+struct SplitF16rArgs {
+    const float* x; int n, D, nks; const float* scales; const float* mu; _Float16* xs;
+    const float* W; int S; _Float16* ws; double* dot_part; float* sq_part; float* W_T;
+    int n_x;
+};
+__global__ __launch_bounds__(1024) void split_f16r_kernel(SplitF16rArgs a) {
+    __shared__ float tile[32][257];
+    __shared__ float mu_s[32];
+    if ((int)blockIdx.x < a.n_x) split_rows_body<2>(blockIdx.x, a.x, a.n, a.D, a.nks, 1.0f, a.scales, a.mu, a.xs);
+    else split_wT_body<2>(blockIdx.x - a.n_x, gridDim.x - a.n_x, tile, mu_s, a.W, a.D, a.S, a.nks, 1.0f, a.scales + 1, a.ws, a.mu, a.dot_part,
+                          a.sq_part, a.W_T);
 }
 
 // b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]) and ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale;
@@ -193,6 +223,16 @@ hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, floa
     if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr);
     else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, mu, dot_part, sq_part, W_T);
     else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, const float* scales, const float* mu, const float* W,
+                             int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream) {
+    SplitF16rArgs a{};
+    a.x = x; a.n = n; a.D = D; a.nks = Dp / 32; a.scales = scales; a.mu = mu; a.xs = reinterpret_cast<_Float16*>(xs);
+    a.W = W; a.S = S; a.ws = reinterpret_cast<_Float16*>(ws); a.dot_part = dot_part; a.sq_part = sq_part; a.W_T = W_T;
+    a.n_x = ((n + 255) / 256) * a.nks;
+    hipLaunchKernelGGL(split_f16r_kernel, dim3(a.n_x + (S_pad / 256) * a.nks), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -300,11 +300,10 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
     }
 }
 
-// PART 0: decoder rows + biases (no LDS: full occupancy for the streams); PART 1: the W_enc tiles (33 KB of LDS per
-// workgroup -- in one kernel with the rows it capped THEIR occupancy too: 1.42 ms at configs[3]'s shape against 0.92 for the
-// flat kernel).  Two launches back to back.
+// PART 2 (shipped): rows, tiles and biases in one grid.  PART 0 / 1: rows + biases, and the W_enc tiles, as separate launches
+// (SAEV_AMD_ADAM_SPLIT=1, for A/B runs).
 template <int NV, int PART>
-__global__ __launch_bounds__(256, 4) void adam_fused_kernel(AdamFusedArgs f) {
+__global__ __launch_bounds__(256, (PART == 2 ? 3 : 4)) void adam_fused_kernel(AdamFusedArgs f) {
     const AdamArgs& a = f.a;
     float norm;
     const float coef = clip_coef(a, &norm);
@@ -316,6 +315,12 @@ __global__ __launch_bounds__(256, 4) void adam_fused_kernel(AdamFusedArgs f) {
         adam_wenc_tile(f, a, gs, step_size, (int)blockIdx.x);
         return;
     }
+    if constexpr (PART == 2) {  // everything in one grid: rows, then tiles, then biases
+        if ((int)blockIdx.x >= f.nb_rows && (int)blockIdx.x < f.nb_rows + f.nb_tiles) {
+            adam_wenc_tile(f, a, gs, step_size, (int)blockIdx.x - f.nb_rows);
+            return;
+        }
+    }
     if ((int)blockIdx.x < f.nb_rows) {
         const int lane = threadIdx.x & 63;
         const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -324,8 +329,8 @@ __global__ __launch_bounds__(256, 4) void adam_fused_kernel(AdamFusedArgs f) {
         return;
     }
     // the two bias segments
-    const long nb = gridDim.x - f.nb_rows;
-    const long bi = blockIdx.x - f.nb_rows;
+    const long nb = gridDim.x - f.nb_rows - (PART == 2 ? f.nb_tiles : 0);
+    const long bi = blockIdx.x - f.nb_rows - (PART == 2 ? f.nb_tiles : 0);
     for (int seg = 0; seg < 2; ++seg) {
         const long off = seg ? f.off_b_enc : f.off_b_dec, n = seg ? f.n_b_enc : f.n_b_dec;
         for (long i = bi * 256 + threadIdx.x; i < n; i += nb * 256) {
@@ -613,8 +618,15 @@ hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const fl
     f.nb_tiles = f.tiles_s * ((D + 31) / 32);
     const int nb_bias = 32;
     return dispatch_nv(D, [&](auto nv) {
-        hipLaunchKernelGGL((adam_fused_kernel<decltype(nv)::value, 0>), dim3(f.nb_rows + nb_bias), dim3(256), 0, stream, f);
-        hipLaunchKernelGGL((adam_fused_kernel<1, 1>), dim3(f.nb_tiles), dim3(256), 0, stream, f);
+        // SAEV_AMD_ADAM_SPLIT=1: rows + biases and tiles as two launches (A/B; one grid overlaps the LDS-bound tile
+        // workgroups with the streaming row workgroups: 302 vs 327 us at configs[1])
+        static const bool split = [] { const char* e = getenv("SAEV_AMD_ADAM_SPLIT"); return e != nullptr && atoi(e) != 0; }();
+        if (split) {
+            hipLaunchKernelGGL((adam_fused_kernel<decltype(nv)::value, 0>), dim3(f.nb_rows + nb_bias), dim3(256), 0, stream, f);
+            hipLaunchKernelGGL((adam_fused_kernel<1, 1>), dim3(f.nb_tiles), dim3(256), 0, stream, f);
+        } else {
+            hipLaunchKernelGGL((adam_fused_kernel<decltype(nv)::value, 2>), dim3(f.nb_rows + f.nb_tiles + nb_bias), dim3(256), 0, stream, f);
+        }
     });
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {

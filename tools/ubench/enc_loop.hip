@@ -1,0 +1,133 @@
+// The encoder's contraction loop alone -- 256 x 256 workgroup tile, four-slot LDS ring filled by global_load_lds three k-steps
+// ahead, one barrier per k-step, v_mfma_f32_16x16x32_f16 -- in two wave layouts over the same images:
+//   NW = 8 (shipped): eight waves as 2 (s) x 4 (b), wave tile 128 x 64, 128 accumulator registers, two waves per SIMD,
+//                     12 ds_read_b128 per 32 MFMAs;
+//   NW = 4:           four waves as 2 x 2, wave tile 128 x 128, 256 accumulator registers (the allocator has to put them into
+//                     AGPRs: one wave per SIMD owns the whole 512-entry file), 16 ds_read_b128 per 64 MFMAs (-33 % LDS reads).
+// No epilogue (the accumulators are summed into one float per lane).  configs[1] geometry: 64 batch blocks x 4 latent
+// ranges = 256 workgroups, 32 tiles of 32 k-steps each.  Question: does the loop get faster with a third fewer LDS reads?
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/enc_loop.hip -o /tmp/enc_loop && /tmp/enc_loop
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((aligned(16))) KSlot {
+    _Float16 a[256][32];
+    _Float16 b[256][32];
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void loop_kernel(const _Float16* __restrict__ wimg, const _Float16* __restrict__ ximg,
+                                                                         int nks, int ntiles, float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    KSlot* slot = reinterpret_cast<KSlot*>(smem_raw);
+    constexpr int JB = NW == 8 ? 4 : 8;          // 16-row blocks along b per wave
+    constexpr int WBN = NW == 8 ? 4 : 2;         // waves along b
+    constexpr int PER = 16384 / NW / 1024;       // 1 KB requests per wave and image
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wid % 2, wb = wid / 2;
+    (void)WBN;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int arow0 = ws * 128 + l15, brow0 = wb * (16 * JB) + l15;
+    const int coff = 8 * (kg ^ ((4 - (l15 >> 2)) & 3));
+    const size_t img = 256 * 32;
+    const int bb = blockIdx.x >> 2, sp = blockIdx.x & 3;
+    const _Float16* x_imgs = ximg + (size_t)bb * nks * img;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)&slot[0].a[0][0] + wid * (16384 / NW);
+    auto stage = [&](int s, int tile, int ks) {
+        const char* wsrc = reinterpret_cast<const char*>(wimg + ((size_t)(sp * ntiles + tile) * nks + ks) * img) + wid * (16384 / NW);
+        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + wid * (16384 / NW);
+        const uint32_t la = lds_w + (uint32_t)s * (uint32_t)sizeof(KSlot);
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la + r * 1024), "v"(lane_off), "s"(wsrc + r * 1024) : "memory", "m0");
+        }
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la + 16384 + r * 1024), "v"(lane_off), "s"(xsrc + r * 1024) : "memory", "m0");
+        }
+    };
+    f32x4 acc[8][JB];
+    float total = 0.f;
+    for (int tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < JB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage(0, tile, 0);
+        stage(1, tile, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage(2, tile, 2);
+        for (int t = 0; t < nks; ++t) {
+            if (t + 3 < nks) stage((t + 3) & 3, tile, t + 3);
+            const KSlot& cs = slot[t & 3];
+            half8 fa[3], fb[JB];
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) fb[jb] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 16 * jb][coff]);
+            fa[0] = *reinterpret_cast<const half8*>(&cs.a[arow0][coff]);
+            fa[1] = *reinterpret_cast<const half8*>(&cs.a[arow0 + 16][coff]);
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) {
+                acc[sb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sb % 3], fb[0], acc[sb][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sb + 2 < 8) fa[(sb + 2) % 3] = *reinterpret_cast<const half8*>(&cs.a[arow0 + 16 * (sb + 2)][coff]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jb = 1; jb < JB; ++jb) acc[sb][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sb % 3], fb[jb], acc[sb][jb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // loads that may stay in flight: those of the k-steps after t + 1 (2 * PER requests per staged k-step)
+            if (t + 3 < nks) { if constexpr (PER == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else if (t + 2 < nks) { if constexpr (PER == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < JB; ++j) total += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    }
+    out[(size_t)blockIdx.x * (NW * 64) + tid] = total;
+}
+
+int main() {
+    const int nks = 32, ntiles = 32, nbb = 64, nsp = 4;
+    const size_t img = 256 * 32;
+    const size_t wn = (size_t)nsp * ntiles * nks * img, xn = (size_t)nbb * nks * img;
+    std::vector<_Float16> h(wn > xn ? wn : xn);
+    srand(1);
+    for (auto& v : h) v = (_Float16)((rand() % 2001 - 1000) * 0.004f);
+    _Float16 *w, *x;
+    float* out;
+    hipMalloc(&w, wn * 2); hipMalloc(&x, xn * 2); hipMalloc(&out, 256 * 512 * 4);
+    hipMemcpy(w, h.data(), wn * 2, hipMemcpyHostToDevice);
+    hipMemcpy(x, h.data(), xn * 2, hipMemcpyHostToDevice);
+    const double flops = 2.0 * 16384 * 1024 * 32768;
+    auto run = [&](auto kern, int nw, const char* name) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)sizeof(KSlot));
+        float best = 1e9f;
+        for (int rep = 0; rep < 6; ++rep) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(kern, dim3(nbb * nsp), dim3(nw * 64), 4 * sizeof(KSlot), 0, w, x, nks, ntiles, out);
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < best) best = ms;
+        }
+        printf("%-34s %.3f ms  %.0f TFLOP/s  (%s)\n", name, best, flops / best * 1e-9, hipGetErrorString(hipGetLastError()));
+    };
+    run(loop_kernel<8>, 8, "8 waves, wave tile 128 x 64");
+    run(loop_kernel<4>, 4, "4 waves, wave tile 128 x 128");
+    return 0;
+}

@@ -4,7 +4,8 @@
 //                     12 ds_read_b128 per 32 MFMAs;
 //   NW = 4:           four waves as 2 x 2, wave tile 128 x 128, 256 accumulator registers (the allocator has to put them into
 //                     AGPRs: one wave per SIMD owns the whole 512-entry file), 16 ds_read_b128 per 64 MFMAs (-33 % LDS reads).
-// No epilogue (the accumulators are summed into one float per lane).  configs[1] geometry: 64 batch blocks x 4 latent
+//   NW = 4, HB = 128: two workgroups per CU (see loop_kernel); EPI adds a stand-in epilogue.  Results: tools/experiments/README.md.
+// No real epilogue (the accumulators are summed into one float per lane).  configs[1] geometry: 64 batch blocks x 4 latent
 // ranges = 256 workgroups, 32 tiles of 32 k-steps each.  Question: does the loop get faster with a third fewer LDS reads?
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/enc_loop.hip -o /tmp/enc_loop && /tmp/enc_loop
 #include <hip/hip_runtime.h>
@@ -16,19 +17,28 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct __attribute__((aligned(16))) KSlot {
+template <int HB>
+struct __attribute__((aligned(16))) KSlotT {
     _Float16 a[256][32];
-    _Float16 b[256][32];
+    _Float16 b[HB][32];
 };
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void loop_kernel(const _Float16* __restrict__ wimg, const _Float16* __restrict__ ximg,
+// HB = 256: one workgroup per CU (NW = 8 or 4 as above).  HB = 128, NW = 4: workgroup tile 256 (s) x 128 (b), wave tile
+// 128 x 64 as shipped, three-slot ring of 24 KB -- TWO workgroups per CU, i.e. two waves per SIMD from DIFFERENT barrier
+// domains (each one's barrier / epilogue time could overlap the other's MFMAs), at 1.5x the L2 -> LDS staging per flop.
+// EPI: a stand-in for the TopK epilogue after every tile: ~8 dependent VALU instructions per accumulator value (~1 000 per
+// wave and tile at 128 values, what profiles/r03_stalls.txt shows for the real one) and two workgroup barriers.
+template <int NW, int HB, bool EPI = false>
+__global__ __launch_bounds__(NW * 64, ((NW == 8 || HB == 128) ? 2 : 1)) void loop_kernel(const _Float16* __restrict__ wimg, const _Float16* __restrict__ ximg,
                                                                          int nks, int ntiles, float* out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef KSlotT<HB> KSlot;
     KSlot* slot = reinterpret_cast<KSlot*>(smem_raw);
-    constexpr int JB = NW == 8 ? 4 : 8;          // 16-row blocks along b per wave
-    constexpr int WBN = NW == 8 ? 4 : 2;         // waves along b
-    constexpr int PER = 16384 / NW / 1024;       // 1 KB requests per wave and image
+    constexpr int NS = HB == 256 ? 4 : 3;         // ring slots
+    constexpr int JB = HB / 16 / (NW / 2);        // 16-row blocks along b per wave
+    constexpr int WBN = NW / 2;                   // waves along b
+    constexpr int PER = 16384 / NW / 1024;        // 1 KB requests per wave and W image
+    constexpr int PERX = HB * 64 / NW / 1024;     // ... and x image share
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ws = wid % 2, wb = wid / 2;
@@ -38,20 +48,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void loop_kernel(const 
     const int coff = 8 * (kg ^ ((4 - (l15 >> 2)) & 3));
     const size_t img = 256 * 32;
     const int bb = blockIdx.x >> 2, sp = blockIdx.x & 3;
-    const _Float16* x_imgs = ximg + (size_t)bb * nks * img;
+    // (HB = 128: workgroup bb uses rows [128 (bb & 1), +128) of x block bb / 2: the first / second 8 KB of every image)
+    const _Float16* x_imgs = ximg + (size_t)(HB == 256 ? bb : bb / 2) * nks * img + (HB == 256 ? 0 : (bb & 1) * 128 * 32);
     const uint32_t lane_off = (uint32_t)lane * 16u;
     const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)&slot[0].a[0][0] + wid * (16384 / NW);
     auto stage = [&](int s, int tile, int ks) {
         const char* wsrc = reinterpret_cast<const char*>(wimg + ((size_t)(sp * ntiles + tile) * nks + ks) * img) + wid * (16384 / NW);
-        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + wid * (16384 / NW);
+        const char* xsrc = reinterpret_cast<const char*>(x_imgs + (size_t)ks * img) + wid * (HB * 64 / NW);
         const uint32_t la = lds_w + (uint32_t)s * (uint32_t)sizeof(KSlot);
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la + r * 1024), "v"(lane_off), "s"(wsrc + r * 1024) : "memory", "m0");
         }
 #pragma unroll
-        for (int r = 0; r < PER; ++r) {
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la + 16384 + r * 1024), "v"(lane_off), "s"(xsrc + r * 1024) : "memory", "m0");
+        for (int r = 0; r < PERX; ++r) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la + 16384 - wid * (16384 / NW) + wid * (HB * 64 / NW) + r * 1024), "v"(lane_off), "s"(xsrc + r * 1024) : "memory", "m0");
         }
     };
     f32x4 acc[8][JB];
@@ -61,14 +72,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void loop_kernel(const 
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < JB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int AH = NS - 1;  // k-steps staged ahead
         stage(0, tile, 0);
-        stage(1, tile, 1);
+        if (AH >= 3) stage(1, tile, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        stage(2, tile, 2);
+        stage(AH - 1, tile, AH - 1);
         for (int t = 0; t < nks; ++t) {
-            if (t + 3 < nks) stage((t + 3) & 3, tile, t + 3);
-            const KSlot& cs = slot[t & 3];
+            if (t + AH < nks) stage((t + AH) % NS, tile, t + AH);
+            const KSlot& cs = slot[t % NS];
             half8 fa[3], fb[JB];
 #pragma unroll
             for (int jb = 0; jb < JB; ++jb) fb[jb] = *reinterpret_cast<const half8*>(&cs.b[brow0 + 16 * jb][coff]);
@@ -85,10 +97,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void loop_kernel(const 
                 __builtin_amdgcn_sched_barrier(0);
             }
             // loads that may stay in flight: those of the k-steps after t + 1 (2 * PER requests per staged k-step)
-            if (t + 3 < nks) { if constexpr (PER == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-            else if (t + 2 < nks) { if constexpr (PER == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            constexpr int RQ = PER + PERX;  // requests per staged k-step and wave
+            if constexpr (AH == 3) {
+                if (t + 3 < nks) { if constexpr (RQ == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+                else if (t + 2 < nks) { if constexpr (RQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {  // two ahead: only k-step t + 2's requests may stay in flight (RQ = 6)
+                if (t + 2 < nks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (EPI) {
+            unsigned m = 0;
+            const float tau = 1.0e30f + (float)tile;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < JB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e];
+                        v = __builtin_fmaf(v, 0.999f, 0.5f);
+                        v = fmaxf(v, -tau);
+                        v = __builtin_fmaf(v, 1.001f, -0.25f);
+                        v = fminf(v, tau);
+                        v = __builtin_fmaf(v, 0.5f, 0.125f);
+                        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(v), "v"(tau) : "vcc");
+                        acc[i][j][e] = v;
+                    }
+            __syncthreads();
+            if (m == 0x12345u) out[tid] = 1.f;
+            __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -107,18 +147,20 @@ int main() {
     for (auto& v : h) v = (_Float16)((rand() % 2001 - 1000) * 0.004f);
     _Float16 *w, *x;
     float* out;
-    hipMalloc(&w, wn * 2); hipMalloc(&x, xn * 2); hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&w, wn * 2); hipMalloc(&x, xn * 2); hipMalloc(&out, 512 * 512 * 4);
     hipMemcpy(w, h.data(), wn * 2, hipMemcpyHostToDevice);
     hipMemcpy(x, h.data(), xn * 2, hipMemcpyHostToDevice);
     const double flops = 2.0 * 16384 * 1024 * 32768;
-    auto run = [&](auto kern, int nw, const char* name) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)sizeof(KSlot));
+    auto run = [&](auto kern, int nw, const char* name, int hb = 256) {
+        const int smem = hb == 256 ? 4 * (int)sizeof(KSlotT<256>) : 3 * (int)sizeof(KSlotT<128>);
+        const int grid = nbb * nsp * (256 / hb);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         float best = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(kern, dim3(nbb * nsp), dim3(nw * 64), 4 * sizeof(KSlot), 0, w, x, nks, ntiles, out);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), smem, 0, w, x, nks, ntiles, out);
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             float ms = 0.f;
@@ -127,7 +169,10 @@ int main() {
         }
         printf("%-34s %.3f ms  %.0f TFLOP/s  (%s)\n", name, best, flops / best * 1e-9, hipGetErrorString(hipGetLastError()));
     };
-    run(loop_kernel<8>, 8, "8 waves, wave tile 128 x 64");
-    run(loop_kernel<4>, 4, "4 waves, wave tile 128 x 128");
+    run(loop_kernel<8, 256>, 8, "8 waves, wave tile 128 x 64");
+    run(loop_kernel<4, 256>, 4, "4 waves, wave tile 128 x 128");
+    run(loop_kernel<4, 128>, 4, "2 WGs/CU x 4 waves, 256 x 128 tile", 128);
+    run(loop_kernel<8, 256, true>, 8, "8 waves + stand-in epilogue");
+    run(loop_kernel<4, 128, true>, 4, "2 WGs/CU x 4 waves + stand-in epilogue", 128);
     return 0;
 }

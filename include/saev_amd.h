@@ -231,10 +231,12 @@ int saev_backward_end(saev_ctx* ctx, void* stream);
  * the ranks, every rank all-gathers what the backward consumes -- x, dL/dx_hat, the codes: (8 D + 8 k) bytes per row --
  * and forms the FULL gradient of the global batch itself, redundantly and bit-identically on every rank:
  *   saev_copy_step_state     this rank's rows of dL/dx_hat and of the codes into caller buffers (the rank's slice of the
- *                            all-gather outputs); n_rows = the rows of the training forward in flight;
+ *                            all-gather outputs); n_rows = the rows of the training forward in flight.  With P Matryoshka
+ *                            prefixes dL/dx_hat is the (n_rows, P, d_model) block of suffix-summed gradients;
  *   saev_backward_override   the gathered buffers (n_all <= max_batch rows of all ranks, rank-major) for the NEXT
  *                            saev_backward_begin / _rows: pairs, db_dec and both weight gradients then cover all n_all
- *                            rows.  One-shot (the next forward cancels it); NULL cancels.  No Matryoshka prefixes.
+ *                            rows.  One-shot (the next forward cancels it); NULL cancels.  Matryoshka: g_all is
+ *                            (n_all, P, d_model) and every rank must have set the same cut points.
  * The auxiliary loss stays local to a rank's rows; its gradient is a few rows: saev_aux_compact_rows rows of
  * [dW_dec | dW_enc^T] for the dead latents, their db_enc and the term's share of db_dec.  Between saev_backward_begin and
  * saev_backward_rows the caller exports them (rows * (2 d_model + 1) + d_model floats), sums over ranks, imports:

@@ -1284,7 +1284,6 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int S = c->cfg.d_sae, D = c->cfg.d_model, K = c->cfg.top_k;
     const bool ov = c->ov_x != nullptr;
-    REQUIRE(c, !ov || c->P_last == 1, SAEV_UNSUPPORTED, "gathered backward: Matryoshka prefixes are not supported");
     const int n = ov ? c->ov_n : c->n_last;  // rows whose (row, latent) pairs this backward covers
     const int words = ((n + 31) / 32 + 7) / 8 * 8;
     c->row_proj_valid = false;
@@ -1370,10 +1369,10 @@ int saev_copy_step_state(saev_ctx* c, int32_t n_rows, float* g_out, int32_t* idx
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, c->n_last > 0 && c->training_last && n_rows == c->n_last, SAEV_INVALID_ARG,
             "saev_copy_step_state: n_rows must be the row count of the training forward in flight");
-    REQUIRE(c, c->P_last == 1, SAEV_UNSUPPORTED, "saev_copy_step_state: Matryoshka prefixes are not supported");
     hipStream_t s = (hipStream_t)stream;
-    const size_t nk = (size_t)n_rows * c->cfg.top_k, nd = (size_t)n_rows * c->cfg.d_model;
-    if (g_out) HIPCHK(c, hipMemcpyAsync(g_out, c->g, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // (Matryoshka: P suffix-summed gradients per row, (n_rows, P, d_model) -- what the backward consumes in that case)
+    const size_t nk = (size_t)n_rows * c->cfg.top_k, nd = (size_t)n_rows * c->cfg.d_model * (size_t)c->P_last;
+    if (g_out) HIPCHK(c, hipMemcpyAsync(g_out, c->P_last > 1 ? c->G : c->g, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (idx_out) HIPCHK(c, hipMemcpyAsync(idx_out, c->idx, nk * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     if (val_out) HIPCHK(c, hipMemcpyAsync(val_out, c->val, nk * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SAEV_OK;

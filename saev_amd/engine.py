@@ -171,9 +171,11 @@ class SaeEngine:
     def set_prefixes(self, prefixes) -> None:
         """Matryoshka cut points for the following steps (ascending, last == d_sae); None / one entry = plain."""
         if prefixes is None:
+            self._n_prefixes = 1
             self._chk(self.lib.saev_set_prefixes(self.ctx, None, 0), "saev_set_prefixes")
             return
         pre = [int(p) for p in prefixes]
+        self._n_prefixes = max(1, len(pre))
         arr = (C.c_int64 * len(pre))(*pre)
         self._chk(self.lib.saev_set_prefixes(self.ctx, arr, len(pre)), "saev_set_prefixes")
 
@@ -297,13 +299,14 @@ class SaeEngine:
     # ---- gathered backward (data-parallel runs that exchange the sparse step state instead of the gradient) -------------
     def gather_buffers(self, world: int, n_local: int):
         """(x_all, g_all, idx_all, val_all) for ``world`` ranks of ``n_local`` rows each, allocated once per shape."""
-        key = (world, n_local)
+        P = getattr(self, "_n_prefixes", 1)  # Matryoshka: dL/dx_hat is P suffix-summed gradients per row
+        key = (world, n_local, P)
         if getattr(self, "_gather_key", None) != key:
             n, D, K = world * n_local, self.cfg.d_model, min(self.cfg.top_k, self.cfg.d_sae)
             if n > self.cfg.max_batch:
                 raise _lib.SaevError(f"gathered backward over {n} rows needs an engine with max_batch >= {n} (the GLOBAL batch), "
                                      f"got {self.cfg.max_batch}")
-            self._gather_bufs = (torch.empty(n, D, device=self.device), torch.empty(n, D, device=self.device),
+            self._gather_bufs = (torch.empty(n, D, device=self.device), torch.empty(n, P * D, device=self.device),
                                  torch.empty(n, K, device=self.device, dtype=torch.int32), torch.empty(n, K, device=self.device))
             self._gather_key = key
         return self._gather_bufs

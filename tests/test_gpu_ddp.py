@@ -154,7 +154,7 @@ def test_chunked_tail_covers_the_padded_layout_exactly(world, encoder_mode):
         assert (flat[pad] == 0).all()
 
 
-def _two_rank_worker(rank, world, port, out, tail, exchange="dense"):
+def _two_rank_worker(rank, world, port, out, tail, exchange="dense", prefixes=None):
     import os
 
     import torch.distributed as dist
@@ -168,6 +168,8 @@ def _two_rank_worker(rank, world, port, out, tail, exchange="dense"):
         g = load_golden("g9_train_b")
         bsz = int(g["bsz"])
         stepper = DataParallelStepper(eng, dist, world, tail=tail, exchange=exchange)
+        if prefixes is not None:
+            eng.set_prefixes(list(prefixes))
         n_dead = []
         for i, xb in enumerate(g["acts"].split(bsz)[:5]):
             stepper.train_step(xb[rank::world].contiguous().cuda(), 1e-3 * i, 0.05)
@@ -179,8 +181,9 @@ def _two_rank_worker(rank, world, port, out, tail, exchange="dense"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tail,exchange", [("replicated", "dense"), ("sharded", "dense"), ("replicated", "sparse")])
-def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, tail, exchange, encoder_mode):
+@pytest.mark.parametrize("tail,exchange,prefixes", [("replicated", "dense", None), ("sharded", "dense", None),
+                                                    ("replicated", "sparse", None), ("replicated", "sparse", (100, 300, 1024))])
+def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, tail, exchange, prefixes, encoder_mode):
     """The REAL engines under a real two-rank exchange: two processes share the one GPU of the test box and talk over
     gloo (RCCL refuses two ranks on one device; gloo stages device tensors through the host, which is all this needs).
     Rank r trains on rows r::2 of every batch; both tails -- and the sparse-state exchange, where no gradient crosses
@@ -193,7 +196,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
 
     out = str(tmp_path / "rank{rank}.pt")
     try:
-        mp.spawn(_two_rank_worker, args=(2, _free_port(), out, tail, exchange), nprocs=2, join=True)
+        mp.spawn(_two_rank_worker, args=(2, _free_port(), out, tail, exchange, prefixes), nprocs=2, join=True)
     except Exception as exc:  # a gloo build without device-tensor support for these collectives
         if "gloo" in str(exc).lower() and ("not support" in str(exc).lower() or "unsupported" in str(exc).lower()):
             pytest.skip(f"gloo cannot run this collective on device tensors here: {exc}")
@@ -203,6 +206,8 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
         assert torch.equal(r0["params"][k], r1["params"][k]), k
     assert torch.equal(r0["toks"], r1["toks"]) and r0["n_dead"] == r1["n_dead"]
     eng, x, s = _setup()
+    if prefixes is not None:  # (Matryoshka: the gathered gradient block is (rows, P, D) suffix sums)
+        eng.set_prefixes(list(prefixes))
     g = load_golden("g9_train_b")
     bsz = int(g["bsz"])
     n_dead = []

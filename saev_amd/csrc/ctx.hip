@@ -83,6 +83,14 @@ struct saev_ctx {
     int32_t* flags = nullptr;  // [0] need_dense_pre [1] need_dense [2] n_overflow [3] cand_max [4] n_dead [5] k_use [6,7,8] dead_update scratch
     int32_t *chunk_starts = nullptr, *part_starts = nullptr, *work_latent = nullptr;
     float *dW_encT = nullptr, *partials = nullptr, *db_partials = nullptr;
+    // column-sliced weight gradients (launch_dw_slices; SAEV_AMD_DW=rows keeps dw_rows): slice-major copies of g and x left by
+    // the decode, pair words / latents in pair order from the CSC build, the per-slice shares of dval
+    bool dws_ok = false;         // geometry fits (d_model % 32 == 0, 32-bit offsets) and not switched off
+    int dws_rows = 0;            // > 0: the copies describe the training forward in flight (that many rows)
+    bool dws_pairs = false;      // the CSC build of this backward left pv / plat
+    float *gS = nullptr, *xS = nullptr, *dvp = nullptr;
+    int2 *pv = nullptr, *pv2 = nullptr;
+    int32_t *plat = nullptr, *cut_lat = nullptr;
     // Matryoshka prefixes of the step (P == 1: plain objective)
     int P = 1;
     int32_t cuts[MAX_PREFIXES] = {0};
@@ -300,6 +308,16 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     }
     A(chunk_starts, S + 1); A(part_starts, S); A(work_latent, c->max_work);
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part); A(row_proj, S); A(enc_sq, S);
+    {
+        const char* e = getenv("SAEV_AMD_DW");  // (read per context: tests build one of each)
+        const bool rows_only = e != nullptr && strcmp(e, "rows") == 0;
+        c->dws_ok = !rows_only && D % DWS_SLICE == 0 && (uint64_t)S * D * 4ull < (1ull << 32) && MB < (1l << 24) &&
+                    (uint64_t)MB * K < (1ull << 31);
+    }
+    if (c->dws_ok) {
+        A(gS, MB * D); A(xS, MB * D); A(dvp, (size_t)(D / DWS_SLICE) * MB * K);
+        A(pv, MB * K); A(pv2, MB * K); A(plat, MB * K); A(cut_lat, (MB * K + DWS_RUN - 1) / DWS_RUN);
+    }
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32 || KA > 0) {  // (the f32 encoder needs the image geometry for AuxK only)
@@ -953,6 +971,8 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.gscale = 2.0f / ((float)n * (float)D * (float)c->P);
     a.training = training ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
+    c->dws_rows = 0;
+    if (training && c->dws_ok && c->P == 1) { a.gS = c->gS; a.xS = c->xS; c->dws_rows = n; }
     if (c->P > 1) {
         MatryArgs m{};
         m.P = c->P;
@@ -1292,6 +1312,8 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals;
     a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
     a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
+    c->dws_pairs = !ov && c->dws_rows == n && c->P_last == 1;
+    if (c->dws_pairs) { a.pv = c->pv; a.plat = c->plat; a.val = c->val; }
     // (the bit map row pitch depends on the batch: a map cleaned for a pitch covers every shorter one, S * words <= before)
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0), formed in the grids of the CSC build's first two
     // launches; the AuxK contractions add theirs
@@ -1340,7 +1362,21 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     a.enc_sq = all_rows ? c->enc_sq : nullptr;
     // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
     const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
-    HIPCHK(c, launch_dw_rows(a, max_work, s));
+    if (all_rows && !ov && c->dws_pairs && c->dws_rows == n) {
+        // one pass over all latents of this context's own batch: column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
+        DwSlicesArgs w{};
+        w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->gS; w.xS = c->xS; w.W_dec = a.W_dec;
+        w.n_rows = n; w.D = D; w.S = S; w.pair_cap = (int)((long)c->cfg.max_batch * K);
+        w.dvp = c->dvp; w.dW_dec = a.dW_dec; w.dW_encT = a.dW_encT; w.db_enc = a.db_enc;
+        const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;
+        w.part_dec = c->partials; w.part_enc = c->partials + 2 * runs_cap * D;  // (max_part * 2 rows hold 4 * runs_cap)
+        w.cut_lat = c->cut_lat;
+        w.row_proj = a.row_proj; w.project = a.project; w.enc_sq = a.enc_sq;
+        w.clear_bitmap = a.clear_bitmap; w.clear_words = a.clear_words;
+        HIPCHK(c, launch_dw_slices(w, (int)((long)n * K), s));
+    } else {
+        HIPCHK(c, launch_dw_rows(a, max_work, s));
+    }
     if (c->aux_route == AUX_DENSE)  // (the count on the device when the host only had a bound of it: aux_dev_count)
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s,

@@ -134,6 +134,10 @@ struct DecodeArgs {
     float* x_hat;           // (n_rows, D) or NULL
     int32_t* fired;         // (S)
     RowStats* rowstats;     // (n_rows) or NULL
+    // optional (training, decode_kernel only): slice-major copies of g and x, [D / 32][n_rows][32 floats], for the column-sliced
+    // weight-gradient passes (launch_dw_slices)
+    float* gS;
+    float* xS;
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 
@@ -163,6 +167,10 @@ struct CscArgs {
     int32_t* chunk_starts;  // (S + 1) or NULL
     int32_t* part_starts;   // (S) partial-sum slot of each multi-chunk latent (with chunk_starts)
     int32_t* work_latent;   // (max_work) or NULL
+    // optional (launch_dw_slices): per pair, in pair order, {128 * row | DWS_FIRST / DWS_LAST flags, coefficient bits} and the latent
+    int2* pv;
+    int32_t* plat;
+    const float* val;       // (n_rows, code_stride) coefficients (with pv)
 };
 // bitmap_clean: the whole bit map is known to be zero (dw_combine_kernel cleared it after the previous build)
 // colsum_*: optional column sums out[d] = sum_b m[b][d] (b < a.n_rows; partials: ceil(n_rows / 64) * D floats) computed in the
@@ -209,6 +217,43 @@ struct DwRowsArgs {
     int clear_words;
 };
 hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream);
+
+// The same gradients from COLUMN slices (the route of a one-pass backward over all latents when d_model % 32 == 0, P == 1).
+// dw_rows gathers whole rows of g and x -- 2 k 4D bytes per activation row out of two matrices far larger than an XCD's L2,
+// every byte of it from the fabric.  A 32-column slice of g is n_rows x 128 B (2 MB at 16 384 rows): XCD x works through slices
+// x, x + 8, ... one after the other (workgroup b runs on XCD b % 8), so its gathers hit in its 4 MB L2.  g and x are read from
+// slice-major copies the decode kernel leaves ([slice][row][32]: consecutive rows of a slice are consecutive 128-byte lines;
+// at a row pitch of 4 D bytes they would all fall into one L2 channel).  An eight-lane group (one 128-byte line per pair) walks
+// a fixed RUN of DWS_RUN consecutive pairs of the latent-major pair list: no load imbalance whatever the firing histogram;
+// a latent that ends inside the run is stored directly when it also began there, otherwise as the run's head / tail partial.
+//   pass A: dW_dec slices from g, per-slice shares of dval = <g[b,:], W_dec[i,:]>;   dval_sum: adds the D / 32 shares;
+//   pass B: dW_enc^T slices from x, weighted with dval;   finalize: one wave per latent and gradient row: partials summed in
+//   run order, unused latents zeroed, db_enc, and the row statistics dw_rows / dw_combine leave (row_proj, enc_sq).
+constexpr int DWS_RUN = 64, DWS_SLICE = 32;
+constexpr int DWS_FIRST = 1, DWS_LAST = 2, DWS_END = 4;  // pair word flags (END is set by the kernels: last pair of a run)
+struct DwSlicesArgs {
+    const int32_t* starts;   // (S + 1); starts[S] = number of pairs
+    const int2* pv;          // (pairs) from the CSC build
+    int2* pv2;               // (pairs) scratch: pv with the coefficient replaced by dval
+    const int32_t* plat;     // (pairs)
+    const float* gS;         // [D / 32][n_rows][32]
+    const float* xS;
+    const float* W_dec;      // (S, D)
+    int n_rows, D, S, pair_cap;  // pair_cap: pitch of dvp (>= n_rows * k)
+    float* dvp;              // (D / 32, pair_cap)
+    float* dW_dec;           // (S, D)
+    float* dW_encT;          // (S, D)
+    float* db_enc;           // (S)
+    float* part_dec;         // (2 * ceil(pair_cap / DWS_RUN), D) head / tail partial of every run
+    float* part_enc;
+    int32_t* cut_lat;        // (ceil(pair_cap / DWS_RUN)) per run: the latent that begins in it and is cut at its end, or -1
+    float2* row_proj;        // optional, as DwRowsArgs
+    int project;
+    float* enc_sq;           // optional
+    uint32_t* clear_bitmap;  // optional, as DwRowsArgs
+    int clear_words;
+};
+hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, hipStream_t stream);
 // sq_part: optional, transpose_blocks(S, D) doubles = per-tile sums of squares of `in`
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part = nullptr);
 int transpose_blocks(int S, int D);

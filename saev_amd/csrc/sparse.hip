@@ -113,6 +113,11 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
                 sumsq64 += (double)xv[e] * (double)xv[e];
             }
             if (a.training) reinterpret_cast<f32x4*>(a.g + (size_t)row * D)[q] = g[n];
+            if (a.training && a.gS != nullptr) {  // slice-major copies for launch_dw_slices: [q / 8][row][8 float4]
+                const size_t o = ((size_t)(q >> 3) * a.n_rows + row) * 8 + (q & 7);
+                reinterpret_cast<f32x4*>(a.gS)[o] = g[n];
+                reinterpret_cast<f32x4*>(a.xS)[o] = xv;
+            }
         }
     }
     // (dval_j = <g, W_dec[idx_j]> is formed by dw_rows_kernel, latent-major, from the rows of g it reads anyway: no second
@@ -400,7 +405,13 @@ __global__ void csc_place_kernel(CscArgs a) {
             const uint32_t m = e < wi ? 0xffffffffu : (e == wi ? ((1u << (b & 31)) - 1u) : 0u);
             rank += __popc(wd[e] & m);
         }
-        a.pairs[a.starts[i] + rank] = int2{b, (int)((size_t)b * a.code_stride + j)};
+        const int slot = a.starts[i] + rank;
+        a.pairs[slot] = int2{b, (int)((size_t)b * a.code_stride + j)};
+        if (a.pv != nullptr) {
+            const int fl = (rank == 0 ? DWS_FIRST : 0) | (rank == a.counts[i] - 1 ? DWS_LAST : 0);
+            a.pv[slot] = int2{(b << 7) | fl, __float_as_int(a.val[(size_t)b * a.code_stride + j])};
+            a.plat[slot] = i;
+        }
     }
 }
 
@@ -655,6 +666,280 @@ __global__ __launch_bounds__(256) void dw_combine_kernel(DwRowsArgs a) {
     }
 }
 
+// ------------------------------- weight gradients from column slices (kernels.h: DwSlicesArgs) ----------------------
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return f32x4{__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+}
+// sum over the eight lanes of a group (every lane receives it)
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+
+// PASS_A: m = gS, out = dW_dec, coefficients pv[].y = val, W slices for the dval shares.  Otherwise m = xS, out = dW_enc^T,
+// coefficients pv2[].y = dval.  A workgroup = 4 waves x 8 lane groups = 32 runs of one slice.
+template <bool PASS_A>
+__global__ __launch_bounds__(256, 4) void dw_slices_kernel(DwSlicesArgs a, int wg_per_slice) {
+    constexpr int L = DWS_RUN;
+    const int lane = threadIdx.x & 63, gi = lane >> 3, li = lane & 7;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slice = xcd + 8 * (q / wg_per_slice);
+    if (slice * DWS_SLICE >= a.D) return;
+    const int NP = a.starts[a.S];
+    const int run0 = ((q % wg_per_slice) * 4 + (threadIdx.x >> 6)) * 8;
+    if (run0 * L >= NP) return;  // (wave-uniform)
+    const int run = run0 + gi;
+    const int col = slice * DWS_SLICE + li * 4;
+    const uint32_t colb = (uint32_t)col * 4u, rowb = (uint32_t)a.D * 4u, li16 = (uint32_t)li * 16u;
+    // run boundaries: nominally r * L; when the latent that holds that pair is short (< L pairs) the boundary moves back to the
+    // latent's first pair, so that only latents of L or more pairs are ever cut (runs of 2 .. 2 L - 2 pairs)
+    auto bound = [&](int r) -> int {
+        const long nb = (long)r * L;
+        if (nb >= NP) return NP;
+        const int lat = a.plat[nb];
+        const int s = a.starts[lat];
+        return (a.starts[lat + 1] - s < L) ? s : (int)nb;
+    };
+    const int p0 = bound(run), p1 = bound(run + 1);
+    const bool live = p0 < p1;
+    const int2* const pv = PASS_A ? a.pv : a.pv2;
+    float* const out = PASS_A ? a.dW_dec : a.dW_encT;
+    float* const part = PASS_A ? a.part_dec : a.part_enc;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+    float* const dvp = PASS_A ? a.dvp + (size_t)slice * a.pair_cap : nullptr;
+    const int sel = (lane & 56) << 2;  // byte address of the group's lane 0 for ds_bpermute
+    const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(PASS_A ? a.gS : a.xS) + (size_t)slice * a.n_rows * DWS_SLICE, 0, (uint32_t)a.n_rows * 128u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W_dec), 0, (uint32_t)a.S * rowb, 0x00020000);
+
+    // pair info of block t (pairs p0 + 8 t + li): END on the run's last pair; past the end: row 0 with coefficient 0 (never stored)
+    auto load_info = [&](int t, int2& e, int& lat) {
+        const int p = p0 + 8 * t + li;
+        e = int2{0, 0};
+        lat = 0;
+        if (p < p1) {
+            const i32x2 v = reinterpret_cast<const i32x2*>(pv)[p];
+            e = int2{v[0], v[1]};
+            lat = a.plat[p];
+            if (p == p1 - 1) e.x |= DWS_END;
+            if (p == p0) e.x &= ~DWS_FIRST;  // (its W slice is loaded below)
+        }
+    };
+    constexpr int PB = 4;  // pairs per sub-block: gathers are issued one sub-block ahead of their use
+    auto issue = [&](const int2& e, int lat, int j0, int (&xj)[PB], int (&lj)[PB], f32x4 (&gt)[PB], f32x4 (&wt)[PB]) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            xj[j] = __builtin_amdgcn_ds_bpermute(sel + 4 * (j0 + j), e.x);
+            lj[j] = __builtin_amdgcn_ds_bpermute(sel + 4 * (j0 + j), lat);
+            gt[j] = buf_load16(mres, ((uint32_t)xj[j] & ~127u) | li16);
+            if (PASS_A && (xj[j] & DWS_FIRST)) wt[j] = buf_load16(wres, (uint32_t)lj[j] * rowb + colb);
+        }
+    };
+    // consume a sub-block; wnext0 = the W slice preloaded for the first pair of the NEXT sub-block
+    auto consume = [&](const int2& e, int j0, const int (&xc)[PB], const int (&lc)[PB], const f32x4 (&gc)[PB], const f32x4 (&wc)[PB],
+                       const f32x4& wnext0, bool& head_open, float& dmine) {
+        float vc[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) vc[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(sel + 4 * (j0 + j), e.y));
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            if (PASS_A) {
+                float d = gc[j][0] * w4[0] + gc[j][1] * w4[1] + gc[j][2] * w4[2] + gc[j][3] * w4[3];
+                d = group8_sum(d);
+                dmine = li == j0 + j ? d : dmine;
+            }
+            acc += vc[j] * gc[j];
+            if (xc[j] & (DWS_LAST | DWS_END)) {
+                float* o;
+                if (head_open) o = part + ((size_t)run * 2 + 0) * a.D + col;                   // began in an earlier run
+                else if (!(xc[j] & DWS_LAST)) o = part + ((size_t)run * 2 + 1) * a.D + col;    // continues in the next run
+                else o = out + (size_t)lc[j] * a.D + col;                                      // the whole latent lies in this run
+                *reinterpret_cast<f32x4*>(o) = acc;
+                // every run leaves word of whether a latent BEGINS in it and continues past its end (its tail partial):
+                // dw_finalize_cut_kernel starts from these
+                if (PASS_A && slice == 0 && li == 0 && (xc[j] & DWS_END))
+                    a.cut_lat[run] = (!head_open && !(xc[j] & DWS_LAST)) ? lc[j] : -1;
+                head_open = false;
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PASS_A) w4 = j + 1 < PB ? wc[j + 1 < PB ? j + 1 : 0] : wnext0;  // (the next pair is the first of its latent)
+            }
+        }
+    };
+    int2 e_c, e_n;
+    int lat_c, lat_n;
+    int xa[PB], xb[PB], la[PB], lb[PB];
+    f32x4 ga[PB], gb[PB], wa[PB], wb[PB];
+    bool head_open = false;
+    load_info(0, e_c, lat_c);
+    if (live) {
+        head_open = (pv[p0].x & DWS_FIRST) == 0;  // the run's first latent began in an earlier run
+        if (PASS_A) w4 = buf_load16(wres, (uint32_t)a.plat[p0] * rowb + colb);
+    }
+    issue(e_c, lat_c, 0, xa, la, ga, wa);
+    load_info(1, e_n, lat_n);
+#pragma unroll 1
+    for (int t = 0; __any(p0 + 8 * t < p1); ++t) {  // (every group of the wave runs the same trip count)
+        float dmine = 0.f;
+        issue(e_c, lat_c, PB, xb, lb, gb, wb);
+        consume(e_c, 0, xa, la, ga, wa, wb[0], head_open, dmine);
+        issue(e_n, lat_n, 0, xa, la, ga, wa);  // (past the last block: row 0, coefficient 0, in bounds)
+        consume(e_c, PB, xb, lb, gb, wb, wa[0], head_open, dmine);
+        if (PASS_A && p0 + 8 * t + li < p1) dvp[p0 + 8 * t + li] = dmine;
+        e_c = e_n; lat_c = lat_n;
+        load_info(t + 2, e_n, lat_n);
+    }
+}
+
+// dval[p] = the D / 32 shares in slice order; pv2 = pv with dval as the coefficient; the CSC bit map word of the pair zeroed
+__global__ __launch_bounds__(256) void dw_dval_sum_kernel(DwSlicesArgs a) {
+    const int NP = a.starts[a.S];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const int n_slices = a.D / DWS_SLICE;
+    float s = 0.f;
+    for (int c = 0; c < n_slices; ++c) s += a.dvp[(size_t)c * a.pair_cap + p];
+    const int2 e = a.pv[p];
+    a.pv2[p] = int2{e.x, __float_as_int(s)};
+    if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)a.plat[p] * a.clear_words + (e.x >> 12)] = 0u;  // word of row e.x >> 7
+}
+
+// Latents that are cut by run boundaries (L or more pairs): one workgroup per run boundary and gradient row (blockIdx.y: 0 decoder
+// row, 1 encoder row + db_enc); the workgroup at the FIRST boundary a latent crosses owns it.  Its four waves sum a quarter of the
+// head partials each (run order, eight rows in flight); wave 0 adds the tail partial of the first run and the four sums in wave
+// order, writes the row and its statistics.  The order is fixed, so the result does not depend on scheduling; a latent that
+// fires on every row (256 partials at 16 384 rows) takes a quarter of the time one wave would.
+template <int NV>
+__global__ __launch_bounds__(256) void dw_finalize_cut_kernel(DwSlicesArgs a) {
+    constexpr int L = DWS_RUN;
+    __shared__ f32x4 sh[3][NV * 64];  // (waves 1-3; wave 0 keeps its sum in registers)
+    __shared__ float shdb[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int NP = a.starts[a.S];
+    const int r0 = blockIdx.x;
+    if ((long)(r0 + 1) * L >= NP) return;
+    const int i = a.cut_lat[r0];  // (written by pass A for every run that holds pairs)
+    if (i < 0) return;            // no latent is first cut at this boundary
+    const int s = a.starts[i], e = a.starts[i + 1];
+    const int r1 = (e - 1) / L;
+    const int enc = blockIdx.y;
+    const int D = a.D, D4 = D >> 2;
+    const float* const part = enc ? a.part_enc : a.part_dec;
+    const int nh = r1 - r0, ch = (nh + 3) / 4;
+    const int ra = r0 + 1 + w * ch, rb = min(r1 + 1, ra + ch);
+    f32x4 acc[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int r = ra;
+    constexpr int TRIP = NV <= 4 ? 4 : 2;  // (partial rows in flight: registers decide how many of these workgroups a CU holds)
+    for (; r + TRIP <= rb; r += TRIP) {
+        f32x4 t[TRIP][NV];
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)(r + u) * 2 * D);
+#pragma unroll
+            for (int n = 0; n < NV; ++n) t[u][n] = (lane + 64 * n < D4) ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            if constexpr (TRIP == 4) acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
+            else acc[n] += t[0][n] + t[1][n];
+        }
+    }
+    for (; r < rb; ++r) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)r * 2 * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+            if (lane + 64 * n < D4) acc[n] += p[lane + 64 * n];
+    }
+    float dbs = 0.f;
+    if (enc) {  // db_enc: a quarter of the latent's pairs per wave
+        const int cnt = e - s, q4 = (cnt + 3) / 4;
+        for (int p = s + w * q4 + lane; p < min(e, s + (w + 1) * q4); p += 64) dbs += __int_as_float(a.pv2[p].y);
+        dbs = wave_sum(dbs);
+    }
+    if (w != 0) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) sh[w - 1][lane + 64 * n] = acc[n];
+    }
+    if (lane == 0) shdb[w] = dbs;
+    __syncthreads();
+    if (w != 0) return;
+    {
+        // (a latent that begins exactly at a run boundary has its first piece stored as that run's tail partial as well)
+        const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)r0 * 2 + 1) * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const f32x4 t = (lane + 64 * n < D4) ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[n] = (((t + acc[n]) + sh[0][lane + 64 * n]) + sh[1][lane + 64 * n]) + sh[2][lane + 64 * n];
+        }
+    }
+    float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+        if (lane + 64 * n < D4) reinterpret_cast<f32x4*>(row)[lane + 64 * n] = acc[n];
+    if (enc) {
+        if (lane == 0) a.db_enc[i] = ((shdb[0] + shdb[1]) + shdb[2]) + shdb[3];
+        if (a.enc_sq != nullptr) {
+            const float sq = row_sumsq<NV>(acc);
+            if (lane == 0) a.enc_sq[i] = sq;
+        }
+    } else if (a.row_proj != nullptr) {
+        f32x4 wv[NV];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+        write_row_proj<NV>(a.row_proj, i, acc, wv, a.project, lane);
+    }
+}
+
+// Everything else, one wave per latent and gradient row: a latent inside one run -- the row the pass stored, read back for its
+// statistics; an unused latent -- zeros.
+template <int NV>
+__global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a) {
+    constexpr int L = DWS_RUN;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.S) return;
+    const int enc = blockIdx.y;
+    const int D = a.D, D4 = D >> 2;
+    const int s = a.starts[i], e = a.starts[i + 1];
+    if (e - s >= L && s / L != (e - 1) / L) return;  // (dw_finalize_cut_kernel's)
+    float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
+    f32x4 acc[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane + 64 * n < D4) {
+            if (e > s) acc[n] = reinterpret_cast<const f32x4*>(row)[lane + 64 * n];
+            else reinterpret_cast<f32x4*>(row)[lane + 64 * n] = acc[n];
+        }
+    }
+    if (enc) {
+        float dbs = 0.f;
+        for (int p = s + lane; p < e; p += 64) dbs += __int_as_float(a.pv2[p].y);
+        dbs = wave_sum(dbs);
+        if (lane == 0) a.db_enc[i] = dbs;
+        if (a.enc_sq != nullptr) {
+            const float sq = row_sumsq<NV>(acc);
+            if (lane == 0) a.enc_sq[i] = sq;
+        }
+    } else if (a.row_proj != nullptr) {
+        f32x4 wv[NV];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+        write_row_proj<NV>(a.row_proj, i, acc, wv, a.project, lane);
+    }
+}
+
 // out (D, S) = in (S, D)^T, 64 x 64 tiles through LDS (padded: conflict-free both ways)
 // sq_part (optional): one double per block = the sum of squares of its tile, block (x, y) at [y * gridDim.x + x] -- the
 // clip norm's share of this matrix without another pass over it
@@ -876,6 +1161,19 @@ hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream)
     return dispatch_nv(a.D, [&](auto nv) {
         hipLaunchKernelGGL(dw_rows_kernel<decltype(nv)::value>, dim3((max_work + 3) / 4), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.lat_hi - a.lat_lo + 3) / 4, 2), dim3(256), 0, stream, a);
+    });
+}
+hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, hipStream_t stream) {
+    if (a.D % DWS_SLICE != 0 || max_pairs <= 0) return hipErrorInvalidValue;
+    const int n_runs = (max_pairs + DWS_RUN - 1) / DWS_RUN;
+    const int wg_per_slice = (n_runs + 31) / 32;
+    const int grid = ((a.D / DWS_SLICE + 7) / 8) * 8 * wg_per_slice;
+    hipLaunchKernelGGL(dw_slices_kernel<true>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
+    hipLaunchKernelGGL(dw_dval_sum_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(dw_slices_kernel<false>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
+    return dispatch_nv(a.D, [&](auto nv) {
+        if (n_runs > 1) hipLaunchKernelGGL(dw_finalize_cut_kernel<decltype(nv)::value>, dim3(n_runs - 1, 2), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(dw_finalize_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4, 2), dim3(256), 0, stream, a);
     });
 }
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part) {

@@ -52,3 +52,12 @@ def encoder_mode(request, monkeypatch):
         return
     monkeypatch.setenv("SAEV_AMD_ENCODER", request.param)
     yield request.param
+
+
+@pytest.fixture
+def dw_rows_route(monkeypatch):
+    """Engines created inside the test use the row kernels for the weight gradients (SAEV_AMD_DW=rows), the route every ranged /
+    two-pass / gathered backward takes: tests that assert BIT-identity between such a backward and the one-pass backward compare
+    like with like (the one-pass default, the column slices, sums dval in another order; tests/test_gpu_dw_slices.py bounds the
+    difference)."""
+    monkeypatch.setenv("SAEV_AMD_DW", "rows")

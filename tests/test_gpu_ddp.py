@@ -25,7 +25,7 @@ def _setup(tag="b", **kw):
 
 
 @pytest.mark.parametrize("prefixes", [None, [100, 300, 1024]])
-def test_ranged_backward_is_bit_identical_to_the_monolithic_one(prefixes):
+def test_ranged_backward_is_bit_identical_to_the_monolithic_one(prefixes, dw_rows_route):
     grads = []
     for ranges in (None, [(0, 1), (1, 130), (130, 131), (131, 1000), (1000, 1024)]):
         eng, x, s = _setup()
@@ -53,7 +53,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def test_overlapped_exchange_matches_plain_step_on_one_rank(encoder_mode):
+def test_overlapped_exchange_matches_plain_step_on_one_rank(encoder_mode, dw_rows_route):
     """world_size 1 through RCCL: every async all-reduce is the identity, so the overlapped path must end in exactly
     the parameters of eng.train_step -- this checks bucket bounds, the host-owned transposed-gradient scratch, stream
     ordering of the async works and the final transpose."""
@@ -82,7 +82,7 @@ def test_overlapped_exchange_matches_plain_step_on_one_rank(encoder_mode):
         dist.destroy_process_group()
 
 
-def test_sharded_tail_matches_plain_step_on_one_rank(encoder_mode):
+def test_sharded_tail_matches_plain_step_on_one_rank(encoder_mode, dw_rows_route):
     """world_size 1 through RCCL with tail='sharded': the in-place reduce-scatter / all-gather of the two halves are the
     identity, rank 0's chunks are everything, the decoder half's gather runs on a side stream and the next forward waits
     for it -- the run must end in exactly the parameters of eng.train_step."""
@@ -223,7 +223,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
 
 @pytest.mark.parametrize("prefixes", [None, (300, 900, 2048)])
 @pytest.mark.parametrize("n_dead", [0, 5, 80])
-def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes):
+def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes, dw_rows_route):
     """saev_backward_rows_part: decoder pass (dval kept per pair), then encoder pass = the one-pass backward, bit for bit --
     with no dead latents, a few (the count-predicated AuxK kernels) and many (dense AuxK route)."""
     import sae_ref as R

@@ -1,0 +1,115 @@
+"""The column-sliced weight-gradient passes (launch_dw_slices, the default route of a one-pass backward) against the row kernels
+(dw_rows / dw_combine, SAEV_AMD_DW=rows) and against an fp64 recomputation of the reference's autograd gradients
+(src/saev/framework/train.py:347-348) from the step's own codes."""
+
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(d, s, k, b, route, seed=0, **kw):
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    old = os.environ.get("SAEV_AMD_DW")
+    os.environ["SAEV_AMD_DW"] = route
+    try:
+        eng = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, max_batch=b, **kw))
+    finally:
+        if old is None:
+            del os.environ["SAEV_AMD_DW"]
+        else:
+            os.environ["SAEV_AMD_DW"] = old
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = (torch.rand(s, d, device="cuda", generator=g) * 2 - 1) * math.sqrt(6.0 / d)
+    W /= W.norm(dim=1, keepdim=True)
+    eng.view("W_dec").copy_(W)
+    eng.view("W_enc").copy_(W.t() + 0.01 * torch.randn(d, s, device="cuda", generator=g))
+    eng.view("b_enc").copy_(0.05 * torch.randn(s, device="cuda", generator=g))
+    eng.view("b_dec").copy_(0.05 * torch.randn(d, device="cuda", generator=g))
+    return eng
+
+
+def _data(d, b, n, kind, seed=1):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(n, d, device="cuda", generator=g)
+    if kind == "dense_latent":
+        # a strong common direction: one latent fires on (nearly) every row, its pairs span hundreds of runs
+        x = x + 6.0 * torch.randn(d, device="cuda", generator=g)
+    elif kind == "few_latents":
+        # rows drawn from a handful of prototypes: a few latents carry most pairs, most latents are unused
+        protos = torch.randn(5, d, device="cuda", generator=g) * 3
+        x = 0.2 * x + protos[torch.randint(0, 5, (n,), device="cuda", generator=g)]
+    return x
+
+
+SHAPES = [
+    # d, s, k, max_batch, n rows, data
+    (1024, 32768, 32, 16384, 16384, "plain"),
+    (1024, 32768, 32, 16384, 16384, "dense_latent"),
+    (1024, 8192, 32, 4096, 4096, "few_latents"),
+    (768, 6144, 32, 4096, 4096, "plain"),        # 24 slices: not a multiple of the eight XCDs
+    (1280, 20480, 64, 2048, 2048, "plain"),      # 40 slices, k = 64
+    (128, 1024, 8, 512, 300, "plain"),           # fewer rows than max_batch, pairs not a multiple of the run length
+    (64, 256, 4, 64, 3, "plain"),                # 12 pairs: a single run
+    (32, 64, 2, 8, 1, "plain"),                  # one row, one slice
+]
+
+
+@pytest.mark.parametrize("d,s,k,b,n,kind", SHAPES)
+def test_slices_match_rows_and_fp64(d, s, k, b, n, kind):
+    x = _data(d, b, n, kind)
+    grads = {}
+    stats = {}
+    for route in ("rows", "slices"):
+        eng = _engine(d, s, k, b, route)
+        eng.step_forward(x)
+        eng.step_dead(n)
+        eng.step_backward()
+        torch.cuda.synchronize()
+        grads[route] = {name: v.clone() for name, v in eng.grad_views().items()}
+        stats[route] = eng
+    # (the codes are the same: the forward does not depend on the route)
+    e_r, e_s = stats["rows"], stats["slices"]
+    idx_r, val_r = e_r.last_codes(n)[:2]
+    idx_s, val_s = e_s.last_codes(n)[:2]
+    assert torch.equal(idx_r, idx_s) and torch.equal(val_r, val_s)
+    for name in ("W_dec", "W_enc", "b_enc", "b_dec"):
+        a, c = grads["rows"][name], grads["slices"][name]
+        scale = a.abs().max().item() + 1e-30
+        assert (a - c).abs().max().item() <= 2e-6 * scale + 1e-12, (name, (a - c).abs().max().item(), scale)
+    # dW_dec sums val * g in the same (row-ascending) order per element on both routes, with fmas
+    # fp64 recomputation of the autograd gradients from the codes: dW_dec = f^T g, dW_enc = x^T (dval), db_enc = colsum(dval)
+    W_dec = e_s.view("W_dec").double()
+    f = torch.zeros(n, s, dtype=torch.float64, device="cuda")
+    f.scatter_(1, idx_s.long(), val_s.double())
+    x_hat = f @ W_dec + e_s.view("b_dec").double()
+    g = 2.0 * (x_hat - x.double()) / (n * d)
+    mask = torch.zeros(n, s, dtype=torch.float64, device="cuda")
+    mask.scatter_(1, idx_s.long(), 1.0)
+    dval = (g @ W_dec.t()) * mask
+    ref = {"W_dec": f.t() @ g, "W_enc": x.double().t() @ dval, "b_enc": dval.sum(0), "b_dec": g.sum(0)}
+    for name, r in ref.items():
+        c = grads["slices"][name].double()
+        scale = r.abs().max().item() + 1e-30
+        assert (c - r).abs().max().item() <= 2e-5 * scale, (name, (c - r).abs().max().item(), scale)
+
+
+def test_train_steps_track_the_row_route():
+    """A few whole steps (clip norm from the row statistics the finalize pass leaves, projection inside Adam): parameters of
+    the two routes stay within rounding of each other, and replicas on the slices route stay bit-identical."""
+    d, s, k, b = 1024, 16384, 32, 8192
+    x = _data(d, b, b, "dense_latent")
+    engs = [_engine(d, s, k, b, "rows"), _engine(d, s, k, b, "slices"), _engine(d, s, k, b, "slices")]
+    for i in range(4):
+        for e in engs:
+            e.train_step(x, 4e-4, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(engs[1].params, engs[2].params)
+    diff = (engs[0].params - engs[1].params).abs().max().item()
+    assert diff < 2e-5, diff
+    sr, ss = engs[0].read_stats(), engs[1].read_stats()
+    assert math.isclose(sr.mse, ss.mse, rel_tol=1e-5) and math.isclose(sr.grad_norm, ss.grad_norm, rel_tol=1e-4)

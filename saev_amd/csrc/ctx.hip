@@ -1362,8 +1362,8 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     a.enc_sq = all_rows ? c->enc_sq : nullptr;
     // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
     const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
-    if (all_rows && !ov && c->dws_pairs && c->dws_rows == n) {
-        // one pass over all latents of this context's own batch: column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
+    if (lat_lo == 0 && lat_hi == S && !ov && c->dws_pairs && c->dws_rows == n) {
+        // all latents of this context's own batch (in one pass or as the decoder / encoder halves of a two-pass backward): column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
         DwSlicesArgs w{};
         w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->gS; w.xS = c->xS; w.W_dec = a.W_dec;
         w.n_rows = n; w.D = D; w.S = S; w.pair_cap = (int)((long)c->cfg.max_batch * K);
@@ -1373,7 +1373,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         w.cut_lat = c->cut_lat;
         w.row_proj = a.row_proj; w.project = a.project; w.enc_sq = a.enc_sq;
         w.clear_bitmap = a.clear_bitmap; w.clear_words = a.clear_words;
-        HIPCHK(c, launch_dw_slices(w, (int)((long)n * K), s));
+        HIPCHK(c, launch_dw_slices(w, (int)((long)n * K), part, s));
     } else {
         HIPCHK(c, launch_dw_rows(a, max_work, s));
     }

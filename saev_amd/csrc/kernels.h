@@ -253,7 +253,8 @@ struct DwSlicesArgs {
     uint32_t* clear_bitmap;  // optional, as DwRowsArgs
     int clear_words;
 };
-hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, hipStream_t stream);
+// part as in DwRowsArgs (0 both gradients; 1 decoder half: passes A + dval sums; 2 encoder half: pass B, after part 1)
+hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream);
 // sq_part: optional, transpose_blocks(S, D) doubles = per-tile sums of squares of `in`
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part = nullptr);
 int transpose_blocks(int S, int D);

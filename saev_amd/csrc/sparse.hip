@@ -686,7 +686,7 @@ __device__ __forceinline__ float group8_sum(float v) {
 // PASS_A: m = gS, out = dW_dec, coefficients pv[].y = val, W slices for the dval shares.  Otherwise m = xS, out = dW_enc^T,
 // coefficients pv2[].y = dval.  A workgroup = 4 waves x 8 lane groups = 32 runs of one slice.
 template <bool PASS_A>
-__global__ __launch_bounds__(256, 4) void dw_slices_kernel(DwSlicesArgs a, int wg_per_slice) {
+__global__ __launch_bounds__(256, PASS_A ? 4 : 6) void dw_slices_kernel(DwSlicesArgs a, int wg_per_slice) {
     constexpr int L = DWS_RUN;
     const int lane = threadIdx.x & 63, gi = lane >> 3, li = lane & 7;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void dw_dval_sum_kernel(DwSlicesArgs a) {
 // order, writes the row and its statistics.  The order is fixed, so the result does not depend on scheduling; a latent that
 // fires on every row (256 partials at 16 384 rows) takes a quarter of the time one wave would.
 template <int NV>
-__global__ __launch_bounds__(256) void dw_finalize_cut_kernel(DwSlicesArgs a) {
+__global__ __launch_bounds__(256) void dw_finalize_cut_kernel(DwSlicesArgs a, int kind0) {
     constexpr int L = DWS_RUN;
     __shared__ f32x4 sh[3][NV * 64];  // (waves 1-3; wave 0 keeps its sum in registers)
     __shared__ float shdb[4];
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void dw_finalize_cut_kernel(DwSlicesArgs a) {
     if (i < 0) return;            // no latent is first cut at this boundary
     const int s = a.starts[i], e = a.starts[i + 1];
     const int r1 = (e - 1) / L;
-    const int enc = blockIdx.y;
+    const int enc = blockIdx.y + kind0;
     const int D = a.D, D4 = D >> 2;
     const float* const part = enc ? a.part_enc : a.part_dec;
     const int nh = r1 - r0, ch = (nh + 3) / 4;
@@ -903,12 +903,12 @@ __global__ __launch_bounds__(256) void dw_finalize_cut_kernel(DwSlicesArgs a) {
 // Everything else, one wave per latent and gradient row: a latent inside one run -- the row the pass stored, read back for its
 // statistics; an unused latent -- zeros.
 template <int NV>
-__global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a) {
+__global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a, int kind0) {
     constexpr int L = DWS_RUN;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.S) return;
-    const int enc = blockIdx.y;
+    const int enc = blockIdx.y + kind0;
     const int D = a.D, D4 = D >> 2;
     const int s = a.starts[i], e = a.starts[i + 1];
     if (e - s >= L && s / L != (e - 1) / L) return;  // (dw_finalize_cut_kernel's)
@@ -1163,17 +1163,21 @@ hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream)
         hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.lat_hi - a.lat_lo + 3) / 4, 2), dim3(256), 0, stream, a);
     });
 }
-hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, hipStream_t stream) {
+hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream) {
     if (a.D % DWS_SLICE != 0 || max_pairs <= 0) return hipErrorInvalidValue;
     const int n_runs = (max_pairs + DWS_RUN - 1) / DWS_RUN;
     const int wg_per_slice = (n_runs + 31) / 32;
     const int grid = ((a.D / DWS_SLICE + 7) / 8) * 8 * wg_per_slice;
-    hipLaunchKernelGGL(dw_slices_kernel<true>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
-    hipLaunchKernelGGL(dw_dval_sum_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(dw_slices_kernel<false>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
+    // part 1: the decoder's half (pass A leaves the dval the encoder's half needs); part 2: the encoder's; 0: both
+    if (part != 2) {
+        hipLaunchKernelGGL(dw_slices_kernel<true>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
+        hipLaunchKernelGGL(dw_dval_sum_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
+    }
+    if (part != 1) hipLaunchKernelGGL(dw_slices_kernel<false>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
+    const int kinds = part == 0 ? 2 : 1, kind0 = part == 2 ? 1 : 0;
     return dispatch_nv(a.D, [&](auto nv) {
-        if (n_runs > 1) hipLaunchKernelGGL(dw_finalize_cut_kernel<decltype(nv)::value>, dim3(n_runs - 1, 2), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(dw_finalize_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4, 2), dim3(256), 0, stream, a);
+        if (n_runs > 1) hipLaunchKernelGGL(dw_finalize_cut_kernel<decltype(nv)::value>, dim3(n_runs - 1, kinds), dim3(256), 0, stream, a, kind0);
+        hipLaunchKernelGGL(dw_finalize_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4, kinds), dim3(256), 0, stream, a, kind0);
     });
 }
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part) {

@@ -82,7 +82,7 @@ def test_overlapped_exchange_matches_plain_step_on_one_rank(encoder_mode, dw_row
         dist.destroy_process_group()
 
 
-def test_sharded_tail_matches_plain_step_on_one_rank(encoder_mode, dw_rows_route):
+def test_sharded_tail_matches_plain_step_on_one_rank(encoder_mode):
     """world_size 1 through RCCL with tail='sharded': the in-place reduce-scatter / all-gather of the two halves are the
     identity, rank 0's chunks are everything, the decoder half's gather runs on a side stream and the next forward waits
     for it -- the run must end in exactly the parameters of eng.train_step."""
@@ -223,7 +223,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
 
 @pytest.mark.parametrize("prefixes", [None, (300, 900, 2048)])
 @pytest.mark.parametrize("n_dead", [0, 5, 80])
-def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes, dw_rows_route):
+def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes):
     """saev_backward_rows_part: decoder pass (dval kept per pair), then encoder pass = the one-pass backward, bit for bit --
     with no dead latents, a few (the count-predicated AuxK kernels) and many (dense AuxK route)."""
     import sae_ref as R

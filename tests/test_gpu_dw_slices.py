@@ -113,3 +113,26 @@ def test_train_steps_track_the_row_route():
     assert diff < 2e-5, diff
     sr, ss = engs[0].read_stats(), engs[1].read_stats()
     assert math.isclose(sr.mse, ss.mse, rel_tol=1e-5) and math.isclose(sr.grad_norm, ss.grad_norm, rel_tol=1e-4)
+
+
+@pytest.mark.parametrize("d,s,k,b,n,kind", [SHAPES[1], SHAPES[3], SHAPES[5]])
+def test_two_pass_slices_are_bit_identical_to_one_pass(d, s, k, b, n, kind):
+    """The decoder half / encoder half form of the backward (what the sharded data-parallel step runs, framework/ddp.py) goes
+    through the same passes in the same order."""
+    x = _data(d, b, n, kind)
+    grads = []
+    for two_pass in (False, True):
+        eng = _engine(d, s, k, b, "slices")
+        eng.step_forward(x)
+        eng.step_dead(n)
+        if two_pass:
+            eng.grad_w_enc_t()
+            eng.backward_begin()
+            eng.backward_rows(0, s, 1)
+            eng.backward_rows(0, s, 2)
+            eng.backward_end()
+        else:
+            eng.step_backward()
+        torch.cuda.synchronize()
+        grads.append(eng.grads.clone())
+    assert torch.equal(grads[0], grads[1]) and grads[0].abs().sum() > 0

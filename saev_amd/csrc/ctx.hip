@@ -95,6 +95,7 @@ struct saev_ctx {
     int P = 1;
     int32_t cuts[MAX_PREFIXES] = {0};
     float* G = nullptr;  // (max_batch, P_cap, D)
+    float* GS = nullptr; // slice-major copy of G for launch_dw_slices: [D / 32][P][rows][32] (with dws_ok)
     int P_cap = 0;
     // AuxK dense-over-dead-set path (auxk.hip)
     int n_dead_host = 0, k_use_host = 0;
@@ -408,6 +409,7 @@ void saev_destroy(saev_ctx* c) {
     for (void* p : c->allocs) hipFree(p);
     for (void* p : c->aux_allocs) hipFree(p);
     if (c->G) hipFree(c->G);
+    if (c->GS) hipFree(c->GS);
     if (c->rec_host) hipHostFree(c->rec_host);
     if (c->dead_ev_created)
         for (int i = 0; i < DEAD_RING; ++i) hipEventDestroy(c->dead_ev[i]);
@@ -457,7 +459,9 @@ int saev_set_prefixes(saev_ctx* c, const int64_t* prefixes_host, int32_t n) {
     if (n > c->P_cap) {
         hipDeviceSynchronize();
         if (c->G) hipFree(c->G);
+        if (c->GS) hipFree(c->GS);
         c->G = nullptr;
+        c->GS = nullptr;
         c->P_cap = 0;
         void* q = nullptr;
         if (hipMalloc(&q, (size_t)c->cfg.max_batch * n * c->cfg.d_model * sizeof(float)) != hipSuccess) {
@@ -465,6 +469,14 @@ int saev_set_prefixes(saev_ctx* c, const int64_t* prefixes_host, int32_t n) {
             return SAEV_HIP_ERROR;
         }
         c->G = (float*)q;
+        // (virtual row p * rows + b of a pair word must fit 24 bits: otherwise the row kernels serve the Matryoshka backward)
+        if (c->dws_ok && (long)c->cfg.max_batch * n < (1l << 24)) {
+            if (hipMalloc(&q, (size_t)c->cfg.max_batch * n * c->cfg.d_model * sizeof(float)) != hipSuccess) {
+                c->err = "out of device memory for the Matryoshka gradient buffer (slice-major copy)";
+                return SAEV_HIP_ERROR;
+            }
+            c->GS = (float*)q;
+        }
         c->P_cap = n;
     }
     c->P = n;
@@ -972,7 +984,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.training = training ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
     c->dws_rows = 0;
-    if (training && c->dws_ok && c->P == 1) { a.gS = c->gS; a.xS = c->xS; c->dws_rows = n; }
+    if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->xS; c->dws_rows = n; }
     if (c->P > 1) {
         MatryArgs m{};
         m.P = c->P;
@@ -1312,8 +1324,12 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals;
     a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
     a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
-    c->dws_pairs = !ov && c->dws_rows == n && c->P_last == 1;
-    if (c->dws_pairs) { a.pv = c->pv; a.plat = c->plat; a.val = c->val; }
+    c->dws_pairs = !ov && c->dws_rows == n;
+    if (c->dws_pairs) {
+        a.pv = c->pv; a.plat = c->plat; a.val = c->val;
+        a.P = c->P_last;
+        for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts_last[p];
+    }
     // (the bit map row pitch depends on the batch: a map cleaned for a pitch covers every shorter one, S * words <= before)
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0), formed in the grids of the CSC build's first two
     // launches; the AuxK contractions add theirs
@@ -1365,7 +1381,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     if (lat_lo == 0 && lat_hi == S && !ov && c->dws_pairs && c->dws_rows == n) {
         // all latents of this context's own batch (in one pass or as the decoder / encoder halves of a two-pass backward): column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
         DwSlicesArgs w{};
-        w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->gS; w.xS = c->xS; w.W_dec = a.W_dec;
+        w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->P_last > 1 ? c->GS : c->gS; w.xS = c->xS; w.W_dec = a.W_dec; w.P = c->P_last;
         w.n_rows = n; w.D = D; w.S = S; w.pair_cap = (int)((long)c->cfg.max_batch * K);
         w.dvp = c->dvp; w.dW_dec = a.dW_dec; w.dW_encT = a.dW_encT; w.db_enc = a.db_enc;
         const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;

@@ -134,8 +134,8 @@ struct DecodeArgs {
     float* x_hat;           // (n_rows, D) or NULL
     int32_t* fired;         // (S)
     RowStats* rowstats;     // (n_rows) or NULL
-    // optional (training, decode_kernel only): slice-major copies of g and x, [D / 32][n_rows][32 floats], for the column-sliced
-    // weight-gradient passes (launch_dw_slices)
+    // optional (training): slice-major copies of g and x, [D / 32][n_rows][32 floats] (decode_matry_kernel: of the suffix sums,
+    // [D / 32][P][n_rows][32]), for the column-sliced weight-gradient passes (launch_dw_slices)
     float* gS;
     float* xS;
 };
@@ -171,6 +171,8 @@ struct CscArgs {
     int2* pv;
     int32_t* plat;
     const float* val;       // (n_rows, code_stride) coefficients (with pv)
+    int P;                  // (with pv) Matryoshka: the pair word carries the virtual row p(latent) * n_rows + row; <= 1: plain
+    int32_t cuts[16];       // MAX_PREFIXES
 };
 // bitmap_clean: the whole bit map is known to be zero (dw_combine_kernel cleared it after the previous build)
 // colsum_*: optional column sums out[d] = sum_b m[b][d] (b < a.n_rows; partials: ceil(n_rows / 64) * D floats) computed in the
@@ -236,10 +238,11 @@ struct DwSlicesArgs {
     const int2* pv;          // (pairs) from the CSC build
     int2* pv2;               // (pairs) scratch: pv with the coefficient replaced by dval
     const int32_t* plat;     // (pairs)
-    const float* gS;         // [D / 32][n_rows][32]
+    const float* gS;         // [D / 32][P][n_rows][32] (P > 1: the suffix sums C_p; a pair of latent i reads block p(i))
     const float* xS;
     const float* W_dec;      // (S, D)
     int n_rows, D, S, pair_cap;  // pair_cap: pitch of dvp (>= n_rows * k)
+    int P;                   // Matryoshka prefixes (<= 1: plain)
     float* dvp;              // (D / 32, pair_cap)
     float* dW_dec;           // (S, D)
     float* dW_encT;          // (S, D)

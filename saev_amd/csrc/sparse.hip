@@ -228,6 +228,10 @@ __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryAr
                 if (q < D4) {
                     c[n] += Grow[(size_t)pp * D4 + q];
                     Grow[(size_t)pp * D4 + q] = c[n];
+                    if (a.gS != nullptr) {  // slice-major copies for launch_dw_slices: [q / 8][p][row][8 float4]
+                        reinterpret_cast<f32x4*>(a.gS)[(((size_t)(q >> 3) * P + pp) * a.n_rows + row) * 8 + (q & 7)] = c[n];
+                        if (pp == 0) reinterpret_cast<f32x4*>(a.xS)[((size_t)(q >> 3) * a.n_rows + row) * 8 + (q & 7)] = xv[n];
+                    }
                 }
             }
         }
@@ -409,7 +413,9 @@ __global__ void csc_place_kernel(CscArgs a) {
         a.pairs[slot] = int2{b, (int)((size_t)b * a.code_stride + j)};
         if (a.pv != nullptr) {
             const int fl = (rank == 0 ? DWS_FIRST : 0) | (rank == a.counts[i] - 1 ? DWS_LAST : 0);
-            a.pv[slot] = int2{(b << 7) | fl, __float_as_int(a.val[(size_t)b * a.code_stride + j])};
+            int pblk = 0;  // Matryoshka: the latent's prefix block selects which suffix sum its pairs read
+            if (a.P > 1) while (pblk < a.P - 1 && i >= a.cuts[pblk]) ++pblk;
+            a.pv[slot] = int2{((pblk * a.n_rows + b) << 7) | fl, __float_as_int(a.val[(size_t)b * a.code_stride + j])};
             a.plat[slot] = i;
         }
     }
@@ -717,7 +723,8 @@ __global__ __launch_bounds__(256, PASS_A ? 4 : 6) void dw_slices_kernel(DwSlices
     float* const dvp = PASS_A ? a.dvp + (size_t)slice * a.pair_cap : nullptr;
     const int sel = (lane & 56) << 2;  // byte address of the group's lane 0 for ds_bpermute
     const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(PASS_A ? a.gS : a.xS) + (size_t)slice * a.n_rows * DWS_SLICE, 0, (uint32_t)a.n_rows * 128u, 0x00020000);
+        const_cast<float*>(PASS_A ? a.gS : a.xS) + (size_t)slice * a.n_rows * DWS_SLICE * (PASS_A && a.P > 1 ? a.P : 1), 0,
+        (uint32_t)a.n_rows * 128u * (uint32_t)(PASS_A && a.P > 1 ? a.P : 1), 0x00020000);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W_dec), 0, (uint32_t)a.S * rowb, 0x00020000);
 
     // pair info of block t (pairs p0 + 8 t + li): END on the run's last pair; past the end: row 0 with coefficient 0 (never stored)
@@ -807,8 +814,9 @@ __global__ __launch_bounds__(256) void dw_dval_sum_kernel(DwSlicesArgs a) {
     float s = 0.f;
     for (int c = 0; c < n_slices; ++c) s += a.dvp[(size_t)c * a.pair_cap + p];
     const int2 e = a.pv[p];
-    a.pv2[p] = int2{e.x, __float_as_int(s)};
-    if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)a.plat[p] * a.clear_words + (e.x >> 12)] = 0u;  // word of row e.x >> 7
+    const int b = a.P > 1 ? (e.x >> 7) % a.n_rows : (e.x >> 7);  // (Matryoshka: pass A's word holds p(latent) * n_rows + row)
+    a.pv2[p] = int2{(b << 7) | (e.x & 127), __float_as_int(s)};
+    if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)a.plat[p] * a.clear_words + (b >> 5)] = 0u;
 }
 
 // Latents that are cut by run boundaries (L or more pairs): one workgroup per run boundary and gradient row (blockIdx.y: 0 decoder

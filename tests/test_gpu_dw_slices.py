@@ -136,3 +136,28 @@ def test_two_pass_slices_are_bit_identical_to_one_pass(d, s, k, b, n, kind):
         torch.cuda.synchronize()
         grads.append(eng.grads.clone())
     assert torch.equal(grads[0], grads[1]) and grads[0].abs().sum() > 0
+
+
+@pytest.mark.parametrize("d,s,k,b,n,prefixes", [
+    (1024, 32768, 32, 16384, 16384, [37, 300, 1200, 5000, 9000, 20000, 32768]),
+    (768, 6144, 32, 4096, 4096, [1, 2, 64, 6144]),
+    (128, 1024, 8, 512, 300, [100, 300, 1024]),
+])
+def test_matryoshka_slices_match_rows(d, s, k, b, n, prefixes):
+    """Matryoshka prefixes (the reference's default objective, objectives.py:125-138): a pair of latent i gathers the suffix sum
+    C_p(i) of its row; the slices read it from the [slice][p][row] copy the decode leaves."""
+    x = _data(d, b, n, "dense_latent")
+    grads = {}
+    for route in ("rows", "slices"):
+        eng = _engine(d, s, k, b, route)
+        eng.set_prefixes(prefixes)
+        eng.step_forward(x)
+        eng.step_dead(n)
+        eng.step_backward()
+        torch.cuda.synchronize()
+        grads[route] = {name: v.clone() for name, v in eng.grad_views().items()}
+    for name in ("W_dec", "W_enc", "b_enc", "b_dec"):
+        a, c = grads["rows"][name], grads["slices"][name]
+        scale = a.abs().max().item() + 1e-30
+        assert (a - c).abs().max().item() <= 2e-6 * scale + 1e-12, (name, (a - c).abs().max().item(), scale)
+    assert grads["slices"]["W_enc"].abs().sum() > 0

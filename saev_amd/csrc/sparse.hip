@@ -921,13 +921,17 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a, int ki
     const int s = a.starts[i], e = a.starts[i + 1];
     if (e - s >= L && s / L != (e - 1) / L) return;  // (dw_finalize_cut_kernel's)
     float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
-    f32x4 acc[NV];
+    f32x4 acc[NV], wv[NV];
+    const bool proj = !enc && a.row_proj != nullptr;
+    const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
 #pragma unroll
-    for (int n = 0; n < NV; ++n) {
+    for (int n = 0; n < NV; ++n) {  // (the gradient row and the decoder row in flight together)
         acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (lane + 64 * n < D4) {
             if (e > s) acc[n] = reinterpret_cast<const f32x4*>(row)[lane + 64 * n];
             else reinterpret_cast<f32x4*>(row)[lane + 64 * n] = acc[n];
+            if (proj) wv[n] = wr[lane + 64 * n];
         }
     }
     if (enc) {
@@ -939,11 +943,7 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a, int ki
             const float sq = row_sumsq<NV>(acc);
             if (lane == 0) a.enc_sq[i] = sq;
         }
-    } else if (a.row_proj != nullptr) {
-        f32x4 wv[NV];
-        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
-#pragma unroll
-        for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (proj) {
         write_row_proj<NV>(a.row_proj, i, acc, wv, a.project, lane);
     }
 }

@@ -438,6 +438,9 @@ def main():
             "config": {"workload": f"configs[1]: d_in={D_MODEL}, d_sae={D_SAE} (32x), k={TOP_K}, batch={B}/GPU, "
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder, "n_saes": args.n_saes,
+                       "weight_gradients": ("whole-row gathers (dw_rows)" if os.environ.get("SAEV_AMD_DW") == "rows" or D_MODEL % 32 != 0
+                                            or stepper.overlap or stepper.exchange == "sparse"
+                                            else "32-column slices out of the XCD L2s (dw_slices)"),
                        "grad_exchange": ("none" if stepper.dist is None else
                                          ("no gradient crosses ranks: all-gather of x, dL/dx_hat and the codes ((8 D + 8 k) bytes per row), "
                                           "backward over the global batch on every rank, the auxiliary term's compact rows all-reduced, "

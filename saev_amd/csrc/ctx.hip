@@ -1324,9 +1324,15 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     a.bitmap = c->bitmap; a.words = words; a.grp_prefix = c->grp_prefix; a.scan_totals = c->scan_totals;
     a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
     a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
-    c->dws_pairs = !ov && c->dws_rows == n;
+    // (a gathered backward -- the rows of all ranks, row-major -- gets its slice-major copies here; Matryoshka ones keep dw_rows)
+    const bool ov_slices = ov && c->dws_ok && c->P_last == 1 && n <= c->cfg.max_batch;
+    c->dws_pairs = ov ? ov_slices : c->dws_rows == n;
+    if (ov_slices) {
+        HIPCHK(c, launch_slice_major_copy(c->ov_g, c->ov_x, n, D, c->gS, c->xS, s));
+        c->dws_rows = 0;  // (the copies no longer describe the forward's own rows)
+    }
     if (c->dws_pairs) {
-        a.pv = c->pv; a.plat = c->plat; a.val = c->val;
+        a.pv = c->pv; a.plat = c->plat; a.val = ov ? c->ov_val : c->val;
         a.P = c->P_last;
         for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts_last[p];
     }
@@ -1378,7 +1384,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     a.enc_sq = all_rows ? c->enc_sq : nullptr;
     // upper bound of the work items of the range (one per latent + one per 64 pairs): the kernel knows the exact count
     const int max_work = (lat_hi - lat_lo) + (int)(((long)n * K + DW_CHUNK - 1) / DW_CHUNK);
-    if (lat_lo == 0 && lat_hi == S && !ov && c->dws_pairs && c->dws_rows == n) {
+    if (lat_lo == 0 && lat_hi == S && c->dws_pairs && (ov || c->dws_rows == n)) {
         // all latents of this context's own batch (in one pass or as the decoder / encoder halves of a two-pass backward): column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
         DwSlicesArgs w{};
         w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->P_last > 1 ? c->GS : c->gS; w.xS = c->xS; w.W_dec = a.W_dec; w.P = c->P_last;

@@ -258,6 +258,8 @@ struct DwSlicesArgs {
 };
 // part as in DwRowsArgs (0 both gradients; 1 decoder half: passes A + dval sums; 2 encoder half: pass B, after part 1)
 hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream);
+// [D / 32][n][32] copies of two row-major (n, D) matrices (the gathered rows of a sparse-state exchange)
+hipError_t launch_slice_major_copy(const float* g, const float* x, int n, int D, float* gS, float* xS, hipStream_t stream);
 // sq_part: optional, transpose_blocks(S, D) doubles = per-tile sums of squares of `in`
 hipError_t launch_transpose(const float* in, float* out, int S, int D, hipStream_t stream, double* sq_part = nullptr);
 int transpose_blocks(int S, int D);

@@ -689,6 +689,21 @@ __device__ __forceinline__ float group8_sum(float v) {
     return v;
 }
 
+// slice-major copies of two row-major (n, D) matrices (a gathered backward: the rows of all ranks arrive row-major): one wave per row
+__global__ __launch_bounds__(256) void slice_major_copy_kernel(const float* __restrict__ g, const float* __restrict__ x, int n, int D,
+                                                               float* __restrict__ gS, float* __restrict__ xS) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const f32x4* gr = reinterpret_cast<const f32x4*>(g + (size_t)row * D);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    for (int q = lane; q < (D >> 2); q += 64) {
+        const size_t o = ((size_t)(q >> 3) * n + row) * 8 + (q & 7);
+        reinterpret_cast<f32x4*>(gS)[o] = gr[q];
+        reinterpret_cast<f32x4*>(xS)[o] = xr[q];
+    }
+}
+
 // PASS_A: m = gS, out = dW_dec, coefficients pv[].y = val, W slices for the dval shares.  Otherwise m = xS, out = dW_enc^T,
 // coefficients pv2[].y = dval.  A workgroup = 4 waves x 8 lane groups = 32 runs of one slice.
 template <bool PASS_A>
@@ -1170,6 +1185,11 @@ hipError_t launch_dw_rows(const DwRowsArgs& a, int max_work, hipStream_t stream)
         hipLaunchKernelGGL(dw_rows_kernel<decltype(nv)::value>, dim3((max_work + 3) / 4), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(dw_combine_kernel<decltype(nv)::value>, dim3((a.lat_hi - a.lat_lo + 3) / 4, 2), dim3(256), 0, stream, a);
     });
+}
+hipError_t launch_slice_major_copy(const float* g, const float* x, int n, int D, float* gS, float* xS, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slice_major_copy_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, g, x, n, D, gS, xS);
+    return hipGetLastError();
 }
 hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream) {
     if (a.D % DWS_SLICE != 0 || max_pairs <= 0) return hipErrorInvalidValue;

@@ -161,3 +161,42 @@ def test_matryoshka_slices_match_rows(d, s, k, b, n, prefixes):
         scale = a.abs().max().item() + 1e-30
         assert (a - c).abs().max().item() <= 2e-6 * scale + 1e-12, (name, (a - c).abs().max().item(), scale)
     assert grads["slices"]["W_enc"].abs().sum() > 0
+
+
+@pytest.mark.parametrize("d,s,k,n", [(1024, 16384, 32, 4096), (768, 6144, 32, 1000), (128, 1024, 8, 150)])
+def test_gathered_backward_on_slices(d, s, k, n):
+    """The backward of a sparse-state exchange (framework/ddp.py: x, dL/dx_hat and the codes of ALL ranks gathered row-major,
+    saev_backward_override): the gathered rows get their slice-major copies in saev_backward_begin.  Two 'ranks' worth of rows
+    through one context: (i) gathered over a single rank's own rows = the plain backward, bit for bit; (ii) over both ranks'
+    rows = the row kernels to rounding."""
+    xs = [_data(d, 2 * n, n, "dense_latent", seed=5), _data(d, 2 * n, n, "plain", seed=6)]
+    out = {}
+    for route in ("rows", "slices"):
+        eng = _engine(d, s, k, 2 * n, route)
+        state = []
+        for x in xs:
+            eng.step_forward(x)
+            eng.step_dead(n)
+            g = torch.empty(n, d, device="cuda"); idx = torch.empty(n, k, device="cuda", dtype=torch.int32); val = torch.empty(n, k, device="cuda")
+            eng.copy_step_state(n, g, idx, val)
+            state.append((x, g, idx, val))
+        # (the forward in flight is the second batch)
+        eng.step_backward()
+        torch.cuda.synchronize()
+        plain = eng.grads.clone()
+        eng.grad_w_enc_t()
+        eng.backward_begin_gathered(*state[1])
+        eng.backward_rows(0, s)
+        eng.backward_end()
+        torch.cuda.synchronize()
+        own = eng.grads.clone()
+        eng.backward_begin_gathered(*[torch.cat([a, b]).contiguous() for a, b in zip(*state)])
+        eng.backward_rows(0, s)
+        eng.backward_end()
+        torch.cuda.synchronize()
+        out[route] = (plain, own, eng.grads.clone())
+    for route in out:
+        assert torch.equal(out[route][0], out[route][1]), route
+    a, c = out["rows"][2], out["slices"][2]
+    assert (a - c).abs().max().item() <= 2e-6 * a.abs().max().item() + 1e-12
+    assert not torch.equal(out["slices"][1], out["slices"][2])

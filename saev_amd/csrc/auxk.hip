@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
                                                                const float* dWe, const float* dbe, float* gW_dec,
                                                                float* gW_encT, float* gb_enc, int lat_lo, int lat_hi,
                                                                const int32_t* nd_dev, int part, float2* row_proj,
-                                                               const float* W_dec, int project, float* enc_sq) {
+                                                               const float* W_dec, int project, float* enc_sq, int32_t* lat_unused) {
     // part: 0 = all three gradients; 1 = the decoder rows only; 2 = the encoder rows and bias only (saev_backward_rows_part)
     if (nd_dev != nullptr) nd = min(nd, *nd_dev);
     const int lane = threadIdx.x & 63;
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
     f32x4* oa = reinterpret_cast<f32x4*>(gW_dec + (size_t)i * D);
     f32x4* oe = reinterpret_cast<f32x4*>(gW_encT + (size_t)i * D);
     float dot = 0.f, nsq = 0.f, esq = 0.f;
+    const bool enc_unwritten = lat_unused != nullptr && lat_unused[i] != 0;  // (wave-uniform)
     for (int q = lane; q < (D >> 2); q += 64) {
         if (part != 2) {
             const f32x4 g = oa[q] + a[q];
@@ -391,13 +392,14 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
             }
         }
         if (part != 1) {
-            const f32x4 ge = oe[q] + e[q];
+            const f32x4 ge = enc_unwritten ? e[q] : oe[q] + e[q];
             oe[q] = ge;
 #pragma unroll
             for (int c = 0; c < 4; ++c) esq = __builtin_fmaf(ge[c], ge[c], esq);
         }
     }
     if (lane == 0 && part != 1) gb_enc[i] += dbe[j];
+    if (enc_unwritten && lane == 0) lat_unused[i] = 0;
     if (enc_sq != nullptr && part != 1) {  // the row changed: its squares again (DwRowsArgs::enc_sq)
         esq = wave_sum(esq);
         if (lane == 0) enc_sq[i] = esq;
@@ -504,9 +506,9 @@ hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStre
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
                                    const int32_t* nd_dev, int part, float2* row_proj, const float* W_dec, int project,
-                                   float* enc_sq) {
+                                   float* enc_sq, int32_t* lat_unused) {
     if (nd <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_add_dead_kernel, dim3((nd + 3) / 4), dim3(256), 0, s, dl, nd, D, dWd, dWe, dbe, gW_dec,
-                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev, part, row_proj, W_dec, project, enc_sq);
+                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev, part, row_proj, W_dec, project, enc_sq, lat_unused);
     return hipGetLastError();
 }

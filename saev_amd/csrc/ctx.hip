@@ -91,6 +91,10 @@ struct saev_ctx {
     float *gS = nullptr, *xS = nullptr, *dvp = nullptr;
     int2 *pv = nullptr, *pv2 = nullptr;
     int32_t *plat = nullptr, *cut_lat = nullptr;
+    // saev_train_step: latents without pairs are flagged instead of having their dW_enc^T row zeroed (DwSlicesArgs::lat_unused)
+    int32_t* lat_unused = nullptr;
+    bool fused_step = false;     // inside saev_train_step: the transposed W_enc gradient is read by the fused Adam alone
+    bool unused_valid = false;   // the backward in flight left lat_unused
     // Matryoshka prefixes of the step (P == 1: plain objective)
     int P = 1;
     int32_t cuts[MAX_PREFIXES] = {0};
@@ -317,7 +321,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     }
     if (c->dws_ok) {
         A(gS, MB * D); A(xS, MB * D); A(dvp, (size_t)(D / DWS_SLICE) * MB * K);
-        A(pv, MB * K); A(pv2, MB * K); A(plat, MB * K); A(cut_lat, (MB * K + DWS_RUN - 1) / DWS_RUN);
+        A(pv, MB * K); A(pv2, MB * K); A(plat, MB * K); A(cut_lat, (MB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
     }
     A(colsum_partials, ((MB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
@@ -942,6 +946,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     c->n_last = n;
     c->training_last = training;
     c->ov_x = nullptr; c->ov_n = 0;  // an override serves one backward
+    c->unused_valid = false;
     // The reference renormalises the rows of W_dec at the top of a training step (train.py:334-335).  Nothing before the
     // decode reads W_dec, so it is done right in front of the decode instead: the rows it has just written are what the
     // decode gathers next (3.053 -> 3.034 ms per step against doing it first), and a caller whose decoder half of the
@@ -1393,20 +1398,25 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;
         w.part_dec = c->partials; w.part_enc = c->partials + 2 * runs_cap * D;  // (max_part * 2 rows hold 4 * runs_cap)
         w.cut_lat = c->cut_lat;
+        static const bool flag_unused = [] { const char* e = getenv("SAEV_AMD_FLAG_UNUSED"); return !(e != nullptr && atoi(e) == 0); }();  // (A/B)
+        w.lat_unused = (all_rows && c->fused_step && flag_unused) ? c->lat_unused : nullptr;
+        c->unused_valid = w.lat_unused != nullptr;
         w.row_proj = a.row_proj; w.project = a.project; w.enc_sq = a.enc_sq;
         w.clear_bitmap = a.clear_bitmap; w.clear_words = a.clear_words;
         HIPCHK(c, launch_dw_slices(w, (int)((long)n * K), part, s));
     } else {
+        c->unused_valid = false;
         HIPCHK(c, launch_dw_rows(a, max_work, s));
     }
     if (c->aux_route == AUX_DENSE)  // (the count on the device when the host only had a bound of it: aux_dev_count)
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s,
-                                          c->aux_dev_count ? c->flags + 4 : nullptr, part, a.row_proj, a.W_dec, a.project, a.enc_sq));
+                                          c->aux_dev_count ? c->flags + 4 : nullptr, part, a.row_proj, a.W_dec, a.project, a.enc_sq,
+                                          c->unused_valid ? c->lat_unused : nullptr));
     else if (c->aux_route != AUX_NONE)  // few dead latents: the device knows how many
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part,
-                                          a.row_proj, a.W_dec, a.project, a.enc_sq));
+                                          a.row_proj, a.W_dec, a.project, a.enc_sq, c->unused_valid ? c->lat_unused : nullptr));
     // gathered backward: the auxiliary term's share of db_dec (summed over the ranks by the caller, like the compact rows)
     if (ov && c->aux_route != AUX_NONE && part != 2 && lat_lo == 0)
         HIPCHK(c, launch_colsum(c->db_aux, 1, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
@@ -1615,7 +1625,8 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
         const long S = c->cfg.d_sae, D = c->cfg.d_model;
         a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = c->n_params;
         HIPCHK(c, launch_adam_fused(a, c->row_proj, c->dW_encT, (int)S, (int)D, S * D, c->off_W_enc - S * D, c->off_W_enc,
-                                    c->off_b_enc, c->n_params - c->off_b_enc, s));
+                                    c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr));
+        c->unused_valid = false;
         return SAEV_OK;
     }
     if (shard_rank < 0 && c->tail_proj_in_adam) {  // decoder rows with the projection applied on the way in, then the rest
@@ -1657,7 +1668,9 @@ int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_
     // -- callers that want to look at gradients use the phases)
     rc = saev_backward_begin(c, stream);
     if (rc != SAEV_OK) return rc;
+    c->fused_step = true;
     rc = saev_backward_rows(c, 0, c->cfg.d_sae, stream);
+    c->fused_step = false;
     if (rc != SAEV_OK) return rc;
     c->wenc_t_pending = true;
     rc = saev_step_tail(c, lr, max_norm, 1.0f, adam_step, stream);

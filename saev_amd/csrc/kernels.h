@@ -255,6 +255,9 @@ struct DwSlicesArgs {
     float* enc_sq;           // optional
     uint32_t* clear_bitmap;  // optional, as DwRowsArgs
     int clear_words;
+    // optional (saev_train_step only): lat_unused[i] = 1 for a latent without pairs; its dW_enc^T row is then NOT written (the
+    // scratch is read by the fused Adam alone, which takes the flag for a row of zeros -- and skips reading the zeroed dW_dec row)
+    int32_t* lat_unused;
 };
 // part as in DwRowsArgs (0 both gradients; 1 decoder half: passes A + dval sums; 2 encoder half: pass B, after part 1)
 hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream);
@@ -305,8 +308,9 @@ hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* r
 // Adam over everything in one launch with the gradients where the backward left them: a.{p,g,m,v} = the flat buffers, the
 // decoder rows projected through row_proj, W_enc's gradient read from the transposed scratch gT (S, D) through LDS tiles,
 // the two bias segments [off, off + n) element-wise (adam_fused_kernel)
+// lat_unused (optional): latents whose gradient rows are zero and not to be read (DwSlicesArgs::lat_unused)
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
-                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream);
+                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused = nullptr);
 constexpr int SUMSQ_EX_BLOCKS = 32;  // blk_part: this many doubles of scratch; ticket: an int, zero between launches
 
 // what the host learns about the dead set of a step without waiting for it (saev_step_dead reads the record of an
@@ -447,4 +451,7 @@ hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float
                                    const int32_t* nd_dev = nullptr, int part = 0,
                                    // optional: refresh row_proj of the rows touched (W_dec = the parameter rows)
                                    float2* row_proj = nullptr, const float* W_dec = nullptr, int project = 1,
-                                   float* enc_sq = nullptr);
+                                   float* enc_sq = nullptr,
+                                   // optional (DwSlicesArgs::lat_unused): a flagged latent's dW_enc^T row was not written -- it is
+                                   // taken as zeros here and the flag cleared (both its rows are gradients now)
+                                   int32_t* lat_unused = nullptr);

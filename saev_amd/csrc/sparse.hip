@@ -934,6 +934,7 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a, int ki
     const int enc = blockIdx.y + kind0;
     const int D = a.D, D4 = D >> 2;
     const int s = a.starts[i], e = a.starts[i + 1];
+    if (!enc && a.lat_unused != nullptr && lane == 0) a.lat_unused[i] = e == s ? 1 : 0;
     if (e - s >= L && s / L != (e - 1) / L) return;  // (dw_finalize_cut_kernel's)
     float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
     f32x4 acc[NV], wv[NV];
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a, int ki
         wv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (lane + 64 * n < D4) {
             if (e > s) acc[n] = reinterpret_cast<const f32x4*>(row)[lane + 64 * n];
-            else reinterpret_cast<f32x4*>(row)[lane + 64 * n] = acc[n];
+            else if (!(enc && a.lat_unused != nullptr)) reinterpret_cast<f32x4*>(row)[lane + 64 * n] = acc[n];  // (unused latent)
             if (proj) wv[n] = wr[lane + 64 * n];
         }
     }

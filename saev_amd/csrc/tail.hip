@@ -189,7 +189,7 @@ __device__ __forceinline__ float clip_coef(const AdamArgs& a, float* norm_out) {
 // between chunks: left alone the compiler interleaves all NV x 4 division / square-root sequences and takes 178 (NV = 4),
 // 256 (NV = 5) or -- spilling thousands of dwords -- more than 256 (NV = 8) VGPRs for a kernel that lives on occupancy.
 template <int NV>
-__device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float sc, float gs, float step_size, int lane) {
+__device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float sc, float gs, float step_size, int lane, bool g_zero = false) {
     const int D4 = D >> 2;
     const size_t base = (size_t)i * D4;
     constexpr int CH = 4;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float 
             const int q = lane + 64 * (n0 + c);
             if (n0 + c < NV && q < D4) {
                 p[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + base + q);
-                g[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
+                g[c] = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
                 m[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + base + q);
                 v[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + base + q);
             }
@@ -249,6 +249,7 @@ struct AdamFusedArgs {
     AdamArgs a;
     const float2* row_proj;
     const float* gT;       // (S, D) transposed W_enc gradient
+    const int32_t* lat_unused;  // optional: 1 = both gradient rows of the latent are zero (gT's is not even written)
     int S, D;
     long off_b_dec, n_b_dec, off_W_enc, off_b_enc, n_b_enc;
     int nb_rows, nb_tiles, tiles_s;
@@ -268,7 +269,8 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
             const int r = idx >> 3, c4 = (idx & 7) * 4;
             const int sidx = s0 + r, d = d0 + c4;
             f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (sidx < S && d < D) g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.gT + (size_t)sidx * D + d));
+            if (sidx < S && d < D && !(f.lat_unused != nullptr && f.lat_unused[sidx] != 0))
+                g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(f.gT + (size_t)sidx * D + d));
             tile[c4][r] = g[0]; tile[c4 + 1][r] = g[1]; tile[c4 + 2][r] = g[2]; tile[c4 + 3][r] = g[3];
         }
         __syncthreads();
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256, (PART == 2 ? 3 : 4)) void adam_fused_kernel(Ad
         const int lane = threadIdx.x & 63;
         const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (i >= S) return;
-        adam_row<NV>(a, i, D, f.row_proj[i].x, gs, step_size, lane);
+        adam_row<NV>(a, i, D, f.row_proj[i].x, gs, step_size, lane, f.lat_unused != nullptr && f.lat_unused[i] != 0);
         return;
     }
     // the two bias segments
@@ -609,9 +611,9 @@ hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, in
     });
 }
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
-                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream) {
+                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused) {
     AdamFusedArgs f{};
-    f.a = a; f.row_proj = row_proj; f.gT = gT; f.S = S; f.D = D;
+    f.a = a; f.row_proj = row_proj; f.gT = gT; f.S = S; f.D = D; f.lat_unused = lat_unused;
     f.off_b_dec = off_b_dec; f.n_b_dec = n_b_dec; f.off_W_enc = off_W_enc; f.off_b_enc = off_b_enc; f.n_b_enc = n_b_enc;
     f.nb_rows = (S + 3) / 4;
     f.tiles_s = (S + 255) / 256;

@@ -439,7 +439,7 @@ def main():
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder, "n_saes": args.n_saes,
                        "weight_gradients": ("whole-row gathers (dw_rows)" if os.environ.get("SAEV_AMD_DW") == "rows" or D_MODEL % 32 != 0
-                                            or stepper.overlap or stepper.exchange == "sparse"
+                                            or stepper.overlap
                                             else "32-column slices out of the XCD L2s (dw_slices)"),
                        "grad_exchange": ("none" if stepper.dist is None else
                                          ("no gradient crosses ranks: all-gather of x, dL/dx_hat and the codes ((8 D + 8 k) bytes per row), "

@@ -11,6 +11,8 @@
 //   dw_dec_kernel     dW_dec[i,:] = sum_{b in latent i} val * g[b,:]   (+ db_enc[i] = sum dval)
 //   dw_enc_kernel     dW_enc[:,i] = sum_{b in latent i} dval * x[b,:]  (32 latents per workgroup,
 //                     transposed through LDS so global stores are 128-byte rows of the (D,S) matrix)
+//   dw_slices_*       the same two gradients from 32-column slices of g / x that an XCD's L2 holds (the route of a backward
+//                     over all latents; kernels.h: DwSlicesArgs): pass A, dval sums, pass B, finalize
 //   colsum            db_dec = sum_b g[b,:]
 //
 // One wave owns one activation row / one latent; lanes stride the d_model axis in float4s.

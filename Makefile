@@ -15,7 +15,11 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/common.h include/saev_amd.h
 saev_amd/libsaev_amd.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
+# the inline-asm staging of gemm_encode_f16x3.hip owns m0: prove on the assembly that the compiler never relies on it
+check-m0:
+	python3 tools/check_m0.py
+
 clean:
 	rm -rf build saev_amd/libsaev_amd.so
 
-.PHONY: all clean
+.PHONY: all clean check-m0

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 5
+#define SAEV_AMD_ABI_VERSION 6
 
 typedef enum {
     SAEV_OK = 0,
@@ -50,9 +50,11 @@ typedef struct {
     int32_t remove_parallel_grads; /* modeling.py:281                                       */
     int32_t max_batch;             /* scratch is sized for this many activation rows        */
     int32_t encoder_mode;          /* SAEV_ENCODER_F32, _F16X3, _BF16 or _F16R              */
-    int32_t aux_dead_cap;          /* largest dead set the AuxK buffers are sized for at saev_create (no allocation
-                                      happens inside a step); 0 = d_sae, i.e. never too small.  A step that meets more
-                                      dead latents than this fails with SAEV_UNSUPPORTED.                            */
+    int32_t aux_dead_cap;          /* largest dead set the dense AuxK buffers are sized for at saev_create (no allocation
+                                      happens inside a healthy step); 0 = min(d_sae, max(4096, 8 k_aux)) -- 4 096 dead latents are
+                                      2.3 GB of buffers at configs[1], d_sae would be 11.5 GB (37 GB at configs[3]).  A step
+                                      that meets more dead latents than this grows the buffers (twice the need, at most d_sae) after its
+                                      read-back of the count -- a device-wide allocation, once; pass d_sae to rule it out.       */
     int32_t shard_world;           /* 0 / 1: the flat buffers are exactly the layout above.  N > 1: each half of it,
                                       [W_dec | b_dec] and [W_enc | b_enc], is padded with zeros to N equal chunks (chunks
                                       of the first half are whole decoder rows) so that N data-parallel ranks can
@@ -114,11 +116,33 @@ typedef struct {
 
 typedef struct saev_ctx saev_ctx;
 
+/* Route switches for A/B measurements and for tests that must reach a particular kernel.  Every field 0 = the shipped
+ * default; results are the same on every route (tests/test_gpu_parity.py, tests/test_gpu_dw_slices.py compare them).
+ * The library itself reads no environment variable: the Python host maps its documented SAEV_AMD_* variables onto this
+ * struct (saev_amd/engine.py: EngineConfig). */
+typedef struct {
+    int32_t struct_size;   /* sizeof(saev_debug_cfg) of the caller (fields past it read as 0)                            */
+    int32_t dw_route;      /* weight gradients: 0 column slices out of the XCD L2s where the geometry allows, 1 whole-row
+                              gathers (dw_rows) always                                                                    */
+    int32_t enc_mfma;      /* single-product encoders: 0 v_mfma_f32_16x16x32 kernel, 32 the 32x32x16 kernel               */
+    int32_t fused_chain;   /* f16r: 1 = survivor select, exact refinement and final select as ONE launch                  */
+    int32_t ngroups;       /* TopK bound groups of the fp16-image encoders: 0 = 32 for top_k <= 32 (64 above), 64 forces
+                              the 64-group bound                                                                          */
+    int32_t enc_wgs;       /* workgroups the fused encoder's grid aims at (0 = 256, one per CU)                           */
+    int32_t refresh_first; /* bound refresh on a workgroup's first N tiles (0 = 8) ...                                    */
+    int32_t refresh_every; /* ... then on every M-th, M a power of two (0 = 2; the 64-group bound defaults to 1)          */
+    int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 48; -1 = never (dense algebra
+                              whatever the count); values above 48 are clamped                                           */
+    int32_t fwd_route;     /* decode / exact refinement: 0 default, 1 whole-row gathers always                            */
+} saev_debug_cfg;
+
 int saev_abi_version(void);
 const char* saev_last_error(const saev_ctx* ctx);
 
 /* Lifetime.  `device` is the HIP device ordinal. */
 int saev_create(const saev_cfg* cfg, int device, saev_ctx** out);
+/* The same with route switches (dbg may be NULL = all defaults). */
+int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, saev_ctx** out);
 void saev_destroy(saev_ctx* ctx);
 
 /* Borrow the caller's flat buffers (see layout above).  grads/adam_m/adam_v may be NULL for a
@@ -280,7 +304,11 @@ int saev_wdec_ready_event(saev_ctx* ctx, void* event);
  * W_enc or b_enc.  NULL cancels. */
 int saev_wenc_ready_event(saev_ctx* ctx, void* event);
 
-/* Phases 1-4 back to back for the single-GPU case. */
+/* Phases 1-4 back to back for the single-GPU case -- with one difference to calling the four phases: the gradient
+ * buffer is NOT a valid gradient afterwards.  The W_enc gradient stays in the transposed scratch (saev_grad_w_enc_t) and
+ * is consumed there by the step's single Adam launch, and the rows of dW_dec are stored un-projected (the projection of
+ * remove_parallel_grads is applied inside Adam as the rows are read).  Callers that want to look at gradients -- the log
+ * steps of train() do -- run the phases: saev_step_backward ends with saev_backward_end, saev_step_tail projects in place. */
 int saev_train_step(saev_ctx* ctx, const float* x, int32_t n_rows, float lr, float max_norm,
                     int64_t adam_step, void* stream);
 

@@ -136,6 +136,8 @@ def g4_auxk(ref):
             f"g4_auxk_{tag}", x=x, h=h, x_hat=x_hat[:, 0], dead=dead, k_aux=k_aux, alpha=1 / 32,
             W_dec=sae.W_dec, b_dec=sae.b_dec, loss=loss, g_h=h.grad, g_W_dec=sae.W_dec.grad,
             g_b_dec=sae.b_dec.grad,
+            # (round 4: the encoder that produced h, so that the HIP step can re-derive h from x: tests/test_gpu_known_answers.py)
+            W_enc=sae.W_enc, b_enc=sae.b_enc,
         )
 
 
@@ -508,6 +510,9 @@ def main():
     ref = _refshim.install()
     if "--only-g10" in sys.argv:
         g10_make_saes(ref)
+        return
+    if "--only-g4" in sys.argv:
+        g4_auxk(ref)
         return
     if "--only-g14" in sys.argv:
         g14_inference(ref, "plain", False)

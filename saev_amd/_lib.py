@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SaevCfg(C.Structure):
@@ -24,6 +24,13 @@ class SaevCfg(C.Structure):
         ("max_batch", C.c_int32), ("encoder_mode", C.c_int32), ("aux_dead_cap", C.c_int32),
         ("shard_world", C.c_int32), ("bound_mode", C.c_int32),
     ]
+
+
+class SaevDebugCfg(C.Structure):
+    """Route switches (include/saev_amd.h: saev_debug_cfg); all zero = shipped defaults."""
+
+    _fields_ = [(n, C.c_int32) for n in ("struct_size", "dw_route", "enc_mfma", "fused_chain", "ngroups", "enc_wgs", "refresh_first",
+                                         "refresh_every", "aux_small_max", "fwd_route")]
 
 
 class SaevLayout(C.Structure):
@@ -48,6 +55,7 @@ _SIGNATURES = {
     "saev_last_error": (C.c_char_p, [P]),
     "saev_layout": (C.c_int, [C.POINTER(SaevCfg), C.POINTER(SaevLayout)]),
     "saev_create": (C.c_int, [C.POINTER(SaevCfg), C.c_int, C.POINTER(P)]),
+    "saev_create_ex": (C.c_int, [C.POINTER(SaevCfg), C.POINTER(SaevDebugCfg), C.c_int, C.POINTER(P)]),
     "saev_destroy": (None, [P]),
     "saev_bind": (C.c_int, [P, P, P, P, P]),
     "saev_bind_tracker": (C.c_int, [P, P, P]),

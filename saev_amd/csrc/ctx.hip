@@ -31,6 +31,7 @@ enum { AUX_NONE = 0, AUX_SMALL_DEVICE = 1, AUX_SMALL_HOST = 2, AUX_DENSE = 3 };
 
 struct saev_ctx {
     saev_cfg cfg{};
+    saev_debug_cfg dbg{};  // route switches (saev_create_ex); all zero = shipped defaults
     int device = 0;
     std::string err;
     // bound buffers
@@ -69,9 +70,9 @@ struct saev_ctx {
     float* colsum_partials = nullptr;
     float* dval_pairs = nullptr;  // <g row, W_dec[latent]> per (row, latent) pair in CSC order (saev_backward_rows_part 1 -> 2)
     double *sumsq_partials = nullptr, *sumsq_total = nullptr;
-    // squares of the W_enc gradient, taken by the transpose that ends the backward: valid until the gradient buffer may
-    // have been touched from outside (wenc_sq_valid), used by the tail only inside saev_train_step (wenc_sq_trusted)
-    bool wenc_sq_valid = false, wenc_sq_trusted = false;
+    // squares of the W_enc gradient, taken by the transpose that ends the backward (saev_backward_end): valid until the
+    // next backward; the tail uses them only when the caller vouches that nothing wrote the gradient since (trust_grads)
+    bool wenc_sq_valid = false;
     // {projection coefficient, projected squares} of every decoder-gradient row, left by the kernels that wrote the rows
     // (DwRowsArgs::row_proj); valid after a one-pass backward over all latents, trusted like wenc_sq
     float2* row_proj = nullptr;
@@ -209,12 +210,11 @@ int alloc(saev_ctx* c, T** p, size_t count) {
 }
 
 // TopK bound of the fp16-image encoders: the minimum over 32 group maxima for top_k <= 32; 64 groups with the top_k-th
-// largest of the group maxima for 32 < top_k <= 64.  SAEV_AMD_NGROUPS=64 forces the second variant for small k as well: it
+// largest of the group maxima for 32 < top_k <= 64.  saev_debug_cfg.ngroups = 64 forces the second variant for small k as well: it
 // cuts the candidates per row from ~980 to ~360 at config 2, but its bound phase (32 published maxima per lane, a
 // bisection over packed 16-bit keys) costs more than the shorter lists save (encoder 1.43-1.51 vs 1.35-1.38 ms).
-int f16_ngroups(const saev_cfg& cfg) {
-    static const int forced = [] { const char* e = getenv("SAEV_AMD_NGROUPS"); return e ? atoi(e) : 0; }();
-    if (cfg.top_k > 32 || forced == 64) return 64;
+int f16_ngroups(const saev_ctx* c) {
+    if (c->cfg.top_k > 32 || c->dbg.ngroups == 64) return 64;
     return 32;
 }
 
@@ -260,7 +260,9 @@ int saev_layout(const saev_cfg* cfg, saev_layout_t* out) {
 
 const char* saev_last_error(const saev_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
+int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) { return saev_create_ex(cfg, nullptr, device, out); }
+
+int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, saev_ctx** out) {
     if (!cfg || !out) return SAEV_INVALID_ARG;
     *out = nullptr;
     if (cfg->d_model <= 0 || cfg->d_sae <= 0 || cfg->top_k <= 0 || cfg->max_batch <= 0) return SAEV_INVALID_ARG;
@@ -274,6 +276,8 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     saev_ctx* c = new saev_ctx();
     c->cfg = *cfg;
     c->cfg.top_k = std::min(cfg->top_k, cfg->d_sae);
+    if (dbg != nullptr && dbg->struct_size > 0)
+        std::memcpy(&c->dbg, dbg, std::min((size_t)dbg->struct_size, sizeof(saev_debug_cfg)));
     c->device = device;
     if (hipSetDevice(device) != hipSuccess) {
         delete c;
@@ -314,8 +318,7 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     A(chunk_starts, S + 1); A(part_starts, S); A(work_latent, c->max_work);
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part); A(row_proj, S); A(enc_sq, S);
     {
-        const char* e = getenv("SAEV_AMD_DW");  // (read per context: tests build one of each)
-        const bool rows_only = e != nullptr && strcmp(e, "rows") == 0;
+        const bool rows_only = c->dbg.dw_route == 1;
         c->dws_ok = !rows_only && D % DWS_SLICE == 0 && (uint64_t)S * D * 4ull < (1ull << 32) && MB < (1l << 24) &&
                     (uint64_t)MB * K < (1ull << 31);
     }
@@ -363,10 +366,12 @@ int saev_create(const saev_cfg* cfg, int device, saev_ctx** out) {
     if (c->xs) hipMemset(c->xs, 0, (size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
     if (c->zero_bias) hipMemset(c->zero_bias, 0, std::max(S, D) * sizeof(float));
     if (KA > 0) {
-        // Every AuxK buffer is sized here, once, for the largest dead set the context accepts (aux_dead_cap, default
-        // d_sae): no allocation ever happens inside a step.
+        // Every AuxK buffer is sized here, once, for the largest dead set the context accepts: no allocation ever happens
+        // inside a step.  Default min(d_sae, max(4096, 8 k_aux)) dead latents (2.3 GB at configs[1]; d_sae would be 11.5 GB
+        // there and 37 GB at configs[3]); a step that meets more fails loudly and names the field to raise.
         const int s4 = (int)((S + 3) / 4 * 4);
-        const int cap = cfg->aux_dead_cap > 0 ? std::min((cfg->aux_dead_cap + 3) / 4 * 4, s4) : s4;
+        const int want = cfg->aux_dead_cap > 0 ? cfg->aux_dead_cap : std::max(4096, 8 * (int)KA);
+        const int cap = std::min((want + 3) / 4 * 4, s4);
         rc = alloc_aux_buffers(c, cap);
         if (rc == SAEV_OK) {
             void* h = nullptr;
@@ -634,11 +639,10 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
             c->wmax_known = true;
         }
         // centre the first pass on the batch's column mean: h = (x - mu) W + (mu W + b)
-        (void)xmax_dev;
         // (mu = column sums / n, scaled in the same kernel so that every consumer sees the same fp32 values)
         if (!x_borrowed) {
             if (!c->mu_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n));
-            HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s));
+            HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s, xmax_dev));
         }
         c->mu_ready = false;
         // (the x scale depends on x alone: a borrowing context recomputes the same value from the leader's maxima, next
@@ -682,22 +686,22 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.scale_dev = f16r ? c->f16r_scales : nullptr;
         a.arith = bf ? 1 : (f16r ? 2 : 0);
         a.row_margin = f16r ? c->row_margin : nullptr;
-        static const int enc_wgs = [] { const char* e = getenv("SAEV_AMD_ENC_WGS"); return e ? atoi(e) : 256; }();
+        const int enc_wgs = c->dbg.enc_wgs > 0 ? c->dbg.enc_wgs : 256;
+        a.mfma32 = c->dbg.enc_mfma == 32 ? 1 : 0;
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), enc_wgs);
         a.h_out = h_out;
-        a.ngroups = f16_ngroups(c->cfg); a.top_k = c->cfg.top_k;
+        a.ngroups = f16_ngroups(c); a.top_k = c->cfg.top_k;
         a.gmax = c->gmax; a.gmax_stride = c->gmax_stride; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
         a.cand_cap = CAND_CAP; a.cand_stride = CAND_STRIDE;
         a.enable_flag = flag; a.enable_when = when;
         if (predicted) { a.heur_z = c->heur_state; a.tau_max = c->tau_max; }
         {
-            static const int rf = [] { const char* e = getenv("SAEV_AMD_REFRESH_FIRST"); return e ? atoi(e) : 8; }();
-            static const int re = [] { const char* e = getenv("SAEV_AMD_REFRESH_EVERY"); return e ? atoi(e) : 2; }();
+            const int rf = c->dbg.refresh_first > 0 ? c->dbg.refresh_first : 8, re = c->dbg.refresh_every;
             a.refresh_first = std::max(1, rf);
             a.refresh_every = (re >= 1 && (re & (re - 1)) == 0) ? re : 2;
             // the 64-group variant (32 < k <= 64, e.g. 82 k latents at k = 64) refreshes on every tile: with twice the codes
             // per row and many more tiles per workgroup its lists would outgrow their 4 096 entries otherwise
-            if (a.ngroups > 32 && getenv("SAEV_AMD_REFRESH_EVERY") == nullptr) a.refresh_every = 1;
+            if (a.ngroups > 32 && re <= 0) a.refresh_every = 1;
         }
         HIPCHK(c, launch_encode_f16x3(a, epi, s));
         return SAEV_OK;
@@ -758,7 +762,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     int32_t* need_dense = c->flags + 1;
     const bool f16r_mode = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
     const bool predict_mode = fused_supported(c->cfg) && c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 &&
-                              f16_ngroups(c->cfg) == 32;
+                              f16_ngroups(c) == 32;
     const bool one_launch_pre = fused_supported(c->cfg) && !predict_mode;  // margins + encoder state + list flags in one launch
     {
         int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev, x_borrowed, one_launch_pre);
@@ -767,7 +771,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         if (rc0 != SAEV_OK) return rc0;
     }
     if (fused_supported(c->cfg)) {
-        const int ng = c->cfg.encoder_mode == SAEV_ENCODER_F32 ? (c->cfg.top_k <= 32 ? 32 : 64) : f16_ngroups(c->cfg);
+        const int ng = c->cfg.encoder_mode == SAEV_ENCODER_F32 ? (c->cfg.top_k <= 32 ? 32 : 64) : f16_ngroups(c);
         const bool f16r = c->cfg.encoder_mode == SAEV_ENCODER_F16R;
         // select -> (f16r: exact refinement -> select) on the candidate lists, predicated on `flag == when`
         auto select_stage = [&](const int32_t* flag, int when, int32_t* bad, const int32_t* tau_max, int32_t* ovf = nullptr,
@@ -786,13 +790,12 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 sc.row_margin = c->row_margin; sc.x = x; sc.W_encT = c->dW_encT; sc.b_enc = c->params + c->off_b_enc;
                 sc.D = c->cfg.d_model; sc.refine_overflow = bad;
                 sc.surv_idx = c->surv_idx; sc.surv_val = c->surv_val; sc.surv_cnt = c->surv_cnt;
-                // SAEV_AMD_FUSED_CHAIN=1: survivors, their exact values and the final cut in ONE launch (select_refine_kernel).
+                // saev_debug_cfg.fused_chain: survivors, their exact values and the final cut in ONE launch (select_refine_kernel).
                 // Opt-in: measured 335 us against 351 for the three kernels when all of them run at seven waves per SIMD,
                 // and slower than them (+0.03 ms per step) once lists of 1 025-2 048 entries stay in registers, which the
                 // survivor select needs (tools/experiments/README.md); a survivor overflow raises `bad` (= need_dense) like
                 // a list overflow does, and the dense route that follows redoes the step exactly
-                const char* fe = getenv("SAEV_AMD_FUSED_CHAIN");
-                const bool chain_fused = fe != nullptr && atoi(fe) != 0;
+                const bool chain_fused = c->dbg.fused_chain != 0;
                 if (chain_fused && tau_max == nullptr && first_flag != nullptr) {
                     HIPCHK(c, launch_select_refine(sc, s));
                     return SAEV_OK;
@@ -1003,7 +1006,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     for (int p = 0; p < c->P; ++p) c->cuts_last[p] = c->cuts[p];  // a later saev_set_prefixes must not reach this step's backward
     // (list statistics from the candidate counters themselves unless the fused encoder is out of play or predicts bounds,
     // where overflow_check_kernel leaves them in flags[2..3])
-    const bool lists = fused_supported(c->cfg) && !(c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 && f16_ngroups(c->cfg) == 32);
+    const bool lists = fused_supported(c->cfg) && !(c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 && f16_ngroups(c) == 32);
     HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper_c, c->flags + 2, c->stats, s, nullptr, c->stats_scratch,
                                   lists ? c->cand_cnt : nullptr, CAND_CAP));
     return SAEV_OK;
@@ -1124,7 +1127,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     const int S = c->cfg.d_sae, D = c->cfg.d_model, n = c->n_last;
     const int nd = c->n_dead_host, ku = c->k_use_host;
     const int ndp = (nd + 3) / 4 * 4;
-    REQUIRE(c, ndp <= c->nd_cap, SAEV_UNSUPPORTED, "AuxK: more dead latents than saev_cfg.aux_dead_cap allows");
+    REQUIRE(c, ndp <= c->nd_cap, SAEV_UNSUPPORTED, "AuxK: more dead latents than the dense buffers hold (raise saev_cfg.aux_dead_cap)");
     int rc = SAEV_OK;
     // Every encoder mode runs the five contractions on the split-fp16 MFMA kernel (three products per fp32 product:
     // fp32-accurate, gemm_encode_f16x3.hip), whatever arithmetic its own encoder uses: the auxiliary loss is defined on
@@ -1272,7 +1275,9 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     // the bound fits the few-dead-latents kernels -- which covers zero, the usual state of a healthy run -- they are
     // enqueued with the count left on the device and nothing is read back.  The wait below is for an event DEAD_LAG
     // steps in the past; it only ever blocks a host that has run further ahead than that, and never drains the queue.
-    const int small_max = std::min(AUX_SMALL_MAX, c->cfg.k_aux);
+    // (saev_debug_cfg.aux_small_max: -1 sends every dead set down the dense route, for tests and A/B runs)
+    const int small_cap = c->dbg.aux_small_max < 0 ? 0 : (c->dbg.aux_small_max == 0 ? AUX_SMALL_MAX : std::min(c->dbg.aux_small_max, (int)AUX_SMALL_MAX));
+    const int small_max = std::min(small_cap, c->cfg.k_aux);
     const int64_t s0 = step - DEAD_LAG;
     if (s0 >= c->rec_valid_from) {
         HIPCHK(c, hipEventSynchronize(c->dead_ev[s0 % DEAD_RING]));
@@ -1304,6 +1309,22 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     c->n_dead_host = host[0];
     c->k_use_host = host[1];
     if (c->n_dead_host <= 0) return SAEV_OK;
+    if ((c->n_dead_host + 3) / 4 * 4 > c->nd_cap && !(c->n_dead_host <= small_max && c->cfg.d_model <= 2048)) {
+        // More dead latents than the dense buffers were sized for (saev_cfg.aux_dead_cap): grow them here -- the stream is
+        // idle after the read-back, the buffers carry nothing from step to step -- to twice the need, capped at d_sae.  An
+        // exceptional event (a run whose dictionary collapses); it costs a device-wide allocation, never a wrong result.
+        const int s4 = (S + 3) / 4 * 4;
+        const int cap = std::min(s4, std::max(2 * c->nd_cap, (2 * c->n_dead_host + 1023) / 1024 * 1024));
+        for (void* q : c->aux_allocs) hipFree(q);
+        c->aux_allocs.clear();
+        c->nd_cap = 0;
+        int rcg = alloc_aux_buffers(c, cap);
+        if (rcg != SAEV_OK) {
+            c->err = "AuxK: " + std::to_string(c->n_dead_host) + " dead latents exceed saev_cfg.aux_dead_cap and the buffers could not be grown to " +
+                     std::to_string(cap) + " (out of device memory)";
+            return rcg;
+        }
+    }
     if (c->n_dead_host <= small_max && c->cfg.d_model <= 2048) {
         c->aux_route = AUX_SMALL_HOST;
         return auxk_small_forward(c, s);
@@ -1398,8 +1419,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;
         w.part_dec = c->partials; w.part_enc = c->partials + 2 * runs_cap * D;  // (max_part * 2 rows hold 4 * runs_cap)
         w.cut_lat = c->cut_lat;
-        static const bool flag_unused = [] { const char* e = getenv("SAEV_AMD_FLAG_UNUSED"); return !(e != nullptr && atoi(e) == 0); }();  // (A/B)
-        w.lat_unused = (all_rows && c->fused_step && flag_unused) ? c->lat_unused : nullptr;
+        w.lat_unused = (all_rows && c->fused_step) ? c->lat_unused : nullptr;
         c->unused_valid = w.lat_unused != nullptr;
         w.row_proj = a.row_proj; w.project = a.project; w.enc_sq = a.enc_sq;
         w.clear_bitmap = a.clear_bitmap; w.clear_words = a.clear_words;
@@ -1567,8 +1587,8 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
         c->tail_proj_in_adam = true;
         return SAEV_OK;
     }
-    if ((c->wenc_sq_trusted || c->trust_grads) && c->wenc_sq_valid && c->row_proj_valid && shard_rank < 0) {
-        // Inside saev_train_step nothing has touched the gradient since the backward: the kernels that wrote the decoder
+    if (c->trust_grads && c->wenc_sq_valid && c->row_proj_valid && shard_rank < 0) {
+        // The caller vouches that nothing has touched the gradient since the backward: the kernels that wrote the decoder
         // rows left each row's projection coefficient and projected squares (row_proj), the transpose the squares of dW_enc
         // tile by tile.  One small reduction gives the clip norm, and Adam applies the projection to the rows as it reads
         // them: the gradient is streamed once by the whole tail instead of three times (rpg read + write, Adam read).
@@ -1590,15 +1610,7 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
                          c->cfg.remove_parallel_grads ? 1 : 0));
     const long rest_lo = std::max(r.a_lo, S * D);
     HIPCHK(c, launch_sumsq_partials(c->grads + rest_lo, std::max(0L, r.a_hi - rest_lo), part, s));
-    // encoder half: inside saev_train_step nothing has touched the gradient since the backward's transpose left the
-    // squares of dW_enc tile by tile -- only b_enc's remain to be summed (one pass over 128 MB less)
-    const bool fused = c->wenc_sq_trusted && c->wenc_sq_valid && shard_rank < 0 && n_rows == (int)S;
     c->wenc_sq_valid = false;
-    if (fused) {
-        HIPCHK(c, launch_sumsq_partials(c->grads + c->off_b_enc, S, part + nb, s));
-        HIPCHK(c, launch_sumsq_final(part, 2 * nb + (n_rows + 3) / 4 + transpose_blocks((int)S, (int)D), saev_sumsq_device(c), s));
-        return SAEV_OK;
-    }
     HIPCHK(c, launch_sumsq_partials(c->grads + r.b_lo, r.b_hi - r.b_lo, part + nb, s));
     HIPCHK(c, launch_sumsq_final(part, 2 * nb + (n_rows + 3) / 4, saev_sumsq_device(c), s));
     return SAEV_OK;

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
     const int blk_imgs = a.blk_imgs > 0 ? a.blk_imgs : nks;  // images per row block in memory
     const int k_first = (EPI == EPI_DENSE) ? (int)blockIdx.y * nks : 0;  // contraction slice of this batch
     const _Float16* x_imgs = a.xs + ((size_t)bb * blk_imgs + k_first) * img;
-    // (staging written out as "uniform base + 32-bit lane offset" global_load_lds: see encode_m16_kernel)
+    // (staging written out as "uniform base + 32-bit lane offset" global_load_lds: see encode_m16_kernel.  The asm sets m0 itself
+    // and does not list it as clobbered -- hipcc treats m0 as reserved and would only warn; that is sound because nothing
+    // the compiler emits in this file keeps a value in m0: tools/check_m0.py proves it on the assembly at every build)
     const uint32_t lane_off = (uint32_t)lane * 16u;
     const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)&sm.slot[0].a[wid * 32][0];
     auto stage_kstep = [&](int slot, int s0, int ks) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
             "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
             "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
             ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(wsrc), "s"(xsrc)
-            : "memory", "m0");
+            : "memory");
     };
 
     // fragment rows of this lane and their chunk swizzles
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
             "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
             "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
             ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(wsrc), "s"(xsrc)
-            : "memory", "m0");
+            : "memory");
     };
 
     const int arow0 = ws * 128 + l15;  // + 16 * sb
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
                 "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                 "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
                 ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(w_tile + koff), "s"(x_blk + koff)
-                : "memory", "m0");
+                : "memory");
             koff += (uint32_t)(img * sizeof(_Float16));
             koff = koff == run_bytes ? 0u : koff;
         };
@@ -1133,10 +1135,8 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
     dim3 grid(n_bblocks * a.s_splits, (epi == EPI_DENSE && a.n_batches > 1) ? a.n_batches : 1), block(HTHREADS);
     const size_t smem = sizeof(HSmem);
     static bool attr_set = false;
-    static bool use_m16 = true;
+    const bool use_m16 = a.mfma32 == 0;
     if (!attr_set) {
-        const char* shape = getenv("SAEV_AMD_ENC_MFMA");
-        use_m16 = !(shape != nullptr && atoi(shape) == 32);
 
         const void* fns[16] = {reinterpret_cast<const void*>(&encode_m16_kernel<1>),
                               reinterpret_cast<const void*>(&encode_m16_kernel<2>),
@@ -1173,7 +1173,7 @@ hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stre
         else if (a.arith == 2) hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 2, true>), grid, block, smem, stream, a);
         else hipLaunchKernelGGL((encode_f16x3_kernel<EPI_TOPK, 32, 0, true>), grid, block, smem, stream, a);
     } else if (a.ngroups <= 32 && a.arith != 0 && use_m16) {
-        // single-product modes: the 16x16x32 kernel (SAEV_AMD_ENC_MFMA=32 brings the 32x32x16 one back for A/B runs)
+        // single-product modes: the 16x16x32 kernel (saev_debug_cfg.enc_mfma = 32 brings the 32x32x16 one back for A/B runs)
         if (a.arith == 1) hipLaunchKernelGGL((encode_m16_kernel<1>), grid, block, smem, stream, a);
         else hipLaunchKernelGGL((encode_m16_kernel<2>), grid, block, smem, stream, a);
     } else if (a.ngroups <= 32) LAUNCH_AR(EPI_TOPK, 32);

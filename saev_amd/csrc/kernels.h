@@ -99,7 +99,8 @@ hipError_t launch_wnorm_max(const float* W_encT, int S, int D, float* wg_scratch
 hipError_t launch_f16r_scales(const float* xmax_part, int n_part, const float* wmax, float* scales, hipStream_t stream);
 hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t stream);
 hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
-                               hipStream_t stream);  // ||x_b - mu|| per row, max |x - mu| per workgroup of 4 rows
+                               hipStream_t stream, const float* xmax = nullptr);  // ||x_b - mu|| per row (squares taken relative to
+                                                                                  // *xmax when given), max |x - mu| per workgroup of 4 rows
 hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
                               int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream);
 // see overflow_check_kernel (select.hip) for the two-stage use
@@ -391,6 +392,7 @@ struct EncodeF16Args {
     int n_batches;
     int blk_imgs;
     long out_bstride;
+    int mfma32;               // host side only: 1 = the 32x32x16 kernels for the single-product modes too (saev_debug_cfg.enc_mfma)
 };
 hipError_t launch_encode_f16x3(const EncodeF16Args& a, int epi, hipStream_t stream);
 int encode_f16x3_tile_rows();

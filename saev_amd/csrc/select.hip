@@ -667,12 +667,17 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n,
 // until every latent survives.  The exact refinement keeps using x and b_enc themselves.
 //
 // per row: ||x_b - mu||; per workgroup: max |x - mu| (thousands of same-address atomics would serialise: two stages)
+//
+// xmax (device scalar max|x| of the batch, or NULL): the squares are taken of (x - mu) / max|x| -- at most 4 each -- and the
+// norm scaled back, so that activations of any magnitude (|x| ~ 1e20 squares to inf in fp32) get a finite margin.
 __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const float* mu, int n, int D,
-                                                           float* xnorm, float* wg_max) {
+                                                           float* xnorm, float* wg_max, const float* xmax) {
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
     float s = 0.f, m = 0.f;
+    const float up = xmax != nullptr ? *xmax : 1.0f;
+    const float back = (up > 0.f && up < 3.0e38f) ? up : 1.0f, inv = 1.0f / back;
     if (r < n) {
         const f32x4* p = reinterpret_cast<const f32x4*>(x + (size_t)r * D);
         const f32x4* mu4 = reinterpret_cast<const f32x4*>(mu);
@@ -686,17 +691,31 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
                 m = fmaxf(fmaxf(fmaxf(m, fabsf(v[u][0])), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+                v[u] = v[u] * inv;
+                s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
             }
         }
         s = wave_sum(s);
-        if (lane == 0) xnorm[r] = sqrtf(s);
+        if (lane == 0) xnorm[r] = back * sqrtf(s);
     }
     m = wave_max(m);
     if (lane == 0) sh[w] = m;
     __syncthreads();
     if (threadIdx.x == 0) wg_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+// The two pieces row_margin_kernel and pre_encode_kernel share (ONE definition: the refinement is only exact if both
+// kernels agree on the margin).  f16r_margin: 2 E_b of the comment below.  f16r_scale_ok: the W images of this step were
+// scaled with the power of two derived from the PREVIOUS call's largest column norm; they are safe while the current
+// norm times that scale stays below the fp16 range and at most two bits under the intended [2^13, 2^14) window (an
+// all-zero W_enc has exact images).
+__device__ __forceinline__ float f16r_margin(float xnorm_row, float wmax, float bmax, int D) {
+    const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
+    return coef * xnorm_row * wmax + 2.0f * 1.1920929e-07f * bmax;
+}
+__device__ __forceinline__ bool f16r_scale_ok(float wmax, float w_scale) {
+    const float t = wmax * w_scale;
+    return t < 60000.0f && (t >= 2048.0f || wmax == 0.f);
 }
 // margin[b] = 2 E_b, E_b = 1.05 * (2^-10 + D * 2^-22) * ||x_b - mu|| * max_s ||W_enc[:, s]|| + 2^-23 max |b_shift|: an
 // upper bound of the error of a pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products;
@@ -725,14 +744,12 @@ __global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int
     const float bmax = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
     const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const float t = wmax * (*w_scale);
-        if (!(t < 60000.0f && (t >= 2048.0f || wmax == 0.f))) *pre_flag = 1;  // (an all-zero W_enc has exact images)
+        if (!f16r_scale_ok(wmax, *w_scale)) *pre_flag = 1;
         *wmax_prev = wmax;
     }
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
-    margin[r] = coef * xnorm[r] * wmax + 2.0f * 1.1920929e-07f * bmax;
+    margin[r] = f16r_margin(xnorm[r], wmax, bmax, D);
 }
 // Everything the fused encoder launch needs zeroed or derived right before it, in one pass (three launches before):
 //   * the per-launch state of the encoder: candidate counters 0, shared group maxima "-inf";
@@ -760,15 +777,13 @@ __global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int 
     const float bmax = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
     const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
     if (i == 0) {
-        const float t = wmax * (*w_scale);
         int pre = *pre_flag != 0 ? 1 : 0;
-        if (!(t < 60000.0f && (t >= 2048.0f || wmax == 0.f))) { pre = 1; *pre_flag = 1; }  // (an all-zero W_enc has exact images)
+        if (!f16r_scale_ok(wmax, *w_scale)) { pre = 1; *pre_flag = 1; }
         *wmax_prev = wmax;
         flags1[0] = pre; flags1[1] = 0; flags1[2] = 0;
     }
     if (i >= n_rows) return;
-    const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
-    margin[i] = coef * xnorm[i] * wmax + 2.0f * 1.1920929e-07f * bmax;
+    margin[i] = f16r_margin(xnorm[i], wmax, bmax, D);
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)
@@ -934,8 +949,8 @@ hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t strea
     return hipGetLastError();
 }
 hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
-                               hipStream_t stream) {
-    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_absmax);
+                               hipStream_t stream, const float* xmax) {
+    hipLaunchKernelGGL(center_stats_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, mu, n, D, xnorm, wg_absmax, xmax);
     return hipGetLastError();
 }
 hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream) {

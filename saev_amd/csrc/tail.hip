@@ -620,15 +620,9 @@ hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const fl
     f.nb_tiles = f.tiles_s * ((D + 31) / 32);
     const int nb_bias = 32;
     return dispatch_nv(D, [&](auto nv) {
-        // SAEV_AMD_ADAM_SPLIT=1: rows + biases and tiles as two launches (A/B; one grid overlaps the LDS-bound tile
-        // workgroups with the streaming row workgroups: 302 vs 327 us at configs[1])
-        static const bool split = [] { const char* e = getenv("SAEV_AMD_ADAM_SPLIT"); return e != nullptr && atoi(e) != 0; }();
-        if (split) {
-            hipLaunchKernelGGL((adam_fused_kernel<decltype(nv)::value, 0>), dim3(f.nb_rows + nb_bias), dim3(256), 0, stream, f);
-            hipLaunchKernelGGL((adam_fused_kernel<1, 1>), dim3(f.nb_tiles), dim3(256), 0, stream, f);
-        } else {
-            hipLaunchKernelGGL((adam_fused_kernel<decltype(nv)::value, 2>), dim3(f.nb_rows + f.nb_tiles + nb_bias), dim3(256), 0, stream, f);
-        }
+        // (rows, tiles and biases share ONE grid: it overlaps the LDS-bound tile workgroups with the streaming row
+        // workgroups -- 302 us against 327 as two launches at configs[1])
+        hipLaunchKernelGGL((adam_fused_kernel<decltype(nv)::value, 2>), dim3(f.nb_rows + f.nb_tiles + nb_bias), dim3(256), 0, stream, f);
     });
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {

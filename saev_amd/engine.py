@@ -32,7 +32,8 @@ class EngineConfig:
     normalize_w_dec: bool = True
     remove_parallel_grads: bool = True
     max_batch: int = 16384
-    aux_dead_cap: int = 0      # largest dead set the AuxK buffers are sized for at creation; 0 = d_sae (always enough)
+    aux_dead_cap: int = 0      # largest dead set the dense AuxK buffers are sized for at creation; 0 = min(d_sae, max(4096,
+                               # 8 k_aux)); a step that meets more dead latents raises and names this field
     shard_world: int = 1       # > 1: flat buffers padded so that this many data-parallel ranks can each own 1/N of the tail
     # TopK candidate bounds of the fused encoder: "guaranteed" (default), or "predicted": verified extrapolated bounds
     # with an automatic guaranteed-bound re-run when a prediction fails -- same codes either way; measured no faster over
@@ -43,6 +44,25 @@ class EngineConfig:
     # "f16r": one fp16 MFMA product as a bounded-error first pass + exact fp32 recomputation of the surviving candidates.
     # The default can be overridden with the SAEV_AMD_ENCODER environment variable.
     encoder: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_ENCODER", DEFAULT_ENCODER))
+    # Route switches for A/B runs and for tests that must reach a particular kernel (saev_debug_cfg; same results on every
+    # route).  The C library reads no environment variable; these defaults do, so that a test or a shell script can flip a
+    # route without touching code:
+    #   SAEV_AMD_DW=rows          weight gradients by whole-row gathers instead of column slices
+    #   SAEV_AMD_FWD=rows         decode / exact refinement by whole-row gathers
+    #   SAEV_AMD_ENC_MFMA=32      single-product encoders on the 32x32x16 MFMA kernel
+    #   SAEV_AMD_FUSED_CHAIN=1    f16r select -> refine -> select as one launch
+    #   SAEV_AMD_NGROUPS=64       64-group TopK bound also for top_k <= 32
+    #   SAEV_AMD_ENC_WGS, SAEV_AMD_REFRESH_FIRST, SAEV_AMD_REFRESH_EVERY   encoder grid / bound-refresh cadence
+    #   SAEV_AMD_AUX_SMALL_MAX    largest dead set of the few-dead-latents AuxK kernels (-1: always the dense algebra)
+    dw_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_DW", "slices"))
+    fwd_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_FWD", "default"))
+    enc_mfma: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_ENC_MFMA", "0")))
+    fused_chain: bool = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_FUSED_CHAIN", "0") not in ("", "0"))
+    ngroups: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_NGROUPS", "0")))
+    enc_wgs: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_ENC_WGS", "0")))
+    refresh_first: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_REFRESH_FIRST", "0")))
+    refresh_every: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_REFRESH_EVERY", "0")))
+    aux_small_max: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_SMALL_MAX", "0")))
 
 
 @dataclasses.dataclass
@@ -118,8 +138,14 @@ class SaeEngine:
                 aux_dead_cap=cfg.aux_dead_cap, shard_world=cfg.shard_world,
                 bound_mode={"guaranteed": 0, "predicted": 1}[cfg.bounds],
             )
+            if cfg.dw_route not in ("slices", "rows") or cfg.fwd_route not in ("default", "rows"):
+                raise ValueError(f"EngineConfig.dw_route must be 'slices' or 'rows' and fwd_route 'default' or 'rows', got {cfg.dw_route!r} / {cfg.fwd_route!r}")
+            dbg = _lib.SaevDebugCfg(
+                struct_size=C.sizeof(_lib.SaevDebugCfg), dw_route=int(cfg.dw_route == "rows"), enc_mfma=cfg.enc_mfma,
+                fused_chain=int(cfg.fused_chain), ngroups=cfg.ngroups, enc_wgs=cfg.enc_wgs, refresh_first=cfg.refresh_first,
+                refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route=int(cfg.fwd_route == "rows"))
             ctx = C.c_void_p()
-            rc = self.lib.saev_create(C.byref(ccfg), self.device.index, C.byref(ctx))
+            rc = self.lib.saev_create_ex(C.byref(ccfg), C.byref(dbg), self.device.index, C.byref(ctx))
             if rc != 0:
                 raise _lib.SaevError(f"saev_create failed with status {rc} for {cfg}")
             self.ctx = ctx
@@ -363,7 +389,11 @@ class SaeEngine:
                   "saev_wenc_ready_event")
 
     def train_step(self, x: torch.Tensor, lr: float, max_norm: float = 1.0):
-        """Phases 1-4 on one GPU (reference train.py:332-460 loop body for one SAE)."""
+        """Phases 1-4 on one GPU (reference train.py:332-460 loop body for one SAE).
+
+        ``grad_views()`` is NOT a valid gradient afterwards: the W_enc gradient stays in the transposed scratch and the
+        dW_dec rows are stored un-projected (the fused Adam projects them as it reads).  To look at gradients run the phases
+        (``step_forward`` / ``step_dead`` / ``step_backward`` / ``step_tail``), as the log steps of ``train()`` do."""
         x = self._check_x(x)
         self._x_keepalive = x
         self.adam_steps += 1

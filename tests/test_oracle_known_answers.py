@@ -2,7 +2,7 @@
 
 Each case names the reference test it restates (tests/test_auxk.py, tests/test_nn_activations.py,
 tests/test_nn_objectives.py, tests/test_nn_modeling.py under /root/reference).  CPU only.
-The same scenarios are replayed through the HIP path in tests/test_gpu_known_answers.py."""
+The same scenarios -- and fixtures G3, G4, G6, G7, G8 -- are fed to the HIP kernels in tests/test_gpu_known_answers.py."""
 
 import pytest
 import torch

@@ -7,18 +7,27 @@ batch 16384 activations per GPU, fp32, synthetic N(mu, 1) activations held in a 
 of 64 batches (the reference's reservoir capacity, data/shuffled.py:45-63).  One step = draw a batch
 from the pool (row gather) + the full train step (renorm, encode+TopK, sparse decode, MSE, AuxK
 bookkeeping, backward, rpg, clip, Adam).  With N > 1 ranks (launched by torch.distributed.run) the
-batch is per-GPU (weak scaling) and each step all-reduces the 268 MB gradient buffer and the
-fired-latent flags over RCCL.
+batch is per-GPU (weak scaling) and each step exchanges the 268 MB gradient over RCCL -- reduce-scatter, 1/N of the
+optimizer tail per rank, all-gather of the parameters (`--tail`, framework/ddp.py) -- plus the fired-latent flags.
+
+Timed region ("steady-state train step"): the loop first trains `--pretrain-steps` steps (default 650: past the
+reference's dead-latent threshold of 10 M tokens = 611 of these steps, and past the 500-step lr warm-up), then runs the
+contract's W untimed warm-up steps and times exactly K steps.  `value` is therefore the step a training run spends its
+life in -- tracker consulted, AuxK on whatever is dead, latent usage spread over ~27 000 latents.  The first 5 + 20 steps
+from random init (what rounds 1-3 reported; ~18 % faster because 19 000 latents are still unused and AuxK is off) are
+timed on the way and reported as `from_random_init`.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  "roofline":     the encoder MFMA kernel's achieved TFLOP/s = algorithmic 2*B*D*S flops / mean kernel
-                  duration (HIP events recorded on the launch stream by the library).  The default
-                  encoder forms each fp32 product from three f16 MFMA products (fp32-accurate, see
-                  DESIGN.md 3.1), so it is priced against the dense f16 MFMA peak (2.5 PFLOP/s);
-                  `executed_tflops` counts the three products.  With --encoder f32 the exact-fp32
-                  MFMA kernel is measured against the 157.3 TFLOP/s fp32 matrix peak;
+  "roofline":     the encoder's first-pass MFMA kernel: achieved TFLOP/s = algorithmic 2*B*D*S flops / mean kernel
+                  duration over the timed steps (HIP events recorded on the launch stream by the library).  The default
+                  encoder (f16r) forms every product ONCE on v_mfma_f32_16x16x32_f16 with a rigorous error margin and
+                  recomputes the survivors exactly in fp32 (separate kernels inside ms_per_step), so it is priced
+                  against the dense f16 MFMA peak (2.5 PFLOP/s); --encoder f16x3 (three products per fp32 product)
+                  reports `executed_tflops` = 3x beside it; --encoder f32 is priced against the 157.3 TFLOP/s fp32
+                  matrix peak;
   "cpu_baseline": the CPU oracle (oracle/sae_ref.py, a restatement of the reference's PyTorch-CPU
-                  step) timed on this box's host cores on a bounded sample of the same workload.
+                  step) timed on this box's host cores on a bounded sample of the same workload;
+  with N > 1:     "collectives": RCCL bus bandwidth of the step's own collectives at their real sizes.
 """
 
 import argparse
@@ -85,7 +94,10 @@ def mse_vs_oracle(eng, x, n_rows: int = 2048):
     params = {k: v.detach().cpu().clone() for k, v in eng.param_views().items()}
     with torch.no_grad():
         ref = R.objective_forward(params, xs.cpu(), cfg, toks_since_active=None, training=False).mse.item()
-    return {"rows": n_rows, "mse_hip": got, "mse_oracle": ref, "mse_rel_err_vs_oracle": abs(got - ref) / ref}
+    return {"rows": n_rows, "mse_hip": got, "mse_oracle": ref, "mse_rel_err_vs_oracle": abs(got - ref) / ref,
+            "mse_check_note": f"forward MSE of the HIP path and of the CPU oracle on {n_rows} rows of the bench's own batch with the bench's own "
+                              "parameters, both reported in fp32: 0.0 means equal after rounding to fp32, not a full-batch statement "
+                              "(tests/test_gpu_fullsize.py holds the full-size checks)"}
 
 
 def other_config_record(dev, *, name, d, s, k, b, encoder, n_prefixes=1, steps=10, warmup=5):
@@ -158,23 +170,27 @@ def main():
                     help="data-parallel optimizer tail: every rank all of it after an all-reduce, or reduce-scatter -> 1/N of "
                          "the tail per rank -> all-gather (framework/ddp.py).  auto: sharded when a start-up self-check on a "
                          "small problem reproduces the all-reduce path on every rank, else replicated")
-    ap.add_argument("--exchange", choices=["dense", "sparse"], default="dense",
+    ap.add_argument("--exchange", choices=["dense", "sparse", "auto"], default="dense",
                     help="what the ranks exchange per step: the gradient (all-reduce, or reduce-scatter / all-gather with --tail "
                          "sharded), or the sparse step state -- x, dL/dx_hat, codes all-gathered, every rank runs the backward "
                          "over the global batch (framework/ddp.py; for small per-rank batches, i.e. strong scaling)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many rows per step in total, split evenly over the ranks (overrides --batch; "
                          "configs[2] at BASELINE's global batch: 16384)")
+    ap.add_argument("--pretrain-steps", type=int, default=650,
+                    help="train this many steps from random init before the warm-up and the timed steps, so that the timed region "
+                         "is the steady-state step (past the 10 M-token dead-latent threshold = 611 steps and the lr warm-up); the "
+                         "first 5 + 20 of them are timed as `from_random_init`.  0 = time from random init (rounds 1-3)")
     ap.add_argument("--sustained-steps", type=int, default=2000,
-                    help="length of the steady-state segment timed after the headline steps (0 = skip); it starts after "
-                         "--sustained-after further steps, past the (lowered) dead-latent threshold")
-    ap.add_argument("--sustained-after", type=int, default=625)
+                    help="length of a long segment timed after the headline steps (0 = skip): the same loop, continued")
+    ap.add_argument("--sustained-after", type=int, default=0, help="further untimed steps between the headline and that segment")
     ap.add_argument("--no-auxk-probe", action="store_true", help="skip the AuxK-active sub-records (forced dead sets)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` sub-records (configs[0], configs[3] in bf16, configs[1] with 10 Matryoshka prefixes)")
     ap.add_argument("--extract-e2e", action="store_true",
                     help="add the `extract_e2e` sub-record: configs[4] on one GPU -- ViT-L/14-shaped transformer forward (random init, "
                          "bf16 autocast) -> hooks -> device reservoir -> SAE train steps, no disk in between")
+    ap.add_argument("--no-busbw", action="store_true", help="skip the `collectives` sub-record (RCCL bus bandwidth of the step's collectives)")
     ap.add_argument("--n-saes", type=int, default=1,
                     help="train this many SAEs on every batch (the reference's parallel groups); the extra ones differ in "
                          "parameters only and share the first one's x statistics / operand images.  value still counts each batch once")
@@ -192,66 +208,35 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or args.force_dist:
-        import torch.distributed as dist
+        from saev_amd.framework.ddp import init_distributed
 
-        os.environ.setdefault("MASTER_PORT", "29531")
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # (timeouts on every collective, abort on a failed rank: framework/ddp.py)
+        dist = init_distributed(args.backend, rank=rank, world_size=world, device=dev if args.backend == "nccl" else None)
 
     from saev_amd.engine import EngineConfig, SaeEngine
-    from saev_amd.framework.ddp import DataParallelStepper
-
-    def sharded_tail_ok() -> bool:
-        """Three steps of a small SAE with the sharded tail against the all-reduce path on identical data, on every rank."""
-        try:
-            outs = []
-            for mode in ("replicated", "sharded"):
-                e = SaeEngine(EngineConfig(d_model=64, d_sae=512, top_k=8, k_aux=16, dead_threshold_tokens=256, max_batch=128,
-                                           shard_world=world if mode == "sharded" else 1), dev)
-                gg = torch.Generator(device=dev).manual_seed(3)
-                W0 = torch.randn(512, 64, device=dev, generator=gg)
-                W0 /= W0.norm(dim=1, keepdim=True)
-                e.view("W_dec").copy_(W0); e.view("W_enc").copy_(W0.t())
-                st = DataParallelStepper(e, dist, world, force=args.force_dist, tail=mode)
-                gx = torch.Generator(device=dev).manual_seed(100 + rank)
-                for i in range(4):
-                    st.train_step(torch.randn(128, 64, device=dev, generator=gx), 1e-3 * i, 0.05)
-                torch.cuda.synchronize()
-                outs.append({k: v.clone() for k, v in e.param_views().items()})
-            ok = all(torch.allclose(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-7) for k in outs[0])
-            # every rank must hold the same parameters as rank 0
-            ref0 = torch.cat([v.reshape(-1) for v in outs[1].values()]).clone()
-            dist.broadcast(ref0, src=0)
-            ok = ok and torch.equal(ref0, torch.cat([v.reshape(-1) for v in outs[1].values()]))
-        except Exception as exc:  # any failure of the new path means: use the old one
-            print(f"[bench] sharded-tail self-check failed on rank {rank}: {exc!r}", file=sys.stderr)
-            ok = False
-        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item())
-
-    tail_mode = "replicated"
-    if dist is not None and not args.overlap and args.exchange == "dense":
-        if args.tail == "sharded" or (args.tail == "auto" and sharded_tail_ok()):
-            tail_mode = "sharded"
+    from saev_amd.framework.ddp import DataParallelStepper, choose_exchange, collective_busbw
 
     B = args.batch
     strong = args.global_batch > 0
     if strong:
         assert args.global_batch % world == 0, "--global-batch must divide evenly over the ranks"
         B = args.global_batch // world
-    sparse = dist is not None and args.exchange == "sparse"
+    # Which exchange runs (framework/ddp.py: choose_exchange): `--tail auto` takes the sharded tail when a start-up self-check
+    # on a small SAE reproduces the all-reduce path on every rank, the replicated one otherwise; `--exchange auto` picks the
+    # sparse step state for per-rank batches of at most 4 096 rows, verified the same way; explicit choices are honoured.
+    tail_mode, exchange_mode, exchange_report = "replicated", "dense", {}
+    if dist is not None and not args.overlap:
+        tail_mode, exchange_mode, exchange_report = choose_exchange(
+            dist, world, rank, dev, B, tail=args.tail if args.exchange == "dense" else "auto", exchange=args.exchange)
+
+    sparse = dist is not None and exchange_mode == "sparse"
     # The reference's dead-latent threshold, 10 M tokens (objectives.py:24), is 611 of these steps: the sustained segment
     # below starts after it, so it runs in the regime a real run spends its life in (tracker consulted every step, AuxK on
     # whatever is dead).
     dead_thr = 10_000_000
     # (the sparse-state exchange runs the backward over every rank's rows: scratch for the global batch)
-    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B * (world if sparse else 1), dead_threshold_tokens=dead_thr,
-                        shard_world=world if tail_mode == "sharded" else 1)
+    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=B, max_backward_rows=B * world if sparse else 0,
+                        dead_threshold_tokens=dead_thr, shard_world=world if tail_mode == "sharded" else 1)
     if args.encoder:
         import dataclasses
 
@@ -290,27 +275,6 @@ def main():
         for st2 in extra:
             st2.train_step(x, lr_sched(i), 1.0)
 
-    for i in range(args.warmup):
-        one_step(i)
-    eng.enable_kernel_timing(True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        one_step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    enc_ms = eng.encoder_ms()
-    stats = eng.read_stats()
-    eng.enable_kernel_timing(False)
-
     def timed(first, n):
         if dist is not None:
             dist.barrier()
@@ -328,9 +292,41 @@ def main():
             t = tt.item()
         return t
 
+    # ---- state preparation: from random init into the regime a run lives in (the first 5 + 20 steps timed on the way) ----
+    step_i = 0
+    early = None
+    if args.pretrain_steps > 0:
+        n_w, n_t = min(5, args.pretrain_steps), min(20, max(0, args.pretrain_steps - 5))
+        for i in range(n_w):
+            one_step(i)
+        step_i = n_w
+        if n_t > 0:
+            eng.enable_kernel_timing(True)
+            t_e = timed(step_i, n_t)
+            step_i += n_t
+            early = {"ms_per_step": t_e / n_t * 1e3, "activations_per_sec": B * world * n_t / t_e, "warmup": n_w, "steps": n_t,
+                     "encoder_kernel_ms": eng.encoder_ms(),
+                     "note": "the first steps from random init (the timed region of rounds 1-3): ~19 000 of 32 768 latents still unused, "
+                             "nothing near the dead-latent threshold, so no AuxK work"}
+            eng.enable_kernel_timing(False)
+        for i in range(step_i, args.pretrain_steps):
+            one_step(i)
+        step_i = max(step_i, args.pretrain_steps)
+    # ---- the contract's region: W untimed warm-up steps, then exactly K timed steps ---------------------------------------
+    first_warm = step_i
+    for i in range(step_i, step_i + args.warmup):
+        one_step(i)
+    step_i += args.warmup
+    eng.enable_kernel_timing(True)
+    dt = timed(step_i, args.steps)
+    step_i += args.steps
+    enc_ms = eng.encoder_ms()
+    stats = eng.read_stats()
+    aux_route_timed = eng.aux_route()
+    eng.enable_kernel_timing(False)
+
     # ---- steady state: a long segment well past the dead-latent threshold -----------------------------------------
     sustained = None
-    step_i = args.warmup + args.steps
     if args.sustained_steps > 0:
         for i in range(step_i, step_i + args.sustained_after):
             one_step(i)
@@ -345,8 +341,8 @@ def main():
             "dead_threshold_tokens": dead_thr, "tokens_seen_at_start": (step_i - args.sustained_steps) * B * world,
             "n_dead_last": st_s.n_dead, "aux_last": st_s.aux, "mse_last": st_s.mse, "aux_route_last": eng.aux_route(),
             "n_dead_readbacks_in_segment": eng.dead_readbacks() - rb0,
-            "note": "same loop as the headline, continued: lr warm-up ends at step 500; every step of the segment is past the "
-                    "dead-latent threshold (tracker consulted, AuxK kernels enqueued on the device-side count)",
+            "note": "the headline's loop, continued for a long window (the step time keeps fluctuating by a few per cent with the "
+                    "number of latents that happen to be dead: tools/experiments/long_run_probe.py)",
         }
 
     # ---- AuxK active on a forced dead set (configs[2]'s single-GPU half) --------------------------------------------
@@ -381,6 +377,15 @@ def main():
             other_config_record(dev, name="configs[1] with the reference's default objective: 10 Matryoshka prefixes sampled per step",
                                 d=D_MODEL, s=D_SAE, k=TOP_K, b=BATCH, encoder=args.encoder, n_prefixes=10),
         ]
+    # ---- the step's own collectives at their real sizes (N > 1): which side of the dense / sparse crossover is this node on? ----
+    collectives = None
+    if dist is not None and args.backend == "nccl" and not args.no_busbw:
+        sparse_rows = min(B, 2048)  # configs[2]'s per-rank share of a 16 384-row global batch
+        collectives = collective_busbw(dist, world, dev, eng.n_params, eng.chunk_a if eng.cfg.shard_world > 1 else (D_SAE + 1 + world - 1) // world * D_MODEL,
+                                       eng.chunk_b if eng.cfg.shard_world > 1 else ((D_MODEL * D_SAE + D_SAE + world - 1) // world + 3) // 4 * 4,
+                                       sparse_bytes_per_rank=sparse_rows * (8 * D_MODEL + 8 * TOP_K))
+        collectives["note"] = ("RCCL on the live communicator, mean of 5 after 2 warm-up calls, max over ranks; busbw = algbw x 2(n-1)/n (all-reduce) "
+                               "or x (n-1)/n (reduce-scatter / all-gather); the sparse step state is sized for 2 048 rows per rank")
     extract_e2e = None
     if world == 1 and args.extract_e2e:
         from tools.bench_extract_e2e import run as extract_run
@@ -454,9 +459,17 @@ def main():
                                 note="predicted row bounds verified by the select stage; `repeats` launches (of `launches`, whole "
                                      "run) had a failed prediction and were re-run with guaranteed bounds on the device"),
             "roofline": roof,
-            "headline_note": f"value = the {args.steps} steps after {args.warmup} warm-up steps from random init (the contract's "
-                             "timed region); see `sustained` for the steady-state figure of the same loop",
+            "timed_region": {"first_step": first_warm + args.warmup, "pretrain_steps": args.pretrain_steps,
+                             "tokens_seen_at_start": (first_warm + args.warmup) * B * world, "dead_threshold_tokens": dead_thr,
+                             "n_dead_last": stats.n_dead, "aux_route_last": aux_route_timed,
+                             "note": (f"value = {args.steps} steps after {args.warmup} warm-up steps, both AFTER {args.pretrain_steps} training steps "
+                                      "from random init (state preparation: past the dead-latent threshold and the lr warm-up) -- the "
+                                      "steady-state train step of SURVEY.md 8d; `from_random_init` has the early-training figure"
+                                      if args.pretrain_steps > 0 else
+                                      f"value = {args.steps} steps after {args.warmup} warm-up steps from random init (--pretrain-steps 0)")},
         }
+        if early is not None:
+            out["from_random_init"] = early
         if sustained is not None:
             out["sustained_ms_per_step"] = sustained["ms_per_step"]
             out["sustained"] = sustained
@@ -466,6 +479,10 @@ def main():
             out["other_configs"] = other_configs
         if extract_e2e is not None:
             out["extract_e2e"] = extract_e2e
+        if collectives is not None:
+            out["collectives"] = collectives
+        if exchange_report:
+            out["exchange_selection"] = exchange_report
         if world == 1 and not args.no_cpu_baseline:
             out.update(mse_vs_oracle(eng, x))
             out["cpu_baseline"] = cpu_baseline()

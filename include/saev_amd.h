@@ -68,6 +68,10 @@ typedef struct {
                                         with an automatic second launch on guaranteed bounds whenever a prediction
                                         fails; codes and values are the same either way (saev_bound_state reports z
                                         and how often the second launch was needed).                                 */
+    int32_t max_backward_rows;     /* 0 = max_batch.  Larger: the backward may cover that many rows (saev_backward_override:
+                                      the rows of ALL data-parallel ranks); sizes only the backward's pair order, slice-major
+                                      copies and partial rows -- the forward's buffers (candidate lists, dense fallback,
+                                      AuxK, ...) stay at max_batch, which is then the LOCAL batch.                      */
 } saev_cfg;
 
 /* Element offsets of the four tensors inside each flat buffer, its total length, and the per-rank chunk lengths of the

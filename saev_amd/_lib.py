@@ -22,7 +22,7 @@ class SaevCfg(C.Structure):
         ("alpha", C.c_float), ("dead_threshold_tokens", C.c_int64),
         ("normalize_w_dec", C.c_int32), ("remove_parallel_grads", C.c_int32),
         ("max_batch", C.c_int32), ("encoder_mode", C.c_int32), ("aux_dead_cap", C.c_int32),
-        ("shard_world", C.c_int32), ("bound_mode", C.c_int32),
+        ("shard_world", C.c_int32), ("bound_mode", C.c_int32), ("max_backward_rows", C.c_int32),
     ]
 
 

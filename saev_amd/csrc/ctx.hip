@@ -62,6 +62,7 @@ struct saev_ctx {
     int32_t* grp_prefix = nullptr;
     int32_t* scan_totals = nullptr;
     int bitmap_words = 0;
+    int back_rows = 0;  // max(max_batch, max_backward_rows): rows a (gathered) backward may cover
     int bitmap_words_last = 0;
     bool bitmap_clean = false;  // every word the next csc build will use is zero (the last full backward cleared behind itself)
     int bitmap_clean_words = 0; // ... for row pitches up to this many words
@@ -284,6 +285,12 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
         return SAEV_HIP_ERROR;
     }
     const long S = cfg->d_sae, D = cfg->d_model, MB = cfg->max_batch, K = c->cfg.top_k, KA = cfg->k_aux;
+    // rows a BACKWARD may cover: the context's own batch, or -- gathered backward of a data-parallel run that exchanges the
+    // sparse step state -- every rank's rows.  Only the latent-major pair order, the slice-major copies and the partial rows
+    // are sized by it; everything the forward writes stays at max_batch.
+    const long MBB = std::max<long>(MB, cfg->max_backward_rows);
+    c->back_rows = (int)MBB;
+    if ((uint64_t)MBB * K >= (1ull << 31)) { delete c; return SAEV_INVALID_ARG; }
     // Flat layout [W_dec | b_dec | pad | W_enc | b_enc | pad].  With shard_world = N > 1 each half is padded to N equal
     // chunks -- chunks of the first half are whole decoder rows -- so that a data-parallel run can reduce-scatter the
     // gradient halves, let every rank run the tail on its chunk of each, and all-gather the parameter halves separately
@@ -305,13 +312,13 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (KA > 0) { A(aux_idx, MB * KA); A(aux_val, MB * KA); A(g_aux, MB * D); A(dead_list, S); }
     A(x_hat, MB * D); A(g, MB * D);
     A(rowstats, MB);
-    c->bitmap_words = (int)(((MB + 31) / 32 + 7) / 8 * 8);
+    c->bitmap_words = (int)(((MBB + 31) / 32 + 7) / 8 * 8);
     A(bitmap, S * c->bitmap_words);
     A(grp_prefix, S * (c->bitmap_words / 8));
     A(scan_totals, ((S + 1023) / 1024) * 3);
-    A(counts, S); A(starts, S + 1); A(pairs, MB * K); A(dval_pairs, MB * (size_t)cfg->top_k);
+    A(counts, S); A(starts, S + 1); A(pairs, MBB * K); A(dval_pairs, MBB * (size_t)cfg->top_k);
     {
-        const long max_pairs = MB * K;
+        const long max_pairs = MBB * K;
         c->max_work = (int)(S + (max_pairs + DW_CHUNK - 1) / DW_CHUNK);
         c->max_part = (int)(2 * ((max_pairs + DW_CHUNK - 1) / DW_CHUNK) + 2);
     }
@@ -319,14 +326,14 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     A(dW_encT, S * D); A(partials, (size_t)c->max_part * 2 * D); A(db_partials, c->max_part); A(row_proj, S); A(enc_sq, S);
     {
         const bool rows_only = c->dbg.dw_route == 1;
-        c->dws_ok = !rows_only && D % DWS_SLICE == 0 && (uint64_t)S * D * 4ull < (1ull << 32) && MB < (1l << 24) &&
-                    (uint64_t)MB * K < (1ull << 31);
+        c->dws_ok = !rows_only && D % DWS_SLICE == 0 && (uint64_t)S * D * 4ull < (1ull << 32) && MBB < (1l << 24) &&
+                    (uint64_t)MBB * K < (1ull << 31);
     }
     if (c->dws_ok) {
-        A(gS, MB * D); A(xS, MB * D); A(dvp, (size_t)(D / DWS_SLICE) * MB * K);
-        A(pv, MB * K); A(pv2, MB * K); A(plat, MB * K); A(cut_lat, (MB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
+        A(gS, MBB * D); A(xS, MBB * D); A(dvp, (size_t)(D / DWS_SLICE) * MBB * K);
+        A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
     }
-    A(colsum_partials, ((MB + 63) / 64) * D);
+    A(colsum_partials, ((MBB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32 || KA > 0) {  // (the f32 encoder needs the image geometry for AuxK only)
         c->Dp = (int)((D + 31) / 32 * 32);
@@ -1351,7 +1358,7 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     a.counts = c->counts; a.starts = c->starts; a.pairs = c->pairs;
     a.chunk_starts = c->chunk_starts; a.part_starts = c->part_starts; a.work_latent = c->work_latent;
     // (a gathered backward -- the rows of all ranks, row-major -- gets its slice-major copies here; Matryoshka ones keep dw_rows)
-    const bool ov_slices = ov && c->dws_ok && c->P_last == 1 && n <= c->cfg.max_batch;
+    const bool ov_slices = ov && c->dws_ok && c->P_last == 1 && n <= c->back_rows;
     c->dws_pairs = ov ? ov_slices : c->dws_rows == n;
     if (ov_slices) {
         HIPCHK(c, launch_slice_major_copy(c->ov_g, c->ov_x, n, D, c->gS, c->xS, s));
@@ -1414,7 +1421,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         // all latents of this context's own batch (in one pass or as the decoder / encoder halves of a two-pass backward): column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
         DwSlicesArgs w{};
         w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->P_last > 1 ? c->GS : c->gS; w.xS = c->xS; w.W_dec = a.W_dec; w.P = c->P_last;
-        w.n_rows = n; w.D = D; w.S = S; w.pair_cap = (int)((long)c->cfg.max_batch * K);
+        w.n_rows = n; w.D = D; w.S = S; w.pair_cap = (int)((long)c->back_rows * K);
         w.dvp = c->dvp; w.dW_dec = a.dW_dec; w.dW_encT = a.dW_encT; w.db_enc = a.db_enc;
         const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;
         w.part_dec = c->partials; w.part_enc = c->partials + 2 * runs_cap * D;  // (max_part * 2 rows hold 4 * runs_cap)
@@ -1471,8 +1478,8 @@ int saev_backward_override(saev_ctx* c, const float* x_all, const float* g_all, 
     if (!c) return SAEV_INVALID_ARG;
     if (x_all == nullptr) { c->ov_x = nullptr; c->ov_n = 0; return SAEV_OK; }
     REQUIRE(c, g_all && idx_all && val_all && n_all > 0, SAEV_INVALID_ARG, "saev_backward_override: NULL buffer");
-    REQUIRE(c, n_all <= c->cfg.max_batch, SAEV_INVALID_ARG,
-            "saev_backward_override: the gathered row count exceeds max_batch (create the context for the GLOBAL batch)");
+    REQUIRE(c, n_all <= c->back_rows, SAEV_INVALID_ARG,
+            "saev_backward_override: the gathered row count exceeds saev_cfg.max_backward_rows (set it to the GLOBAL batch)");
     REQUIRE(c, c->x_last && c->training_last, SAEV_INVALID_ARG, "saev_backward_override: no training forward in flight");
     REQUIRE(c, ((uintptr_t)x_all % 16) == 0 && ((uintptr_t)g_all % 16) == 0, SAEV_INVALID_ARG, "x_all / g_all must be 16-byte aligned");
     c->ov_x = x_all; c->ov_g = g_all; c->ov_idx = idx_all; c->ov_val = val_all; c->ov_n = n_all;
@@ -1628,6 +1635,7 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     hipStream_t s = (hipStream_t)stream;
     AdamArgs a{};
     a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
+    a.omb1 = (float)(1.0 - 0.9); a.omb2 = (float)(1.0 - 0.999);
     a.bc1 = (float)(1.0 - std::pow(0.9, (double)adam_step));
     a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(0.999, (double)adam_step));
     a.grad_scale = grad_scale; a.max_norm = max_norm; a.sumsq = saev_sumsq_device(c); a.stats = c->stats;

@@ -294,6 +294,8 @@ struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     long n;
     float lr, beta1, beta2, eps, bc1, bc2_sqrt;  // bias corrections for this step
+    float omb1, omb2;       // 1 - beta1, 1 - beta2 formed in DOUBLE and rounded once, as torch does with its Python-float betas
+                            // (1.f - 0.999f is 1.3e-5 below float(1 - 0.999): fixture G8 on the HIP kernel found it)
     float grad_scale;       // applied to g before everything else (1/world_size)
     float max_norm;         // torch semantics for >= 0 (0 zeroes the gradient); < 0 disables clipping
     const double* sumsq;    // device: sum of squares of the *unscaled* grads

@@ -164,8 +164,8 @@ struct AdamElem { float p, m, v; };
 __device__ __forceinline__ AdamElem adam_elem(float p, float ge, float m, float v, const AdamArgs& a, float step_size) {
 #pragma clang fp contract(off)
     const float d = ge - m;
-    m = __builtin_fmaf(d, 1.f - a.beta1, m);
-    const float g2 = (1.f - a.beta2) * ge;
+    m = __builtin_fmaf(d, a.omb1, m);
+    const float g2 = a.omb2 * ge;
     const float g3 = g2 * ge;
     v = __builtin_fmaf(a.beta2, v, g3);
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;

@@ -238,9 +238,14 @@ class ExtractionFeed:
                 if res.room() < self._block_rows:
                     raise RuntimeError("reservoir cannot take another block and holds nothing to draw")
                 continue
-            got = res.get(min(self.local_batch, left))
+            asked = min(self.local_batch, left)
+            got = res.get(asked)
             act, ex, tk = got
+            if act.shape[0] < asked and not more and self.world > 1:
+                # fewer rows than asked for: the images ran out mid-epoch on this rank only -- the same hang as above
+                raise RuntimeError(f"rank {self.rank}: images exhausted with {left} of {self.n_epoch} rows of the epoch still to deliver "
+                                   f"(a draw of {asked} rows returned {act.shape[0]}); every rank must be given examples for n_examples / world_size")
             if act.shape[0] < self.local_batch and self.drop_last:
-                return
+                return  # (the epoch's last, partial batch: n_epoch is the same on every rank, so all ranks stop here together)
             left -= act.shape[0]
             yield {"act": act, "example_idx": ex, "token_idx": tk}

@@ -35,6 +35,8 @@ class EngineConfig:
     aux_dead_cap: int = 0      # largest dead set the dense AuxK buffers are sized for at creation; 0 = min(d_sae, max(4096,
                                # 8 k_aux)); a step that meets more dead latents raises and names this field
     shard_world: int = 1       # > 1: flat buffers padded so that this many data-parallel ranks can each own 1/N of the tail
+    max_backward_rows: int = 0  # 0 = max_batch; the GLOBAL batch for the sparse-state exchange (gathered backward over every
+                                # rank's rows): sizes the backward's scratch only, the forward's buffers stay at max_batch
     # TopK candidate bounds of the fused encoder: "guaranteed" (default), or "predicted": verified extrapolated bounds
     # with an automatic guaranteed-bound re-run when a prediction fails -- same codes either way; measured no faster over
     # a training run (tools/experiments/README.md), kept as an option.  SAEV_AMD_BOUNDS overrides the default
@@ -136,7 +138,7 @@ class SaeEngine:
                 normalize_w_dec=int(cfg.normalize_w_dec), remove_parallel_grads=int(cfg.remove_parallel_grads),
                 max_batch=cfg.max_batch, encoder_mode={"f32": 0, "f16x3": 1, "bf16": 2, "f16r": 3}[cfg.encoder],
                 aux_dead_cap=cfg.aux_dead_cap, shard_world=cfg.shard_world,
-                bound_mode={"guaranteed": 0, "predicted": 1}[cfg.bounds],
+                bound_mode={"guaranteed": 0, "predicted": 1}[cfg.bounds], max_backward_rows=cfg.max_backward_rows,
             )
             if cfg.dw_route not in ("slices", "rows") or cfg.fwd_route not in ("default", "rows"):
                 raise ValueError(f"EngineConfig.dw_route must be 'slices' or 'rows' and fwd_route 'default' or 'rows', got {cfg.dw_route!r} / {cfg.fwd_route!r}")
@@ -329,9 +331,10 @@ class SaeEngine:
         key = (world, n_local, P)
         if getattr(self, "_gather_key", None) != key:
             n, D, K = world * n_local, self.cfg.d_model, min(self.cfg.top_k, self.cfg.d_sae)
-            if n > self.cfg.max_batch:
-                raise _lib.SaevError(f"gathered backward over {n} rows needs an engine with max_batch >= {n} (the GLOBAL batch), "
-                                     f"got {self.cfg.max_batch}")
+            cap = max(self.cfg.max_batch, self.cfg.max_backward_rows)
+            if n > cap:
+                raise _lib.SaevError(f"gathered backward over {n} rows needs an engine with max_backward_rows >= {n} (the GLOBAL batch), "
+                                     f"got {cap}")
             self._gather_bufs = (torch.empty(n, D, device=self.device), torch.empty(n, P * D, device=self.device),
                                  torch.empty(n, K, device=self.device, dtype=torch.int32), torch.empty(n, K, device=self.device))
             self._gather_key = key

@@ -202,16 +202,26 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
     saes = saes.to(device)
     objs.train()
     steppers, scheds, lrs = [], [], []
-    # how the optimizer tail is spread over data-parallel ranks (framework/ddp.py): every rank all of it, or 1/world each
-    tail_mode = os.environ.get("SAEV_AMD_DDP_TAIL", "replicated") if world > 1 else "replicated"
-    # how the ranks exchange a step (framework/ddp.py): the gradient ("dense"), or -- small per-rank batches, strong scaling
-    # -- the sparse step state, every rank running the backward over the global batch ("sparse")
-    exchange = os.environ.get("SAEV_AMD_DDP_EXCHANGE", "dense") if world > 1 else "dense"
+    # How the ranks exchange a step (framework/ddp.py: choose_exchange).  Default "auto", the selection bench.py makes: the
+    # sparse step state when a rank holds at most 4 096 rows, else the gradient with the sharded tail (reduce-scatter, 1/world
+    # of the tail per rank, all-gather) -- each taken only if a start-up self-check on a small SAE reproduces the plain
+    # all-reduce path on every rank; the flat all-reduce with a replicated tail otherwise.  SAEV_AMD_DDP_TAIL
+    # (replicated | sharded) and SAEV_AMD_DDP_EXCHANGE (dense | sparse) pin a choice.
+    tail_mode, exchange = "replicated", "dense"
+    if world > 1:
+        from .ddp import choose_exchange
+
+        tail_mode, exchange, report = choose_exchange(dist, world, rank, device, dataloader.local_batch,
+                                                      tail=os.environ.get("SAEV_AMD_DDP_TAIL", "auto"),
+                                                      exchange=os.environ.get("SAEV_AMD_DDP_EXCHANGE", "auto"))
+        logger.info("data-parallel exchange: tail=%s exchange=%s (%s)", tail_mode, exchange, report)
     for sae, obj, c in zip(saes, objs, cfgs):
         if tail_mode == "sharded":
             sae._shard_world = world  # the engine lays its flat buffers out in `world` equal chunks per half
-        # (the gathered backward covers every rank's rows: its scratch is sized for the global batch)
-        eng = obj._bind(sae, dataloader.local_batch * (world if exchange == "sparse" else 1))
+        if exchange == "sparse":
+            # the gathered backward covers every rank's rows: ITS scratch is sized for the global batch, the forward's stays local
+            sae._max_backward_rows = dataloader.local_batch * world
+        eng = obj._bind(sae, dataloader.local_batch)
         if world > 1:  # identical replicas: rank 0's initial parameters everywhere
             dist.broadcast(eng.params, src=0)
         if steppers:  # one batch feeds every SAE of the group (train.py:334-348): the first engine's x statistics,

@@ -236,7 +236,7 @@ class SparseAutoencoder(torch.nn.Module):
             k_aux=aux.k_aux if isinstance(aux, AuxK) else 0, alpha=aux.alpha if isinstance(aux, AuxK) else 0.0,
             dead_threshold_tokens=thr, normalize_w_dec=self.cfg.normalize_w_dec,
             remove_parallel_grads=self.cfg.remove_parallel_grads, max_batch=max_batch,
-            shard_world=getattr(self, "_shard_world", 1),
+            shard_world=getattr(self, "_shard_world", 1), max_backward_rows=getattr(self, "_max_backward_rows", 0),
         )
 
     def _eng(self, max_batch: int = 0) -> SaeEngine:
@@ -252,6 +252,7 @@ class SparseAutoencoder(torch.nn.Module):
             eng is None or eng.device != dev or eng.cfg.max_batch < want_batch
             or eng.cfg.dead_threshold_tokens != getattr(self, "_dead_threshold_tokens", eng.cfg.dead_threshold_tokens)
             or eng.cfg.shard_world != getattr(self, "_shard_world", eng.cfg.shard_world)
+            or max(eng.cfg.max_batch, eng.cfg.max_backward_rows) < getattr(self, "_max_backward_rows", 0)
             or any(getattr(self, n).data_ptr() != eng.view(n).data_ptr() for n in eng.offsets)
         )
         if stale:

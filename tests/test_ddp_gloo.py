@@ -315,3 +315,73 @@ def test_ranks_reproduce_single_process_step(tmp_path, world, overlap, tail, exc
         R.train_step(ref_state, x, cfg, sched)
     for k in R.PARAM_ORDER:
         torch.testing.assert_close(single.state.params[k], ref_state.params[k], rtol=1e-5, atol=1e-7)
+
+
+# ---- failure policy ("rank-failure = abort") -------------------------------------------------------------
+
+
+def test_watchdog_names_the_last_collective_of_a_stalled_step():
+    """A step that makes no progress for `timeout_s` is reported with rank, step and the last collective enqueued (the
+    product ends the process there; the test swaps the exit for a callback)."""
+    import time
+
+    from saev_amd.framework.ddp import CollectiveWatchdog
+
+    seen = []
+    wd = CollectiveWatchdog(rank=3, timeout_s=0.2, poll_s=0.05, on_stall=seen.append)
+    try:
+        wd.begin_step(7)
+        wd.enter("reduce_scatter(decoder half of the gradient)")
+        wd.leave()
+        time.sleep(0.1)
+        assert seen == [], "inside the budget: nothing reported"
+        wd.enter("all_reduce(sum of squares for the clip norm)")
+        time.sleep(0.6)  # ... and the step never ends
+        assert seen == ["all_reduce(sum of squares for the clip norm)"]
+        # a finished step is never reported, however long the pause between steps
+        wd.begin_step(8)
+        wd.end_step()
+        time.sleep(0.5)
+        assert len(seen) == 1
+    finally:
+        wd.close()
+
+
+def _failing_worker(rank, world, port, out):
+    """Rank 1 dies before its third step; rank 0 must not hang: the stepper's watchdog ends it with exit code 13."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    torch.set_num_threads(1)
+    cfg, params, batches = _problem()
+    eng = OracleEngine(params, cfg)
+    stepper = DataParallelStepper(eng, dist, world, timeout_s=2.0)
+    for i, x in enumerate(batches):
+        if rank == 1 and i == 2:
+            os._exit(0)  # a crashed peer: no destroy_process_group, no goodbye
+        stepper.train_step(x[rank::world].contiguous(), 1e-3, cfg.grad_clip)
+        if rank == 0:
+            with open(out, "a") as f:
+                f.write(f"{i}\n")
+
+
+@pytest.mark.timeout(120)
+def test_a_dead_rank_aborts_the_survivor_instead_of_hanging_it(tmp_path):
+    import time
+
+    out = tmp_path / "progress.txt"
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, str(out))) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(90)
+    assert all(not p.is_alive() for p in procs), "the surviving rank hung"
+    assert procs[1].exitcode == 0
+    # rank 0 finished two steps, then either its watchdog (13) or gloo's own error on the broken pipe ended it -- never a clean 0
+    assert out.read_text().split() == ["0", "1"]
+    assert procs[0].exitcode not in (0, None), procs[0].exitcode
+    assert time.time() - t0 < 90

@@ -293,7 +293,7 @@ def _train_worker(rank, world, port, shards, out, env):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["replicated", "sharded", "sparse"])
+@pytest.mark.parametrize("mode", ["replicated", "sharded", "sparse", "auto"])
 def test_two_rank_train_on_one_gpu_ends_with_identical_checkpoints(tmp_path, mode, encoder_mode):
     """framework.train.train() itself under two ranks (two processes on the test box's one GPU, gloo): both ranks take the
     same number of optimizer steps -- the number one process takes on the same global batches -- log the same global-batch
@@ -310,8 +310,9 @@ def test_two_rank_train_on_one_gpu_ends_with_identical_checkpoints(tmp_path, mod
     basis = rng.standard_normal((24, 64)).astype(np.float32)
     acts = (rng.standard_normal((300, 1, 4, 24)).astype(np.float32) ** 3) @ basis + 0.1 * rng.standard_normal((300, 1, 4, 64)).astype(np.float32)
     shards = data.write_shards(tmp_path / "cache", acts, layers=(5,), cls_token=False, max_tokens_per_shard=4 * 40)
-    env = {"SAEV_AMD_DDP_TAIL": "sharded" if mode == "sharded" else "replicated",
-           "SAEV_AMD_DDP_EXCHANGE": "sparse" if mode == "sparse" else "dense"}
+    # ("auto": train()'s default -- choose_exchange's start-up self-check picks the exchange; 128 rows per rank: the sparse one)
+    env = {} if mode == "auto" else {"SAEV_AMD_DDP_TAIL": "sharded" if mode == "sharded" else "replicated",
+                                     "SAEV_AMD_DDP_EXCHANGE": "sparse" if mode == "sparse" else "dense"}
     out = str(tmp_path / "rank{rank}.pt")
     mp.spawn(_train_worker, args=(2, _free_port(), str(shards), out, env), nprocs=2, join=True)
     r0, r1 = (torch.load(out.format(rank=r)) for r in range(2))

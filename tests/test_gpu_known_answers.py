@@ -29,7 +29,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-BIG = 1024.0
+BIG = 64.0  # (the opt-in f16x3 encoder pre-scales W_enc by 2^8 before its fp16 split: |W_enc| must stay below 255 there)
 THR = 1000
 
 

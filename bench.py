@@ -10,8 +10,9 @@ bookkeeping, backward, rpg, clip, Adam).  With N > 1 ranks (launched by torch.di
 batch is per-GPU (weak scaling) and each step exchanges the 268 MB gradient over RCCL -- reduce-scatter, 1/N of the
 optimizer tail per rank, all-gather of the parameters (`--tail`, framework/ddp.py) -- plus the fired-latent flags.
 
-Timed region ("steady-state train step"): the loop first trains `--pretrain-steps` steps (default 650: past the
-reference's dead-latent threshold of 10 M tokens = 611 of these steps, and past the 500-step lr warm-up), then runs the
+Timed region ("steady-state train step"): the loop first trains `--pretrain-steps` steps (default 1 500: past the
+reference's dead-latent threshold of 10 M tokens = 611 of these steps, past the 500-step lr warm-up, and past the ~1 000 steps
+over which latent usage spreads and the gather kernels lose their L2 hits -- the step time is flat from there on), then runs the
 contract's W untimed warm-up steps and times exactly K steps.  `value` is therefore the step a training run spends its
 life in -- tracker consulted, AuxK on whatever is dead, latent usage spread over ~27 000 latents.  The first 5 + 20 steps
 from random init (what rounds 1-3 reported; ~18 % faster because 19 000 latents are still unused and AuxK is off) are
@@ -177,9 +178,11 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many rows per step in total, split evenly over the ranks (overrides --batch; "
                          "configs[2] at BASELINE's global batch: 16384)")
-    ap.add_argument("--pretrain-steps", type=int, default=650,
+    ap.add_argument("--pretrain-steps", type=int, default=1500,
                     help="train this many steps from random init before the warm-up and the timed steps, so that the timed region "
-                         "is the steady-state step (past the 10 M-token dead-latent threshold = 611 steps and the lr warm-up); the "
+                         "is the steady-state step: past the 10 M-token dead-latent threshold (611 steps), the lr warm-up (500) and "
+                         "the ~1 000 steps over which latent usage keeps spreading and the step keeps slowing down "
+                         "(tools/experiments/long_run_probe.py: 2.8 ms at step 100, 3.07 at 700, 3.25-3.35 from 1 200 to 8 000); the "
                          "first 5 + 20 of them are timed as `from_random_init`.  0 = time from random init (rounds 1-3)")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="length of a long segment timed after the headline steps (0 = skip): the same loop, continued")

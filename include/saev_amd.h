@@ -135,9 +135,12 @@ typedef struct {
     int32_t enc_wgs;       /* workgroups the fused encoder's grid aims at (0 = 256, one per CU)                           */
     int32_t refresh_first; /* bound refresh on a workgroup's first N tiles (0 = 8) ...                                    */
     int32_t refresh_every; /* ... then on every M-th, M a power of two (0 = 2; the 64-group bound defaults to 1)          */
-    int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 48; -1 = never (dense algebra
-                              whatever the count); values above 48 are clamped                                           */
-    int32_t fwd_route;     /* decode / exact refinement: 0 default, 1 whole-row gathers always                            */
+    int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 16; -1 = never (dense algebra
+                              whatever the count); values above 64 are clamped                                           */
+    int32_t fwd_route;     /* exact refinement of the f16r encoder: 0 = from 32-column slices of W_enc^T that the XCD L2s hold
+                              where the geometry allows, 1 = whole-row gathers always                                   */
+    int32_t dead_lag;      /* saev_step_dead sizes the auxiliary work from the tracker record of this many steps ago
+                              (0 = 4, at most 8): shorter = tighter bound of the dead count, longer = more host run-ahead  */
 } saev_debug_cfg;
 
 int saev_abi_version(void);
@@ -224,7 +227,7 @@ int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_r
  * forward (modeling.py:75-103).  Training mode only.  The reference reads n_dead back on every step
  * (`.item()`, modeling.py:92).  Here the update kernel leaves a record in pinned host memory each step; the
  * call looks at the record of four steps earlier, which bounds the current count from above, and while that
- * bound is <= min(48, k_aux) -- zero dead latents included -- it enqueues kernels that take the count from
+ * bound is <= min(16, k_aux) -- zero dead latents included -- it enqueues kernels that take the count from
  * the device: no read-back, no stream synchronisation.  Only when the bound is larger (or no valid record
  * exists yet: the first four steps after creation / saev_bind_tracker / saev_tracker_touched) does it read
  * n_dead back and size the dense AuxK algebra on the host.  saev_last_aux_route tells which happened:
@@ -232,6 +235,9 @@ int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_r
  * 3 dense algebra after a read-back; saev_dead_readbacks counts the read-backs so far. */
 int saev_step_dead(saev_ctx* ctx, int64_t n_rows_global, void* stream);
 int saev_last_aux_route(const saev_ctx* ctx);
+/* Device memory the context itself owns, in bytes (the four flat buffers belong to the caller): which = 0 everything,
+ * 1 the AuxK dead-set buffers (sized by saev_cfg.aux_dead_cap), 2 the Matryoshka gradient blocks (saev_set_prefixes). */
+int64_t saev_scratch_bytes(const saev_ctx* ctx, int32_t which);
 int64_t saev_dead_readbacks(const saev_ctx* ctx);
 /* Phase 3: all four parameter gradients into the bound grad buffer (replaces autograd,
  * train.py:347-348), un-projected and un-clipped. */

@@ -30,7 +30,7 @@ class SaevDebugCfg(C.Structure):
     """Route switches (include/saev_amd.h: saev_debug_cfg); all zero = shipped defaults."""
 
     _fields_ = [(n, C.c_int32) for n in ("struct_size", "dw_route", "enc_mfma", "fused_chain", "ngroups", "enc_wgs", "refresh_first",
-                                         "refresh_every", "aux_small_max", "fwd_route")]
+                                         "refresh_every", "aux_small_max", "fwd_route", "dead_lag")]
 
 
 class SaevLayout(C.Structure):
@@ -77,6 +77,7 @@ _SIGNATURES = {
     "saev_step_forward": (C.c_int, [P, P, C.c_int32, C.c_int64, C.c_int32, P]),
     "saev_step_dead": (C.c_int, [P, C.c_int64, P]),
     "saev_last_aux_route": (C.c_int, [P]),
+    "saev_scratch_bytes": (C.c_int64, [P, C.c_int32]),
     "saev_dead_readbacks": (C.c_int64, [P]),
     "saev_step_backward": (C.c_int, [P, P]),
     "saev_backward_begin": (C.c_int, [P, P]),

@@ -49,6 +49,7 @@ struct saev_ctx {
     hipEvent_t wenc_ready = nullptr;  // one-shot: ... before it touches W_enc / b_enc (the x-only preparation runs ahead of it)
     // scratch
     std::vector<void*> allocs;
+    size_t scratch_bytes = 0, aux_bytes = 0;  // device memory the context owns: per-step scratch, AuxK dead-set buffers
     int cuts_last[MAX_PREFIXES] = {0};  // the cut points the forward in flight used (the backward must see the same)
     int32_t *cand_cnt = nullptr, *gmax = nullptr, *cand_idx = nullptr;
     int gmax_stride = 0;
@@ -91,6 +92,12 @@ struct saev_ctx {
     int dws_rows = 0;            // > 0: the copies describe the training forward in flight (that many rows)
     bool dws_pairs = false;      // the CSC build of this backward left pv / plat
     float *gS = nullptr, *xS = nullptr, *dvp = nullptr;
+    // exact refinement of the f16r encoder from 32-column slices (select.hip: refine_slices_kernel): split_f16r leaves x and
+    // W_enc^T slice-major (xS; dW_encT in that layout), rs_part holds the per-slice shares of the survivors' dot products
+    bool fwd_slices = false;     // geometry fits and not switched off (saev_debug_cfg.fwd_route)
+    bool fwd_step = false;       // the forward in flight took that route: xS_c describes its batch, W_enc^T is slice-major
+    float* rs_part = nullptr;
+    float* xS_c = nullptr;       // the slice-major x of the step in flight (own xS, or the leader's: saev_share_x)
     int2 *pv = nullptr, *pv2 = nullptr;
     int32_t *plat = nullptr, *cut_lat = nullptr;
     // saev_train_step: latents without pairs are flagged instead of having their dW_enc^T row zeroed (DwSlicesArgs::lat_unused)
@@ -133,7 +140,8 @@ struct saev_ctx {
     int aux_Dp2 = 0;
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
     float *row_margin = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
-    int32_t *surv_idx = nullptr, *surv_cnt = nullptr;
+    int32_t *surv_idx = nullptr, *surv_cnt = nullptr, *surv_rng = nullptr;
+    int rs_lat_range = 0, rs_n_ranges = 0;
     int32_t* tau_max = nullptr;   // (max_batch) largest predicted bound used per row
     float* heur_state = nullptr;  // [0] z  [1] failed predictions  [2] predicted-bound launches  [3] mean list length
     float *f16r_scales = nullptr, *mu = nullptr, *xnorm = nullptr, *b_shift = nullptr, *dot_part = nullptr, *xabs_part = nullptr,
@@ -206,6 +214,7 @@ int alloc(saev_ctx* c, T** p, size_t count) {
         return SAEV_HIP_ERROR;
     }
     c->allocs.push_back(q);
+    c->scratch_bytes += count * sizeof(T);
     *p = static_cast<T*>(q);
     return SAEV_OK;
 }
@@ -329,6 +338,15 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
         c->dws_ok = !rows_only && D % DWS_SLICE == 0 && (uint64_t)S * D * 4ull < (1ull << 32) && MBB < (1l << 24) &&
                     (uint64_t)MBB * K < (1ull << 31);
     }
+    c->fwd_slices = c->cfg.encoder_mode == SAEV_ENCODER_F16R && c->dbg.fwd_route == 0 && c->dbg.fused_chain == 0 && D % RS_SLICE == 0 &&
+                    (uint64_t)S * 128ull < (1ull << 32) - 256ull && fused_supported(c->cfg);
+    if (c->fwd_slices) {
+        A(rs_part, (size_t)(D / RS_SLICE) * MB * REFINE_CAP); A(surv_rng, MB * RS_MAX_RANGES);
+        // passes over a slice cover RS_LAT_RANGE latents each (x 128 bytes = 2 MB: what an XCD's L2 holds), at most RS_MAX_RANGES
+        c->rs_lat_range = (int)std::max<long>(RS_LAT_RANGE, ((S + RS_MAX_RANGES - 1) / RS_MAX_RANGES + 255) / 256 * 256);
+        c->rs_n_ranges = (int)((S + c->rs_lat_range - 1) / c->rs_lat_range);
+    }
+    if (c->fwd_slices && !c->dws_ok) A(xS, MBB * D);
     if (c->dws_ok) {
         A(gS, MBB * D); A(xS, MBB * D); A(dvp, (size_t)(D / DWS_SLICE) * MBB * K);
         A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
@@ -522,6 +540,11 @@ int saev_share_x(saev_ctx* c, saev_ctx* leader) {
 }
 
 int saev_last_aux_route(const saev_ctx* c) { return c ? c->aux_route : -1; }
+int64_t saev_scratch_bytes(const saev_ctx* c, int32_t which) {
+    if (!c) return -1;
+    const size_t matry = (c->G ? (size_t)c->cfg.max_batch * c->P_cap * c->cfg.d_model * sizeof(float) : 0) * (c->GS ? 2 : 1);
+    return (int64_t)(which == 1 ? c->aux_bytes : which == 2 ? matry : c->scratch_bytes + c->aux_bytes + matry);
+}
 int64_t saev_dead_readbacks(const saev_ctx* c) { return c ? c->n_readbacks : -1; }
 
 int saev_copy_last(saev_ctx* c, int32_t n_rows, int32_t* idx_out, float* val_out, float* x_hat_out, void* stream) {
@@ -612,6 +635,10 @@ static bool bind_x_sources(saev_ctx* c, const float* x, int n, bool allow_borrow
     const bool borrow = allow_borrow && l != nullptr && l->xprep_x == x && l->xprep_n == n && l->xprep_serial != c->leader_serial_seen;
     saev_ctx* src = borrow ? l : c;
     c->upper_c = src->upper; c->mu_c = src->mu; c->xnorm_c = src->xnorm; c->xabs_c = src->xabs_part; c->xs_c = src->xs;
+    // (the slice route of the refinement needs the source's slice-major x as well: a leader without it sends this step down
+    // the row route)
+    c->fwd_step = c->fwd_slices && (src == c || src->fwd_slices);
+    c->xS_c = c->fwd_step ? src->xS : nullptr;
     if (borrow) c->leader_serial_seen = l->xprep_serial;
     return borrow;
 }
@@ -659,12 +686,13 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         if (!x_borrowed && c->wenc_ready == nullptr) {
             // the usual case: nobody's parameter all-gather to wait for in between -- both image passes in one launch
             HIPCHK(c, launch_split_f16r(x, n, D, c->Dp, c->xs, c->f16r_scales, c->mu, c->params + c->off_W_enc, S, c->S_pad, c->ws,
-                                        reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT, s));
+                                        reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT, s, c->fwd_step ? c->xS : nullptr,
+                                        c->fwd_step ? 1 : 0));
         } else {
-            if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu));
+            if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu, c->fwd_step ? c->xS : nullptr));
             { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }  // x is prepared; from here on W_enc / b_enc are read
             HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
-                                      c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT));
+                                      c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT, c->fwd_step ? 1 : 0));
         }
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
                                      c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
@@ -797,6 +825,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 sc.row_margin = c->row_margin; sc.x = x; sc.W_encT = c->dW_encT; sc.b_enc = c->params + c->off_b_enc;
                 sc.D = c->cfg.d_model; sc.refine_overflow = bad;
                 sc.surv_idx = c->surv_idx; sc.surv_val = c->surv_val; sc.surv_cnt = c->surv_cnt;
+                if (c->fwd_step) { sc.surv_rng = c->surv_rng; sc.lat_range = c->rs_lat_range; sc.n_ranges = c->rs_n_ranges; }
                 // saev_debug_cfg.fused_chain: survivors, their exact values and the final cut in ONE launch (select_refine_kernel).
                 // Opt-in: measured 335 us against 351 for the three kernels when all of them run at seven waves per SIMD,
                 // and slower than them (+0.03 ms per step) once lists of 1 025-2 048 entries stay in registers, which the
@@ -809,7 +838,17 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 }
                 HIPCHK(c, launch_select_cand(sc, s));
                 sc.enable_flag = flag; sc.ovf = nullptr;
-                HIPCHK(c, launch_refine_exact(sc, s));
+                if (c->fwd_step) {  // exact values from 32-column slices of W_enc^T that the XCD L2s hold (select.hip)
+                    RefineSlicesArgs rs{};
+                    rs.surv_idx = c->surv_idx; rs.surv_cnt = c->surv_cnt; rs.surv_val = c->surv_val; rs.surv_rng = c->surv_rng;
+                    rs.xS = c->xS_c; rs.WeS = c->dW_encT; rs.b_enc = sc.b_enc; rs.part = c->rs_part;
+                    rs.n_rows = n; rs.S = c->cfg.d_sae; rs.D = c->cfg.d_model;
+                    rs.lat_range = c->rs_lat_range; rs.n_ranges = c->rs_n_ranges;
+                    rs.enable_flag = flag; rs.enable_when = when;
+                    HIPCHK(c, launch_refine_slices(rs, s));
+                } else {
+                    HIPCHK(c, launch_refine_exact(sc, s));
+                }
                 sc.row_margin = nullptr; sc.tau_max = nullptr;
                 sc.cand_cnt = c->surv_cnt; sc.cand_val = c->surv_val; sc.cand_idx = c->surv_idx; sc.cand_cap = REFINE_CAP; sc.cand_stride = REFINE_CAP;
             }
@@ -999,7 +1038,8 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.training = training ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
     c->dws_rows = 0;
-    if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->xS; c->dws_rows = n; }
+    // (slice-major copies for the weight gradients: dL/dx_hat always from the decode, x only when split_f16r has not left one)
+    if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->fwd_step ? nullptr : c->xS; c->dws_rows = n; }
     if (c->P > 1) {
         MatryArgs m{};
         m.P = c->P;
@@ -1028,6 +1068,7 @@ int alloc_aux_buffers(saev_ctx* c, int cap) {
         void* q = nullptr;
         if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
         c->aux_allocs.push_back(q);
+        c->aux_bytes += bytes;
         return q;
     };
     c->Wenc_dead = (float*)grab(D * capA * 4);
@@ -1264,7 +1305,10 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     d.toks = c->toks; d.fired = c->fired; d.dead = c->dead; d.S = S;
     d.add_tokens = n_rows_global; d.threshold = c->cfg.dead_threshold_tokens; d.k_aux = c->cfg.k_aux;
     d.n_dead = c->flags + 4; d.k_use = c->flags + 5; d.stats = c->stats; d.scratch = c->flags + 6;
-    d.horizon_tokens = (int64_t)DEAD_LAG * n_rows_global;
+    // (saev_debug_cfg.dead_lag: how many steps old the record is that sizes this step's auxiliary work -- a shorter lag gives a
+    // tighter bound of the dead count, a longer one lets the host run further ahead of the device)
+    const int lag = c->dbg.dead_lag > 0 ? std::min(c->dbg.dead_lag, DEAD_RING / 2) : DEAD_LAG;
+    d.horizon_tokens = (int64_t)lag * n_rows_global;
     d.step = step; d.cum_tokens = c->tokens_seen;
     d.rec = c->rec_dev ? c->rec_dev + step % DEAD_RING : nullptr;
     HIPCHK(c, launch_dead_update(d, s));
@@ -1283,9 +1327,11 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     // enqueued with the count left on the device and nothing is read back.  The wait below is for an event DEAD_LAG
     // steps in the past; it only ever blocks a host that has run further ahead than that, and never drains the queue.
     // (saev_debug_cfg.aux_small_max: -1 sends every dead set down the dense route, for tests and A/B runs)
-    const int small_cap = c->dbg.aux_small_max < 0 ? 0 : (c->dbg.aux_small_max == 0 ? AUX_SMALL_MAX : std::min(c->dbg.aux_small_max, (int)AUX_SMALL_MAX));
+    // Default AUX_SMALL_DEFAULT: where the two routes cost the same at configs[1] (tools/experiments/r4_aux_sweep.sh: the
+    // few-dead-latents kernels grow with the count, the dense algebra is flat up to 256 dead latents).
+    const int small_cap = c->dbg.aux_small_max < 0 ? 0 : (c->dbg.aux_small_max == 0 ? AUX_SMALL_DEFAULT : std::min(c->dbg.aux_small_max, (int)AUX_SMALL_MAX));
     const int small_max = std::min(small_cap, c->cfg.k_aux);
-    const int64_t s0 = step - DEAD_LAG;
+    const int64_t s0 = step - lag;
     if (s0 >= c->rec_valid_from) {
         HIPCHK(c, hipEventSynchronize(c->dead_ev[s0 % DEAD_RING]));
         const volatile DeadRecord* r = c->rec_host + s0 % DEAD_RING;
@@ -1324,6 +1370,7 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
         const int cap = std::min(s4, std::max(2 * c->nd_cap, (2 * c->n_dead_host + 1023) / 1024 * 1024));
         for (void* q : c->aux_allocs) hipFree(q);
         c->aux_allocs.clear();
+        c->aux_bytes = 0;
         c->nd_cap = 0;
         int rcg = alloc_aux_buffers(c, cap);
         if (rcg != SAEV_OK) {
@@ -1420,7 +1467,8 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     if (lat_lo == 0 && lat_hi == S && c->dws_pairs && (ov || c->dws_rows == n)) {
         // all latents of this context's own batch (in one pass or as the decoder / encoder halves of a two-pass backward): column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
         DwSlicesArgs w{};
-        w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->P_last > 1 ? c->GS : c->gS; w.xS = c->xS; w.W_dec = a.W_dec; w.P = c->P_last;
+        w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->P_last > 1 ? c->GS : c->gS; w.W_dec = a.W_dec; w.P = c->P_last;
+        w.xS = (!ov && c->fwd_step) ? c->xS_c : c->xS;  // (the forward's own slice-major x: split_f16r's -- possibly the leader's -- or the decode's)
         w.n_rows = n; w.D = D; w.S = S; w.pair_cap = (int)((long)c->back_rows * K);
         w.dvp = c->dvp; w.dW_dec = a.dW_dec; w.dW_encT = a.dW_encT; w.db_enc = a.db_enc;
         const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;

@@ -77,11 +77,29 @@ struct SelectCandArgs {
     // optional, first select after the encoder: ovf[0] |= any list longer than cand_cap (the step's dense-route flag;
     // the list statistics of the step come from stats_reduce)
     int32_t* ovf;
+    // survivor emission grouped by latent range (refine_slices_kernel): surv_rng[row][r] = end of range r's sub-list, ranges of
+    // lat_range latents, n_ranges <= RS_MAX_RANGES of them; NULL = one list in candidate order
+    int32_t* surv_rng;
+    int lat_range, n_ranges;
 };
 hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream);
 // survivors -> exact values -> final cut in one launch (f16r with guaranteed bounds); a.row_margin, x, W_encT, b_enc set
 hipError_t launch_select_refine(const SelectCandArgs& a, hipStream_t stream);
 constexpr int REFINE_CAP = 512;
+// The exact refinement from 32-column slices of W_enc^T (select.hip: refine_slices_kernel).  xS: slice-major x
+// ([D / 32][n_rows][32]); WeS: slice-major W_enc^T ([D / 32][S][32]); part: [D / 32][n_rows][REFINE_CAP] shares of the dot
+// products.  lat_range latents (x 128 bytes = the tile an XCD's L2 has to hold) per pass over a slice.
+constexpr int RS_SLICE = 32;
+constexpr int RS_ROWS = 4;        // activation rows an eight-lane group works through
+constexpr int RS_LAT_RANGE = 16384;
+constexpr int RS_MAX_RANGES = 8;  // (more latents than 8 x 16 384: wider ranges)
+struct RefineSlicesArgs {
+    const int32_t* surv_idx; const int32_t* surv_cnt; float* surv_val; const int32_t* surv_rng;
+    const float* xS; const float* WeS; const float* b_enc; float* part;
+    int n_rows, S, D, lat_range, n_ranges;
+    const int32_t* enable_flag; int enable_when;
+};
+hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream);
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream,
@@ -402,16 +420,19 @@ int encode_f16x3_tile_latents();
 // image mode: 0 = fp16 hi/lo (16 k per image), 1 = bf16 single, 2 = fp16 single (32 k per image)
 hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale = 1.0f,
                              const float* scale_dev = nullptr,  // effective scale = scale * *scale_dev
-                             const float* mu = nullptr);  // rows are x - mu
+                             const float* mu = nullptr,  // rows are x - mu
+                             float* xS = nullptr);  // mode 2: also the slice-major fp32 copy of x, [D / 32][n][32] (D % 32 == 0)
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
                            hipStream_t stream, const float* scale_dev = nullptr,
                            // mode 2 with mu (f16r): also dot_part[ks][s] = shares of <mu, W*scale>, sq_part = shares of
                            // ||W*scale||^2 per column, W_T = fp32 transpose of W
                            const float* mu = nullptr, double* dot_part = nullptr, float* sq_part = nullptr,
-                           float* W_T = nullptr);
+                           float* W_T = nullptr,
+                           int wt_slices = 0);  // W_T written slice-major: [D / 32][S][32]
 // launch_split_rows(mode 2, scale_dev = scales, mu) and launch_split_wT(mode 2, scale_dev = scales + 1, mu, ...) in ONE launch
 hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, const float* scales, const float* mu, const float* W,
-                             int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream);
+                             int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream,
+                             float* xS = nullptr, int wt_slices = 0);
 // f16r: b_shift = float(sum_ks dot_part / *w_scale + b_enc); wg_part[0..nwg) = per-workgroup max |b_shift|,
 // wg_part[nwg..2 nwg) = per-workgroup max column norm of W_enc (nwg = ceil(S/256)); launch_row_margins reduces them and
 // raises *pre_flag when the largest norm times *w_scale is outside the safe fp16 window, then wmax_prev = that norm
@@ -435,7 +456,8 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
                             const int32_t* nd_dev = nullptr);  // *nd_dev <= 0: zero gradient, zero loss
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 // a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
-constexpr int AUX_SMALL_MAX = 48;
+constexpr int AUX_SMALL_MAX = 64;  // (one lane per dead latent in aux_small_fwd_kernel: at most the wave width)
+constexpr int AUX_SMALL_DEFAULT = 16;  // largest dead set that takes them unless saev_debug_cfg.aux_small_max says otherwise
 // The few-dead-latents kernels take the dead count from the device (*nd_dev; they exit unless 1 <= nd <= AUX_SMALL_MAX), so
 // the host can enqueue them without knowing it.  Leading dimension of A / dA and row count of the compact weight buffers:
 // AUX_SMALL_MAX.

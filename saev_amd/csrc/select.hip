@@ -244,13 +244,20 @@ __device__ __forceinline__ void select_cand_row(const SelectCandArgs& a, int row
         const uint32_t key_lo = f2ukey(ukey2f(T) - a.row_margin[row]);
         int32_t* so = a.surv_idx + (size_t)row * REFINE_CAP;
         int base = 0;
+        // (surv_rng: the survivors grouped by latent range -- range r ends at surv_rng[row][r] -- for refine_slices_kernel, whose
+        // passes each cover one range of latents; one range = the plain list)
+        const int n_rng = a.surv_rng != nullptr ? a.n_ranges : 1;
+        for (int r = 0; r < n_rng; ++r) {
+            const int32_t lo = r * a.lat_range, hi = (r == n_rng - 1) ? 0x7ffffffe : lo + a.lat_range;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const bool sv = key[e] >= key_lo && idx[e] != 0x7fffffff;
-            const unsigned long long m = __ballot(sv);
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (sv && pos < REFINE_CAP) so[pos] = idx[e];
-            base += __popcll(m);
+            for (int e = 0; e < EPL; ++e) {
+                const bool sv = key[e] >= key_lo && idx[e] >= lo && idx[e] <= hi - (r == n_rng - 1 ? 0 : 1);
+                const unsigned long long m = __ballot(sv);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (sv && pos < REFINE_CAP) so[pos] = idx[e];
+                base += __popcll(m);
+            }
+            if (a.surv_rng != nullptr && lane == 0) a.surv_rng[(size_t)row * RS_MAX_RANGES + r] = min(base, REFINE_CAP);
         }
         if (lane == 0) {
             a.surv_cnt[row] = min(base, REFINE_CAP);
@@ -335,13 +342,19 @@ __device__ __forceinline__ int stream_survivors(const SelectCandArgs& a, int row
     *T_out = T;
     const uint32_t key_lo = f2ukey(ukey2f(T) - a.row_margin[row]);
     int base = 0;
-    for (int p0 = 0; p0 < n; p0 += 64) {
-        const int p = p0 + lane;
-        const bool sv = p < n && f2ukey(cv[p]) >= key_lo;
-        const unsigned long long m = __ballot(sv);
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (sv && pos < REFINE_CAP) out[pos] = ci[p];
-        base += __popcll(m);
+    const int n_rng = a.surv_rng != nullptr ? a.n_ranges : 1;  // (grouped by latent range like select_cand_row's)
+    for (int r = 0; r < n_rng; ++r) {
+        const int32_t lo = r * a.lat_range, hi = (r == n_rng - 1) ? 0x7ffffffe : lo + a.lat_range - 1;
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            const int p = p0 + lane;
+            bool sv = p < n && f2ukey(cv[p]) >= key_lo;
+            if (sv && n_rng > 1) { const int32_t i = ci[p]; sv = i >= lo && i <= hi; }
+            const unsigned long long m = __ballot(sv);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (sv && pos < REFINE_CAP) out[pos] = ci[p];
+            base += __popcll(m);
+        }
+        if (a.surv_rng != nullptr && lane == 0) a.surv_rng[(size_t)row * RS_MAX_RANGES + r] = min(base, REFINE_CAP);
     }
     return base;
 }
@@ -627,6 +640,114 @@ __global__ __launch_bounds__(256) void refine_exact_kernel(SelectCandArgs a) {
             const int t = lane >> 3;
             if (j0 + t < ns) sv[j0 + t] = r + a.b_enc[si[j0 + t]];
         }
+    }
+}
+
+// ---- the same exact values from 32-column slices that an XCD's L2 holds (kernels.h: RefineSlicesArgs) ---------------------------
+// refine_exact_kernel gathers ~45 whole 4 KB rows of W_enc^T per activation row out of a 134 MB matrix: L2 hits while a young
+// dictionary uses a few thousand latents, fabric traffic once usage has spread (0.23 -> 0.36 ms over the first thousand steps
+// of the benchmark, 0.39 on isotropic data).  Tiled the other way the working set is bounded by construction: a 32-column
+// slice of W_enc^T for a range of 16 384 latents is 2 MB.  Workgroup b runs on XCD b mod 8 and the workgroups of an XCD walk
+// (slice, latent range) combinations one after the other, so at any time an XCD gathers from ONE such tile; x comes from the
+// slice-major copy split_f16r leaves ([slice][row][32]: the rows of a slice are consecutive 128-byte lines) and W_enc^T is
+// written slice-major by the same pass ([slice][latent][32]).  An eight-lane group owns a row: its x slice sits in one float4 per
+// lane, a survivor is one 128-byte gather, four fmas and -- eight survivors at a time -- a reduce-scatter over the group, so
+// lane l stores survivor l's share of the dot product (one 32-byte store per group).  Survivors outside the latent range
+// of the pass cost an out-of-bounds buffer load (no memory access).  refine_sum_kernel adds the D / 32 shares in slice
+// order and the bias: the same fp32 products as the row kernel, summed in another (fixed) order.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 rs_buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return f32x4{__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+}
+// reduce-scatter over the eight lanes of a group: lane l (0..7) ends up with the group-wide sum of p[l]
+__device__ __forceinline__ float group8_reduce_scatter(float (&p)[8], int li) {
+    {
+        const bool up = (li & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = up ? p[i + 4] : p[i], send = up ? p[i] : p[i + 4];
+            p[i] = keep + __shfl_xor(send, 4, 64);
+        }
+    }
+    {
+        const bool up = (li & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = up ? p[i + 2] : p[i], send = up ? p[i] : p[i + 2];
+            p[i] = keep + __shfl_xor(send, 2, 64);
+        }
+    }
+    const bool up = (li & 1) != 0;
+    const float keep = up ? p[1] : p[0], send = up ? p[0] : p[1];
+    return keep + __shfl_xor(send, 1, 64);
+}
+__global__ __launch_bounds__(256) void refine_slices_kernel(RefineSlicesArgs a, int wg_per_combo) {
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+    const int lane = threadIdx.x & 63, gi = lane >> 3, li = lane & 7;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int combo = q / wg_per_combo;
+    const int slice = xcd + 8 * (combo / a.n_ranges), range = combo % a.n_ranges;
+    if (slice * RS_SLICE >= a.D) return;
+    const int wgi = q % wg_per_combo;
+    const int lat_lo = range * a.lat_range, lat_hi = min(a.S, lat_lo + a.lat_range);
+    const int sel = (lane & 56) << 2;  // byte address of the group's lane 0 for ds_bpermute
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.WeS) + (size_t)slice * a.S * RS_SLICE, 0, (uint32_t)a.S * 128u, 0x00020000);
+    const f32x4* const xs = reinterpret_cast<const f32x4*>(a.xS + (size_t)slice * a.n_rows * RS_SLICE);
+    float* const part = a.part + (size_t)slice * a.n_rows * REFINE_CAP;
+    const uint32_t li16 = (uint32_t)li * 16u;
+#pragma unroll 1
+    for (int t = 0; t < RS_ROWS; ++t) {
+        const int row = ((wgi * RS_ROWS + t) * 4 + (int)(threadIdx.x >> 6)) * 8 + gi;
+        const bool rok = row < a.n_rows;
+        // this pass's survivors: the row's sub-list of the latent range (select_cand_kernel groups them; one range: all)
+        const int j_end = rok ? a.surv_rng[(size_t)row * RS_MAX_RANGES + range] : 0;
+        const int j_beg = (rok && range > 0) ? a.surv_rng[(size_t)row * RS_MAX_RANGES + range - 1] : 0;
+        const f32x4 x4 = rok ? xs[(size_t)row * 8 + li] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int32_t* const si = a.surv_idx + (size_t)row * REFINE_CAP;
+#pragma unroll 1
+        for (int j0 = j_beg; __any(j0 < j_end); j0 += 8) {
+            const int32_t my = (j0 + li < j_end) ? si[j0 + li] : -1;
+            const bool mine = my >= lat_lo && my < lat_hi;
+            // (no survivor: -1 becomes an out-of-bounds offset: zeros, no memory access)
+            const uint32_t off_my = mine ? (uint32_t)my * 128u : 0xFFFFFF00u;
+            f32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 4 * u, (int)off_my);
+                w[u] = rs_buf_load16(wres, off | li16);
+            }
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = x4[0] * w[u][0] + x4[1] * w[u][1] + x4[2] * w[u][2] + x4[3] * w[u][3];
+            const float r = group8_reduce_scatter(p, li);
+            if (mine) part[(size_t)row * REFINE_CAP + j0 + li] = r;
+        }
+    }
+}
+// surv_val[row][j] = b_enc[latent] + the D / 32 shares in slice order; one wave per row
+__global__ __launch_bounds__(256) void refine_sum_kernel(RefineSlicesArgs a) {
+    if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int cnt = a.surv_cnt[row];
+    const int n_slices = a.D / RS_SLICE;
+    const size_t plane = (size_t)a.n_rows * REFINE_CAP;
+    for (int j = lane; j < cnt; j += 64) {
+        const size_t o = (size_t)row * REFINE_CAP + j;
+        float s = 0.f;
+        int c = 0;
+        for (; c + 8 <= n_slices; c += 8) {  // eight loads in flight, added in slice order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.part[(size_t)(c + u) * plane + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < n_slices; ++c) s += a.part[(size_t)c * plane + o];
+        a.surv_val[o] = s + a.b_enc[a.surv_idx[o]];
     }
 }
 
@@ -973,6 +1094,18 @@ hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream) {
     else if (nv <= 6) RF(6); else if (nv <= 8) RF(8); else if (nv <= 12) RF(12); else if (nv <= 16) RF(16);
     else return hipErrorInvalidValue;
 #undef RF
+    return hipGetLastError();
+}
+
+hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream) {
+    if (a.n_rows <= 0) return hipSuccess;
+    if (a.D % RS_SLICE != 0 || (uint64_t)a.S * 128ull >= (1ull << 32) - 256ull || a.n_ranges <= 0) return hipErrorInvalidValue;
+    const int wg_per_combo = (a.n_rows + 32 * RS_ROWS - 1) / (32 * RS_ROWS);
+    const int slice_blocks = (a.D / RS_SLICE + 7) / 8;
+    hipLaunchKernelGGL(refine_slices_kernel, dim3(8 * slice_blocks * a.n_ranges * wg_per_combo), dim3(256), 0, stream, a, wg_per_combo);
+    // (adding the shares inside the final select instead -- 32 dependent loads per lane of a kernel that lives on its bit
+    // search -- took that select from 20 to 80 us against 42 for this pass)
+    hipLaunchKernelGGL(refine_sum_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

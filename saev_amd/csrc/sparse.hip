@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
             if (a.training && a.gS != nullptr) {  // slice-major copies for launch_dw_slices: [q / 8][row][8 float4]
                 const size_t o = ((size_t)(q >> 3) * a.n_rows + row) * 8 + (q & 7);
                 reinterpret_cast<f32x4*>(a.gS)[o] = g[n];
-                reinterpret_cast<f32x4*>(a.xS)[o] = xv;
+                if (a.xS != nullptr) reinterpret_cast<f32x4*>(a.xS)[o] = xv;  // (NULL: split_f16r has left it already)
             }
         }
     }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryAr
                     Grow[(size_t)pp * D4 + q] = c[n];
                     if (a.gS != nullptr) {  // slice-major copies for launch_dw_slices: [q / 8][p][row][8 float4]
                         reinterpret_cast<f32x4*>(a.gS)[(((size_t)(q >> 3) * P + pp) * a.n_rows + row) * 8 + (q & 7)] = c[n];
-                        if (pp == 0) reinterpret_cast<f32x4*>(a.xS)[((size_t)(q >> 3) * a.n_rows + row) * 8 + (q & 7)] = xv[n];
+                        if (pp == 0 && a.xS != nullptr) reinterpret_cast<f32x4*>(a.xS)[((size_t)(q >> 3) * a.n_rows + row) * 8 + (q & 7)] = xv[n];
                     }
                 }
             }

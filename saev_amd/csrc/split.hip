@@ -48,10 +48,12 @@ __device__ __forceinline__ half8 pack8(const float (&v)[8], int part) {
 }
 
 // one thread = one 16-byte chunk of the image; grid.x = ceil(n/256) * nks images, 1024 threads each
+// xS (MODE 2, optional): the slice-major fp32 copy of x itself ([k / 32][row][32]) for the kernels that gather 32-column slices
+// (refine_slices_kernel, dw_slices_kernel) -- an image of this mode IS a 32-column slice of 256 rows, the values are in registers
 template <int MODE>
 __device__ __forceinline__ void split_rows_body(int bid, const float* __restrict__ x, int n, int D, int nks, float scale,
                                                 const float* __restrict__ scale_dev, const float* __restrict__ mu,
-                                                _Float16* __restrict__ xs) {
+                                                _Float16* __restrict__ xs, float* __restrict__ xS = nullptr) {
     if (scale_dev != nullptr) scale *= *scale_dev;
     const int blk = bid / nks, ks = bid % nks;
     const int i = threadIdx.x;           // chunk index inside the image
@@ -62,6 +64,11 @@ __device__ __forceinline__ void split_rows_body(int bid, const float* __restrict
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (r < n && k < D) {  // D % 4 == 0: load in two float4s, the second may fall off the end
         f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k);
+        if (MODE == 2 && xS != nullptr) {  // (D % 32 == 0 on this route: the chunk's eight values exist)
+            f32x4* o = reinterpret_cast<f32x4*>(xS + ((size_t)ks * n + r) * 32 + c * 8);
+            o[0] = a;
+            o[1] = *reinterpret_cast<const f32x4*>(x + (size_t)r * D + k + 4);
+        }
         if (mu != nullptr) a -= *reinterpret_cast<const f32x4*>(mu + k);  // centred images (f16r)
         v[0] = a[0] * scale; v[1] = a[1] * scale; v[2] = a[2] * scale; v[3] = a[3] * scale;
         if (k + 4 < D) {
@@ -75,8 +82,8 @@ __device__ __forceinline__ void split_rows_body(int bid, const float* __restrict
 template <int MODE>
 __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restrict__ x, int n, int D, int nks, float scale,
                                                           const float* __restrict__ scale_dev, const float* __restrict__ mu,
-                                                          _Float16* __restrict__ xs) {
-    split_rows_body<MODE>(blockIdx.x, x, n, D, nks, scale, scale_dev, mu, xs);
+                                                          _Float16* __restrict__ xs, float* __restrict__ xS) {
+    split_rows_body<MODE>(blockIdx.x, x, n, D, nks, scale, scale_dev, mu, xs, xS);
 }
 
 // one workgroup = one image of W_enc^T: 256 latents x 16 k (32 k for bf16).  The k-rows of W_enc (1 KB each) are
@@ -94,7 +101,7 @@ __device__ __forceinline__ void split_wT_body(int bid, int nblk, float (&tile)[(
                                               const float* __restrict__ W, int D, int S, int nks, float scale,
                                               const float* __restrict__ scale_dev, _Float16* __restrict__ ws,
                                               const float* __restrict__ mu, double* __restrict__ dot_part,
-                                              float* __restrict__ sq_part, float* __restrict__ W_T) {
+                                              float* __restrict__ sq_part, float* __restrict__ W_T, int wt_slices = 0) {
     if (scale_dev != nullptr) scale *= *scale_dev;
     constexpr int KS = MODE != 0 ? 32 : 16;
     const int blk = bid / nks, ks = bid % nks;
@@ -137,7 +144,9 @@ __device__ __forceinline__ void split_wT_body(int bid, int nblk, float (&tile)[(
             const int k = k0 + c * 8;
             if (s0 + rl < S && k < D) {  // D % 4 == 0
                 const float inv = 1.0f / scale;  // power of two
-                f32x4* o = reinterpret_cast<f32x4*>(W_T + (size_t)(s0 + rl) * D + k);
+                // row-major (S, D), or -- wt_slices -- slice-major [k / 32][latent][32]: this image's 256 x 32 block is contiguous
+                f32x4* o = reinterpret_cast<f32x4*>(wt_slices ? W_T + ((size_t)ks * S + s0 + rl) * 32 + c * 8
+                                                              : W_T + (size_t)(s0 + rl) * D + k);
                 o[0] = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
                 if (k + 4 < D) o[1] = f32x4{v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv};
             }
@@ -149,11 +158,11 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict__ W, int D, int S, int nks, float scale,
                                                         const float* __restrict__ scale_dev, _Float16* __restrict__ ws,
                                                         const float* __restrict__ mu, double* __restrict__ dot_part,
-                                                        float* __restrict__ sq_part, float* __restrict__ W_T) {
+                                                        float* __restrict__ sq_part, float* __restrict__ W_T, int wt_slices) {
     constexpr int KS = MODE != 0 ? 32 : 16;
     __shared__ float tile[KS][257];
     __shared__ float mu_s[KS];
-    split_wT_body<MODE>(blockIdx.x, gridDim.x, tile, mu_s, W, D, S, nks, scale, scale_dev, ws, mu, dot_part, sq_part, W_T);
+    split_wT_body<MODE>(blockIdx.x, gridDim.x, tile, mu_s, W, D, S, nks, scale, scale_dev, ws, mu, dot_part, sq_part, W_T, wt_slices);
 }
 // The f16r step's two image passes in one launch (they depend on the same scales and on nothing of each other): workgroups
 // [0, n_x) write the centred x images, the rest the W_enc^T images with everything else that pass produces.
@@ -161,13 +170,14 @@ struct SplitF16rArgs {
     const float* x; int n, D, nks; const float* scales; const float* mu; _Float16* xs;
     const float* W; int S; _Float16* ws; double* dot_part; float* sq_part; float* W_T;
     int n_x;
+    float* xS; int wt_slices;  // the slice-major fp32 copy of x / W_T written slice-major (see the two bodies)
 };
 __global__ __launch_bounds__(1024) void split_f16r_kernel(SplitF16rArgs a) {
     __shared__ float tile[32][257];
     __shared__ float mu_s[32];
-    if ((int)blockIdx.x < a.n_x) split_rows_body<2>(blockIdx.x, a.x, a.n, a.D, a.nks, 1.0f, a.scales, a.mu, a.xs);
+    if ((int)blockIdx.x < a.n_x) split_rows_body<2>(blockIdx.x, a.x, a.n, a.D, a.nks, 1.0f, a.scales, a.mu, a.xs, a.xS);
     else split_wT_body<2>(blockIdx.x - a.n_x, gridDim.x - a.n_x, tile, mu_s, a.W, a.D, a.S, a.nks, 1.0f, a.scales + 1, a.ws, a.mu, a.dot_part,
-                          a.sq_part, a.W_T);
+                          a.sq_part, a.W_T, a.wt_slices);
 }
 
 // b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]) and ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale;
@@ -204,31 +214,33 @@ __global__ __launch_bounds__(256) void bias_finish_kernel(const double* __restri
 }  // namespace
 
 hipError_t launch_split_rows(const float* x, int n, int D, int Dp, void* xs, int mode, hipStream_t stream, float scale,
-                             const float* scale_dev, const float* mu) {
+                             const float* scale_dev, const float* mu, float* xS) {
     const int nks = Dp / (mode != 0 ? 32 : 16), nblk = (n + 255) / 256;
     if (nblk <= 0) return hipSuccess;
     _Float16* o = reinterpret_cast<_Float16*>(xs);
-    if (mode == 1) hipLaunchKernelGGL(split_rows_kernel<1>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o);
-    else if (mode == 2) hipLaunchKernelGGL(split_rows_kernel<2>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o);
-    else hipLaunchKernelGGL(split_rows_kernel<0>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o);
+    if (mode == 1) hipLaunchKernelGGL(split_rows_kernel<1>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o, nullptr);
+    else if (mode == 2) hipLaunchKernelGGL(split_rows_kernel<2>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o, xS);
+    else hipLaunchKernelGGL(split_rows_kernel<0>, dim3(nblk * nks), dim3(1024), 0, stream, x, n, D, nks, scale, scale_dev, mu, o, nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, float scale, void* ws, int mode,
                            hipStream_t stream, const float* scale_dev, const float* mu, double* dot_part, float* sq_part,
-                           float* W_T) {
+                           float* W_T, int wt_slices) {
     const int nks = Dp / (mode != 0 ? 32 : 16);
     const dim3 grid((S_pad / 256) * nks);
     _Float16* o = reinterpret_cast<_Float16*>(ws);
-    if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr);
-    else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, mu, dot_part, sq_part, W_T);
-    else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr);
+    if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr, 0);
+    else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, mu, dot_part, sq_part, W_T, wt_slices);
+    else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr, 0);
     return hipGetLastError();
 }
 
 hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, const float* scales, const float* mu, const float* W,
-                             int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream) {
+                             int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream, float* xS,
+                             int wt_slices) {
     SplitF16rArgs a{};
+    a.xS = xS; a.wt_slices = wt_slices;
     a.x = x; a.n = n; a.D = D; a.nks = Dp / 32; a.scales = scales; a.mu = mu; a.xs = reinterpret_cast<_Float16*>(xs);
     a.W = W; a.S = S; a.ws = reinterpret_cast<_Float16*>(ws); a.dot_part = dot_part; a.sq_part = sq_part; a.W_T = W_T;
     a.n_x = ((n + 255) / 256) * a.nks;

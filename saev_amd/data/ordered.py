@@ -53,10 +53,7 @@ class DataLoader:
         assert cfg.layer in self.md.layers, f"Layer {cfg.layer} not in {self.md.layers}"
         self.layer_i = self.md.layers.index(cfg.layer)
         self.info = shards_lib.ShardInfo.load(root)
-        for name, n_ex in self.info:
-            f = root / name
-            if not f.exists() or f.stat().st_size == 0:
-                raise FileNotFoundError(f"shard {f} is missing or empty")
+        self.info.validate(root, self.md)  # (reference ordered.py:226: every shard file checked before the first batch)
         for _, n_ex in self.info.shards[:-1]:
             assert n_ex == self.md.examples_per_shard, "all shards but the last hold examples_per_shard examples"
         self.device = torch.device(device)

@@ -98,6 +98,41 @@ class ShardInfo:
     def __len__(self):
         return len(self.shards)
 
+    def validate(self, shards_dir: pathlib.Path | str, md: "Metadata | None" = None) -> None:
+        """Check every shard file of shards.json BEFORE a loader starts reading (reference data/shards.py:638-694, called from
+        its loaders' constructors): files that are missing, empty, unreadable or not regular files are collected and reported
+        together in one FileNotFoundError, instead of surfacing one at a time from a reader thread in the middle of an
+        epoch.  With ``md`` a file shorter than its (n_examples, layers, tokens, d_model) float32 block counts as truncated."""
+        import stat
+
+        root = pathlib.Path(shards_dir)
+        problems: dict[str, list[str]] = {"Missing files": [], "Empty files": [], "Unreadable files": [], "Not regular files": [],
+                                          "Truncated files": []}
+        for name, n_examples in self.shards:
+            fpath = root / name
+            shown = str(fpath.resolve())
+            try:
+                st = fpath.stat()
+            except FileNotFoundError:
+                problems["Missing files"].append(shown)
+                continue
+            except OSError:  # (PermissionError included)
+                problems["Unreadable files"].append(shown)
+                continue
+            if not stat.S_ISREG(st.st_mode):
+                problems["Not regular files"].append(shown)
+            elif st.st_size == 0:
+                problems["Empty files"].append(shown)
+            elif md is not None and st.st_size < 4 * n_examples * len(md.layers) * md.tokens_per_example * md.d_model:
+                problems["Truncated files"].append(f"{shown} ({st.st_size} bytes, shards.json promises {n_examples} examples)")
+        if not any(problems.values()):
+            return
+        lines = [f"Shard validation failed in '{root.resolve()}':"]
+        for title, items in problems.items():
+            if items:
+                lines += ["", f"{title} ({len(items)}):", *(f"  - {it}" for it in items)]
+        raise FileNotFoundError("\n".join(lines))
+
 
 def locate_content_token(md: Metadata, g: int, layer: int) -> tuple[int, int, int, int, int, int]:
     """Global content-token index -> (example, content token, shard, example in shard, layer slot, token slot in the

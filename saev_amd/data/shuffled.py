@@ -98,6 +98,9 @@ class DataLoader:
             raise FileNotFoundError(f"no metadata.json under {d}")
         md = shards_lib.Metadata.load(d)
         info = shards_lib.ShardInfo.load(d)
+        # every shard file checked up front, all problems in ONE error (reference shuffled.py:421 -> shards.py:638-694): a bad
+        # shard must not surface mid-epoch as "reservoir reader failed"
+        info.validate(d, md)
         self.metadata = md
         if cfg.layer == "all":
             layer_ids = list(range(len(md.layers)))

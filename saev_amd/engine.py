@@ -50,12 +50,13 @@ class EngineConfig:
     # route).  The C library reads no environment variable; these defaults do, so that a test or a shell script can flip a
     # route without touching code:
     #   SAEV_AMD_DW=rows          weight gradients by whole-row gathers instead of column slices
-    #   SAEV_AMD_FWD=rows         decode / exact refinement by whole-row gathers
+    #   SAEV_AMD_FWD=rows         exact refinement of the f16r encoder by whole-row gathers instead of 32-column slices
     #   SAEV_AMD_ENC_MFMA=32      single-product encoders on the 32x32x16 MFMA kernel
     #   SAEV_AMD_FUSED_CHAIN=1    f16r select -> refine -> select as one launch
     #   SAEV_AMD_NGROUPS=64       64-group TopK bound also for top_k <= 32
     #   SAEV_AMD_ENC_WGS, SAEV_AMD_REFRESH_FIRST, SAEV_AMD_REFRESH_EVERY   encoder grid / bound-refresh cadence
     #   SAEV_AMD_AUX_SMALL_MAX    largest dead set of the few-dead-latents AuxK kernels (-1: always the dense algebra)
+    #   SAEV_AMD_DEAD_LAG         age in steps of the tracker record that sizes a step's auxiliary work (default 4)
     dw_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_DW", "slices"))
     fwd_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_FWD", "default"))
     enc_mfma: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_ENC_MFMA", "0")))
@@ -65,6 +66,7 @@ class EngineConfig:
     refresh_first: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_REFRESH_FIRST", "0")))
     refresh_every: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_REFRESH_EVERY", "0")))
     aux_small_max: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_SMALL_MAX", "0")))
+    dead_lag: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_DEAD_LAG", "0")))
 
 
 @dataclasses.dataclass
@@ -145,7 +147,8 @@ class SaeEngine:
             dbg = _lib.SaevDebugCfg(
                 struct_size=C.sizeof(_lib.SaevDebugCfg), dw_route=int(cfg.dw_route == "rows"), enc_mfma=cfg.enc_mfma,
                 fused_chain=int(cfg.fused_chain), ngroups=cfg.ngroups, enc_wgs=cfg.enc_wgs, refresh_first=cfg.refresh_first,
-                refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route=int(cfg.fwd_route == "rows"))
+                refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route=int(cfg.fwd_route == "rows"),
+                dead_lag=cfg.dead_lag)
             ctx = C.c_void_p()
             rc = self.lib.saev_create_ex(C.byref(ccfg), C.byref(dbg), self.device.index, C.byref(ctx))
             if rc != 0:
@@ -419,6 +422,10 @@ class SaeEngine:
         """What the last step_dead did for the auxiliary loss: 0 nothing, 1 few-dead-latents kernels without reading
         n_dead back, 2 the same after a read-back, 3 dense algebra after a read-back."""
         return int(self.lib.saev_last_aux_route(self.ctx))
+
+    def scratch_bytes(self, which: int = 0) -> int:
+        """Device memory the context owns besides the four flat buffers: 0 all of it, 1 AuxK dead-set buffers, 2 Matryoshka blocks."""
+        return int(self.lib.saev_scratch_bytes(self.ctx, which))
 
     def dead_readbacks(self) -> int:
         """Blocking reads of n_dead so far."""

@@ -176,8 +176,10 @@ def choose_exchange(dist, world: int, rank: int, device, local_batch: int, *, ta
                 exchange gets the same check against the all-reduce path.  Explicit settings are honoured unchecked.
     Returns (tail, exchange, report); the report says what was checked and why a fallback was taken."""
     report: dict = {"requested": {"tail": tail, "exchange": exchange}}
-    if dist is None or world <= 1:
+    if dist is None:
         return "replicated", "dense", report
+    if world <= 1:  # one rank over a real backend (bench.py --force-dist): explicit choices run as they are, "auto" has nothing to check
+        return (tail if tail != "auto" else "replicated"), (exchange if exchange != "auto" else "dense"), report
     if exchange == "sparse" and tail not in ("auto", "replicated"):
         raise ValueError("exchange='sparse' goes with the replicated tail")
     if exchange == "sparse":  # pinned by the caller: honoured as it is

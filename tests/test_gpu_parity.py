@@ -541,9 +541,9 @@ def test_f16r_survives_replaced_parameters(encoder_mode):
     assert routes == [0, 1, 0, 1, 0], routes
 
 
-@pytest.mark.parametrize("n_dead", [1, 5, 24, 48, 49, 60])
+@pytest.mark.parametrize("n_dead", [1, 5, 24, 48, 64, 65, 80])
 def test_auxk_gradients_across_the_small_dead_set_boundary(n_dead):
-    """Up to 48 dead latents (all of them selected: n_dead <= k_aux) the AuxK branch runs as two row-oriented kernels, above
+    """Up to 64 dead latents (all of them selected: n_dead <= k_aux) the AuxK branch runs as two row-oriented kernels, above
     that as dense algebra over the compacted dead set.  Both must give the oracle's loss and gradients."""
     d, s, k, n, k_aux = 128, 1024, 8, 200, 64
     p = rand_params(d, s, seed=60 + n_dead)
@@ -571,7 +571,7 @@ def test_auxk_gradients_across_the_small_dead_set_boundary(n_dead):
         torch.testing.assert_close(gv[key].cpu(), leaves[key].grad, rtol=2e-3, atol=1e-7, msg=lambda m: f"{key}: {m}")
 
 
-@pytest.mark.parametrize("n_dead", [0, 3, 48])
+@pytest.mark.parametrize("n_dead", [0, 3, 48, 64])
 def test_steady_state_needs_no_readback_of_n_dead(n_dead):
     """saev_step_dead without the reference's per-step `.item()` (modeling.py:92): four steps after the tracker was last
     written by the host, the record the device left four steps earlier bounds the dead count; while that bound fits the
@@ -619,13 +619,13 @@ def test_steady_state_needs_no_readback_of_n_dead(n_dead):
 def test_growing_dead_set_switches_to_the_dense_route_in_time():
     """The bound comes from four steps back: latents that will cross the threshold within four steps count as near-dead,
     so the step in which the dead set outgrows the few-dead-latents kernels already runs the exact read-back + dense
-    algebra.  60 latents die at once in step 6."""
+    algebra.  80 latents die at once in step 6 (the few-dead-latents kernels take up to 64)."""
     d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
     p = rand_params(d, s, seed=90)
     gen = torch.Generator().manual_seed(91)
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
     toks = torch.zeros(s, dtype=torch.int64)
-    late = torch.randperm(s, generator=torch.Generator().manual_seed(92))[:60]
+    late = torch.randperm(s, generator=torch.Generator().manual_seed(92))[:80]
     toks[late] = thr - 6 * n  # dead after six more steps of n tokens
     p["b_enc"][late] = -100.0
     eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)
@@ -648,22 +648,22 @@ def test_growing_dead_set_switches_to_the_dense_route_in_time():
         assert math.isclose(st.aux, ref["aux"], rel_tol=1e-4, abs_tol=1e-12), (i, st.aux, ref["aux"])
         for key in R.PARAM_ORDER:
             torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6, msg=lambda m: f"step {i} {key}: {m}")
-    assert deads == [0] * 5 + [60] * 4, deads
+    assert deads == [0] * 5 + [80] * 4, deads
     # steps 1-4: read-backs (no record yet, nothing dead); step 5: the record of step 1 has nobody within four steps of
-    # the threshold -> no read-back, no AuxK launch; step 6 on: the record of step 2 counts the 60 as near-dead ->
+    # the threshold -> no read-back, no AuxK launch; step 6 on: the record of step 2 counts the 80 as near-dead ->
     # read-back -> dense
     assert routes == [0, 0, 0, 0, 0, 3, 3, 3, 3], routes
 
 
-@pytest.mark.parametrize("n_dead,n_near", [(80, 100), (0, 600), (55, 0)])
-def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near):
+@pytest.mark.parametrize("n_dead,n_near,k_aux", [(80, 100, 64), (0, 600, 64), (100, 0, 128)])
+def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near, k_aux):
     """A dead set too large for the few-dead-latents kernels used to cost one blocking read of n_dead per step (round 2:
     configs[2]'s regime).  Now the dense algebra is sized by the BOUND the tracker record of four steps earlier gives
     (latents dead or within four steps of the threshold then) and the true count stays on the device: columns past it are
     padding.  `n_near` latents sit two steps short of the threshold and mostly fire again, so the bound exceeds the count
     -- by a lot in the (0, 600) case, where next to nothing is dead and the auxiliary term must come out (nearly) zero;
-    (55, 0) is the every-dead-latent-selected mode (48 < n_dead <= k_aux).  Teacher-forced against the oracle on every step."""
-    d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
+    (100, 0, k_aux 128) is the every-dead-latent-selected mode (64 < n_dead <= k_aux).  Teacher-forced against the oracle on every step."""
+    d, s, k, n, thr = 128, 1024, 8, 200, 100_000
     p = rand_params(d, s, seed=380 + n_dead)
     gen = torch.Generator().manual_seed(381 + n_dead)
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)

@@ -548,3 +548,35 @@ def test_device_reservoir_rejects_oversized_blocks_with_a_value_error():
     with pytest.raises(ValueError, match="reservoir overflow"):
         r.put(torch.zeros(3, 4), torch.zeros(3, dtype=torch.int32), torch.zeros(3, dtype=torch.int32))
     assert r.room() == 2 and r._n_filled == 6
+
+
+def test_shard_validation_reports_every_bad_file_up_front(tmp_path):
+    """ShardInfo.validate (reference data/shards.py:638-694): missing, empty, non-regular and truncated shard files are all
+    named in one FileNotFoundError, and the loaders call it in their constructors' shard scan."""
+    import numpy as np
+
+    from saev_amd import data
+    from saev_amd.data import shards as shards_lib
+
+    acts = np.random.default_rng(0).standard_normal((40, 1, 4, 16)).astype(np.float32)
+    d = data.write_shards(tmp_path / "cache", acts, layers=(3,), max_tokens_per_shard=4 * 8)  # five shards of eight examples
+    md, info = shards_lib.Metadata.load(d), shards_lib.ShardInfo.load(d)
+    assert len(info) == 5
+    info.validate(d, md)  # a healthy cache passes
+    names = [n for n, _ in info]
+    (d / names[0]).unlink()
+    (d / names[1]).write_bytes(b"")
+    (d / names[2]).unlink(); (d / names[2]).mkdir()
+    (d / names[3]).write_bytes((d / names[3]).read_bytes()[:100])
+    with pytest.raises(FileNotFoundError) as exc:
+        info.validate(d, md)
+    msg = str(exc.value)
+    assert "Shard validation failed" in msg
+    for title, name in (("Missing files (1)", names[0]), ("Empty files (1)", names[1]), ("Not regular files (1)", names[2]),
+                        ("Truncated files (1)", names[3])):
+        assert title in msg and name in msg
+    assert names[4] not in msg
+    # without the metadata only the reference's four categories are checked
+    with pytest.raises(FileNotFoundError) as exc:
+        info.validate(d)
+    assert "Truncated" not in str(exc.value)

@@ -28,13 +28,15 @@ eng.enable_kernel_timing(True)
 for w in range(n_win):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    routes = [0, 0, 0, 0]
     for _ in range(200):
         rows = perm[(step % 64) * B : (step % 64 + 1) * B]
         eng.gather_rows(pool, rows, out=x)
         eng.train_step(x, 4e-4 * min(1.0, step / 500), 1.0)
+        routes[eng.aux_route()] += 1  # (host-side decision of the step just enqueued: no synchronisation)
         step += 1
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 200 * 1e3
     st = eng.read_stats()
     print(f"steps {step - 200:5d}-{step:5d}: {dt:.3f} ms/step  encoder {eng.encoder_ms():.3f} ms  mse {st.mse:.4f} n_dead {st.n_dead} "
-          f"cand_max {st.cand_max} dense_route {st.dense_route}", flush=True)
+          f"cand_max {st.cand_max} dense_route {st.dense_route}  aux routes none/small/small+read/dense {routes}", flush=True)

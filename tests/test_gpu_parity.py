@@ -553,7 +553,7 @@ def test_auxk_gradients_across_the_small_dead_set_boundary(n_dead):
     dead = torch.randperm(s, generator=torch.Generator().manual_seed(62))[:n_dead]
     toks[dead] = 1000
     p["b_enc"][dead] = -100.0  # never among the top-k, so they stay dead in this step
-    eng = make_engine(d, s, k, k_aux=k_aux, thr=1000, max_batch=n)
+    eng = make_engine(d, s, k, k_aux=k_aux, thr=1000, max_batch=n, aux_small_max=64)
     eng.load_params(p)
     eng.set_tracker(toks)
     leaves = {k_: p[k_].clone().requires_grad_(True) for k_ in R.PARAM_ORDER}
@@ -585,7 +585,8 @@ def test_steady_state_needs_no_readback_of_n_dead(n_dead):
     dead = torch.randperm(s, generator=torch.Generator().manual_seed(82))[:n_dead]
     toks[dead] = thr
     p["b_enc"][dead] = -100.0  # never selected: they stay dead
-    eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)
+    # (aux_small_max = 64: the few-dead-latents kernels up to their capacity -- the default hands sets above 16 to the dense algebra)
+    eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n, aux_small_max=64)
     eng.load_params(p)
     eng.set_tracker(toks)
     routes = []

@@ -306,6 +306,140 @@ __global__ __launch_bounds__(256) void aux_small_fwd_kernel(const float* x, cons
     }
 }
 
+// The same forward with the dead latents' weight rows staged through LDS (the shipped form; the kernel above stays as the
+// fallback for shapes whose rows do not fit).  aux_small_fwd_kernel fetches every row of W_enc^T[dl] / W_dec[dl] from L2 once
+// per PAIR of activation rows, three times over (codes, reconstruction, dA): 12 KB of loads per dead latent and row pair,
+// 2.9 GB per launch at 30 dead latents -- the kernel was bound by the vector-memory path (0.36 ms at 30, growing linearly).
+// Here a workgroup (four waves x RW rows) copies a chunk of LC weight rows into LDS once and all its rows use it: L2 traffic
+// drops by the rows per workgroup, the per-latent loads become conflict-free ds_read_b128, and the kernel is bound by its fmas.
+// Codes and dA pass from the reduce-scatter's owner lanes to "lane j holds latent j" through a per-wave LDS array.
+template <int NV, int RW>
+__global__ __launch_bounds__(256) void aux_small_fwd_lds_kernel(const float* x, const float* x_hat, const float* WencT_dead,
+                                                                const float* Wdec_dead, const float* b_enc, const float* b_dec,
+                                                                const int32_t* dl, int n_rows, int D, const int32_t* nd_dev,
+                                                                float gscale, float* A, float* dA, float* g_aux,
+                                                                RowStats* rowstats, int LC) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > AUX_SMALL_MAX) return;  // (uniform over the grid: no barrier is skipped by a part of a workgroup)
+    constexpr int ndp = AUX_SMALL_MAX;
+    constexpr int LPB = 8 / RW;  // latents per reduce-scatter batch (RW rows each)
+    extern __shared__ float aux_smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int D4 = D >> 2;
+    f32x4* const Wl = reinterpret_cast<f32x4*>(aux_smem);                 // [LC][D4]
+    float* const Hs = aux_smem + (size_t)LC * D + (size_t)w * 2 * RW * 64;  // per wave: codes [RW][64], then dA [RW][64]
+    float* const Ds = Hs + RW * 64;
+    const int row0 = (blockIdx.x * 4 + w) * RW;
+    const int n_chunks = (nd + LC - 1) / LC;
+    f32x4 v[RW][NV];  // x rows in phase 1, reconstruction / g_aux afterwards
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)min(row0 + r, n_rows - 1) * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[r][n] = (lane + 64 * n < D4) ? xr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto stage = [&](const float* W, int c) {  // chunk c of a (nd, D) row-major matrix -> LDS (all 256 threads)
+        __syncthreads();  // the previous chunk has been consumed
+        const int cn = min(LC, nd - c * LC);
+        const f32x4* src = reinterpret_cast<const f32x4*>(W + (size_t)c * LC * D);
+        for (int q = threadIdx.x; q < cn * D4; q += 256) Wl[q] = src[q];
+        __syncthreads();
+        return cn;
+    };
+    // <v[r], chunk row jl> for the wave's RW rows, LPB latents per reduce-scatter; owner lanes (lane & 7 == 0) leave the sums in
+    // out[r * 64 + latent] (+ bias)
+    auto dots = [&](int c, int cn, float* out, const float* bias) {
+        for (int j0 = 0; j0 < cn; j0 += LPB) {
+            float p[8];
+#pragma unroll
+            for (int t = 0; t < LPB; ++t) {
+                const bool ok = j0 + t < cn;
+                f32x4 wv[NV];
+#pragma unroll
+                for (int n = 0; n < NV; ++n)
+                    wv[n] = (ok && lane + 64 * n < D4) ? Wl[(size_t)(j0 + t) * D4 + lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NV; ++n)
+                        acc += v[r][n][0] * wv[n][0] + v[r][n][1] * wv[n][1] + v[r][n][2] * wv[n][2] + v[r][n][3] * wv[n][3];
+                    p[t * RW + r] = acc;
+                }
+            }
+            const float sum = aux_reduce_scatter8(p, lane);  // lane l holds slot (l >> 3) & 7
+            if ((lane & 7) == 0) {
+                const int slot = lane >> 3, t = slot / RW, r = slot % RW;
+                const int j = c * LC + j0 + t;
+                if (j0 + t < cn) out[r * 64 + j] = sum + (bias != nullptr ? bias[dl[j]] : 0.f);
+            }
+        }
+    };
+    // ---- codes H = x W_enc[:, dl] + b_enc[dl] ----
+    for (int c = 0; c < n_chunks; ++c) {
+        const int cn = stage(WencT_dead, c);
+        dots(c, cn, Hs, b_enc);
+    }
+    // ---- reconstruction E = H W_dec[dl] + b_dec ----
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+            v[r][n] = (lane + 64 * n < D4) ? reinterpret_cast<const f32x4*>(b_dec)[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < n_chunks; ++c) {
+        const int cn = stage(Wdec_dead, c);  // (its barriers also make the owner lanes' codes visible to the whole wave)
+        for (int jl = 0; jl < cn; ++jl) {
+            f32x4 wv[NV];
+#pragma unroll
+            for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? Wl[(size_t)jl * D4 + lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float h = Hs[r * 64 + c * LC + jl];  // (one address per wave: broadcast)
+#pragma unroll
+                for (int n = 0; n < NV; ++n) v[r][n] += h * wv[n];
+            }
+        }
+    }
+    // ---- residual, loss, g_aux; the codes go out as A ----
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = min(row0 + r, n_rows - 1);
+        const bool live = row0 + r < n_rows;
+        float sse = 0.f;
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+        const f32x4* hr = reinterpret_cast<const f32x4*>(x_hat + (size_t)row * D);
+        f32x4* gr = reinterpret_cast<f32x4*>(g_aux + (size_t)row * D);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q < D4) {
+                const f32x4 xv = xr[q], hv = hr[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float diff = v[r][n][e] - (xv[e] - hv[e]);
+                    sse += diff * diff;
+                    v[r][n][e] = gscale * diff;
+                }
+                if (live) gr[q] = v[r][n];
+            } else {
+                v[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        sse = wave_sum(sse);
+        if (lane == 0 && live) rowstats[row].aux_sse = sse;
+        if (live && lane < ndp) A[(size_t)row * ndp + lane] = lane < nd ? Hs[r * 64 + lane] : 0.f;
+    }
+    // ---- dA = g_aux W_dec[dl]^T (a single chunk is still in LDS) ----
+    for (int c = 0; c < n_chunks; ++c) {
+        const int cn = n_chunks == 1 ? nd : stage(Wdec_dead, c);
+        dots(c, cn, Ds, nullptr);
+    }
+    __syncthreads();  // the owner lanes' dA visible to the wave
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+        if (row0 + r < n_rows && lane < ndp) dA[(size_t)(row0 + r) * ndp + lane] = lane < nd ? Ds[r * 64 + lane] : 0.f;
+}
+
 // Weight gradients of the same: per block of 64 rows, part[blk][0][j][:] = sum_b A[b][j] g_aux[b][:] and
 // part[blk][1][j][:] = sum_b dA[b][j] x[b][:] (rows in ascending order); a column sum over the blocks finishes them.
 __global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, const float* dA, const float* g_aux, const float* x,
@@ -315,11 +449,17 @@ __global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, co
     constexpr int ndp = AUX_SMALL_MAX;
     const int r0 = blockIdx.x * 64, r1 = min(n_rows, r0 + 64);
     const int D4 = D >> 2;
-    for (int j0 = 0; j0 < nd; j0 += 8) {
+    // (one group of eight dead latents per workgroup, blockIdx.y: a launch covers AUX_SMALL_MAX / 8 groups and the ones past the
+    // device-side count leave at once -- with one workgroup per 64 rows looping over the groups the kernel had a single wave
+    // per SIMD and spent its time waiting for row loads: 165 us at 30 dead latents)
+    {
+        const int j0 = blockIdx.y * 8;
+        if (j0 >= nd) return;
         for (int q = threadIdx.x; q < D4; q += 256) {
             f32x4 ad[8], ae[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) { ad[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ae[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 4
             for (int r = r0; r < r1; ++r) {
                 const f32x4 g4 = reinterpret_cast<const f32x4*>(g_aux + (size_t)r * D)[q];
                 const f32x4 x4 = reinterpret_cast<const f32x4*>(x + (size_t)r * D)[q];
@@ -356,6 +496,28 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* parts, int 
         f32x4 acc = p[q];
         for (int j = 1; j < n_parts; ++j) acc += p[(long)j * n4 + q];
         reinterpret_cast<f32x4*>(out)[q] = acc;
+    }
+}
+// out[which][c] = sum_blk part[blk][which][c] for c < nd * D (which = blockIdx.y: 0 decoder rows, 1 encoder rows; blocks in
+// ascending order): the finish of aux_small_wgrad_kernel.  The generic column sum splits over ROWS of its input -- four
+// workgroups for these 256 block rows of 30 000+ columns; this one splits over columns.
+__global__ __launch_bounds__(256) void aux_small_wsum_kernel(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd,
+                                                             float* dWe) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > AUX_SMALL_MAX) return;
+    const long n4 = (long)nd * (D >> 2), stride4 = (long)2 * AUX_SMALL_MAX * (D >> 2);
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (long)blockIdx.y * AUX_SMALL_MAX * (D >> 2);
+    f32x4* out = reinterpret_cast<f32x4*>(blockIdx.y == 0 ? dWd : dWe);
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        int b = 0;
+        for (; b + 4 <= n_blk; b += 4) {  // four loads in flight, added in block order
+            const f32x4 a0 = p[(long)b * stride4 + q], a1 = p[(long)(b + 1) * stride4 + q], a2 = p[(long)(b + 2) * stride4 + q],
+                        a3 = p[(long)(b + 3) * stride4 + q];
+            acc += a0; acc += a1; acc += a2; acc += a3;
+        }
+        for (; b < n_blk; ++b) acc += p[(long)b * stride4 + q];
+        out[q] = acc;
     }
 }
 __global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
@@ -484,15 +646,43 @@ hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float*
                                 const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D,
                                 const int32_t* nd_dev, float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats,
                                 hipStream_t s) {
-    return dispatch_nv(D, [&](auto nv) {
-        hipLaunchKernelGGL(aux_small_fwd_kernel<decltype(nv)::value>, dim3((n_rows + 7) / 8), dim3(256), 0, s, x, x_hat,
+    // the LDS-staged kernel: chunks of LC weight rows (<= 64 KB), four rows per wave up to d_model 1024, two up to 2048
+    const int nv = (D / 4 + 63) / 64;
+    const int LC = std::max(1, std::min(16, 16384 / D));
+    auto lds = [&](auto kern, int RW) -> hipError_t {
+        const size_t smem = ((size_t)LC * D + (size_t)4 * 2 * RW * 64) * sizeof(float);
+        static size_t granted[9] = {0};  // per instantiation (indexed by NV): the largest dynamic LDS size already allowed
+        if (smem > granted[nv]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            granted[nv] = smem;
+        }
+        hipLaunchKernelGGL(kern, dim3((n_rows + 4 * RW - 1) / (4 * RW)), dim3(256), smem, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec,
+                           dl, n_rows, D, nd_dev, gscale, A, dA, g_aux, rowstats, LC);
+        return hipGetLastError();
+    };
+    switch (nv) {
+        case 1: return lds(aux_small_fwd_lds_kernel<1, 4>, 4);
+        case 2: return lds(aux_small_fwd_lds_kernel<2, 4>, 4);
+        case 3: return lds(aux_small_fwd_lds_kernel<3, 4>, 4);
+        case 4: return lds(aux_small_fwd_lds_kernel<4, 4>, 4);
+        case 5: case 6: return lds(aux_small_fwd_lds_kernel<6, 2>, 2);
+        case 7: case 8: return lds(aux_small_fwd_lds_kernel<8, 2>, 2);
+        default: break;
+    }
+    return dispatch_nv(D, [&](auto nvc) {
+        hipLaunchKernelGGL(aux_small_fwd_kernel<decltype(nvc)::value>, dim3((n_rows + 7) / 8), dim3(256), 0, s, x, x_hat,
                            WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev, gscale, A, dA, g_aux, rowstats);
     });
 }
+hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s) {
+    hipLaunchKernelGGL(aux_small_wsum_kernel, dim3(64, 2), dim3(256), 0, s, part, n_blk, D, nd_dev, dWd, dWe);
+    return hipGetLastError();
+}
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
                                   const int32_t* nd_dev, float* part, hipStream_t s) {
-    hipLaunchKernelGGL(aux_small_wgrad_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, s, A, dA, g_aux, x, n_rows, D, nd_dev,
-                       part);
+    hipLaunchKernelGGL(aux_small_wgrad_kernel, dim3((n_rows + 63) / 64, AUX_SMALL_MAX / 8), dim3(256), 0, s, A, dA, g_aux, x, n_rows, D,
+                       nd_dev, part);
     return hipGetLastError();
 }
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s) {

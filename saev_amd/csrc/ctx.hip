@@ -1249,9 +1249,7 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         const int nb = (n + 63) / 64, L = AUX_SMALL_MAX;
         const int32_t* nd_dev = c->flags + 4;
         HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
-        HIPCHK(c, launch_colsum(c->aux_small_part, nb, L * D, c->aux_small_part2, c->dWd, 0, nd_dev, s, (long)2 * L * D, 1.0f, D));
-        HIPCHK(c, launch_colsum(c->aux_small_part + (size_t)L * D, nb, L * D, c->aux_small_part2, c->dWe, 0, nd_dev, s,
-                                (long)2 * L * D, 1.0f, D));
+        HIPCHK(c, launch_aux_small_wsum(c->aux_small_part, nb, D, nd_dev, c->dWd, c->dWe, s));
         HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
         if (c->ov_x != nullptr) {  // gathered backward: the local share travels with the compact rows (saev_aux_compact_export)
             HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));  // (the count may be zero on the device)

@@ -467,6 +467,8 @@ hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float*
                                 const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D,
                                 const int32_t* nd_dev, float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats,
                                 hipStream_t s);
+// dWd / dWe (nd x D each) = the block partials of launch_aux_small_wgrad summed in block order
+hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s);
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
                                   const int32_t* nd_dev, float* part, hipStream_t s);  // part: ceil(n/64) x 2 x AUX_SMALL_MAX x D
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s);  // out = sum_j parts[j], n % 4 == 0

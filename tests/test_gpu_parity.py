@@ -579,11 +579,15 @@ def test_steady_state_needs_no_readback_of_n_dead(n_dead):
     few-dead-latents kernels the step reads nothing back (route 1) and still gives the oracle's losses, gradients and
     parameters -- including when the count is zero.  Teacher-forced against the oracle on every step."""
     d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
-    p = rand_params(d, s, seed=80 + n_dead)
-    gen = torch.Generator().manual_seed(81 + n_dead)
+    # (seeds free of near-ties at a row's k-th place in all three encoder modes: with base 80 the 64-dead case has one in step 6
+    # under the f32 encoder -- nine W_dec rows move by 6e-4 on BOTH AuxK routes, none of them a dead latent's;
+    # tools/experiments/r4_diag_aux64.py)
+    base = 180 if n_dead == 64 else 80
+    p = rand_params(d, s, seed=base + n_dead)
+    gen = torch.Generator().manual_seed(base + 1 + n_dead)
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
     toks = torch.zeros(s, dtype=torch.int64)
-    dead = torch.randperm(s, generator=torch.Generator().manual_seed(82))[:n_dead]
+    dead = torch.randperm(s, generator=torch.Generator().manual_seed(base + 2))[:n_dead]
     toks[dead] = thr
     p["b_enc"][dead] = -100.0  # never selected: they stay dead
     # (aux_small_max = 64: the few-dead-latents kernels up to their capacity -- the default hands sets above 16 to the dense algebra)

@@ -627,11 +627,14 @@ def test_growing_dead_set_switches_to_the_dense_route_in_time():
     so the step in which the dead set outgrows the few-dead-latents kernels already runs the exact read-back + dense
     algebra.  80 latents die at once in step 6 (the few-dead-latents kernels take up to 64)."""
     d, s, k, n, k_aux, thr = 128, 1024, 8, 200, 64, 100_000
-    p = rand_params(d, s, seed=90)
-    gen = torch.Generator().manual_seed(91)
+    # (seeds free of near-ties at a row's k-th place: with 90 / 91 / 92 one row of step 5 has its k-th and (k+1)-th
+    # pre-activation 5e-7 apart (relative) and the f16x3 encoder -- 22 significant bits -- picks the other one; the smallest
+    # gap over the nine steps here is 2e-5.  tools/experiments/r4_diag_growing.py)
+    p = rand_params(d, s, seed=290)
+    gen = torch.Generator().manual_seed(291)
     cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
     toks = torch.zeros(s, dtype=torch.int64)
-    late = torch.randperm(s, generator=torch.Generator().manual_seed(92))[:80]
+    late = torch.randperm(s, generator=torch.Generator().manual_seed(292))[:80]
     toks[late] = thr - 6 * n  # dead after six more steps of n tokens
     p["b_enc"][late] = -100.0
     eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)

@@ -126,8 +126,10 @@ typedef struct saev_ctx saev_ctx;
  * struct (saev_amd/engine.py: EngineConfig). */
 typedef struct {
     int32_t struct_size;   /* sizeof(saev_debug_cfg) of the caller (fields past it read as 0)                            */
-    int32_t dw_route;      /* weight gradients: 0 column slices out of the XCD L2s where the geometry allows, 1 whole-row
-                              gathers (dw_rows) always                                                                    */
+    int32_t dw_route;      /* weight gradients: 0 column slices out of the XCD L2s where the geometry allows, with the products
+                              dval = <dL/dx_hat row, decoder row> left by the decode where the shape allows (top_k <= 32,
+                              d_model 256 / 512 / 768 / 1024); 1 whole-row gathers (dw_rows) always; 2 column slices with dval
+                              formed by their first pass (the only form for other shapes and for gathered backwards)         */
     int32_t enc_mfma;      /* single-product encoders: 0 v_mfma_f32_16x16x32 kernel, 32 the 32x32x16 kernel               */
     int32_t fused_chain;   /* f16r: 1 = survivor select, exact refinement and final select as ONE launch                  */
     int32_t ngroups;       /* TopK bound groups of the fp16-image encoders: 0 = 32 for top_k <= 32 (64 above), 64 forces

@@ -92,6 +92,11 @@ struct saev_ctx {
     int dws_rows = 0;            // > 0: the copies describe the training forward in flight (that many rows)
     bool dws_pairs = false;      // the CSC build of this backward left pv / plat
     float *gS = nullptr, *xS = nullptr, *dvp = nullptr;
+    // dval[b][j] = <g_b, W_dec[idx[b][j]]> left by the decode itself (decode_q_kernel; kernels.h: DecodeArgs::dval_out): pass A of
+    // the slices then forms dW_dec only.  dval_fwd: the forward in flight has left it (same condition as dws_rows, plus the shape)
+    float* dval_rows = nullptr;
+    bool dval_fwd = false;
+    bool dval_pairs_ready = false;  // the CSC build of this backward has written pv2 from it
     // exact refinement of the f16r encoder from 32-column slices (select.hip: refine_slices_kernel): split_f16r leaves x and
     // W_enc^T slice-major (xS; dW_encT in that layout), rs_part holds the per-slice shares of the survivors' dot products
     bool fwd_slices = false;     // geometry fits and not switched off (saev_debug_cfg.fwd_route)
@@ -349,6 +354,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (c->fwd_slices && !c->dws_ok) A(xS, MBB * D);
     if (c->dws_ok) {
         A(gS, MBB * D); A(xS, MBB * D); A(dvp, (size_t)(D / DWS_SLICE) * MBB * K);
+        if (c->dbg.dw_route != 2 && decode_forms_dval((int)D, (int)K)) A(dval_rows, MB * K);
         A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
     }
     A(colsum_partials, ((MBB + 63) / 64) * D);
@@ -1038,8 +1044,11 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.training = training ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
     c->dws_rows = 0;
+    c->dval_fwd = false;
     // (slice-major copies for the weight gradients: dL/dx_hat always from the decode, x only when split_f16r has not left one)
     if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->fwd_step ? nullptr : c->xS; c->dws_rows = n; }
+    // (... and the products dval, from the decoder rows while the decode holds them in registers)
+    if (c->dws_rows == n && c->P == 1 && c->dval_rows != nullptr) { a.dval_out = c->dval_rows; c->dval_fwd = true; }
     if (c->P > 1) {
         MatryArgs m{};
         m.P = c->P;
@@ -1413,7 +1422,9 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
         a.pv = c->pv; a.plat = c->plat; a.val = ov ? c->ov_val : c->val;
         a.P = c->P_last;
         for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts_last[p];
+        if (!ov && c->dval_fwd && c->P_last == 1) { a.pv2 = c->pv2; a.dval = c->dval_rows; }
     }
+    c->dval_pairs_ready = c->dws_pairs && a.pv2 != nullptr;
     // (the bit map row pitch depends on the batch: a map cleaned for a pitch covers every shorter one, S * words <= before)
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0), formed in the grids of the CSC build's first two
     // launches; the AuxK contractions add theirs
@@ -1476,6 +1487,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         c->unused_valid = w.lat_unused != nullptr;
         w.row_proj = a.row_proj; w.project = a.project; w.enc_sq = a.enc_sq;
         w.clear_bitmap = a.clear_bitmap; w.clear_words = a.clear_words;
+        w.have_dval = c->dval_pairs_ready ? 1 : 0;
         HIPCHK(c, launch_dw_slices(w, (int)((long)n * K), part, s));
     } else {
         c->unused_valid = false;

@@ -157,8 +157,13 @@ struct DecodeArgs {
     // [D / 32][P][n_rows][32]), for the column-sliced weight-gradient passes (launch_dw_slices)
     float* gS;
     float* xS;
+    // optional (training, k <= 32, D = 256 / 512 / 768 / 1024): dval_out[b][j] = <g_b, W_dec[idx[b][j]]> (n_rows, code_stride), formed
+    // from the decoder rows while they are still in registers (decode_q_kernel) -- the backward's pass A then needs no W_dec slices
+    float* dval_out;
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
+// whether launch_decode forms dval_out for this shape (otherwise the pointer is ignored and pass A forms the products)
+bool decode_forms_dval(int D, int k);
 
 // Matryoshka prefixes (objectives.py:125-138, modeling.py:369-409): P ascending cut points ending at S; prefix p
 // reconstructs from the codes with latent index < cuts[p].
@@ -190,6 +195,10 @@ struct CscArgs {
     int2* pv;
     int32_t* plat;
     const float* val;       // (n_rows, code_stride) coefficients (with pv)
+    // optional (with pv, P <= 1): the decode has left dval (n_rows, code_stride); pv2 = pv with dval as the coefficient is written here
+    // instead of by dw_dval_sum_kernel
+    int2* pv2;
+    const float* dval;
     int P;                  // (with pv) Matryoshka: the pair word carries the virtual row p(latent) * n_rows + row; <= 1: plain
     int32_t cuts[16];       // MAX_PREFIXES
 };
@@ -277,6 +286,8 @@ struct DwSlicesArgs {
     // optional (saev_train_step only): lat_unused[i] = 1 for a latent without pairs; its dW_enc^T row is then NOT written (the
     // scratch is read by the fused Adam alone, which takes the flag for a row of zeros -- and skips reading the zeroed dW_dec row)
     int32_t* lat_unused;
+    // pv2 already holds dval (CscArgs::pv2): pass A forms dW_dec only, no dval shares, no dw_dval_sum_kernel
+    int have_dval;
 };
 // part as in DwRowsArgs (0 both gradients; 1 decoder half: passes A + dval sums; 2 encoder half: pass B, after part 1)
 hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream);

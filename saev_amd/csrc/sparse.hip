@@ -68,6 +68,27 @@ __device__ __forceinline__ float wave_reduce_scatter(float (&p)[KC], int lane) {
     return r;
 }
 
+// the same with every step a compile-time constant (the loop form above leaves hipcc a dynamically indexed array at KC = 32: a
+// 32-way select chain per access)
+template <int H, int BIT>
+__device__ __forceinline__ void wave_rs_step(float* p, int lane) {
+    if constexpr (H >= 1) {
+        const bool up = (lane & BIT) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const float keep = up ? p[i + H] : p[i];
+            const float send = up ? p[i] : p[i + H];
+            p[i] = keep + __shfl_xor(send, BIT, 64);
+        }
+        wave_rs_step<H / 2, BIT / 2>(p, lane);
+    }
+}
+// KC = 32: lane l ends up with the wave-wide sum of p[(l >> 1) & 31]
+__device__ __forceinline__ float wave_reduce_scatter32(float (&p)[32], int lane) {
+    wave_rs_step<16, 32>(p, lane);
+    return p[0] + __shfl_xor(p[0], 1, 64);
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int lane = threadIdx.x & 63;
@@ -145,6 +166,112 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
             RowStats rs;
             rs.sse_scaled = sse_scaled; rs.l0 = l0; rs.l1 = l1; rs.aux_sse = 0.f;
             rs.sse64 = sse64; rs.sumsq64 = sumsq64;
+            a.rowstats[row] = rs;
+        }
+    }
+}
+
+// decode_kernel with the row spread over NW = D / 256 waves (one float4 of the row per lane) and ALL k <= 32 decoder rows of the
+// codes held in registers (32 float4 per lane) until dL/dx_hat is known: dval_j = <g, W_dec[idx_j]> then costs no second gather
+// and no W_dec slices in the backward's pass A (DwSlicesArgs::have_dval).  x_hat is accumulated in code order, as decode_kernel does.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void decode_q_kernel(DecodeArgs a) {
+    __shared__ float sh_dv[NW][32];
+    __shared__ float sh_f[NW];
+    __shared__ double sh_d[NW][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x;
+    constexpr int D4 = 64 * NW;
+    const int q = w * 64 + lane;
+    const int32_t* idx_row = a.idx + (size_t)row * a.code_stride;
+    const float* val_row = a.val + (size_t)row * a.code_stride;
+    int32_t raw_i = -1;
+    float raw_v = 0.f;
+    if (lane < a.k) { raw_i = idx_row[lane]; raw_v = val_row[lane]; }
+    const int32_t my_i = (raw_i < 0 || raw_i >= a.idx_limit) ? -1 : raw_i;
+    // (vmcnt counts in order: what the sum starts from is requested before the gathers)
+    f32x4 acc = reinterpret_cast<const f32x4*>(a.b_dec)[q];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(a.x + (size_t)row * a.D)[q];
+    __builtin_amdgcn_sched_barrier(0);
+    // all 32 gathers in flight together (an absent code reads row 0 and is not used): buffer loads with the row offset in an SGPR
+    // and one lane offset -- written as address arithmetic hipcc forms 64-bit VGPR addresses and sinks the loads into the sum
+    // below, eight in flight
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W_dec), 0, (uint32_t)a.S * (uint32_t)(D4 * 16), 0x00020000);
+    const uint32_t voff = (uint32_t)q * 16u;
+    f32x4 wv[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int i = __builtin_amdgcn_readlane(my_i, j);
+        const i32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(wres, voff, (uint32_t)max(i, 0) * (uint32_t)(D4 * 16), 0);
+        wv[j] = f32x4{__int_as_float(t[0]), __int_as_float(t[1]), __int_as_float(t[2]), __int_as_float(t[3])};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int i = __builtin_amdgcn_readlane(my_i, j);
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw_v), j));
+        if (i >= 0) acc += v * wv[j];
+    }
+    if (a.x_hat) reinterpret_cast<f32x4*>(a.x_hat + (size_t)row * a.D)[q] = acc;
+    const float u = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
+    float sse_scaled = 0.f;
+    double sse64 = 0.0, sumsq64 = 0.0;
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = acc[e] / u - xv[e] / u;
+        sse_scaled += t * t * u * u;
+        g[e] = a.gscale * t * u;
+        const float r = xv[e] - acc[e];
+        sse64 += (double)r * (double)r;
+        sumsq64 += (double)xv[e] * (double)xv[e];
+    }
+    if (a.training) {
+        reinterpret_cast<f32x4*>(a.g + (size_t)row * a.D)[q] = g;
+        if (a.gS != nullptr) {
+            const size_t o = ((size_t)(q >> 3) * a.n_rows + row) * 8 + (q & 7);
+            reinterpret_cast<f32x4*>(a.gS)[o] = g;
+            if (a.xS != nullptr) reinterpret_cast<f32x4*>(a.xS)[o] = xv;
+        }
+    }
+    {
+        float pd[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) pd[j] = (g[0] * wv[j][0] + g[1] * wv[j][1]) + (g[2] * wv[j][2] + g[3] * wv[j][3]);
+        const float r = wave_reduce_scatter32(pd, lane);  // lane l: the wave's sum of pd[(l >> 1) & 31]
+        if ((lane & 1) == 0) sh_dv[w][lane >> 1] = r;
+    }
+    sse_scaled = wave_sum(sse_scaled);
+    sse64 = wave_sum_d(sse64);
+    sumsq64 = wave_sum_d(sumsq64);
+    if (lane == 0) { sh_f[w] = sse_scaled; sh_d[w][0] = sse64; sh_d[w][1] = sumsq64; }
+    __syncthreads();
+    if (w != 0) return;
+    if (lane < 32) {
+        float s = sh_dv[0][lane];
+#pragma unroll
+        for (int v = 1; v < NW; ++v) s += sh_dv[v][lane];
+        if (lane < a.k) a.dval_out[(size_t)row * a.code_stride + lane] = s;
+    }
+    float l0 = 0.f, l1 = 0.f;
+    if (raw_i >= 0 && raw_v != 0.f) {
+        l0 = 1.f;
+        l1 = fabsf(raw_v);
+        if (a.training && a.fired) a.fired[raw_i] = 1;
+    }
+    if (a.rowstats) {
+        l0 = wave_sum(l0);
+        l1 = wave_sum(l1);
+        if (lane == 0) {
+            RowStats rs;
+            float f = sh_f[0];
+            double d0 = sh_d[0][0], d1 = sh_d[0][1];
+#pragma unroll
+            for (int v = 1; v < NW; ++v) { f += sh_f[v]; d0 += sh_d[v][0]; d1 += sh_d[v][1]; }
+            rs.sse_scaled = f; rs.l0 = l0; rs.l1 = l1; rs.aux_sse = 0.f;
+            rs.sse64 = d0; rs.sumsq64 = d1;
             a.rowstats[row] = rs;
         }
     }
@@ -419,6 +546,7 @@ __global__ void csc_place_kernel(CscArgs a) {
             if (a.P > 1) while (pblk < a.P - 1 && i >= a.cuts[pblk]) ++pblk;
             a.pv[slot] = int2{((pblk * a.n_rows + b) << 7) | fl, __float_as_int(a.val[(size_t)b * a.code_stride + j])};
             a.plat[slot] = i;
+            if (a.pv2 != nullptr) a.pv2[slot] = int2{(b << 7) | fl, __float_as_int(a.dval[(size_t)b * a.code_stride + j])};
         }
     }
 }
@@ -706,10 +834,11 @@ __global__ __launch_bounds__(256) void slice_major_copy_kernel(const float* __re
     }
 }
 
-// PASS_A: m = gS, out = dW_dec, coefficients pv[].y = val, W slices for the dval shares.  Otherwise m = xS, out = dW_enc^T,
+// DEC (pass A): m = gS, out = dW_dec, coefficients pv[].y = val, W slices for the dval shares (DVAL).  Otherwise m = xS, out = dW_enc^T,
 // coefficients pv2[].y = dval.  A workgroup = 4 waves x 8 lane groups = 32 runs of one slice.
-template <bool PASS_A>
-__global__ __launch_bounds__(256, PASS_A ? 4 : 6) void dw_slices_kernel(DwSlicesArgs a, int wg_per_slice) {
+template <bool DEC, bool DVAL = true>
+__global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : (DEC ? 5 : 6)) void dw_slices_kernel(DwSlicesArgs a, int wg_per_slice) {
+    constexpr bool PASS_A = DEC && DVAL;  // the dval shares are formed here (DVAL = false: the decode has left them, DwSlicesArgs::have_dval)
     constexpr int L = DWS_RUN;
     const int lane = threadIdx.x & 63, gi = lane >> 3, li = lane & 7;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -732,16 +861,16 @@ __global__ __launch_bounds__(256, PASS_A ? 4 : 6) void dw_slices_kernel(DwSlices
     };
     const int p0 = bound(run), p1 = bound(run + 1);
     const bool live = p0 < p1;
-    const int2* const pv = PASS_A ? a.pv : a.pv2;
-    float* const out = PASS_A ? a.dW_dec : a.dW_encT;
-    float* const part = PASS_A ? a.part_dec : a.part_enc;
+    const int2* const pv = DEC ? a.pv : a.pv2;
+    float* const out = DEC ? a.dW_dec : a.dW_encT;
+    float* const part = DEC ? a.part_dec : a.part_enc;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
     float* const dvp = PASS_A ? a.dvp + (size_t)slice * a.pair_cap : nullptr;
     const int sel = (lane & 56) << 2;  // byte address of the group's lane 0 for ds_bpermute
     const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(PASS_A ? a.gS : a.xS) + (size_t)slice * a.n_rows * DWS_SLICE * (PASS_A && a.P > 1 ? a.P : 1), 0,
-        (uint32_t)a.n_rows * 128u * (uint32_t)(PASS_A && a.P > 1 ? a.P : 1), 0x00020000);
+        const_cast<float*>(DEC ? a.gS : a.xS) + (size_t)slice * a.n_rows * DWS_SLICE * (DEC && a.P > 1 ? a.P : 1), 0,
+        (uint32_t)a.n_rows * 128u * (uint32_t)(DEC && a.P > 1 ? a.P : 1), 0x00020000);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W_dec), 0, (uint32_t)a.S * rowb, 0x00020000);
 
     // pair info of block t (pairs p0 + 8 t + li): END on the run's last pair; past the end: row 0 with coefficient 0 (never stored)
@@ -789,7 +918,7 @@ __global__ __launch_bounds__(256, PASS_A ? 4 : 6) void dw_slices_kernel(DwSlices
                 *reinterpret_cast<f32x4*>(o) = acc;
                 // every run leaves word of whether a latent BEGINS in it and continues past its end (its tail partial):
                 // dw_finalize_cut_kernel starts from these
-                if (PASS_A && slice == 0 && li == 0 && (xc[j] & DWS_END))
+                if (DEC && slice == 0 && li == 0 && (xc[j] & DWS_END))
                     a.cut_lat[run] = (!head_open && !(xc[j] & DWS_LAST)) ? lc[j] : -1;
                 head_open = false;
                 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -834,6 +963,14 @@ __global__ __launch_bounds__(256) void dw_dval_sum_kernel(DwSlicesArgs a) {
     const int b = a.P > 1 ? (e.x >> 7) % a.n_rows : (e.x >> 7);  // (Matryoshka: pass A's word holds p(latent) * n_rows + row)
     a.pv2[p] = int2{(b << 7) | (e.x & 127), __float_as_int(s)};
     if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)a.plat[p] * a.clear_words + (b >> 5)] = 0u;
+}
+
+// have_dval: pv2 is there already; only the CSC bit map words of the pairs are zeroed (what dw_dval_sum_kernel does on its way)
+__global__ __launch_bounds__(256) void dw_clear_bitmap_kernel(DwSlicesArgs a) {
+    const int NP = a.starts[a.S];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    a.clear_bitmap[(size_t)a.plat[p] * a.clear_words + (a.pv2[p].x >> 12)] = 0u;
 }
 
 // Latents that are cut by run boundaries (L or more pairs): one workgroup per run boundary and gradient row (blockIdx.y: 0 decoder
@@ -1150,8 +1287,18 @@ hipError_t dispatch_nv(int D, F&& f) {
 
 }  // namespace
 
+bool decode_forms_dval(int D, int k) { return k <= 32 && D % 256 == 0 && D >= 256 && D <= 1024; }
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
+    if (a.dval_out != nullptr && a.x != nullptr && decode_forms_dval(a.D, a.k)) {
+        switch (a.D / 256) {
+            case 1: hipLaunchKernelGGL(decode_q_kernel<1>, dim3(a.n_rows), dim3(64), 0, stream, a); break;
+            case 2: hipLaunchKernelGGL(decode_q_kernel<2>, dim3(a.n_rows), dim3(128), 0, stream, a); break;
+            case 3: hipLaunchKernelGGL(decode_q_kernel<3>, dim3(a.n_rows), dim3(192), 0, stream, a); break;
+            default: hipLaunchKernelGGL(decode_q_kernel<4>, dim3(a.n_rows), dim3(256), 0, stream, a); break;
+        }
+        return hipGetLastError();
+    }
     return dispatch_nv(a.D, [&](auto nv) {
         hipLaunchKernelGGL(decode_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     });
@@ -1200,7 +1347,10 @@ hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipS
     const int wg_per_slice = (n_runs + 31) / 32;
     const int grid = ((a.D / DWS_SLICE + 7) / 8) * 8 * wg_per_slice;
     // part 1: the decoder's half (pass A leaves the dval the encoder's half needs); part 2: the encoder's; 0: both
-    if (part != 2) {
+    if (part != 2 && a.have_dval) {
+        hipLaunchKernelGGL((dw_slices_kernel<true, false>), dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
+        if (a.clear_bitmap != nullptr) hipLaunchKernelGGL(dw_clear_bitmap_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
+    } else if (part != 2) {
         hipLaunchKernelGGL(dw_slices_kernel<true>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
         hipLaunchKernelGGL(dw_dval_sum_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
     }

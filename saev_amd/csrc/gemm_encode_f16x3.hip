@@ -814,13 +814,17 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
             static_for<8>([&](auto G) {
                 constexpr int sb = decltype(G)::value;
                 constexpr int as = sb % 3;
-                acc[sb][0] = mfma16<AR>(fa[as], fb[0], acc[sb][0]);
+                // (odd latent blocks walk the row blocks 3..0: the B operand of a group's last MFMA is that of the next group's first,
+                // 32 operand changes in front of the matrix pipe per k-step instead of 40 -- worth 0.7 % of this power-limited loop,
+                // tools/ubench/enc_loop2.hip SNAKE)
+                constexpr int j0 = (sb & 1) ? 3 : 0, j1 = (sb & 1) ? 2 : 1, j2 = (sb & 1) ? 1 : 2, j3 = (sb & 1) ? 0 : 3;
+                acc[sb][j0] = mfma16<AR>(fa[as], fb[j0], acc[sb][j0]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (sb + 2 < 8) load_a((sb + 2) % 3, sb + 2);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[sb][1] = mfma16<AR>(fa[as], fb[1], acc[sb][1]);
-                acc[sb][2] = mfma16<AR>(fa[as], fb[2], acc[sb][2]);
-                acc[sb][3] = mfma16<AR>(fa[as], fb[3], acc[sb][3]);
+                acc[sb][j1] = mfma16<AR>(fa[as], fb[j1], acc[sb][j1]);
+                acc[sb][j2] = mfma16<AR>(fa[as], fb[j2], acc[sb][j2]);
+                acc[sb][j3] = mfma16<AR>(fa[as], fb[j3], acc[sb][j3]);
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");

@@ -25,7 +25,7 @@ struct __attribute__((aligned(16))) KSlot {
     _Float16 b[256][32];
 };
 
-enum { NOBAR = 1, NOLDS = 2, NOSTAGE = 4, PAIR = 8, NOMFMA = 16, PREF = 32 };
+enum { NOBAR = 1, NOLDS = 2, NOSTAGE = 4, PAIR = 8, NOMFMA = 16, PREF = 32, SNAKE = 64 };
 
 __device__ __forceinline__ unsigned long long shader_cycles() { return __builtin_readcyclecounter(); }  // s_memtime: tick = shader cycle
 
@@ -74,8 +74,13 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(const _Float16* __restrict
         }
 #pragma unroll
         for (int sb = 0; sb < 8; ++sb) {
-            if constexpr (!(FL & NOMFMA)) acc[sb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sb % 3], fb[0], acc[sb][0], 0, 0, 0);
+            // SNAKE: odd latent blocks walk the row blocks 3..0, so the B operand of the last MFMA of a group is that of the first MFMA
+            // of the next (fewer operand changes in front of the matrix pipe: does the power-limited clock notice?)
+            constexpr int j0 = 0;
+            const int jf = ((FL & SNAKE) && (sb & 1)) ? 3 : 0;
+            if constexpr (!(FL & NOMFMA)) acc[sb][jf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sb % 3], fb[jf], acc[sb][jf], 0, 0, 0);
             else acc[sb][0][0] += (float)fa[sb % 3][0] + (float)fb[0][0];
+            (void)j0;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(FL & NOLDS)) {
                 if (sb + 2 < 8) fa[(sb + 2) % 3] = *reinterpret_cast<const half8*>(&cs.a[arow0 + 16 * (sb + 2)][coff]);
@@ -83,7 +88,10 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(const _Float16* __restrict
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(FL & NOMFMA)) {
 #pragma unroll
-                for (int jb = 1; jb < 4; ++jb) acc[sb][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sb % 3], fb[jb], acc[sb][jb], 0, 0, 0);
+                for (int jq = 1; jq < 4; ++jq) {
+                    const int jb = ((FL & SNAKE) && (sb & 1)) ? 3 - jq : jq;
+                    acc[sb][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sb % 3], fb[jb], acc[sb][jb], 0, 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int jb = 1; jb < 4; ++jb) acc[sb][jb][0] += (float)fb[jb][0];
@@ -260,8 +268,13 @@ int main() {
         run(loop_kernel<NOLDS | NOSTAGE | NOBAR>, "MFMA only");
         run(loop_kernel<NOMFMA>, "NOMFMA");
         run(loop_kernel<PAIR>, "PAIR");
-        run(loop_kernel<PREF>, "PREF");
+        run(loop_kernel<SNAKE>, "SNAKE");
         run(loop_kernel<0>, "shipped loop (again)");
+        run(loop_kernel<SNAKE>, "SNAKE (again)");
+        run(loop_kernel<SNAKE | NOLDS | NOSTAGE | NOBAR>, "SNAKE MFMA only");
+        run(loop_kernel<NOLDS | NOSTAGE | NOBAR>, "MFMA only (again)");
+        run(loop_kernel<PREF>, "PREF");
+        run(loop_kernel<0>, "shipped loop (3)");
         run(loop_kernel<PREF>, "PREF (again)");
         run(loop_kernel<PREF | NOBAR>, "PREF NOBAR");
     }

@@ -97,6 +97,7 @@ struct saev_ctx {
     float* dval_rows = nullptr;
     bool dval_fwd = false;
     bool dval_pairs_ready = false;  // the CSC build of this backward has written pv2 from it
+    bool fused_forward = false;     // saev_train_step's forward: Matryoshka G blocks past the first are not needed row-major
     // exact refinement of the f16r encoder from 32-column slices (select.hip: refine_slices_kernel): split_f16r leaves x and
     // W_enc^T slice-major (xS; dW_encT in that layout), rs_part holds the per-slice shares of the survivors' dot products
     bool fwd_slices = false;     // geometry fits and not switched off (saev_debug_cfg.fwd_route)
@@ -1048,12 +1049,13 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     // (slice-major copies for the weight gradients: dL/dx_hat always from the decode, x only when split_f16r has not left one)
     if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->fwd_step ? nullptr : c->xS; c->dws_rows = n; }
     // (... and the products dval, from the decoder rows while the decode holds them in registers)
-    if (c->dws_rows == n && c->P == 1 && c->dval_rows != nullptr) { a.dval_out = c->dval_rows; c->dval_fwd = true; }
+    if (c->dws_rows == n && c->dval_rows != nullptr) { a.dval_out = c->dval_rows; c->dval_fwd = true; }
     if (c->P > 1) {
         MatryArgs m{};
         m.P = c->P;
         for (int p = 0; p < c->P; ++p) m.cuts[p] = c->cuts[p];
         m.G = c->G;
+        m.g_rows_all = c->fused_forward ? 0 : 1;  // (saev_train_step's own backward reads the slice-major copy and block 0 alone)
         HIPCHK(c, launch_decode_matry(a, m, s));
     } else {
         HIPCHK(c, launch_decode(a, s));
@@ -1422,7 +1424,7 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
         a.pv = c->pv; a.plat = c->plat; a.val = ov ? c->ov_val : c->val;
         a.P = c->P_last;
         for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts_last[p];
-        if (!ov && c->dval_fwd && c->P_last == 1) { a.pv2 = c->pv2; a.dval = c->dval_rows; }
+        if (!ov && c->dval_fwd) { a.pv2 = c->pv2; a.dval = c->dval_rows; }
     }
     c->dval_pairs_ready = c->dws_pairs && a.pv2 != nullptr;
     // (the bit map row pitch depends on the batch: a map cleaned for a pitch covers every shorter one, S * words <= before)
@@ -1737,7 +1739,9 @@ int saev_step_tail(saev_ctx* c, float lr, float max_norm, float grad_scale, int6
 
 int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_norm, int64_t adam_step,
                     void* stream) {
+    c->fused_forward = c->dws_ok && c->GS != nullptr;  // (the backward below takes the column slices: nothing reads G's blocks 1..P-1)
     int rc = saev_step_forward(c, x, n, n, 1, stream);
+    c->fused_forward = false;
     if (rc != SAEV_OK) return rc;
     rc = saev_step_dead(c, n, stream);
     if (rc != SAEV_OK) return rc;

@@ -172,6 +172,9 @@ struct MatryArgs {
     int P;
     int32_t cuts[MAX_PREFIXES];
     float* G;  // (n_rows, P, D): first dL/dx_hat_p, then (in place) C_p = sum_{p' >= p} dL/dx_hat_p'
+    // decode_matry_q_kernel only (DecodeArgs::dval_out set): 0 = only block 0 of G is written (C_0: db_dec's column sums) -- the
+    // backward that follows is known to read the slice-major copy alone (saev_train_step)
+    int g_rows_all;
 };
 hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStream_t stream);
 

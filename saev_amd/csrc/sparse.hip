@@ -391,6 +391,134 @@ __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryAr
     }
 }
 
+// decode_matry_kernel in decode_q_kernel's layout: the k <= 32 decoder rows of the codes stay in registers (one float4 per lane and
+// code), the P prefix gradients of the lane's four columns in LDS (P x D floats per row = workgroup), so the suffix sums C_p
+// never make the round trip through G that the row kernel pays (P x 4 KB written, read and rewritten per row), and
+// dval_j = <C_p(j), W_dec[idx_j]> comes from the registers (DwSlicesArgs::have_dval).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void decode_matry_q_kernel(DecodeArgs a, MatryArgs m) {
+    extern __shared__ __attribute__((aligned(16))) char matry_smem[];
+    f32x4* const shG = reinterpret_cast<f32x4*>(matry_smem);  // [P][64 * NW]
+    __shared__ float sh_dv[NW][32];
+    __shared__ float sh_f[NW];
+    __shared__ double sh_d[NW][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x;
+    constexpr int D4 = 64 * NW;
+    const int q = w * 64 + lane;
+    const int P = m.P;
+    const int32_t* idx_row = a.idx + (size_t)row * a.code_stride;
+    const float* val_row = a.val + (size_t)row * a.code_stride;
+    int32_t raw_i = -1;
+    float raw_v = 0.f;
+    if (lane < a.k) { raw_i = idx_row[lane]; raw_v = val_row[lane]; }
+    const int32_t my_i = raw_i < 0 ? -1 : raw_i;
+    f32x4 acc = reinterpret_cast<const f32x4*>(a.b_dec)[q];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(a.x + (size_t)row * a.D)[q];
+    __builtin_amdgcn_sched_barrier(0);
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W_dec), 0, (uint32_t)a.S * (uint32_t)(D4 * 16), 0x00020000);
+    const uint32_t voff = (uint32_t)q * 16u;
+    f32x4 wv[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int i = __builtin_amdgcn_readlane(my_i, j);
+        const i32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(wres, voff, (uint32_t)max(i, 0) * (uint32_t)(D4 * 16), 0);
+        wv[j] = f32x4{__int_as_float(t[0]), __int_as_float(t[1]), __int_as_float(t[2]), __int_as_float(t[3])};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float u = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
+    float sse_scaled = 0.f;
+    double sse64 = 0.0, sumsq64 = 0.0;
+    auto emit = [&](int p) {
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = acc[e] / u - xv[e] / u;
+            sse_scaled += t * t * u * u;
+            g[e] = a.gscale * t * u;
+        }
+        shG[p * D4 + q] = g;
+    };
+    int p = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int i = __builtin_amdgcn_readlane(my_i, j);
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw_v), j));
+        if (i >= 0) {
+            while (p < P - 1 && i >= m.cuts[p]) { emit(p); ++p; }
+            acc += v * wv[j];
+        }
+    }
+    while (p < P) { emit(p); ++p; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // statistics of the full reconstruction
+        const float r = xv[e] - acc[e];
+        sse64 += (double)r * (double)r;
+        sumsq64 += (double)xv[e] * (double)xv[e];
+    }
+    if (a.x_hat) reinterpret_cast<f32x4*>(a.x_hat + (size_t)row * a.D)[q] = acc;
+    if (a.training) {
+        // suffix sums in place (a lane re-reads only what it wrote), out to the slice-major copy [q / 8][p][row][8 float4]
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        f32x4* const Grow = reinterpret_cast<f32x4*>(m.G + (size_t)row * P * a.D);
+        for (int pp = P - 1; pp >= 0; --pp) {
+            c += shG[pp * D4 + q];
+            shG[pp * D4 + q] = c;
+            if (pp == 0 || m.g_rows_all) Grow[(size_t)pp * D4 + q] = c;
+            if (a.gS != nullptr) reinterpret_cast<f32x4*>(a.gS)[(((size_t)(q >> 3) * P + pp) * a.n_rows + row) * 8 + (q & 7)] = c;
+        }
+        if (a.gS != nullptr && a.xS != nullptr) reinterpret_cast<f32x4*>(a.xS)[((size_t)(q >> 3) * a.n_rows + row) * 8 + (q & 7)] = xv;
+        float pd[32];
+        int pb = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int i = __builtin_amdgcn_readlane(my_i, j);
+            pd[j] = 0.f;
+            if (i >= 0) {
+                while (pb < P - 1 && i >= m.cuts[pb]) ++pb;
+                const f32x4 cj = shG[pb * D4 + q];
+                pd[j] = (cj[0] * wv[j][0] + cj[1] * wv[j][1]) + (cj[2] * wv[j][2] + cj[3] * wv[j][3]);
+            }
+        }
+        const float r = wave_reduce_scatter32(pd, lane);
+        if ((lane & 1) == 0) sh_dv[w][lane >> 1] = r;
+    }
+    sse_scaled = wave_sum(sse_scaled);
+    sse64 = wave_sum_d(sse64);
+    sumsq64 = wave_sum_d(sumsq64);
+    if (lane == 0) { sh_f[w] = sse_scaled; sh_d[w][0] = sse64; sh_d[w][1] = sumsq64; }
+    __syncthreads();
+    if (w != 0) return;
+    if (a.training && lane < 32) {
+        float s = sh_dv[0][lane];
+#pragma unroll
+        for (int v = 1; v < NW; ++v) s += sh_dv[v][lane];
+        if (lane < a.k) a.dval_out[(size_t)row * a.code_stride + lane] = s;
+    }
+    float l0 = 0.f, l1 = 0.f;
+    if (raw_i >= 0 && raw_v != 0.f) {
+        l0 = 1.f;
+        l1 = fabsf(raw_v);
+        if (a.training && a.fired) a.fired[raw_i] = 1;
+    }
+    if (a.rowstats) {
+        l0 = wave_sum(l0);
+        l1 = wave_sum(l1);
+        if (lane == 0) {
+            RowStats rs;
+            float f = sh_f[0];
+            double d0 = sh_d[0][0], d1 = sh_d[0][1];
+#pragma unroll
+            for (int v = 1; v < NW; ++v) { f += sh_f[v]; d0 += sh_d[v][0]; d1 += sh_d[v][1]; }
+            rs.sse_scaled = f; rs.l0 = l0; rs.l1 = l1; rs.aux_sse = 0.f;
+            rs.sse64 = d0; rs.sumsq64 = d1;
+            a.rowstats[row] = rs;
+        }
+    }
+}
+
 // ------------------------------- CSC build -------------------------------------------------
 
 // zero the bit map; skipped entirely when the (device-side) code count is 0
@@ -1305,6 +1433,26 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
 }
 hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
+    if (a.dval_out != nullptr && a.x != nullptr && a.training && decode_forms_dval(a.D, a.k)) {
+        const size_t smem = (size_t)m.P * a.D * sizeof(float);  // <= 64 KB (P <= 16, D <= 1024), next to < 1 KB of static LDS
+        static bool attr_set = false;
+        if (!attr_set) {
+            const void* fns[4] = {reinterpret_cast<const void*>(&decode_matry_q_kernel<1>), reinterpret_cast<const void*>(&decode_matry_q_kernel<2>),
+                                  reinterpret_cast<const void*>(&decode_matry_q_kernel<3>), reinterpret_cast<const void*>(&decode_matry_q_kernel<4>)};
+            for (const void* f : fns) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_PREFIXES * 1024 * (int)sizeof(float));
+                if (e != hipSuccess) return e;
+            }
+            attr_set = true;
+        }
+        switch (a.D / 256) {
+            case 1: hipLaunchKernelGGL(decode_matry_q_kernel<1>, dim3(a.n_rows), dim3(64), smem, stream, a, m); break;
+            case 2: hipLaunchKernelGGL(decode_matry_q_kernel<2>, dim3(a.n_rows), dim3(128), smem, stream, a, m); break;
+            case 3: hipLaunchKernelGGL(decode_matry_q_kernel<3>, dim3(a.n_rows), dim3(192), smem, stream, a, m); break;
+            default: hipLaunchKernelGGL(decode_matry_q_kernel<4>, dim3(a.n_rows), dim3(256), smem, stream, a, m); break;
+        }
+        return hipGetLastError();
+    }
     return dispatch_nv(a.D, [&](auto nv) {
         hipLaunchKernelGGL(decode_matry_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a, m);
     });

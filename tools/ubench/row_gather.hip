@@ -1,0 +1,126 @@
+// Floor of the sparse decode's access pattern: every batch row sums k = 32 rows (4 KB each) of a 32 768 x 1024 fp32 matrix (134 MB:
+// past the 4 MB L2 of an XCD, inside the 256 MB Infinity Cache), latent indices drawn uniformly from `used` latents, ascending per
+// row.  Nothing but the gathers and the sum (one store of 4 KB per row), in the two layouts the step has:
+//   rows4   decode_q_kernel's: a workgroup of four waves per batch row, one float4 per lane and code, ALL 32 gathers in flight
+//   rows1   decode_kernel's:   one wave per batch row, four float4 per lane and code, four codes (16 loads) in flight
+//   slices  dw_slices / refine_slices': the matrix slice-major [D / 32][S][32], XCD x walks slices x, x + 8, ...; an eight-lane group
+//           sums one (row, slice): 32 gathers of 128 B out of a 4 MB slice (two 2 MB halves by latent range, one after the other)
+// Prints the gathered bytes per second: what "whole-row gathers at the fabric rate" and "line gathers out of L2" mean in DESIGN.md.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/row_gather.hip -o /tmp/row_gather && /tmp/row_gather
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int S = 32768, D = 1024, B = 16384, K = 32;
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return f32x4{__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+}
+
+__global__ __launch_bounds__(256) void rows4_kernel(const float* __restrict__ W, const int* __restrict__ idx, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, q = threadIdx.x, row = blockIdx.x;
+    const int my = lane < K ? idx[(size_t)row * K + lane] : 0;
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (uint32_t)S * D * 4u, 0x00020000);
+    f32x4 w[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) w[j] = bload(res, (uint32_t)q * 16u, (uint32_t)__builtin_amdgcn_readlane(my, j) * (uint32_t)(D * 4));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc += w[j];
+    reinterpret_cast<f32x4*>(out + (size_t)row * D)[q] = acc;
+}
+
+__global__ __launch_bounds__(256) void rows1_kernel(const float* __restrict__ W, const int* __restrict__ idx, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int my = lane < K ? idx[(size_t)row * K + lane] : 0;
+    f32x4 acc[4] = {};
+#pragma unroll 4
+    for (int j = 0; j < K; ++j) {
+        const int i = __shfl(my, j, 64);
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)i * D);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] += wr[lane + 64 * n];
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) reinterpret_cast<f32x4*>(out + (size_t)row * D)[lane + 64 * n] = acc[n];
+}
+
+// WS: [D / 32][S][32 floats].  Grid: 8 XCDs x 4 slices each x (B / 32 rows per workgroup); a workgroup = 32 eight-lane groups = 32 rows
+// of one slice; `half` = 0 / 1: only the codes below / from S / 2 (each launch keeps a 2 MB half slice per XCD hot)
+__global__ __launch_bounds__(256) void slices_kernel(const float* __restrict__ WS, const int* __restrict__ idx, float* __restrict__ outS, int half,
+                                                    int wg_per_slice) {
+    const int lane = threadIdx.x & 63, gi = threadIdx.x >> 3, li = lane & 7;
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int slice = xcd + 8 * (qq / wg_per_slice);
+    const int row = (qq % wg_per_slice) * 32 + gi;
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WS) + (size_t)slice * S * 32, 0, (uint32_t)S * 128u, 0x00020000);
+    const int* ir = idx + (size_t)row * K;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int lo = half * (S / 2), hi = lo + S / 2;
+#pragma unroll
+    for (int j0 = 0; j0 < K; j0 += 8) {
+        f32x4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = ir[j0 + u];
+            // (a code outside this half: offset past the buffer, the load returns zeros without touching memory)
+            w[u] = bload(res, ((i >= lo && i < hi) ? (uint32_t)i * 128u : 0xFFFFFF00u) | ((uint32_t)li * 16u), 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u];
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(outS) + ((size_t)slice * B + row) * 8 + li;
+    if (half) acc += *o;
+    *o = acc;
+}
+
+int main() {
+    float *W, *out;
+    int* idx;
+    hipMalloc(&W, (size_t)S * D * 4); hipMalloc(&out, (size_t)B * D * 4); hipMalloc(&idx, (size_t)B * K * 4);
+    hipMemset(W, 0, (size_t)S * D * 4);
+    for (int used : {14000, 27000, 32768}) {
+        std::mt19937 rng(1);
+        std::vector<int> perm(S);
+        for (int i = 0; i < S; ++i) perm[i] = i;
+        std::shuffle(perm.begin(), perm.end(), rng);
+        std::vector<int> h((size_t)B * K);
+        for (int b = 0; b < B; ++b) {
+            for (int j = 0; j < K; ++j) h[(size_t)b * K + j] = perm[rng() % used];
+            std::sort(h.begin() + (size_t)b * K, h.begin() + (size_t)(b + 1) * K);
+        }
+        hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        const double bytes = (double)B * K * D * 4;
+        auto time = [&](const char* name, auto launch) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 12; ++rep) {
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0, 0);
+                launch();
+                hipEventRecord(e1, 0);
+                hipDeviceSynchronize();
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep >= 2 && ms < best) best = ms;
+            }
+            printf("latents in use %5d  %-8s %.3f ms  %5.1f TB/s of gathered rows  (%s)\n", used, name, best, bytes / best * 1e-9, hipGetErrorString(hipGetLastError()));
+        };
+        time("rows4", [&] { hipLaunchKernelGGL(rows4_kernel, dim3(B), dim3(256), 0, 0, W, idx, out); });
+        time("rows1", [&] { hipLaunchKernelGGL(rows1_kernel, dim3(B / 4), dim3(256), 0, 0, W, idx, out); });
+        time("slices", [&] {
+            const int wps = B / 32;
+            hipLaunchKernelGGL(slices_kernel, dim3(8 * 4 * wps), dim3(256), 0, 0, W, idx, out, 0, wps);
+            hipLaunchKernelGGL(slices_kernel, dim3(8 * 4 * wps), dim3(256), 0, 0, W, idx, out, 1, wps);
+        });
+    }
+    return 0;
+}

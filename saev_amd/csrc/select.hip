@@ -682,6 +682,13 @@ __device__ __forceinline__ float group8_reduce_scatter(float (&p)[8], int li) {
     const float keep = up ? p[1] : p[0], send = up ? p[0] : p[1];
     return keep + __shfl_xor(send, 1, 64);
 }
+// An eight-lane group works through RS_ROWS activation rows; the eight groups of a wave run one instruction stream, so a group is
+// busy ceil(survivors / 8) trips per row.  Rows differ (22 +- 5 survivors per latent range at configs[1]): with every group on its
+// t-th row at the same time the wave waits for the longest list of each octet of rows (3.8 trips against 2.8 on average).  Here a
+// group moves on to its next row as soon as its list is done -- the rows' list bounds and x slices are fetched up front, the
+// advance is a few selects -- so the wave runs as long as its busiest GROUP over all its rows: 283 -> 259 us at RS_ROWS = 8
+// (4: 281; the same with the bounds in LDS, a run-time advance loop and the next trip's indices requested behind the gathers:
+// 289 at 8 rows, 327 at 16 -- tools/experiments/r4_kernel_ab.sh).
 __global__ __launch_bounds__(256) void refine_slices_kernel(RefineSlicesArgs a, int wg_per_combo) {
     if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
     const int lane = threadIdx.x & 63, gi = lane >> 3, li = lane & 7;
@@ -697,33 +704,52 @@ __global__ __launch_bounds__(256) void refine_slices_kernel(RefineSlicesArgs a, 
     const f32x4* const xs = reinterpret_cast<const f32x4*>(a.xS + (size_t)slice * a.n_rows * RS_SLICE);
     float* const part = a.part + (size_t)slice * a.n_rows * REFINE_CAP;
     const uint32_t li16 = (uint32_t)li * 16u;
-#pragma unroll 1
+    // this pass's survivors of the group's rows: each row's sub-list of the latent range (select_cand_kernel groups them; one range: all)
+    const int row0 = (wgi * RS_ROWS * 4 + (int)(threadIdx.x >> 6)) * 8 + gi;  // row of trip t: row0 + 32 t
+    int jb[RS_ROWS], je[RS_ROWS];
+    f32x4 xr[RS_ROWS];
+#pragma unroll
     for (int t = 0; t < RS_ROWS; ++t) {
-        const int row = ((wgi * RS_ROWS + t) * 4 + (int)(threadIdx.x >> 6)) * 8 + gi;
+        const int row = row0 + 32 * t;
         const bool rok = row < a.n_rows;
-        // this pass's survivors: the row's sub-list of the latent range (select_cand_kernel groups them; one range: all)
-        const int j_end = rok ? a.surv_rng[(size_t)row * RS_MAX_RANGES + range] : 0;
-        const int j_beg = (rok && range > 0) ? a.surv_rng[(size_t)row * RS_MAX_RANGES + range - 1] : 0;
-        const f32x4 x4 = rok ? xs[(size_t)row * 8 + li] : f32x4{0.f, 0.f, 0.f, 0.f};
-        const int32_t* const si = a.surv_idx + (size_t)row * REFINE_CAP;
-#pragma unroll 1
-        for (int j0 = j_beg; __any(j0 < j_end); j0 += 8) {
-            const int32_t my = (j0 + li < j_end) ? si[j0 + li] : -1;
-            const bool mine = my >= lat_lo && my < lat_hi;
-            // (no survivor: -1 becomes an out-of-bounds offset: zeros, no memory access)
-            const uint32_t off_my = mine ? (uint32_t)my * 128u : 0xFFFFFF00u;
-            f32x4 w[8];
+        je[t] = rok ? a.surv_rng[(size_t)row * RS_MAX_RANGES + range] : 0;
+        jb[t] = (rok && range > 0) ? a.surv_rng[(size_t)row * RS_MAX_RANGES + range - 1] : 0;
+        xr[t] = rok ? xs[(size_t)row * 8 + li] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int t = 0, j0 = jb[0], j_end = je[0];
+    f32x4 x4 = xr[0];
+    auto advance = [&]() {  // on to the next row that has survivors in this range (each step only fires when the one before it did)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 4 * u, (int)off_my);
-                w[u] = rs_buf_load16(wres, off | li16);
-            }
-            float p[8];
+        for (int s = 1; s < RS_ROWS; ++s) {
+            const bool adv = j0 >= j_end && t == s - 1;
+            t = adv ? s : t;
+            j0 = adv ? jb[s] : j0;
+            j_end = adv ? je[s] : j_end;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = x4[0] * w[u][0] + x4[1] * w[u][1] + x4[2] * w[u][2] + x4[3] * w[u][3];
-            const float r = group8_reduce_scatter(p, li);
-            if (mine) part[(size_t)row * REFINE_CAP + j0 + li] = r;
+            for (int e = 0; e < 4; ++e) x4[e] = adv ? xr[s][e] : x4[e];
         }
+    };
+    advance();
+#pragma unroll 1
+    while (__any(j0 < j_end)) {
+        const int row = row0 + 32 * t;
+        const int32_t my = (j0 + li < j_end) ? a.surv_idx[(size_t)row * REFINE_CAP + j0 + li] : -1;
+        const bool mine = my >= lat_lo && my < lat_hi;
+        // (no survivor: -1 becomes an out-of-bounds offset: zeros, no memory access)
+        const uint32_t off_my = mine ? (uint32_t)my * 128u : 0xFFFFFF00u;
+        f32x4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 4 * u, (int)off_my);
+            w[u] = rs_buf_load16(wres, off | li16);
+        }
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = x4[0] * w[u][0] + x4[1] * w[u][1] + x4[2] * w[u][2] + x4[3] * w[u][3];
+        const float r = group8_reduce_scatter(p, li);
+        if (mine) part[(size_t)row * REFINE_CAP + j0 + li] = r;
+        j0 += 8;
+        advance();
     }
 }
 // surv_val[row][j] = b_enc[latent] + the D / 32 shares in slice order; one wave per row

@@ -137,7 +137,7 @@ typedef struct {
     int32_t enc_wgs;       /* workgroups the fused encoder's grid aims at (0 = 256, one per CU)                           */
     int32_t refresh_first; /* bound refresh on a workgroup's first N tiles (0 = 8) ...                                    */
     int32_t refresh_every; /* ... then on every M-th, M a power of two (0 = 2; the 64-group bound defaults to 1)          */
-    int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 16; -1 = never (dense algebra
+    int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 40; -1 = never (dense algebra
                               whatever the count); values above 64 are clamped                                           */
     int32_t fwd_route;     /* exact refinement of the f16r encoder: 0 = from 32-column slices of W_enc^T that the XCD L2s hold
                               where the geometry allows, 1 = whole-row gathers always                                   */

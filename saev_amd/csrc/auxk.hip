@@ -440,6 +440,171 @@ __global__ __launch_bounds__(256) void aux_small_fwd_lds_kernel(const float* x, 
         if (row0 + r < n_rows && lane < ndp) dA[(size_t)(row0 + r) * ndp + lane] = lane < nd ? Ds[r * 64 + lane] : 0.f;
 }
 
+// ---- at most AUX_FUSED_MAX dead latents: forward AND weight-gradient partials in ONE pass over x and x_hat ---------------------
+// The steady state of a healthy run: a handful of dead latents on nearly every step.  The kernels above cost ~0.2 ms whatever
+// the count -- five passes over (rows x d_model) matrices: x and x_hat read, g_aux written, g_aux and x read again by the weight
+// gradients, two column sums -- for a few MFLOP.  Everything the auxiliary term needs of a row is local to the row, so here a
+// workgroup (D / 256 waves, one float4 of the row per lane as in decode_q_kernel) keeps the dead latents' encoder and decoder
+// rows AND the weight-gradient accumulators of its block of rows in registers (16 registers per dead latent), walks its rows two
+// at a time -- codes H = x W_enc[:, dl] + b_enc[dl], E = H W_dec[dl] + b_dec, diff = E - (x - x_hat), g = gscale diff,
+// dA = g W_dec[dl]^T (the two sets of dot products: reduce-scatter per wave, then four floats per value through LDS, two barriers
+// per pair of rows) -- and leaves per-block partials of dWd, dWe, db_dec and db_enc[dl]; launch_aux_small_wsum / launch_colsum add
+// the blocks in order.  g_aux, A and dA are never written.
+template <int H, int BIT>
+__device__ __forceinline__ void aux_rs_step(float* p, int lane) {
+    if constexpr (H >= 1) {
+        const bool up = (lane & BIT) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const float keep = up ? p[i + H] : p[i];
+            const float send = up ? p[i] : p[i + H];
+            p[i] = keep + __shfl_xor(send, BIT, 64);
+        }
+        aux_rs_step<H / 2, BIT / 2>(p, lane);
+    }
+}
+// 16 values: lane l ends up with the wave-wide sum of p[(l >> 2) & 15]
+__device__ __forceinline__ float aux_reduce_scatter16(float (&p)[16], int lane) {
+    aux_rs_step<8, 32>(p, lane);
+    float r = p[0];
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void aux_small_fused_kernel(const float* __restrict__ x, const float* __restrict__ x_hat,
+                                                                  const float* __restrict__ WencT_dead, const float* __restrict__ Wdec_dead,
+                                                                  const float* __restrict__ b_enc, const float* __restrict__ b_dec,
+                                                                  const int32_t* __restrict__ dl, int n_rows, const int32_t* nd_dev, float gscale,
+                                                                  int rows_per_wg, float* __restrict__ part, float* __restrict__ partb,
+                                                                  float* __restrict__ partbe, RowStats* __restrict__ rowstats) {
+    constexpr int ND = AUX_FUSED_MAX, D4 = 64 * NW, NVAL = 2 * ND;
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > ND) return;  // (uniform over the grid)
+    __shared__ __attribute__((aligned(16))) float shA[NVAL][4];
+    __shared__ __attribute__((aligned(16))) float shB[NVAL + 2][4];
+    extern __shared__ __attribute__((aligned(16))) float aux_smem[];  // the dead latents' encoder and decoder rows: [2][ND][D4] float4
+    f32x4 (*const We)[D4] = reinterpret_cast<f32x4 (*)[D4]>(aux_smem);
+    f32x4 (*const Wd)[D4] = We + ND;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = threadIdx.x;
+    f32x4 accD[ND], accE[ND];
+    float be[ND], accbe[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const bool ok = j < nd;
+        We[j][q] = ok ? reinterpret_cast<const f32x4*>(WencT_dead)[(size_t)j * D4 + q] : f32x4{0.f, 0.f, 0.f, 0.f};  // (only this lane reads its column group back)
+        Wd[j][q] = ok ? reinterpret_cast<const f32x4*>(Wdec_dead)[(size_t)j * D4 + q] : f32x4{0.f, 0.f, 0.f, 0.f};  // (only this lane reads it back)
+        be[j] = ok ? b_enc[dl[j]] : 0.f;
+        accD[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accE[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accbe[j] = 0.f;
+    }
+    const f32x4 bd4 = reinterpret_cast<const f32x4*>(b_dec)[q];
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+    if (NW < 4 && threadIdx.x < NVAL + 2) {  // columns of the exchange arrays that no wave writes
+        for (int v = NW; v < 4; ++v) { if (threadIdx.x < NVAL) shA[threadIdx.x][v] = 0.f; shB[threadIdx.x][v] = 0.f; }
+    }
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(n_rows, r0 + rows_per_wg);
+    auto load_pair = [&](int r, f32x4 (&xv)[2], f32x4 (&hv)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = min(r + u, n_rows - 1);
+            xv[u] = reinterpret_cast<const f32x4*>(x + (size_t)row * (D4 * 4))[q];
+            hv[u] = reinterpret_cast<const f32x4*>(x_hat + (size_t)row * (D4 * 4))[q];
+        }
+    };
+    f32x4 xn[2], hn[2];
+    if (r0 < r1) load_pair(r0, xn, hn);
+    for (int r = r0; r < r1; r += 2) {
+        f32x4 xc[2] = {xn[0], xn[1]}, hc[2] = {hn[0], hn[1]};
+        if (r + 2 < r1) load_pair(r + 2, xn, hn);
+        const bool live1 = r + 1 < r1;
+        float p[NVAL];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const f32x4 we = We[j][q];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) p[u * ND + j] = (xc[u][0] * we[0] + xc[u][1] * we[1]) + (xc[u][2] * we[2] + xc[u][3] * we[3]);
+        }
+        {
+            const float rs = aux_reduce_scatter16(p, lane);
+            if ((lane & 3) == 0) shA[lane >> 2][w] = rs;
+        }
+        __syncthreads();
+        float Hc[2][ND];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&shA[u * ND + j][0]);
+                Hc[u][j] = (j < nd) ? (((t[0] + t[1]) + t[2]) + t[3]) + be[j] : 0.f;
+            }
+        f32x4 g[2];
+        float sse[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 e = bd4;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) e += Hc[u][j] * Wd[j][q];
+            sse[u] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float diff = e[c] - (xc[u][c] - hc[u][c]);
+                sse[u] += diff * diff;
+                g[u][c] = gscale * diff;
+            }
+        }
+        if (!live1) { g[1] = f32x4{0.f, 0.f, 0.f, 0.f}; sse[1] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const f32x4 wd = Wd[j][q];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) p[u * ND + j] = (g[u][0] * wd[0] + g[u][1] * wd[1]) + (g[u][2] * wd[2] + g[u][3] * wd[3]);
+        }
+        {
+            const float rs = aux_reduce_scatter16(p, lane);
+            if ((lane & 3) == 0) shB[lane >> 2][w] = rs;
+            const float s0 = wave_sum(sse[0]), s1 = wave_sum(sse[1]);
+            if (lane == 0) { shB[NVAL][w] = s0; shB[NVAL + 1][w] = s1; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&shB[u * ND + j][0]);
+                const float da = ((t[0] + t[1]) + t[2]) + t[3];
+                accD[j] += Hc[u][j] * g[u];
+                accE[j] += da * xc[u];
+                accbe[j] += da;
+            }
+            accb += g[u];
+        }
+        if (threadIdx.x == 0) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(&shB[NVAL][0]), t1 = *reinterpret_cast<const f32x4*>(&shB[NVAL + 1][0]);
+            rowstats[r].aux_sse = ((t0[0] + t0[1]) + t0[2]) + t0[3];
+            if (live1) rowstats[r + 1].aux_sse = ((t1[0] + t1[1]) + t1[2]) + t1[3];
+        }
+    }
+    // block partials, in launch_aux_small_wgrad's layout with ND rows per half: [blk][2][ND][D]
+    f32x4* const pb = reinterpret_cast<f32x4*>(part) + (size_t)blockIdx.x * 2 * ND * D4;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        if (j < nd) {
+            pb[(size_t)j * D4 + q] = accD[j];
+            pb[(size_t)(ND + j) * D4 + q] = accE[j];
+        }
+    }
+    reinterpret_cast<f32x4*>(partb)[(size_t)blockIdx.x * D4 + q] = accb;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) partbe[(size_t)blockIdx.x * ND + j] = accbe[j];
+    }
+}
+
 // Weight gradients of the same: per block of 64 rows, part[blk][0][j][:] = sum_b A[b][j] g_aux[b][:] and
 // part[blk][1][j][:] = sum_b dA[b][j] x[b][:] (rows in ascending order); a column sum over the blocks finishes them.
 __global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, const float* dA, const float* g_aux, const float* x,
@@ -502,11 +667,11 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* parts, int 
 // ascending order): the finish of aux_small_wgrad_kernel.  The generic column sum splits over ROWS of its input -- four
 // workgroups for these 256 block rows of 30 000+ columns; this one splits over columns.
 __global__ __launch_bounds__(256) void aux_small_wsum_kernel(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd,
-                                                             float* dWe) {
+                                                             float* dWe, int ndp) {
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > AUX_SMALL_MAX) return;
-    const long n4 = (long)nd * (D >> 2), stride4 = (long)2 * AUX_SMALL_MAX * (D >> 2);
-    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (long)blockIdx.y * AUX_SMALL_MAX * (D >> 2);
+    if (nd <= 0 || nd > ndp) return;
+    const long n4 = (long)nd * (D >> 2), stride4 = (long)2 * ndp * (D >> 2);
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (long)blockIdx.y * ndp * (D >> 2);
     f32x4* out = reinterpret_cast<f32x4*>(blockIdx.y == 0 ? dWd : dWe);
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -519,6 +684,42 @@ __global__ __launch_bounds__(256) void aux_small_wsum_kernel(const float* part, 
         for (; b < n_blk; ++b) acc += p[(long)b * stride4 + q];
         out[q] = acc;
     }
+}
+// The same finish for aux_small_fused_kernel's partials ([blk][2][AUX_FUSED_MAX][D], a block = AUX_FUSED_ROWS activation rows: a
+// thousand blocks of a few KB).  A workgroup of sixteen waves owns 64 float4 columns of one half; wave w adds blocks
+// [w n/16, (w + 1) n/16) in order, eight loads in flight, and wave 0 adds the sixteen sums in wave order: the result does not
+// depend on scheduling, and no wave walks more than n/16 blocks (aux_small_wsum_kernel on these partials: 125 us for ONE dead
+// latent -- 256 lanes walking 1 024 blocks four loads at a time).
+__global__ __launch_bounds__(1024) void aux_fused_wsum_kernel(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd,
+                                                              float* dWe) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > AUX_FUSED_MAX) return;
+    __shared__ f32x4 sh[16][64];
+    const int D4 = D >> 2;
+    const long n4 = (long)nd * D4, stride4 = (long)2 * AUX_FUSED_MAX * D4;
+    if ((long)blockIdx.x * 64 >= n4) return;  // (uniform)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long col = (long)blockIdx.x * 64 + lane;
+    const bool ok = col < n4;
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (long)blockIdx.y * AUX_FUSED_MAX * D4 + (ok ? col : 0);
+    const int chunk = (n_blk + 15) / 16, b0 = w * chunk, b1 = min(n_blk, b0 + chunk);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long)(b + u) * stride4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < b1; ++b) acc += p[(long)b * stride4];
+    sh[w][lane] = acc;
+    __syncthreads();
+    if (w != 0 || !ok) return;
+    f32x4 tot = sh[0][lane];
+#pragma unroll
+    for (int v = 1; v < 16; ++v) tot += sh[v][lane];
+    reinterpret_cast<f32x4*>(blockIdx.y == 0 ? dWd : dWe)[col] = tot;
 }
 __global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
     if (threadIdx.x == 0) { out[0] = *a; out[1] = *b; }
@@ -675,8 +876,41 @@ hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float*
                            WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev, gscale, A, dA, g_aux, rowstats);
     });
 }
-hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s) {
-    hipLaunchKernelGGL(aux_small_wsum_kernel, dim3(64, 2), dim3(256), 0, s, part, n_blk, D, nd_dev, dWd, dWe);
+hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s, int ndp) {
+    hipLaunchKernelGGL(aux_small_wsum_kernel, dim3(64, 2), dim3(256), 0, s, part, n_blk, D, nd_dev, dWd, dWe, ndp);
+    return hipGetLastError();
+}
+hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s) {
+    hipLaunchKernelGGL(aux_fused_wsum_kernel, dim3((AUX_FUSED_MAX * (D >> 2) + 63) / 64, 2), dim3(1024), 0, s, part, n_blk, D, nd_dev, dWd, dWe);
+    return hipGetLastError();
+}
+bool aux_fused_supported(int D) { return D % 256 == 0 && D >= 256 && D <= 1024; }
+int aux_fused_blocks(int n_rows) { return (n_rows + AUX_FUSED_ROWS - 1) / AUX_FUSED_ROWS; }
+hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
+                                  const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale,
+                                  float* part, float* partb, float* partbe, RowStats* rowstats, hipStream_t s) {
+    if (!aux_fused_supported(D)) return hipErrorInvalidValue;
+    const dim3 grid(aux_fused_blocks(n_rows));
+    const size_t smem = (size_t)2 * AUX_FUSED_MAX * D * sizeof(float);  // 64 KB at d_model 1024, next to < 1 KB of static LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* fns[4] = {reinterpret_cast<const void*>(&aux_small_fused_kernel<1>), reinterpret_cast<const void*>(&aux_small_fused_kernel<2>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<3>), reinterpret_cast<const void*>(&aux_small_fused_kernel<4>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AUX_FUSED_MAX * 1024 * (int)sizeof(float));
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+#define AF(NW_) hipLaunchKernelGGL(aux_small_fused_kernel<NW_>, grid, dim3(64 * NW_), smem, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, \
+                                   n_rows, nd_dev, gscale, AUX_FUSED_ROWS, part, partb, partbe, rowstats)
+    switch (D / 256) {
+        case 1: AF(1); break;
+        case 2: AF(2); break;
+        case 3: AF(3); break;
+        default: AF(4); break;
+    }
+#undef AF
     return hipGetLastError();
 }
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,

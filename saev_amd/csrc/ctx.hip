@@ -136,6 +136,7 @@ struct saev_ctx {
           *dbe = nullptr, *aux_partials = nullptr, *WencT_dead = nullptr, *aux_small_part = nullptr, *aux_small_part2 = nullptr;
     bool aux_dev_count = false;  // dense branch sized by a host-side BOUND of the dead count; the count itself stays on the device
     bool aux_small = false;  // this step's AuxK ran on the few-dead-latents path
+    bool aux_fused = false;  // ... in its one-pass form (at most AUX_FUSED_MAX dead latents: block partials instead of g_aux / A / dA)
     bool aux_all = false;    // dense branch with every dead latent selected (n_dead <= k_aux): no select, no mask
     uint8_t* A_mask = nullptr;
     // AuxK contractions on the f16x3 encoder kernel (F16X3 mode): operand images and compact vectors
@@ -1166,14 +1167,25 @@ int ksplit_f16x3(saev_ctx* c, const float* P, const float* sP, int R, const floa
 // A handful of dead latents, all of them selected (n_dead <= min(AUX_SMALL_MAX, k_aux)): one row-wise pass instead of the
 // dense algebra.  Every kernel takes the count from the device (flags[4]) and exits when it is zero, so this sequence is
 // what a step enqueues when the host only knows a bound of the count.
-int auxk_small_forward(saev_ctx* c, hipStream_t s) {
+int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
     const int S = c->cfg.d_sae, D = c->cfg.d_model, n = c->n_last;
     const int32_t* nd_dev = c->flags + 4;
     c->aux_small = true;
     c->aux_all = false;
+    c->aux_fused = false;
     HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s, nd_dev));
     HIPCHK(c, launch_gather_dead_small(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd_dev, D, S,
                                        c->WencT_dead, c->Wdec_dead, s));
+    if (bound <= AUX_FUSED_MAX && aux_fused_supported(D) && c->dbg.aux_small_max != AUX_SMALL_MAX) {
+        // a handful of dead latents: one pass over x and x_hat leaves the block partials of every gradient of the auxiliary term
+        // (partials in the buffers the two-kernel form uses for its own: aux_small_part; g_aux and A_dead are free in this form)
+        c->aux_fused = true;
+        HIPCHK(c, launch_aux_small_fused(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
+                                         c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
+                                         c->cfg.alpha * 2.0f / ((float)n * (float)D), c->aux_small_part, c->g_aux, c->A_dead, c->rowstats, s));
+        HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, nullptr, c->stats, s, nd_dev, c->stats_scratch));
+        return SAEV_OK;
+    }
     HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                    c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
                                    c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
@@ -1259,6 +1271,18 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
                          // all predicated on the device-side count like the forward (rows past it are never scattered)
         const int nb = (n + 63) / 64, L = AUX_SMALL_MAX;
         const int32_t* nd_dev = c->flags + 4;
+        if (c->aux_fused) {  // the forward has left block partials of all four gradients: three ordered sums finish them
+            const int blocks = aux_fused_blocks(n);
+            HIPCHK(c, launch_aux_fused_wsum(c->aux_small_part, blocks, D, nd_dev, c->dWd, c->dWe, s));
+            HIPCHK(c, launch_colsum(c->A_dead, blocks, AUX_FUSED_MAX, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
+            if (c->ov_x != nullptr) {
+                HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));
+                HIPCHK(c, launch_colsum(c->g_aux, blocks, D, c->colsum_partials, c->db_aux, 0, nd_dev, s));
+            } else {
+                HIPCHK(c, launch_colsum(c->g_aux, blocks, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nd_dev, s));
+            }
+            return SAEV_OK;
+        }
         HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
         HIPCHK(c, launch_aux_small_wsum(c->aux_small_part, nb, D, nd_dev, c->dWd, c->dWe, s));
         HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
@@ -1351,7 +1375,7 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
             if (bound == 0) return SAEV_OK;
             if (bound <= small_max && c->cfg.d_model <= 2048) {
                 c->aux_route = AUX_SMALL_DEVICE;
-                return auxk_small_forward(c, s);
+                return auxk_small_forward(c, s, bound);
             }
             // A larger dead set: the dense algebra, sized by the bound, with the count left on the device (round 2 read it
             // back here: one blocking read per step whenever more than a few dozen latents were dead -- configs[2]'s regime)
@@ -1390,7 +1414,7 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     }
     if (c->n_dead_host <= small_max && c->cfg.d_model <= 2048) {
         c->aux_route = AUX_SMALL_HOST;
-        return auxk_small_forward(c, s);
+        return auxk_small_forward(c, s, c->n_dead_host);
     }
     c->aux_route = AUX_DENSE;
     return auxk_forward(c, s);

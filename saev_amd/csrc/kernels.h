@@ -471,7 +471,7 @@ hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const 
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 // a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
 constexpr int AUX_SMALL_MAX = 64;  // (one lane per dead latent in aux_small_fwd_kernel: at most the wave width)
-constexpr int AUX_SMALL_DEFAULT = 16;  // largest dead set that takes them unless saev_debug_cfg.aux_small_max says otherwise
+constexpr int AUX_SMALL_DEFAULT = 40;  // largest dead set that takes them unless saev_debug_cfg.aux_small_max says otherwise
 // The few-dead-latents kernels take the dead count from the device (*nd_dev; they exit unless 1 <= nd <= AUX_SMALL_MAX), so
 // the host can enqueue them without knowing it.  Leading dimension of A / dA and row count of the compact weight buffers:
 // AUX_SMALL_MAX.
@@ -482,7 +482,20 @@ hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float*
                                 const int32_t* nd_dev, float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats,
                                 hipStream_t s);
 // dWd / dWe (nd x D each) = the block partials of launch_aux_small_wgrad summed in block order
-hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s);
+hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,
+                                 int ndp = AUX_SMALL_MAX);  // ndp: rows per half of a block partial
+// at most AUX_FUSED_MAX dead latents (d_model 256 / 512 / 768 / 1024): codes, loss, g_aux, dA and the block partials of all four
+// gradients in one pass over x and x_hat (auxk.hip: aux_small_fused_kernel).  part: blocks x 2 x AUX_FUSED_MAX x D (the layout of
+// launch_aux_small_wgrad with AUX_FUSED_MAX rows per half), partb: blocks x D (db_dec's share), partbe: blocks x AUX_FUSED_MAX
+// (db_enc[dl]); blocks = aux_fused_blocks(n_rows)
+constexpr int AUX_FUSED_MAX = 8;
+constexpr int AUX_FUSED_ROWS = 16;  // activation rows per workgroup
+bool aux_fused_supported(int D);
+hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s);
+int aux_fused_blocks(int n_rows);
+hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
+                                  const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale,
+                                  float* part, float* partb, float* partbe, RowStats* rowstats, hipStream_t s);
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
                                   const int32_t* nd_dev, float* part, hipStream_t s);  // part: ceil(n/64) x 2 x AUX_SMALL_MAX x D
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s);  // out = sum_j parts[j], n % 4 == 0

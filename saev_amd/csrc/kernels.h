@@ -489,7 +489,7 @@ hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int3
 // launch_aux_small_wgrad with AUX_FUSED_MAX rows per half), partb: blocks x D (db_dec's share), partbe: blocks x AUX_FUSED_MAX
 // (db_enc[dl]); blocks = aux_fused_blocks(n_rows)
 constexpr int AUX_FUSED_MAX = 8;
-constexpr int AUX_FUSED_ROWS = 16;  // activation rows per workgroup
+constexpr int AUX_FUSED_ROWS = 32;  // activation rows per workgroup
 bool aux_fused_supported(int D);
 hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s);
 int aux_fused_blocks(int n_rows);

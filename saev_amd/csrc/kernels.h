@@ -90,7 +90,7 @@ constexpr int REFINE_CAP = 512;
 // ([D / 32][n_rows][32]); WeS: slice-major W_enc^T ([D / 32][S][32]); part: [D / 32][n_rows][REFINE_CAP] shares of the dot
 // products.  lat_range latents (x 128 bytes = the tile an XCD's L2 has to hold) per pass over a slice.
 constexpr int RS_SLICE = 32;
-constexpr int RS_ROWS = 8;        // activation rows an eight-lane group works through
+constexpr int RS_ROWS_MAX = 8;    // activation rows an eight-lane group works through (4 for batches below 8 192 rows)
 constexpr int RS_LAT_RANGE = 16384;
 constexpr int RS_MAX_RANGES = 8;  // (more latents than 8 x 16 384: wider ranges)
 struct RefineSlicesArgs {

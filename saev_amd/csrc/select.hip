@@ -689,6 +689,7 @@ __device__ __forceinline__ float group8_reduce_scatter(float (&p)[8], int li) {
 // advance is a few selects -- so the wave runs as long as its busiest GROUP over all its rows: 283 -> 259 us at RS_ROWS = 8
 // (4: 281; the same with the bounds in LDS, a run-time advance loop and the next trip's indices requested behind the gathers:
 // 289 at 8 rows, 327 at 16 -- tools/experiments/r4_kernel_ab.sh).
+template <int RS_ROWS>
 __global__ __launch_bounds__(256) void refine_slices_kernel(RefineSlicesArgs a, int wg_per_combo) {
     if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
     const int lane = threadIdx.x & 63, gi = lane >> 3, li = lane & 7;
@@ -1126,9 +1127,14 @@ hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream) {
 hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
     if (a.D % RS_SLICE != 0 || (uint64_t)a.S * 128ull >= (1ull << 32) - 256ull || a.n_ranges <= 0) return hipErrorInvalidValue;
-    const int wg_per_combo = (a.n_rows + 32 * RS_ROWS - 1) / (32 * RS_ROWS);
+    // rows per eight-lane group: 8 evens out the survivor lists of a group's rows (283 -> 257 us at 16 384 rows); a small batch
+    // does not have the workgroups for it (4 096 rows, d_model 768: 47 us at 4 rows per group, 71 at 8)
+    const int rows = a.n_rows >= 8192 ? RS_ROWS_MAX : 4;
+    const int wg_per_combo = (a.n_rows + 32 * rows - 1) / (32 * rows);
     const int slice_blocks = (a.D / RS_SLICE + 7) / 8;
-    hipLaunchKernelGGL(refine_slices_kernel, dim3(8 * slice_blocks * a.n_ranges * wg_per_combo), dim3(256), 0, stream, a, wg_per_combo);
+    const dim3 grid(8 * slice_blocks * a.n_ranges * wg_per_combo);
+    if (rows == 4) hipLaunchKernelGGL(refine_slices_kernel<4>, grid, dim3(256), 0, stream, a, wg_per_combo);
+    else hipLaunchKernelGGL(refine_slices_kernel<RS_ROWS_MAX>, grid, dim3(256), 0, stream, a, wg_per_combo);
     // (adding the shares inside the final select instead -- 32 dependent loads per lane of a kernel that lives on its bit
     // search -- took that select from 20 to 80 us against 42 for this pass)
     hipLaunchKernelGGL(refine_sum_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);

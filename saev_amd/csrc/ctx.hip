@@ -349,7 +349,8 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
                     (uint64_t)S * 128ull < (1ull << 32) - 256ull && fused_supported(c->cfg);
     if (c->fwd_slices) {
         A(rs_part, (size_t)(D / RS_SLICE) * MB * REFINE_CAP); A(surv_rng, MB * RS_MAX_RANGES);
-        // passes over a slice cover RS_LAT_RANGE latents each (x 128 bytes = 2 MB: what an XCD's L2 holds), at most RS_MAX_RANGES
+        // passes over a slice cover RS_LAT_RANGE latents each (x 128 bytes = 4 MB = an XCD's L2: tools/ubench/row_gather.hip gathers
+        // out of a whole 4 MB slice at 20-22 TB/s; 16 384-latent ranges made refine_slices 4 % slower), at most RS_MAX_RANGES
         c->rs_lat_range = (int)std::max<long>(RS_LAT_RANGE, ((S + RS_MAX_RANGES - 1) / RS_MAX_RANGES + 255) / 256 * 256);
         c->rs_n_ranges = (int)((S + c->rs_lat_range - 1) / c->rs_lat_range);
     }

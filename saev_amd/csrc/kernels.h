@@ -91,7 +91,7 @@ constexpr int REFINE_CAP = 512;
 // products.  lat_range latents (x 128 bytes = the tile an XCD's L2 has to hold) per pass over a slice.
 constexpr int RS_SLICE = 32;
 constexpr int RS_ROWS_MAX = 8;    // activation rows an eight-lane group works through (4 for batches below 8 192 rows)
-constexpr int RS_LAT_RANGE = 16384;
+constexpr int RS_LAT_RANGE = 32768;
 constexpr int RS_MAX_RANGES = 8;  // (more latents than 8 x 16 384: wider ranges)
 struct RefineSlicesArgs {
     const int32_t* surv_idx; const int32_t* surv_cnt; float* surv_val; const int32_t* surv_rng;

@@ -686,9 +686,13 @@ __device__ __forceinline__ float group8_reduce_scatter(float (&p)[8], int li) {
 // busy ceil(survivors / 8) trips per row.  Rows differ (22 +- 5 survivors per latent range at configs[1]): with every group on its
 // t-th row at the same time the wave waits for the longest list of each octet of rows (3.8 trips against 2.8 on average).  Here a
 // group moves on to its next row as soon as its list is done -- the rows' list bounds and x slices are fetched up front, the
-// advance is a few selects -- so the wave runs as long as its busiest GROUP over all its rows: 283 -> 259 us at RS_ROWS = 8
+// advance is a few selects -- so the wave runs as long as its busiest GROUP over all its rows: 283 -> 259 us at RS_ROWS = 8;
+// sixteen gathers per trip instead of eight and one 32 768-latent range per slice instead of two: -> 233 us (24 / 32 per trip: 248 / 264)
 // (4: 281; the same with the bounds in LDS, a run-time advance loop and the next trip's indices requested behind the gathers:
 // 289 at 8 rows, 327 at 16 -- tools/experiments/r4_kernel_ab.sh).
+#ifndef RS_BATCHES
+#define RS_BATCHES 2
+#endif
 template <int RS_ROWS>
 __global__ __launch_bounds__(256) void refine_slices_kernel(RefineSlicesArgs a, int wg_per_combo) {
     if (a.enable_flag != nullptr && (*a.enable_flag != 0) != (a.enable_when != 0)) return;
@@ -733,23 +737,35 @@ __global__ __launch_bounds__(256) void refine_slices_kernel(RefineSlicesArgs a, 
     advance();
 #pragma unroll 1
     while (__any(j0 < j_end)) {
+        // a trip = RS_BATCHES batches of eight survivors: 8 RS_BATCHES gathers in flight per group before the first is used
         const int row = row0 + 32 * t;
-        const int32_t my = (j0 + li < j_end) ? a.surv_idx[(size_t)row * REFINE_CAP + j0 + li] : -1;
-        const bool mine = my >= lat_lo && my < lat_hi;
-        // (no survivor: -1 becomes an out-of-bounds offset: zeros, no memory access)
-        const uint32_t off_my = mine ? (uint32_t)my * 128u : 0xFFFFFF00u;
-        f32x4 w[8];
+        int32_t my[RS_BATCHES];
+        bool mine[RS_BATCHES];
+        f32x4 w[RS_BATCHES][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 4 * u, (int)off_my);
-            w[u] = rs_buf_load16(wres, off | li16);
+        for (int h = 0; h < RS_BATCHES; ++h) {
+            my[h] = (j0 + 8 * h + li < j_end) ? a.surv_idx[(size_t)row * REFINE_CAP + j0 + 8 * h + li] : -1;
+            mine[h] = my[h] >= lat_lo && my[h] < lat_hi;
         }
-        float p[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = x4[0] * w[u][0] + x4[1] * w[u][1] + x4[2] * w[u][2] + x4[3] * w[u][3];
-        const float r = group8_reduce_scatter(p, li);
-        if (mine) part[(size_t)row * REFINE_CAP + j0 + li] = r;
-        j0 += 8;
+        for (int h = 0; h < RS_BATCHES; ++h) {
+            // (no survivor: -1 becomes an out-of-bounds offset: zeros, no memory access)
+            const uint32_t off_my = mine[h] ? (uint32_t)my[h] * 128u : 0xFFFFFF00u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 4 * u, (int)off_my);
+                w[h][u] = rs_buf_load16(wres, off | li16);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < RS_BATCHES; ++h) {
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = x4[0] * w[h][u][0] + x4[1] * w[h][u][1] + x4[2] * w[h][u][2] + x4[3] * w[h][u][3];
+            const float r = group8_reduce_scatter(p, li);
+            if (mine[h]) part[(size_t)row * REFINE_CAP + j0 + 8 * h + li] = r;
+        }
+        j0 += 8 * RS_BATCHES;
         advance();
     }
 }

@@ -4,7 +4,8 @@
 //   rows4   decode_q_kernel's: a workgroup of four waves per batch row, one float4 per lane and code, ALL 32 gathers in flight
 //   rows1   decode_kernel's:   one wave per batch row, four float4 per lane and code, four codes (16 loads) in flight
 //   slices  dw_slices / refine_slices': the matrix slice-major [D / 32][S][32], XCD x walks slices x, x + 8, ...; an eight-lane group
-//           sums one (row, slice): 32 gathers of 128 B out of a 4 MB slice (two 2 MB halves by latent range, one after the other)
+//           sums one (row, slice): 32 gathers of 128 B out of a 4 MB slice (two 2 MB halves by latent range, one after the other;
+//           slices1: the whole slice in one launch)
 // Prints the gathered bytes per second: what "whole-row gathers at the fabric rate" and "line gathers out of L2" mean in DESIGN.md.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/row_gather.hip -o /tmp/row_gather && /tmp/row_gather
 #include <hip/hip_runtime.h>
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void slices_kernel(const float* __restrict__ W
     const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WS) + (size_t)slice * S * 32, 0, (uint32_t)S * 128u, 0x00020000);
     const int* ir = idx + (size_t)row * K;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int lo = half * (S / 2), hi = lo + S / 2;
+    const int lo = half == 2 ? 0 : half * (S / 2), hi = half == 2 ? S : lo + S / 2;  // half = 2: the whole 4 MB slice in one launch
 #pragma unroll
     for (int j0 = 0; j0 < K; j0 += 8) {
         f32x4 w[8];
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void slices_kernel(const float* __restrict__ W
         for (int u = 0; u < 8; ++u) acc += w[u];
     }
     f32x4* o = reinterpret_cast<f32x4*>(outS) + ((size_t)slice * B + row) * 8 + li;
-    if (half) acc += *o;
+    if (half == 1) acc += *o;
     *o = acc;
 }
 
@@ -116,6 +117,10 @@ int main() {
         };
         time("rows4", [&] { hipLaunchKernelGGL(rows4_kernel, dim3(B), dim3(256), 0, 0, W, idx, out); });
         time("rows1", [&] { hipLaunchKernelGGL(rows1_kernel, dim3(B / 4), dim3(256), 0, 0, W, idx, out); });
+        time("slices1", [&] {  // one launch per slice over all latents: a 4 MB slice in a 4 MB L2
+            const int wps = B / 32;
+            hipLaunchKernelGGL(slices_kernel, dim3(8 * 4 * wps), dim3(256), 0, 0, W, idx, out, 2, wps);
+        });
         time("slices", [&] {
             const int wps = B / 32;
             hipLaunchKernelGGL(slices_kernel, dim3(8 * 4 * wps), dim3(256), 0, 0, W, idx, out, 0, wps);

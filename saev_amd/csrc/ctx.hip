@@ -96,6 +96,11 @@ struct saev_ctx {
     // the slices then forms dW_dec only.  dval_fwd: the forward in flight has left it (same condition as dws_rows, plus the shape)
     float* dval_rows = nullptr;
     bool dval_fwd = false;
+    // the decode out of 32-column slices (sparse.hip: decode_s_kernel): slice-major copy of the normalised W_dec left by the step's
+    // normalize_rows, per (slice, row) loss terms; the dval shares go through dvp
+    float* WdS = nullptr;
+    double* dec_part = nullptr;
+    bool wds_fresh = false;  // WdS describes W_dec as it is now (this step's normalize_rows wrote both)
     bool dval_pairs_ready = false;  // the CSC build of this backward has written pv2 from it
     bool fused_forward = false;     // saev_train_step's forward: Matryoshka G blocks past the first are not needed row-major
     // exact refinement of the f16r encoder from 32-column slices (select.hip: refine_slices_kernel): split_f16r leaves x and
@@ -358,6 +363,9 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (c->dws_ok) {
         A(gS, MBB * D); A(xS, MBB * D); A(dvp, (size_t)(D / DWS_SLICE) * MBB * K);
         if (c->dbg.dw_route != 2 && decode_forms_dval((int)D, (int)K)) A(dval_rows, MB * K);
+        if (c->dval_rows != nullptr && c->dbg.dw_route != 3 && decode_slices_supported((int)D, (int)S, (int)K, (int)K) && c->cfg.normalize_w_dec) {
+            A(WdS, S * D); A(dec_part, (size_t)(D / 32) * MB * 3);
+        }
         A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
     }
     A(colsum_partials, ((MBB + 63) / 64) * D);
@@ -1033,9 +1041,17 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     if (rc != SAEV_OK) return rc;
     if (!borrowed) { c->xprep_x = x; c->xprep_n = n; c->xprep_serial++; }
     if (wdec_ev != nullptr) HIPCHK(c, hipStreamWaitEvent(s, wdec_ev, 0));
+    c->wds_fresh = false;
     if (training) {
-        rc = saev_normalize_w_dec(c, stream);
-        if (rc != SAEV_OK) return rc;
+        // (a training step whose decode can take the slices: normalize_rows leaves the slice-major copy on its way)
+        const bool want_slices = c->WdS != nullptr && c->cfg.normalize_w_dec && c->P == 1 && c->dws_ok;
+        if (want_slices) {
+            HIPCHK(c, launch_normalize_rows(c->params + c->off_W_dec, S, D, s, c->WdS));
+            c->wds_fresh = true;
+        } else {
+            rc = saev_normalize_w_dec(c, stream);
+            if (rc != SAEV_OK) return rc;
+        }
     }
 
     DecodeArgs a{};
@@ -1052,7 +1068,11 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->fwd_step ? nullptr : c->xS; c->dws_rows = n; }
     // (... and the products dval, from the decoder rows while the decode holds them in registers)
     if (c->dws_rows == n && c->dval_rows != nullptr) { a.dval_out = c->dval_rows; c->dval_fwd = true; }
-    if (c->P > 1) {
+    if (c->P == 1 && c->wds_fresh && a.dval_out != nullptr && a.gS != nullptr) {
+        DecodeSliceArgs ds{};
+        ds.d = a; ds.WdS = c->WdS; ds.part = c->dec_part; ds.dvp = c->dvp; ds.dvp_pitch = (long)c->back_rows * K;
+        HIPCHK(c, launch_decode_slices(ds, s));
+    } else if (c->P > 1) {
         MatryArgs m{};
         m.P = c->P;
         for (int p = 0; p < c->P; ++p) m.cuts[p] = c->cuts[p];

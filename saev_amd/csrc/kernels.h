@@ -164,6 +164,18 @@ struct DecodeArgs {
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 // whether launch_decode forms dval_out for this shape (otherwise the pointer is ignored and pass A forms the products)
 bool decode_forms_dval(int D, int k);
+// The same decode out of 32-column slices of W_dec that an XCD's L2 holds (decode_s_kernel + decode_s_finish_kernel): the route of a
+// training step whose normalize_rows has just left the slice-major copy WdS.  part: per (slice, row) {sse_scaled, pad, sse64, sumsq64}
+// (n_slices x n_rows x 3 doubles), dvp: per slice the 32 dval shares of every row (pitch dvp_pitch floats per slice, >= n_rows * 32).
+struct DecodeSliceArgs {
+    DecodeArgs d;          // W_dec unused; dval_out receives the summed shares (n_rows, code_stride)
+    const float* WdS;      // [D / 32][S][32]
+    double* part;
+    float* dvp;
+    long dvp_pitch;
+};
+bool decode_slices_supported(int D, int S, int k, int code_stride);
+hipError_t launch_decode_slices(const DecodeSliceArgs& a, hipStream_t stream);
 
 // Matryoshka prefixes (objectives.py:125-138, modeling.py:369-409): P ascending cut points ending at S; prefix p
 // reconstructs from the codes with latent index < cuts[p].
@@ -312,7 +324,8 @@ hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partia
                                 saev_step_stats* zero_stats = nullptr, int32_t* zero_flag = nullptr);
 
 // ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
-hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream);
+// WS: optional slice-major copy [D / 32][S][32] of the normalised rows (d_model % 32 == 0)
+hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream, float* WS = nullptr);
 // rows [0, S) of gW projected orthogonal to the rows of W (project != 0); with sq_partials, ceil(S / 4) doubles: the sums
 // of squares of the rows as written (the clip norm's share of W_dec, from the same pass)
 hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream, double* sq_partials = nullptr,

@@ -1413,6 +1413,188 @@ hipError_t dispatch_nv(int D, F&& f) {
     return hipGetLastError();
 }
 
+// ---- the decode out of 32-column slices (DecodeSliceArgs) ----------------------------------------------------------------------
+// decode_q_kernel gathers whole 4 KB rows of a 134 MB matrix: past the L2 the fabric delivers 7.5 TB/s of them however many are in
+// flight (tools/ubench/row_gather.hip).  A 32-column slice of W_dec is S x 128 B = 4 MB -- an XCD's L2 -- and gathers out of it run
+// at 20 TB/s.  So: XCD x walks slices x, x + 8, ...; an eight-lane group owns one (activation row, slice): the 32 codes' 128-byte
+// pieces in flight together (32 float4 per lane), x_hat / g / the loss terms of its 32 columns, and the slice's share of the 32
+// dval = <g, W_dec[idx_j]>; decode_s_finish_kernel adds the D / 32 shares and loss terms per row in slice order.  x_hat is summed in
+// code order exactly as decode_q_kernel does, so the two give the same x_hat and g bit for bit.
+__global__ __launch_bounds__(256) void decode_s_kernel(DecodeSliceArgs s, int wg_per_slice) {
+    const DecodeArgs& a = s.d;
+    const int lane = threadIdx.x & 63, li = lane & 7;
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int slice = xcd + 8 * (qq / wg_per_slice);
+    if (slice * 32 >= a.D) return;
+    const int row_raw = (qq % wg_per_slice) * 32 + (int)(threadIdx.x >> 3);
+    const bool live = row_raw < a.n_rows;
+    const int row = live ? row_raw : a.n_rows - 1;
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    // the row's 32 codes (one 128-byte line each for idx and val), read by every lane of the group: 16 broadcast loads that hit
+    // L1 / L2 (handing them round the group instead takes 64 ds_bpermute per wave)
+    const i32x4_* ir = reinterpret_cast<const i32x4_*>(a.idx + (size_t)row * a.code_stride);
+    const f32x4* vr = reinterpret_cast<const f32x4*>(a.val + (size_t)row * a.code_stride);
+    i32x4_ ci[8];
+    f32x4 cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ci[u] = ir[u]; cv[u] = vr[u]; }
+    const int col4 = slice * 8 + li;  // this lane's float4 of the row
+    f32x4 acc = reinterpret_cast<const f32x4*>(a.b_dec)[col4];
+    // (what streams through -- x in, x_hat / g / the shares out -- is marked non-temporal: the XCD's 4 MB L2 is for the slice of W_dec)
+    const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (size_t)row * a.D) + col4);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.WdS) + (size_t)slice * a.S * 32, 0,
+                                                                           (uint32_t)a.S * 128u, 0x00020000);
+    const uint32_t li16 = (uint32_t)li * 16u;
+    f32x4 wv[32];
+    uint32_t okmask = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int j = 4 * u + h;
+            const int i = ci[u][h];
+            const bool ok = j < a.k && i >= 0 && i < a.idx_limit;
+            okmask |= ok ? (1u << j) : 0u;
+            // (an absent code: an offset past the buffer -- zeros, no memory access)
+            const i32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(wres, (ok ? (uint32_t)i * 128u : 0xFFFFFF00u) | li16, 0, 0);
+            wv[j] = f32x4{__int_as_float(t[0]), __int_as_float(t[1]), __int_as_float(t[2]), __int_as_float(t[3])};
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            if (okmask & (1u << (4 * u + h))) acc += cv[u][h] * wv[4 * u + h];
+    const float u_ = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
+    float sse_scaled = 0.f;
+    double sse64 = 0.0, sumsq64 = 0.0;
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = acc[e] / u_ - xv[e] / u_;
+        sse_scaled += t * t * u_ * u_;
+        g[e] = a.gscale * t * u_;
+        const float r = xv[e] - acc[e];
+        sse64 += (double)r * (double)r;
+        sumsq64 += (double)xv[e] * (double)xv[e];
+    }
+    if (live) {
+        if (a.x_hat) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.x_hat + (size_t)row * a.D) + col4);
+        if (a.g) __builtin_nontemporal_store(g, reinterpret_cast<f32x4*>(a.g + (size_t)row * a.D) + col4);
+        const size_t o = ((size_t)slice * a.n_rows + row) * 8 + li;
+        if (a.gS != nullptr) __builtin_nontemporal_store(g, reinterpret_cast<f32x4*>(a.gS) + o);
+        if (a.xS != nullptr) __builtin_nontemporal_store(xv, reinterpret_cast<f32x4*>(a.xS) + o);
+    }
+    // the slice's shares of the 32 dval: batch h leaves code 4 li + h with lane li.  Reduce-scatter over the eight lanes of the
+    // group on the VALU (DPP): lane l pairs with 7 - l (row_half_mirror), then with l ^ 2 and l ^ 1 (quad_perm); at every step a lane
+    // keeps the half of its values its own index lies in and adds the partner's copy of that half.
+    auto dpp_mirror8 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true)); };
+    auto dpp_xor2 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); };
+    auto dpp_xor1 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };
+    f32x4 sh;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float p[8];
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) {
+            const f32x4& w = wv[4 * uu + h];
+            p[uu] = (g[0] * w[0] + g[1] * w[1]) + (g[2] * w[2] + g[3] * w[3]);
+        }
+        {
+            const bool up = (li & 4) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float keep = up ? p[i + 4] : p[i], send = up ? p[i] : p[i + 4];
+                p[i] = keep + dpp_mirror8(send);
+            }
+        }
+        {
+            const bool up = (li & 2) != 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float keep = up ? p[i + 2] : p[i], send = up ? p[i] : p[i + 2];
+                p[i] = keep + dpp_xor2(send);
+            }
+        }
+        const bool up = (li & 1) != 0;
+        const float keep = up ? p[1] : p[0], send = up ? p[0] : p[1];
+        sh[h] = keep + dpp_xor1(send);  // lane l ends up with index l of the batch: code 4 l + h
+    }
+    if (live) __builtin_nontemporal_store(sh, reinterpret_cast<f32x4*>(s.dvp + (size_t)slice * s.dvp_pitch + (size_t)row * 32) + li);
+    // loss terms of the 32 columns
+    sse_scaled = group8_sum(sse_scaled);
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) {
+        sse64 += __shfl_xor(sse64, o, 64);
+        sumsq64 += __shfl_xor(sumsq64, o, 64);
+    }
+    if (live && li == 0) {
+        double* pp = s.part + ((size_t)slice * a.n_rows + row) * 3;
+        pp[0] = (double)sse_scaled; pp[1] = sse64; pp[2] = sumsq64;
+    }
+    if (live && slice == 0 && a.training && a.fired) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            // (lane li marks the codes 4 li .. 4 li + 3; ci[li] is a run-time index into registers: a select chain over 8)
+            int ii = -1;
+            float vv = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ii = (u == li) ? ci[u][h] : ii; vv = (u == li) ? cv[u][h] : vv; }
+            if (4 * li + h < a.k && ii >= 0 && vv != 0.f) a.fired[ii] = 1;
+        }
+    }
+}
+
+// one wave per row: dval[j] = the D / 32 shares, the row's loss terms, code statistics (fixed summation trees)
+__global__ __launch_bounds__(256) void decode_s_finish_kernel(DecodeSliceArgs s) {
+    const DecodeArgs& a = s.d;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int n_slices = a.D / 32;
+    {
+        // lanes 0-31: code j over the first half of the slices, lanes 32-63: over the second half; the halves are added lower first
+        const int j = lane & 31, half = lane >> 5;
+        const int c0 = half * ((n_slices + 1) / 2), c1 = half ? n_slices : (n_slices + 1) / 2;
+        float sum = 0.f;
+        const float* p = s.dvp + (size_t)row * 32 + j;
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu) v[uu] = p[(size_t)(c + uu) * s.dvp_pitch];
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu) sum += v[uu];
+        }
+        for (; c < c1; ++c) sum += p[(size_t)c * s.dvp_pitch];
+        const float other = __shfl_xor(sum, 32, 64);
+        if (lane < a.k) a.dval_out[(size_t)row * a.code_stride + lane] = sum + other;
+    }
+    float sse_scaled = 0.f;
+    double sse64 = 0.0, sumsq64 = 0.0;
+    for (int c = lane; c < n_slices; c += 64) {
+        const double* pp = s.part + ((size_t)c * a.n_rows + row) * 3;
+        sse_scaled += (float)pp[0]; sse64 += pp[1]; sumsq64 += pp[2];
+    }
+    sse_scaled = wave_sum(sse_scaled);
+    sse64 = wave_sum_d(sse64);
+    sumsq64 = wave_sum_d(sumsq64);
+    float l0 = 0.f, l1 = 0.f;
+    if (lane < a.k) {
+        const int32_t i = a.idx[(size_t)row * a.code_stride + lane];
+        const float v = a.val[(size_t)row * a.code_stride + lane];
+        if (i >= 0 && v != 0.f) { l0 = 1.f; l1 = fabsf(v); }
+    }
+    l0 = wave_sum(l0);
+    l1 = wave_sum(l1);
+    if (a.rowstats && lane == 0) {
+        RowStats rs;
+        rs.sse_scaled = sse_scaled; rs.l0 = l0; rs.l1 = l1; rs.aux_sse = 0.f;
+        rs.sse64 = sse64; rs.sumsq64 = sumsq64;
+        a.rowstats[row] = rs;
+    }
+}
+
 }  // namespace
 
 bool decode_forms_dval(int D, int k) { return k <= 32 && D % 256 == 0 && D >= 256 && D <= 1024; }
@@ -1430,6 +1612,19 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
     return dispatch_nv(a.D, [&](auto nv) {
         hipLaunchKernelGGL(decode_kernel<decltype(nv)::value>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     });
+}
+bool decode_slices_supported(int D, int S, int k, int code_stride) {
+    return k <= 32 && code_stride == 32 && D % 32 == 0 && (uint64_t)S * 128ull < (1ull << 32) - 256ull;
+}
+hipError_t launch_decode_slices(const DecodeSliceArgs& a, hipStream_t stream) {
+    const DecodeArgs& d = a.d;
+    if (d.n_rows <= 0) return hipSuccess;
+    if (!decode_slices_supported(d.D, d.S, d.k, d.code_stride) || d.x == nullptr || d.dval_out == nullptr) return hipErrorInvalidValue;
+    const int wg_per_slice = (d.n_rows + 31) / 32;
+    const int slice_blocks = (d.D / 32 + 7) / 8;
+    hipLaunchKernelGGL(decode_s_kernel, dim3(8 * slice_blocks * wg_per_slice), dim3(256), 0, stream, a, wg_per_slice);
+    hipLaunchKernelGGL(decode_s_finish_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;

@@ -8,7 +8,7 @@
 namespace {
 
 template <int NV>
-__global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, int D) {
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, int D, float* WS) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= S) return;
@@ -32,6 +32,8 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, in
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[n][e] / nrm;
             r[q] = o;
+            // slice-major copy [D / 32][S][32] for the slice decode (sparse.hip: decode_s_kernel), 128 bytes per (row, slice)
+            if (WS != nullptr) reinterpret_cast<f32x4*>(WS)[((size_t)(q >> 3) * S + i) * 8 + (q & 7)] = o;
         }
     }
 }
@@ -571,9 +573,9 @@ hipError_t dispatch_nv(int D, F&& f) {
 
 }  // namespace
 
-hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream) {
+hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream, float* WS) {
     return dispatch_nv(D, [&](auto nv) {
-        hipLaunchKernelGGL(normalize_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, W, S, D);
+        hipLaunchKernelGGL(normalize_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, W, S, D, WS);
     });
 }
 hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream, double* sq_partials, int project) {

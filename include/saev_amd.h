@@ -129,8 +129,8 @@ typedef struct {
     int32_t dw_route;      /* weight gradients: 0 column slices out of the XCD L2s where the geometry allows, with the products
                               dval = <dL/dx_hat row, decoder row> left by the decode where the shape allows (top_k <= 32,
                               d_model 256 / 512 / 768 / 1024); 1 whole-row gathers (dw_rows) always; 2 column slices with dval
-                              formed by their first pass (the only form for other shapes and for gathered backwards); 3 as 0, but
-                              the decode itself gathers whole decoder rows instead of 32-column slices of W_dec           */
+                              formed by their first pass (the only form for other shapes and for gathered backwards); 4 as 0, but
+                              the decode itself gathers 32-column slices of W_dec out of the XCD L2s (a wash: DESIGN.md 3.3)  */
     int32_t enc_mfma;      /* single-product encoders: 0 v_mfma_f32_16x16x32 kernel, 32 the 32x32x16 kernel               */
     int32_t fused_chain;   /* f16r: 1 = survivor select, exact refinement and final select as ONE launch                  */
     int32_t ngroups;       /* TopK bound groups of the fp16-image encoders: 0 = 32 for top_k <= 32 (64 above), 64 forces

@@ -362,8 +362,8 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (c->fwd_slices && !c->dws_ok) A(xS, MBB * D);
     if (c->dws_ok) {
         A(gS, MBB * D); A(xS, MBB * D); A(dvp, (size_t)(D / DWS_SLICE) * MBB * K);
-        if (c->dbg.dw_route != 2 && decode_forms_dval((int)D, (int)K)) A(dval_rows, MB * K);
-        if (c->dval_rows != nullptr && c->dbg.dw_route != 3 && decode_slices_supported((int)D, (int)S, (int)K, (int)K) && c->cfg.normalize_w_dec) {
+        if (c->dbg.dw_route != 2 && decode_forms_dval((int)D, (int)K)) A(dval_rows, MB * K);  // (routes 0, 4: dval from the decode)
+        if (c->dval_rows != nullptr && c->dbg.dw_route == 4 && decode_slices_supported((int)D, (int)S, (int)K, (int)K) && c->cfg.normalize_w_dec) {
             A(WdS, S * D); A(dec_part, (size_t)(D / 32) * MB * 3);
         }
         A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);

@@ -1420,6 +1420,10 @@ hipError_t dispatch_nv(int D, F&& f) {
 // pieces in flight together (32 float4 per lane), x_hat / g / the loss terms of its 32 columns, and the slice's share of the 32
 // dval = <g, W_dec[idx_j]>; decode_s_finish_kernel adds the D / 32 shares and loss terms per row in slice order.  x_hat is summed in
 // code order exactly as decode_q_kernel does, so the two give the same x_hat and g bit for bit.
+// OPT-IN (saev_debug_cfg.dw_route = 4): measured at configs[1] 255-265 us + 25 (finish) + 20 (the slice-major copy normalize_rows
+// leaves) against decode_q's 196 us while a young dictionary reuses few latents and 324 once usage has spread -- a wash in the
+// steady state, 0.1 ms slower early.  Of the 255: the 32 dot products + reduce-scatters of the dval shares 55 (VALU), the row-major
+// x_hat / g pieces 14; the same gathers alone run in 100 us (tools/ubench/row_gather.hip: slices1 ... full V=3 167 us).
 __global__ __launch_bounds__(256) void decode_s_kernel(DecodeSliceArgs s, int wg_per_slice) {
     const DecodeArgs& a = s.d;
     const int lane = threadIdx.x & 63, li = lane & 7;
@@ -1434,10 +1438,6 @@ __global__ __launch_bounds__(256) void decode_s_kernel(DecodeSliceArgs s, int wg
     // L1 / L2 (handing them round the group instead takes 64 ds_bpermute per wave)
     const i32x4_* ir = reinterpret_cast<const i32x4_*>(a.idx + (size_t)row * a.code_stride);
     const f32x4* vr = reinterpret_cast<const f32x4*>(a.val + (size_t)row * a.code_stride);
-    i32x4_ ci[8];
-    f32x4 cv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { ci[u] = ir[u]; cv[u] = vr[u]; }
     const int col4 = slice * 8 + li;  // this lane's float4 of the row
     f32x4 acc = reinterpret_cast<const f32x4*>(a.b_dec)[col4];
     // (what streams through -- x in, x_hat / g / the shares out -- is marked non-temporal: the XCD's 4 MB L2 is for the slice of W_dec)
@@ -1445,26 +1445,33 @@ __global__ __launch_bounds__(256) void decode_s_kernel(DecodeSliceArgs s, int wg
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.WdS) + (size_t)slice * a.S * 32, 0,
                                                                            (uint32_t)a.S * 128u, 0x00020000);
     const uint32_t li16 = (uint32_t)li * 16u;
+    // the 32 pieces stay in registers until dL/dx_hat is known (128 VGPRs); the codes themselves do not: indices are read four at
+    // a time in front of their gathers, values four at a time in front of their fmas (L1 hits) -- 64 VGPRs of codes held across the
+    // gathers cost the kernel its third wave per SIMD
     f32x4 wv[32];
     uint32_t okmask = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 8; ++u) {
+        const i32x4_ ci = ir[u];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int j = 4 * u + h;
-            const int i = ci[u][h];
+            const int i = ci[h];
             const bool ok = j < a.k && i >= 0 && i < a.idx_limit;
             okmask |= ok ? (1u << j) : 0u;
             // (an absent code: an offset past the buffer -- zeros, no memory access)
             const i32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(wres, (ok ? (uint32_t)i * 128u : 0xFFFFFF00u) | li16, 0, 0);
             wv[j] = f32x4{__int_as_float(t[0]), __int_as_float(t[1]), __int_as_float(t[2]), __int_as_float(t[3])};
         }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 8; ++u) {
+        const f32x4 cv = vr[u];
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-            if (okmask & (1u << (4 * u + h))) acc += cv[u][h] * wv[4 * u + h];
+            if (okmask & (1u << (4 * u + h))) acc += cv[h] * wv[4 * u + h];
+    }
     const float u_ = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
     float sse_scaled = 0.f;
     double sse64 = 0.0, sumsq64 = 0.0;
@@ -1534,13 +1541,13 @@ __global__ __launch_bounds__(256) void decode_s_kernel(DecodeSliceArgs s, int wg
     }
     if (live && slice == 0 && a.training && a.fired) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            // (lane li marks the codes 4 li .. 4 li + 3; ci[li] is a run-time index into registers: a select chain over 8)
-            int ii = -1;
-            float vv = 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { ii = (u == li) ? ci[u][h] : ii; vv = (u == li) ? cv[u][h] : vv; }
-            if (4 * li + h < a.k && ii >= 0 && vv != 0.f) a.fired[ii] = 1;
+        for (int h = 0; h < 4; ++h) {  // (lane li marks the codes 4 li .. 4 li + 3)
+            const int jj = 4 * li + h;
+            if (jj < a.k) {
+                const int ii = a.idx[(size_t)row * a.code_stride + jj];
+                const float vv = a.val[(size_t)row * a.code_stride + jj];
+                if (ii >= 0 && vv != 0.f) a.fired[ii] = 1;
+            }
         }
     }
 }

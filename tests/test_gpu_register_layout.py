@@ -161,3 +161,34 @@ def test_one_pass_auxk_matches_the_oracle_and_the_five_pass_kernels(d, n_dead, e
     diff = (engs["one_pass"].params - engs["five_pass"].params).abs().max().item()
     assert diff < 5e-5, diff
     assert engs["one_pass"].aux_route() in (1, 2) and engs["five_pass"].aux_route() in (1, 2)
+
+
+@pytest.mark.parametrize("d,n", [(1024, 1000), (768, 300), (256, 515)])
+def test_slice_decode_agrees_with_the_row_decode(d, n, encoder_mode):
+    """SAEV_AMD_DW=slices_s: the decode out of 32-column slices of W_dec (sparse.hip: decode_s_kernel; opt-in) against the default
+    register decode: the same codes, x_hat and loss bit for bit (both sum x_hat in code order), gradients to rounding (the dval
+    shares are added in another order)."""
+    if encoder_mode != "f16r":
+        pytest.skip("the decode does not depend on the encoder arithmetic: run once")
+    s, k = 8 * d, 32
+    p = rand_params(d, s, seed=600 + d)
+    x = (torch.randn(n, d, generator=torch.Generator().manual_seed(601 + d)) + 0.2).cuda()
+    out = {}
+    for route in ("slices", "slices_s"):
+        with _env("SAEV_AMD_DW", route):
+            eng = make_engine(d, s, k, k_aux=0, max_batch=n)
+        eng.load_params(p)
+        eng.step_forward(x)
+        eng.step_dead(n)
+        eng.step_backward()
+        torch.cuda.synchronize()
+        idx, val, x_hat = eng.last_codes(n)
+        st = eng.read_stats()
+        out[route] = ({name: v.clone() for name, v in eng.grad_views().items()}, st.mse, idx.clone(), x_hat.clone(), st.l0, eng.fired.clone())
+    assert torch.equal(out["slices"][2], out["slices_s"][2]) and torch.equal(out["slices"][3], out["slices_s"][3])
+    assert math.isclose(out["slices"][1], out["slices_s"][1], rel_tol=1e-6) and out["slices"][4] == out["slices_s"][4]
+    assert torch.equal(out["slices"][5], out["slices_s"][5])
+    for name in ("W_dec", "W_enc", "b_enc", "b_dec"):
+        a, c = out["slices"][0][name], out["slices_s"][0][name]
+        scale = a.abs().max().item() + 1e-30
+        assert (a - c).abs().max().item() <= 2e-6 * scale + 1e-12, (name, (a - c).abs().max().item(), scale)

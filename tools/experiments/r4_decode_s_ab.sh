@@ -1,8 +1,8 @@
 #!/bin/bash
-# slice decode (default) against the whole-row decode (SAEV_AMD_DW=slices_q): tests, kernel times, step
+# slice decode (SAEV_AMD_DW=slices_s) against the whole-row decode (default): tests, kernel times, step
 export PYTHONPATH=$PWD
 python -m pytest tests/test_gpu_dw_slices.py tests/test_gpu_register_layout.py -x -q -m gpu -k "f16r" 2>&1 | grep -E "passed|failed|Error" | tail -3
-for r in slices_q slices slices_q slices; do
+for r in slices slices_s slices slices_s; do
   SAEV_AMD_DW=$r python bench.py --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0 --steps 100 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

@@ -83,11 +83,76 @@ __global__ __launch_bounds__(256) void slices_kernel(const float* __restrict__ W
     *o = acc;
 }
 
+
+// slices1 grown step by step into the real slice decode (sparse.hip: decode_s_kernel): which addition costs what?
+//   V = 1: + val (16 broadcast code loads instead of 32), x_hat = sum val_j w_j, all 32 gathers in flight
+//   V = 2: + x, the loss arithmetic, g; stores of x_hat slice-major... (one more 128-byte store per group)
+//   V = 3: + the 32 dval shares (dots, DPP reduce-scatter) and their store
+template <int V>
+__global__ __launch_bounds__(256) void slices_full_kernel(const float* __restrict__ WS, const int* __restrict__ idx, const float* __restrict__ val,
+                                                         const float* __restrict__ x, float* __restrict__ outS, float* __restrict__ gS,
+                                                         float* __restrict__ dvp, int wg_per_slice) {
+    const int lane = threadIdx.x & 63, gi = threadIdx.x >> 3, li = lane & 7;
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int slice = xcd + 8 * (qq / wg_per_slice);
+    const int row = (qq % wg_per_slice) * 32 + gi;
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WS) + (size_t)slice * S * 32, 0, (uint32_t)S * 128u, 0x00020000);
+    const i32x4* ir = reinterpret_cast<const i32x4*>(idx + (size_t)row * K);
+    const f32x4* vr = reinterpret_cast<const f32x4*>(val + (size_t)row * K);
+    i32x4 ci[8];
+    f32x4 cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ci[u] = ir[u]; cv[u] = vr[u]; }
+    f32x4 w[32];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) w[4 * u + h] = bload(res, (uint32_t)ci[u][h] * 128u | ((uint32_t)li * 16u), 0);
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+    if (V >= 2) xv = reinterpret_cast<const f32x4*>(x + (size_t)row * D)[slice * 8 + li];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc += cv[u][h] * w[4 * u + h];
+    const size_t o = ((size_t)slice * B + row) * 8 + li;
+    reinterpret_cast<f32x4*>(outS)[o] = acc;
+    if (V >= 2) {
+        f32x4 g;
+        float sse = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = acc[e] / 3.f - xv[e] / 3.f; sse += t * t; g[e] = 1e-4f * t; }
+        reinterpret_cast<f32x4*>(gS)[o] = g;
+        if (sse == 12345.f) outS[0] = 1.f;
+        if (V >= 3) {
+            f32x4 sh;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float p[8];
+#pragma unroll
+                for (int uu = 0; uu < 8; ++uu) { const f32x4& ww = w[4 * uu + h]; p[uu] = (g[0] * ww[0] + g[1] * ww[1]) + (g[2] * ww[2] + g[3] * ww[3]); }
+                float r = 0.f;
+#pragma unroll
+                for (int uu = 0; uu < 8; ++uu) r += p[uu];  // (stand-in for the reduce-scatter: same number of adds)
+                r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0x141, 0xF, 0xF, true));
+                r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0x4E, 0xF, 0xF, true));
+                r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0xB1, 0xF, 0xF, true));
+                sh[h] = r;
+            }
+            reinterpret_cast<f32x4*>(dvp)[o] = sh;
+        }
+    }
+}
+
 int main() {
     float *W, *out;
     int* idx;
     hipMalloc(&W, (size_t)S * D * 4); hipMalloc(&out, (size_t)B * D * 4); hipMalloc(&idx, (size_t)B * K * 4);
     hipMemset(W, 0, (size_t)S * D * 4);
+    float *val, *xin, *gS, *dvp;
+    hipMalloc(&val, (size_t)B * K * 4); hipMalloc(&xin, (size_t)B * D * 4); hipMalloc(&gS, (size_t)B * D * 4); hipMalloc(&dvp, (size_t)B * D * 4);
+    hipMemset(val, 0, (size_t)B * K * 4); hipMemset(xin, 0, (size_t)B * D * 4);
     for (int used : {14000, 27000, 32768}) {
         std::mt19937 rng(1);
         std::vector<int> perm(S);
@@ -121,6 +186,9 @@ int main() {
             const int wps = B / 32;
             hipLaunchKernelGGL(slices_kernel, dim3(8 * 4 * wps), dim3(256), 0, 0, W, idx, out, 2, wps);
         });
+        time("full V=1", [&] { hipLaunchKernelGGL(slices_full_kernel<1>, dim3(8 * 4 * (B / 32)), dim3(256), 0, 0, W, idx, val, xin, out, gS, dvp, B / 32); });
+        time("full V=2", [&] { hipLaunchKernelGGL(slices_full_kernel<2>, dim3(8 * 4 * (B / 32)), dim3(256), 0, 0, W, idx, val, xin, out, gS, dvp, B / 32); });
+        time("full V=3", [&] { hipLaunchKernelGGL(slices_full_kernel<3>, dim3(8 * 4 * (B / 32)), dim3(256), 0, 0, W, idx, val, xin, out, gS, dvp, B / 32); });
         time("slices", [&] {
             const int wps = B / 32;
             hipLaunchKernelGGL(slices_kernel, dim3(8 * 4 * wps), dim3(256), 0, 0, W, idx, out, 0, wps);

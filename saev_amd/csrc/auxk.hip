@@ -691,17 +691,24 @@ __global__ __launch_bounds__(256) void aux_small_wsum_kernel(const float* part, 
 // depend on scheduling, and no wave walks more than n/16 blocks (aux_small_wsum_kernel on these partials: 125 us for ONE dead
 // latent -- 256 lanes walking 1 024 blocks four loads at a time).
 __global__ __launch_bounds__(1024) void aux_fused_wsum_kernel(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd,
-                                                              float* dWe) {
+                                                              float* dWe, const float* partb, float* db_out, int db_accumulate,
+                                                              const float* partbe, float* dbe) {
     const int nd = *nd_dev;
     if (nd <= 0 || nd > AUX_FUSED_MAX) return;
     __shared__ f32x4 sh[16][64];
     const int D4 = D >> 2;
-    const long n4 = (long)nd * D4, stride4 = (long)2 * AUX_FUSED_MAX * D4;
+    // blockIdx.y: 0 decoder rows, 1 encoder rows (nd x D out of [blk][2][AUX_FUSED_MAX][D]); 2 db_dec's share (D out of [blk][D]);
+    // 3 db_enc[dl] (AUX_FUSED_MAX out of [blk][AUX_FUSED_MAX]) -- the last two used to be two column-sum launches each
+    const int kind = blockIdx.y;
+    const long n4 = kind < 2 ? (long)nd * D4 : (kind == 2 ? (long)D4 : (long)(AUX_FUSED_MAX / 4));
+    const long stride4 = kind < 2 ? (long)2 * AUX_FUSED_MAX * D4 : (kind == 2 ? (long)D4 : (long)(AUX_FUSED_MAX / 4));
     if ((long)blockIdx.x * 64 >= n4) return;  // (uniform)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long col = (long)blockIdx.x * 64 + lane;
     const bool ok = col < n4;
-    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (long)blockIdx.y * AUX_FUSED_MAX * D4 + (ok ? col : 0);
+    const f32x4* base = kind < 2 ? reinterpret_cast<const f32x4*>(part) + (long)kind * AUX_FUSED_MAX * D4
+                                 : reinterpret_cast<const f32x4*>(kind == 2 ? partb : partbe);
+    const f32x4* p = base + (ok ? col : 0);
     const int chunk = (n_blk + 15) / 16, b0 = w * chunk, b1 = min(n_blk, b0 + chunk);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     int b = b0;
@@ -719,7 +726,14 @@ __global__ __launch_bounds__(1024) void aux_fused_wsum_kernel(const float* part,
     f32x4 tot = sh[0][lane];
 #pragma unroll
     for (int v = 1; v < 16; ++v) tot += sh[v][lane];
-    reinterpret_cast<f32x4*>(blockIdx.y == 0 ? dWd : dWe)[col] = tot;
+    if (kind < 2) {
+        reinterpret_cast<f32x4*>(kind == 0 ? dWd : dWe)[col] = tot;
+    } else if (kind == 2) {
+        f32x4* o = reinterpret_cast<f32x4*>(db_out) + col;
+        *o = db_accumulate ? *o + tot : tot;
+    } else {
+        reinterpret_cast<f32x4*>(dbe)[col] = tot;
+    }
 }
 __global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
     if (threadIdx.x == 0) { out[0] = *a; out[1] = *b; }
@@ -880,8 +894,10 @@ hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int3
     hipLaunchKernelGGL(aux_small_wsum_kernel, dim3(64, 2), dim3(256), 0, s, part, n_blk, D, nd_dev, dWd, dWe, ndp);
     return hipGetLastError();
 }
-hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s) {
-    hipLaunchKernelGGL(aux_fused_wsum_kernel, dim3((AUX_FUSED_MAX * (D >> 2) + 63) / 64, 2), dim3(1024), 0, s, part, n_blk, D, nd_dev, dWd, dWe);
+hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,
+                                 const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe) {
+    hipLaunchKernelGGL(aux_fused_wsum_kernel, dim3((AUX_FUSED_MAX * (D >> 2) + 63) / 64, 4), dim3(1024), 0, s, part, n_blk, D, nd_dev, dWd, dWe,
+                       partb, db_out, db_accumulate, partbe, dbe);
     return hipGetLastError();
 }
 bool aux_fused_supported(int D) { return D % 256 == 0 && D >= 256 && D <= 1024; }

@@ -1292,16 +1292,13 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
                          // all predicated on the device-side count like the forward (rows past it are never scattered)
         const int nb = (n + 63) / 64, L = AUX_SMALL_MAX;
         const int32_t* nd_dev = c->flags + 4;
-        if (c->aux_fused) {  // the forward has left block partials of all four gradients: three ordered sums finish them
+        if (c->aux_fused) {  // the forward has left block partials of all four gradients: one launch of ordered sums finishes them
             const int blocks = aux_fused_blocks(n);
-            HIPCHK(c, launch_aux_fused_wsum(c->aux_small_part, blocks, D, nd_dev, c->dWd, c->dWe, s));
-            HIPCHK(c, launch_colsum(c->A_dead, blocks, AUX_FUSED_MAX, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
-            if (c->ov_x != nullptr) {
-                HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));
-                HIPCHK(c, launch_colsum(c->g_aux, blocks, D, c->colsum_partials, c->db_aux, 0, nd_dev, s));
-            } else {
-                HIPCHK(c, launch_colsum(c->g_aux, blocks, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nd_dev, s));
-            }
+            // (the dead count may be zero on the device: db_aux must then read as zeros, and b_dec's gradient stay untouched -- the
+            // kernel leaves at once in that case, hence the memset)
+            if (c->ov_x != nullptr) HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));
+            HIPCHK(c, launch_aux_fused_wsum(c->aux_small_part, blocks, D, nd_dev, c->dWd, c->dWe, s, c->g_aux,
+                                            c->ov_x != nullptr ? c->db_aux : c->grads + c->off_b_dec, c->ov_x != nullptr ? 0 : 1, c->A_dead, c->dbe));
             return SAEV_OK;
         }
         HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));

@@ -504,7 +504,10 @@ hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int3
 constexpr int AUX_FUSED_MAX = 8;
 constexpr int AUX_FUSED_ROWS = 32;  // activation rows per workgroup
 bool aux_fused_supported(int D);
-hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s);
+// the ordered sums of all four partial sets in one launch: dWd / dWe rows, db_dec's share (db_out, added to what is there when
+// db_accumulate) and db_enc[dl] (dbe)
+hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,
+                                 const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe);
 int aux_fused_blocks(int n_rows);
 hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                   const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale,

@@ -379,9 +379,9 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
-        A(row_margin, MB); A(wnorm_scratch, (S + 3) / 4); A(f16r_scales, 4); A(mu, D); A(xnorm, MB); A(b_shift, S);
+        A(row_margin, MB); A(wnorm_scratch, std::max((S + 3) / 4, 3 * ((S + 255) / 256))); A(f16r_scales, 4); A(mu, D); A(xnorm, 2 * MB); A(b_shift, S);
         A(xabs_part, (MB + 3) / 4);
-        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)(c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
+        if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);

@@ -834,12 +834,19 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const float* v, int n,
 //
 // xmax (device scalar max|x| of the batch, or NULL): the squares are taken of (x - mu) / max|x| -- at most 4 each -- and the
 // norm scaled back, so that activations of any magnitude (|x| ~ 1e20 squares to inf in fp32) get a finite margin.
+// v rounded to fp16's 11 significant bits (round to nearest even) without fp16's range: what the image of v * 2^e holds,
+// divided by 2^e again, for every power of two that keeps the product a normal fp16 number
+__device__ __forceinline__ float round_f16_sig(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return __uint_as_float((b + 0x0FFFu + ((b >> 13) & 1u)) & 0xFFFFE000u);
+}
+// xnorm: two floats per row -- ||x_b - mu|| and ||delta_b||, delta = the rounding error of the row's fp16 image
 __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const float* mu, int n, int D,
                                                            float* xnorm, float* wg_max, const float* xmax) {
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
-    float s = 0.f, m = 0.f;
+    float s = 0.f, m = 0.f, sd = 0.f;
     const float up = xmax != nullptr ? *xmax : 1.0f;
     const float back = (up > 0.f && up < 3.0e38f) ? up : 1.0f, inv = 1.0f / back;
     if (r < n) {
@@ -856,12 +863,17 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 m = fmaxf(fmaxf(fmaxf(m, fabsf(v[u][0])), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = (v[u][e] - round_f16_sig(v[u][e])) * inv;
                 v[u] = v[u] * inv;
                 s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+                sd += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
             }
         }
         s = wave_sum(s);
-        if (lane == 0) xnorm[r] = back * sqrtf(s);
+        sd = wave_sum(sd);
+        if (lane == 0) { xnorm[2 * r] = back * sqrtf(s); xnorm[2 * r + 1] = back * sqrtf(sd) * 1.000001f; }
     }
     m = wave_max(m);
     if (lane == 0) sh[w] = m;
@@ -873,20 +885,26 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
 // scaled with the power of two derived from the PREVIOUS call's largest column norm; they are safe while the current
 // norm times that scale stays below the fp16 range and at most two bits under the intended [2^13, 2^14) window (an
 // all-zero W_enc has exact images).
-__device__ __forceinline__ float f16r_margin(float xnorm_row, float wmax, float bmax, int D) {
-    const float coef = 2.0f * 1.05f * (0.0009765625f + (float)D * 2.384185791015625e-07f);
-    return coef * xnorm_row * wmax + 2.0f * 1.1920929e-07f * bmax;
+__device__ __forceinline__ float f16r_margin(float xnorm_row, float xdelta_row, float wmax, float dwmax, float bmax, int D) {
+    const float rnd = 1.02f * (xdelta_row * wmax + xnorm_row * dwmax + xdelta_row * dwmax);
+    const float acc = (1.05f * (float)D * 2.384185791015625e-07f + 7.62939453125e-06f) * xnorm_row * wmax;
+    return 2.0f * (rnd + acc) + 2.0f * 1.1920929e-07f * bmax;
 }
 __device__ __forceinline__ bool f16r_scale_ok(float wmax, float w_scale) {
     const float t = wmax * w_scale;
     return t < 60000.0f && (t >= 2048.0f || wmax == 0.f);
 }
-// margin[b] = 2 E_b, E_b = 1.05 * (2^-10 + D * 2^-22) * ||x_b - mu|| * max_s ||W_enc[:, s]|| + 2^-23 max |b_shift|: an
-// upper bound of the error of a pre-activation formed from fp16-rounded operands (relative 2^-11 each, exact products;
-// 2^-10 by Cauchy-Schwarz) plus the fp32 accumulation of D terms (counted at 2^-22 per add so that a truncating adder
-// is covered) plus the rounding of the shifted bias.  The operands are pre-scaled so that their largest element sits in
-// [2^13, 2^14): whatever the matrix cores do with fp16 subnormals (flush or keep) then changes a pre-activation by less
-// than 3e-7 of the same product of norms.  DESIGN.md 3.1.
+// margin[b] = 2 E_b,
+//   E_b = 1.02 (||dx_b|| wmax + ||x_b - mu|| dwmax + ||dx_b|| dwmax) + (1.05 D 2^-22 + 2^-17) ||x_b - mu|| wmax + 2^-23 max |b_shift|,
+// wmax = max_s ||W_enc[:, s]||, dwmax = max_s ||dW[:, s]||: an upper bound of the error of a pre-activation formed from
+// fp16-rounded operands.  dx_b and dW[:, s] are the rounding errors the images ACTUALLY carry (center_stats_kernel and the W
+// image pass measure their norms; products of fp16 numbers are exact in fp32), so that
+// |sum (x + dx)(w + dw) - sum x w| <= ||dx|| ||w|| + ||x|| ||dw|| + ||dx|| ||dw|| by Cauchy-Schwarz -- on real data 0.35-0.4 of
+// the a-priori 2^-11 per operand this margin used until round 4.  Then the fp32 accumulation of D terms (counted at 2^-22 per
+// add so that a truncating adder is covered) and the rounding of the shifted bias.  The operands are pre-scaled so that
+// their largest element sits in [2^13, 2^14): whatever the matrix cores do with fp16 subnormals (flush or keep) then changes a
+// pre-activation by less than sqrt(D) 2^-25 of the product of norms (the 2^-17 term, with the fp32 rounding of x - mu).
+// DESIGN.md 3.1.
 //
 // wg_part holds the per-workgroup maxima bias_finish_kernel left behind: |b_shift| in [0, n_part), column norms in
 // [n_part, 2 n_part).  Every workgroup reduces them again (a few hundred values) instead of waiting for two more tiny
@@ -899,21 +917,22 @@ __device__ __forceinline__ bool f16r_scale_ok(float wmax, float w_scale) {
 __global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int n, int D, const float* wg_part, int n_part,
                                                          const float* w_scale, int32_t* pre_flag, float* wmax_prev,
                                                          float* margin) {
-    __shared__ float sh[2][4];
-    float bm = 0.f, wm = 0.f;
-    for (int i = threadIdx.x; i < n_part; i += 256) { bm = fmaxf(bm, wg_part[i]); wm = fmaxf(wm, wg_part[n_part + i]); }
-    bm = wave_max(bm); wm = wave_max(wm);
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = bm; sh[1][threadIdx.x >> 6] = wm; }
+    __shared__ float sh[3][4];
+    float bm = 0.f, wm = 0.f, dm = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) { bm = fmaxf(bm, wg_part[i]); wm = fmaxf(wm, wg_part[n_part + i]); dm = fmaxf(dm, wg_part[2 * n_part + i]); }
+    bm = wave_max(bm); wm = wave_max(wm); dm = wave_max(dm);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = bm; sh[1][threadIdx.x >> 6] = wm; sh[2][threadIdx.x >> 6] = dm; }
     __syncthreads();
     const float bmax = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
     const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
+    const float dwmax = fmaxf(fmaxf(sh[2][0], sh[2][1]), fmaxf(sh[2][2], sh[2][3]));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (!f16r_scale_ok(wmax, *w_scale)) *pre_flag = 1;
         *wmax_prev = wmax;
     }
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    margin[r] = f16r_margin(xnorm[r], wmax, bmax, D);
+    margin[r] = f16r_margin(xnorm[2 * r], xnorm[2 * r + 1], wmax, dwmax, bmax, D);
 }
 // Everything the fused encoder launch needs zeroed or derived right before it, in one pass (three launches before):
 //   * the per-launch state of the encoder: candidate counters 0, shared group maxima "-inf";
@@ -932,14 +951,15 @@ __global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int 
         return;
     }
     if ((int)blockIdx.x * 256 >= n_rows && blockIdx.x != 0) return;  // (blocks past the rows only initialise)
-    __shared__ float sh[2][4];
-    float bm = 0.f, wm = 0.f;
-    for (int j = threadIdx.x; j < n_part; j += 256) { bm = fmaxf(bm, wg_part[j]); wm = fmaxf(wm, wg_part[n_part + j]); }
-    bm = wave_max(bm); wm = wave_max(wm);
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = bm; sh[1][threadIdx.x >> 6] = wm; }
+    __shared__ float sh[3][4];
+    float bm = 0.f, wm = 0.f, dm = 0.f;
+    for (int j = threadIdx.x; j < n_part; j += 256) { bm = fmaxf(bm, wg_part[j]); wm = fmaxf(wm, wg_part[n_part + j]); dm = fmaxf(dm, wg_part[2 * n_part + j]); }
+    bm = wave_max(bm); wm = wave_max(wm); dm = wave_max(dm);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = bm; sh[1][threadIdx.x >> 6] = wm; sh[2][threadIdx.x >> 6] = dm; }
     __syncthreads();
     const float bmax = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
     const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
+    const float dwmax = fmaxf(fmaxf(sh[2][0], sh[2][1]), fmaxf(sh[2][2], sh[2][3]));
     if (i == 0) {
         int pre = *pre_flag != 0 ? 1 : 0;
         if (!f16r_scale_ok(wmax, *w_scale)) { pre = 1; *pre_flag = 1; }
@@ -947,7 +967,7 @@ __global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int 
         flags1[0] = pre; flags1[1] = 0; flags1[2] = 0;
     }
     if (i >= n_rows) return;
-    margin[i] = f16r_margin(xnorm[i], wmax, bmax, D);
+    margin[i] = f16r_margin(xnorm[2 * i], xnorm[2 * i + 1], wmax, dwmax, bmax, D);
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)

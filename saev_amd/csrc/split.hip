@@ -93,6 +93,7 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
 // the tile is in LDS anyway:
 //   * this image's share of <mu, W[:, s]> in fp64 -> dot_part[ks][s]   (bias of the centred first pass)
 //   * this image's share of ||W[:, s]||^2         -> sq_part[ks][s]    (largest column norm: error margin, next scale)
+//   * this image's share of ||dW[:, s]||^2        -> sq_part[nks + ks][s]  (dW = W - its fp16 image: the measured margin)
 //   * the fp32 transpose W_T[s][k]                                      (rows for the exact refinement)
 // bias_finish_kernel adds the nks shares in a fixed order.  The tile holds W * scale with a power-of-two scale: exact,
 // undone where it matters.
@@ -126,20 +127,26 @@ __device__ __forceinline__ void split_wT_body(int bid, int nblk, float (&tile)[(
     if constexpr (MODE == 2) {
         if (mu != nullptr) {  // the four threads of a latent hold its 32 k of this image
             double acc = 0.0;
-            float sq = 0.f;
+            float sq = 0.f, dsq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 acc += (double)mu_s[c * 8 + e] * (double)v[e];
                 sq += v[e] * v[e];
+                const float d = v[e] - (float)(_Float16)v[e];  // the rounding error this image carries (inf on overflow: margin inf)
+                dsq += d * d;
             }
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             sq += __shfl_xor(sq, 1, 64);
             sq += __shfl_xor(sq, 2, 64);
+            dsq += __shfl_xor(dsq, 1, 64);
+            dsq += __shfl_xor(dsq, 2, 64);
             if (p == 0) {
-                const size_t o = (size_t)ks * ((size_t)nblk / nks * 256) + s0 + rl;
+                const size_t S_pad = (size_t)nblk / nks * 256;
+                const size_t o = (size_t)ks * S_pad + s0 + rl;
                 dot_part[o] = acc;
                 sq_part[o] = sq;
+                sq_part[(size_t)nks * S_pad + o] = dsq;  // second plane: shares of ||dW[:, s]||^2
             }
             const int k = k0 + c * 8;
             if (s0 + rl < S && k < D) {  // D % 4 == 0
@@ -180,31 +187,34 @@ __global__ __launch_bounds__(1024) void split_f16r_kernel(SplitF16rArgs a) {
                           a.sq_part, a.W_T, a.wt_slices);
 }
 
-// b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]) and ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale;
-// per workgroup one maximum of |b_shift| (wg_max[0..nwg)) and one of the norms (wg_max[nwg..2 nwg))
+// b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]), ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale and
+// ||dW[:, s]|| from the second plane of sq_part; per workgroup one maximum of |b_shift| (wg_max[0..nwg)), one of the norms
+// (wg_max[nwg..2 nwg)) and one of the rounding-error norms (wg_max[2 nwg..3 nwg))
 __global__ __launch_bounds__(256) void bias_finish_kernel(const double* __restrict__ dot_part,
                                                           const float* __restrict__ sq_part, int nks, int S, int S_pad,
                                                           const float* __restrict__ w_scale, const float* __restrict__ b_enc,
                                                           float* __restrict__ b_shift, float* __restrict__ wg_max) {
-    __shared__ float sh[2][4];
+    __shared__ float sh[3][4];
     const int sidx = blockIdx.x * 256 + threadIdx.x;
-    float out = 0.f, nrm = 0.f;
+    float out = 0.f, nrm = 0.f, dnrm = 0.f;
     if (sidx < S) {
-        double acc = 0.0, sq = 0.0;
+        double acc = 0.0, sq = 0.0, dsq = 0.0;
         for (int ks = 0; ks < nks; ++ks) {
             acc += dot_part[(size_t)ks * S_pad + sidx];
             sq += (double)sq_part[(size_t)ks * S_pad + sidx];
+            dsq += (double)sq_part[(size_t)(nks + ks) * S_pad + sidx];
         }
         const double sc = (double)(*w_scale);
         out = (float)(acc / sc + (double)b_enc[sidx]);
         b_shift[sidx] = out;
         nrm = (float)(sqrt(sq) / sc) * 1.000001f;  // (rounded up: it bounds an error)
+        dnrm = (float)(sqrt(dsq) / sc) * 1.00001f;  // (the shares are fp32 sums of 32 squares: rounded up a little further)
     }
     float m = fabsf(out);
-    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); nrm = fmaxf(nrm, __shfl_xor(nrm, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = m; sh[1][threadIdx.x >> 6] = nrm; }
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); nrm = fmaxf(nrm, __shfl_xor(nrm, o, 64)); dnrm = fmaxf(dnrm, __shfl_xor(dnrm, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = m; sh[1][threadIdx.x >> 6] = nrm; sh[2][threadIdx.x >> 6] = dnrm; }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         const float* q = sh[threadIdx.x];
         wg_max[threadIdx.x * gridDim.x + blockIdx.x] = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
     }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 6
+#define SAEV_AMD_ABI_VERSION 7
 
 typedef enum {
     SAEV_OK = 0,
@@ -144,6 +144,8 @@ typedef struct {
                               where the geometry allows, 1 = whole-row gathers always                                   */
     int32_t dead_lag;      /* saev_step_dead sizes the auxiliary work from the tracker record of this many steps ago
                               (0 = 4, at most 8): shorter = tighter bound of the dead count, longer = more host run-ahead  */
+    int32_t csc_route;     /* latent-major pair list of the backward: 0 = the training decode sets the (latent, row) bits of the
+                              build's bit map while it holds the codes, 1 = the build's own fill pass always                 */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SaevCfg(C.Structure):
@@ -30,7 +30,7 @@ class SaevDebugCfg(C.Structure):
     """Route switches (include/saev_amd.h: saev_debug_cfg); all zero = shipped defaults."""
 
     _fields_ = [(n, C.c_int32) for n in ("struct_size", "dw_route", "enc_mfma", "fused_chain", "ngroups", "enc_wgs", "refresh_first",
-                                         "refresh_every", "aux_small_max", "fwd_route", "dead_lag")]
+                                         "refresh_every", "aux_small_max", "fwd_route", "dead_lag", "csc_route")]
 
 
 class SaevLayout(C.Structure):

@@ -32,7 +32,20 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const int32_t* dead,
     const int per = (S + 1023) / 1024;
     const int i0 = tid * per, i1 = min(S, i0 + per);
     int cnt = 0;
-    for (int i = i0; i < i1; ++i) cnt += dead[i] ? 1 : 0;
+    uint64_t bits = 0;  // the chunk's flags (per <= 64: every d_sae up to 65 536), fetched as 16-byte words, all in flight
+    const bool packed = per <= 64 && (per & 3) == 0 && i0 + per <= S;
+    if (packed) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        const i32x4_t* p4 = reinterpret_cast<const i32x4_t*>(dead + i0);
+#pragma unroll 8
+        for (int q = 0; q < (per >> 2); ++q) {
+            const i32x4_t v = p4[q];
+            bits |= (uint64_t)((v[0] ? 1 : 0) | (v[1] ? 2 : 0) | (v[2] ? 4 : 0) | (v[3] ? 8 : 0)) << (4 * q);
+        }
+        cnt = __popcll(bits);
+    } else {
+        for (int i = i0; i < i1; ++i) cnt += dead[i] ? 1 : 0;
+    }
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -43,9 +56,18 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const int32_t* dead,
     __syncthreads();
     int pos = incl - cnt;
     for (int j = 0; j < w; ++j) pos += wave_tot[j];
-    if (cnt > 0)
-        for (int i = i0; i < i1; ++i)
-            if (dead[i]) list[pos++] = i;
+    if (cnt > 0) {
+        if (packed) {
+            while (bits != 0) {
+                const int b = __ffsll((long long)bits) - 1;
+                list[pos++] = i0 + b;
+                bits &= bits - 1;
+            }
+        } else {
+            for (int i = i0; i < i1; ++i)
+                if (dead[i]) list[pos++] = i;
+        }
+    }
 }
 
 // Wenc_dead (D, ndp) = W_enc[:, dl] (zero columns beyond nd);  Wdec_dead (ndp, D) = W_dec[dl, :] (zero rows beyond nd)
@@ -472,18 +494,24 @@ __device__ __forceinline__ float aux_reduce_scatter16(float (&p)[16], int lane) 
     return r;
 }
 
-template <int NW>
+// ND = dead latents a workgroup provides for (the host picks it from its bound of the count: 4 or AUX_FUSED_MAX), RU = 16 / ND
+// activation rows per trip -- sixteen dot products per reduce-scatter either way, half the barriers per row at ND = 4.
+// PF trips of rows are in flight per lane (a ring of register sets, the loop unrolled over it).  The kernel is bound by its two
+// barriers and reduce-scatters per trip, not by the latency of its loads: four rows per trip took it from 61.5 to 43.6 us at three
+// dead latents, a deeper ring made it slower (kernels.h: AUX_FUSED_PF4).
+template <int NW, int ND, int PF>
 __global__ __launch_bounds__(64 * NW, 2) void aux_small_fused_kernel(const float* __restrict__ x, const float* __restrict__ x_hat,
                                                                   const float* __restrict__ WencT_dead, const float* __restrict__ Wdec_dead,
                                                                   const float* __restrict__ b_enc, const float* __restrict__ b_dec,
                                                                   const int32_t* __restrict__ dl, int n_rows, const int32_t* nd_dev, float gscale,
                                                                   int rows_per_wg, float* __restrict__ part, float* __restrict__ partb,
                                                                   float* __restrict__ partbe, RowStats* __restrict__ rowstats) {
-    constexpr int ND = AUX_FUSED_MAX, D4 = 64 * NW, NVAL = 2 * ND;
+    constexpr int D4 = 64 * NW, NVAL = 16, RU = NVAL / ND, NDO = AUX_FUSED_MAX;  // (NDO: rows per half of a block partial)
+    static_assert(ND * RU == NVAL && ND <= NDO, "aux_small_fused_kernel: ND must divide 16");
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > ND) return;  // (uniform over the grid)
+    if (nd <= 0 || nd > ND) return;  // (uniform over the grid; the host's bound of the count chose ND)
     __shared__ __attribute__((aligned(16))) float shA[NVAL][4];
-    __shared__ __attribute__((aligned(16))) float shB[NVAL + 2][4];
+    __shared__ __attribute__((aligned(16))) float shB[NVAL + RU][4];
     extern __shared__ __attribute__((aligned(16))) float aux_smem[];  // the dead latents' encoder and decoder rows: [2][ND][D4] float4
     f32x4 (*const We)[D4] = reinterpret_cast<f32x4 (*)[D4]>(aux_smem);
     f32x4 (*const Wd)[D4] = We + ND;
@@ -504,48 +532,55 @@ __global__ __launch_bounds__(64 * NW, 2) void aux_small_fused_kernel(const float
     }
     const f32x4 bd4 = reinterpret_cast<const f32x4*>(b_dec)[q];
     f32x4 accb = {0.f, 0.f, 0.f, 0.f};
-    if (NW < 4 && threadIdx.x < NVAL + 2) {  // columns of the exchange arrays that no wave writes
+    if (NW < 4 && threadIdx.x < NVAL + RU) {  // columns of the exchange arrays that no wave writes
         for (int v = NW; v < 4; ++v) { if (threadIdx.x < NVAL) shA[threadIdx.x][v] = 0.f; shB[threadIdx.x][v] = 0.f; }
     }
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(n_rows, r0 + rows_per_wg);
-    auto load_pair = [&](int r, f32x4 (&xv)[2], f32x4 (&hv)[2]) {
+    auto load_rows = [&](int r, f32x4 (&xv)[RU], f32x4 (&hv)[RU]) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RU; ++u) {
             const int row = min(r + u, n_rows - 1);
             xv[u] = reinterpret_cast<const f32x4*>(x + (size_t)row * (D4 * 4))[q];
             hv[u] = reinterpret_cast<const f32x4*>(x_hat + (size_t)row * (D4 * 4))[q];
         }
     };
-    f32x4 xn[2], hn[2];
-    if (r0 < r1) load_pair(r0, xn, hn);
-    for (int r = r0; r < r1; r += 2) {
-        f32x4 xc[2] = {xn[0], xn[1]}, hc[2] = {hn[0], hn[1]};
-        if (r + 2 < r1) load_pair(r + 2, xn, hn);
-        const bool live1 = r + 1 < r1;
+    f32x4 xq[PF][RU], hq[PF][RU];
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (r0 + RU * s < r1) load_rows(r0 + RU * s, xq[s], hq[s]);
+    for (int rb = r0; rb < r1; rb += RU * PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        const int r = rb + RU * s;
+        if (r >= r1) break;  // (uniform over the workgroup)
+        f32x4 xc[RU], hc[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) { xc[u] = xq[s][u]; hc[u] = hq[s][u]; }
+        if (r + RU * PF < r1) load_rows(r + RU * PF, xq[s], hq[s]);
         float p[NVAL];
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
             const f32x4 we = We[j][q];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) p[u * ND + j] = (xc[u][0] * we[0] + xc[u][1] * we[1]) + (xc[u][2] * we[2] + xc[u][3] * we[3]);
+            for (int u = 0; u < RU; ++u) p[u * ND + j] = (xc[u][0] * we[0] + xc[u][1] * we[1]) + (xc[u][2] * we[2] + xc[u][3] * we[3]);
         }
         {
             const float rs = aux_reduce_scatter16(p, lane);
             if ((lane & 3) == 0) shA[lane >> 2][w] = rs;
         }
         __syncthreads();
-        float Hc[2][ND];
+        float Hc[RU][ND];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < RU; ++u)
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&shA[u * ND + j][0]);
                 Hc[u][j] = (j < nd) ? (((t[0] + t[1]) + t[2]) + t[3]) + be[j] : 0.f;
             }
-        f32x4 g[2];
-        float sse[2];
+        f32x4 g[RU];
+        float sse[RU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RU; ++u) {
             f32x4 e = bd4;
 #pragma unroll
             for (int j = 0; j < ND; ++j) e += Hc[u][j] * Wd[j][q];
@@ -556,23 +591,26 @@ __global__ __launch_bounds__(64 * NW, 2) void aux_small_fused_kernel(const float
                 sse[u] += diff * diff;
                 g[u][c] = gscale * diff;
             }
+            if (u > 0 && r + u >= r1) { g[u] = f32x4{0.f, 0.f, 0.f, 0.f}; sse[u] = 0.f; }  // (rows past the block: clamped loads)
         }
-        if (!live1) { g[1] = f32x4{0.f, 0.f, 0.f, 0.f}; sse[1] = 0.f; }
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
             const f32x4 wd = Wd[j][q];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) p[u * ND + j] = (g[u][0] * wd[0] + g[u][1] * wd[1]) + (g[u][2] * wd[2] + g[u][3] * wd[3]);
+            for (int u = 0; u < RU; ++u) p[u * ND + j] = (g[u][0] * wd[0] + g[u][1] * wd[1]) + (g[u][2] * wd[2] + g[u][3] * wd[3]);
         }
         {
             const float rs = aux_reduce_scatter16(p, lane);
             if ((lane & 3) == 0) shB[lane >> 2][w] = rs;
-            const float s0 = wave_sum(sse[0]), s1 = wave_sum(sse[1]);
-            if (lane == 0) { shB[NVAL][w] = s0; shB[NVAL + 1][w] = s1; }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const float su = wave_sum(sse[u]);
+                if (lane == 0) shB[NVAL + u][w] = su;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RU; ++u) {
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&shB[u * ND + j][0]);
@@ -583,25 +621,25 @@ __global__ __launch_bounds__(64 * NW, 2) void aux_small_fused_kernel(const float
             }
             accb += g[u];
         }
-        if (threadIdx.x == 0) {
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(&shB[NVAL][0]), t1 = *reinterpret_cast<const f32x4*>(&shB[NVAL + 1][0]);
-            rowstats[r].aux_sse = ((t0[0] + t0[1]) + t0[2]) + t0[3];
-            if (live1) rowstats[r + 1].aux_sse = ((t1[0] + t1[1]) + t1[2]) + t1[3];
+        if (threadIdx.x < RU && r + (int)threadIdx.x < r1) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&shB[NVAL + threadIdx.x][0]);
+            rowstats[r + threadIdx.x].aux_sse = ((t[0] + t[1]) + t[2]) + t[3];
         }
+      }
     }
-    // block partials, in launch_aux_small_wgrad's layout with ND rows per half: [blk][2][ND][D]
-    f32x4* const pb = reinterpret_cast<f32x4*>(part) + (size_t)blockIdx.x * 2 * ND * D4;
+    // block partials, in launch_aux_small_wgrad's layout with NDO rows per half: [blk][2][NDO][D]
+    f32x4* const pb = reinterpret_cast<f32x4*>(part) + (size_t)blockIdx.x * 2 * NDO * D4;
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
         if (j < nd) {
             pb[(size_t)j * D4 + q] = accD[j];
-            pb[(size_t)(ND + j) * D4 + q] = accE[j];
+            pb[(size_t)(NDO + j) * D4 + q] = accE[j];
         }
     }
     reinterpret_cast<f32x4*>(partb)[(size_t)blockIdx.x * D4 + q] = accb;
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) partbe[(size_t)blockIdx.x * ND + j] = accbe[j];
+        for (int j = 0; j < NDO; ++j) partbe[(size_t)blockIdx.x * NDO + j] = j < ND ? accbe[j < ND ? j : 0] : 0.f;
     }
 }
 
@@ -904,22 +942,39 @@ bool aux_fused_supported(int D) { return D % 256 == 0 && D >= 256 && D <= 1024; 
 int aux_fused_blocks(int n_rows) { return (n_rows + AUX_FUSED_ROWS - 1) / AUX_FUSED_ROWS; }
 hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                   const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale,
-                                  float* part, float* partb, float* partbe, RowStats* rowstats, hipStream_t s) {
+                                  float* part, float* partb, float* partbe, RowStats* rowstats, hipStream_t s, int bound) {
     if (!aux_fused_supported(D)) return hipErrorInvalidValue;
     const dim3 grid(aux_fused_blocks(n_rows));
-    const size_t smem = (size_t)2 * AUX_FUSED_MAX * D * sizeof(float);  // 64 KB at d_model 1024, next to < 1 KB of static LDS
+    // `bound` >= the device-side count: at most four dead latents (the usual state of a healthy run) take the variant that
+    // provides for four -- half the registers in accumulators, four rows per trip, two trips in flight
+    const bool four = bound <= 4;
+    const size_t smem = (size_t)2 * (four ? 4 : AUX_FUSED_MAX) * D * sizeof(float);  // 64 KB at d_model 1024 and eight latents, next to < 1 KB of static LDS
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&aux_small_fused_kernel<1>), reinterpret_cast<const void*>(&aux_small_fused_kernel<2>),
-                              reinterpret_cast<const void*>(&aux_small_fused_kernel<3>), reinterpret_cast<const void*>(&aux_small_fused_kernel<4>)};
+        const void* fns[8] = {reinterpret_cast<const void*>(&aux_small_fused_kernel<1, AUX_FUSED_MAX, AUX_FUSED_PF8>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<2, AUX_FUSED_MAX, AUX_FUSED_PF8>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<3, AUX_FUSED_MAX, AUX_FUSED_PF8>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<4, AUX_FUSED_MAX, AUX_FUSED_PF8>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<1, 4, AUX_FUSED_PF4>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<2, 4, AUX_FUSED_PF4>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<3, 4, AUX_FUSED_PF4>),
+                              reinterpret_cast<const void*>(&aux_small_fused_kernel<4, 4, AUX_FUSED_PF4>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AUX_FUSED_MAX * 1024 * (int)sizeof(float));
             if (e != hipSuccess) return e;
         }
         attr_set = true;
     }
-#define AF(NW_) hipLaunchKernelGGL(aux_small_fused_kernel<NW_>, grid, dim3(64 * NW_), smem, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, \
-                                   n_rows, nd_dev, gscale, AUX_FUSED_ROWS, part, partb, partbe, rowstats)
+#define AF(NW_)                                                                                                                            \
+    do {                                                                                                                                   \
+        if (four)                                                                                                                          \
+            hipLaunchKernelGGL((aux_small_fused_kernel<NW_, 4, AUX_FUSED_PF4>), grid, dim3(64 * NW_), smem, s, x, x_hat, WencT_dead,      \
+                               Wdec_dead, b_enc, b_dec, dl, n_rows, nd_dev, gscale, AUX_FUSED_ROWS, part, partb, partbe, rowstats);        \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((aux_small_fused_kernel<NW_, AUX_FUSED_MAX, AUX_FUSED_PF8>), grid, dim3(64 * NW_), smem, s, x, x_hat,      \
+                               WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, nd_dev, gscale, AUX_FUSED_ROWS, part, partb, partbe,       \
+                               rowstats);                                                                                                  \
+    } while (0)
     switch (D / 256) {
         case 1: AF(1); break;
         case 2: AF(2); break;

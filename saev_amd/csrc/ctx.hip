@@ -67,6 +67,8 @@ struct saev_ctx {
     int bitmap_words_last = 0;
     bool bitmap_clean = false;  // every word the next csc build will use is zero (the last full backward cleared behind itself)
     int bitmap_clean_words = 0; // ... for row pitches up to this many words
+    int bitmap_prefill_words = 0, bitmap_prefill_rows = 0;  // the training decode in flight has set the bits of its codes at this pitch (0: no)
+    bool last_backward_gathered = false;  // the previous backward ran over gathered rows (saev_backward_override): its forward's bits were wasted
     int32_t *counts = nullptr, *starts = nullptr;
     int2* pairs = nullptr;
     float* colsum_partials = nullptr;
@@ -1068,7 +1070,20 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->fwd_step ? nullptr : c->xS; c->dws_rows = n; }
     // (... and the products dval, from the decoder rows while the decode holds them in registers)
     if (c->dws_rows == n && c->dval_rows != nullptr) { a.dval_out = c->dval_rows; c->dval_fwd = true; }
-    if (c->P == 1 && c->wds_fresh && a.dval_out != nullptr && a.gS != nullptr) {
+    // The decode reads every code anyway: it sets the (latent, row) bits of the backward's pair-list build (0.5 M scattered atomics
+    // that csc_fill paid 35 us for on their own), provided the bit map is clean at this row pitch -- the previous full backward
+    // cleared it behind itself -- and this context's backwards run over its own rows.
+    c->bitmap_prefill_words = 0;
+    const bool slices_decode = c->P == 1 && c->wds_fresh && a.dval_out != nullptr && a.gS != nullptr;
+    if (training && c->dbg.csc_route == 0 && c->bitmap != nullptr && c->bitmap_clean && !c->last_backward_gathered && !slices_decode) {
+        const int words = ((n + 31) / 32 + 7) / 8 * 8;
+        if (words <= c->bitmap_clean_words) {
+            a.csc_bitmap = c->bitmap; a.csc_words = words;
+            c->bitmap_prefill_words = words; c->bitmap_prefill_rows = n;
+            c->bitmap_clean = false;
+        }
+    }
+    if (slices_decode) {
         DecodeSliceArgs ds{};
         ds.d = a; ds.WdS = c->WdS; ds.part = c->dec_part; ds.dvp = c->dvp; ds.dvp_pitch = (long)c->back_rows * K;
         HIPCHK(c, launch_decode_slices(ds, s));
@@ -1203,7 +1218,7 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
         c->aux_fused = true;
         HIPCHK(c, launch_aux_small_fused(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                          c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
-                                         c->cfg.alpha * 2.0f / ((float)n * (float)D), c->aux_small_part, c->g_aux, c->A_dead, c->rowstats, s));
+                                         c->cfg.alpha * 2.0f / ((float)n * (float)D), c->aux_small_part, c->g_aux, c->A_dead, c->rowstats, s, bound));
         HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, nullptr, c->stats, s, nd_dev, c->stats_scratch));
         return SAEV_OK;
     }
@@ -1473,8 +1488,12 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0), formed in the grids of the CSC build's first two
     // launches; the AuxK contractions add theirs
     const float* gmat = ov ? c->ov_g : (c->P_last > 1 ? c->G : c->g);
+    // (prefilled: this forward's decode has set the bits of exactly these codes: no clear, no fill pass)
+    const bool prefilled = !ov && c->bitmap_prefill_words == words && c->bitmap_prefill_rows == n;
     HIPCHK(c, launch_csc_build(a, s, c->bitmap_clean && words <= c->bitmap_clean_words, gmat, D, (long)c->P_last * D,
-                               c->colsum_partials, c->grads + c->off_b_dec));
+                               c->colsum_partials, c->grads + c->off_b_dec, prefilled));
+    c->bitmap_prefill_words = 0;
+    c->last_backward_gathered = ov;
     c->bitmap_clean = false;
     c->bitmap_words_last = words;
     if (c->aux_route != AUX_NONE) {

@@ -160,6 +160,10 @@ struct DecodeArgs {
     // optional (training, k <= 32, D = 256 / 512 / 768 / 1024): dval_out[b][j] = <g_b, W_dec[idx[b][j]]> (n_rows, code_stride), formed
     // from the decoder rows while they are still in registers (decode_q_kernel) -- the backward's pass A then needs no W_dec slices
     float* dval_out;
+    // optional (training): the CSC build's bit map (S x csc_words words, all zero on entry) -- the decode reads every code anyway and
+    // sets bit (latent, row) for it, so that the backward's build starts at its count pass (launch_csc_build: prefilled)
+    uint32_t* csc_bitmap;
+    int csc_words;
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 // whether launch_decode forms dval_out for this shape (otherwise the pointer is ignored and pass A forms the products)
@@ -222,7 +226,7 @@ struct CscArgs {
 // grids of the fill / count launches (db_dec of the same backward: two launches instead of four)
 hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean = false, const float* colsum_m = nullptr,
                             int colsum_D = 0, long colsum_row_stride = 0, float* colsum_partials = nullptr,
-                            float* colsum_out = nullptr);
+                            float* colsum_out = nullptr, bool prefilled = false);  // prefilled: the decode has set the bits (DecodeArgs::csc_bitmap)
 
 constexpr int DW_CHUNK = 64;   // pairs per work item of the weight-gradient kernels
 
@@ -503,6 +507,14 @@ hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int3
 // (db_enc[dl]); blocks = aux_fused_blocks(n_rows)
 constexpr int AUX_FUSED_MAX = 8;
 constexpr int AUX_FUSED_ROWS = 32;  // activation rows per workgroup
+// trips of rows a lane keeps in flight beyond the current one (measured at three dead latents, tools/experiments/r4_aux_pf_ab.sh:
+// four latents / four rows per trip 43.6 us at 1, 47.3 at 2 (8 spilled registers), 66 at 3; eight latents / two rows 61.5 at 1)
+#ifndef AUX_FUSED_PF8
+#define AUX_FUSED_PF8 1
+#endif
+#ifndef AUX_FUSED_PF4
+#define AUX_FUSED_PF4 1
+#endif
 bool aux_fused_supported(int D);
 // the ordered sums of all four partial sets in one launch: dWd / dWe rows, db_dec's share (db_out, added to what is there when
 // db_accumulate) and db_enc[dl] (dbe)
@@ -511,7 +523,8 @@ hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int3
 int aux_fused_blocks(int n_rows);
 hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                   const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale,
-                                  float* part, float* partb, float* partbe, RowStats* rowstats, hipStream_t s);
+                                  float* part, float* partb, float* partbe, RowStats* rowstats, hipStream_t s,
+                                  int bound = AUX_FUSED_MAX);  // bound >= the device-side count (<= 4: the four-latent variant)
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
                                   const int32_t* nd_dev, float* part, hipStream_t s);  // part: ceil(n/64) x 2 x AUX_SMALL_MAX x D
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s);  // out = sum_j parts[j], n % 4 == 0

@@ -885,10 +885,13 @@ __global__ __launch_bounds__(256) void center_stats_kernel(const float* x, const
 // scaled with the power of two derived from the PREVIOUS call's largest column norm; they are safe while the current
 // norm times that scale stays below the fp16 range and at most two bits under the intended [2^13, 2^14) window (an
 // all-zero W_enc has exact images).
-__device__ __forceinline__ float f16r_margin(float xnorm_row, float xdelta_row, float wmax, float dwmax, float bmax, int D) {
+__device__ __forceinline__ float f16r_margin(float xnorm_row, float xdelta_row, float wmax, float dwmax, float bmax, int D, float x_scale) {
     const float rnd = 1.02f * (xdelta_row * wmax + xnorm_row * dwmax + xdelta_row * dwmax);
     const float acc = (1.05f * (float)D * 2.384185791015625e-07f + 7.62939453125e-06f) * xnorm_row * wmax;
-    return 2.0f * (rnd + acc) + 2.0f * 1.1920929e-07f * bmax;
+    // elements of the x image below fp16's normal range (2^-14 after scaling; the scale follows the BATCH's largest element, so a
+    // row far smaller than its batch can sit there whole): each is off by at most 2^-14 / x_scale, flushed or not
+    const float sub = sqrtf((float)D) * 6.103515625e-05f / x_scale * wmax;
+    return 2.0f * (rnd + acc + sub) + 2.0f * 1.1920929e-07f * bmax;
 }
 __device__ __forceinline__ bool f16r_scale_ok(float wmax, float w_scale) {
     const float t = wmax * w_scale;
@@ -903,7 +906,8 @@ __device__ __forceinline__ bool f16r_scale_ok(float wmax, float w_scale) {
 // the a-priori 2^-11 per operand this margin used until round 4.  Then the fp32 accumulation of D terms (counted at 2^-22 per
 // add so that a truncating adder is covered) and the rounding of the shifted bias.  The operands are pre-scaled so that
 // their largest element sits in [2^13, 2^14): whatever the matrix cores do with fp16 subnormals (flush or keep) then changes a
-// pre-activation by less than sqrt(D) 2^-25 of the product of norms (the 2^-17 term, with the fp32 rounding of x - mu).
+// pre-activation by less than sqrt(D) 2^-14 / scale times the other operand's norm -- for W that is inside the 2^-17 term
+// (with the fp32 rounding of x - mu), for x it is the absolute term `sub` (a row may be far smaller than its batch).
 // DESIGN.md 3.1.
 //
 // wg_part holds the per-workgroup maxima bias_finish_kernel left behind: |b_shift| in [0, n_part), column norms in
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int
     }
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    margin[r] = f16r_margin(xnorm[2 * r], xnorm[2 * r + 1], wmax, dwmax, bmax, D);
+    margin[r] = f16r_margin(xnorm[2 * r], xnorm[2 * r + 1], wmax, dwmax, bmax, D, w_scale[-1]);  // (f16r_scales: {x scale, W scale, ...})
 }
 // Everything the fused encoder launch needs zeroed or derived right before it, in one pass (three launches before):
 //   * the per-launch state of the encoder: candidate counters 0, shared group maxima "-inf";
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int 
         flags1[0] = pre; flags1[1] = 0; flags1[2] = 0;
     }
     if (i >= n_rows) return;
-    margin[i] = f16r_margin(xnorm[2 * i], xnorm[2 * i + 1], wmax, dwmax, bmax, D);
+    margin[i] = f16r_margin(xnorm[2 * i], xnorm[2 * i + 1], wmax, dwmax, bmax, D, w_scale[-1]);  // (f16r_scales: {x scale, W scale, ...})
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)

@@ -89,6 +89,11 @@ __device__ __forceinline__ float wave_reduce_scatter32(float (&p)[32], int lane)
     return p[0] + __shfl_xor(p[0], 1, 64);
 }
 
+// bit (latent i, row) of the CSC build's bit map (DecodeArgs::csc_bitmap; csc_fill_body does the same for builds the decode has
+// not prepared)
+__device__ __forceinline__ void csc_mark(const DecodeArgs& a, int32_t i, int row) {
+    if (a.csc_bitmap != nullptr && i >= 0 && i < a.S) atomicOr(&a.csc_bitmap[(size_t)i * a.csc_words + (row >> 5)], 1u << (row & 31));
+}
 template <int NV>
 __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int lane = threadIdx.x & 63;
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
             l1 += fabsf(v);
             if (a.training && a.fired) a.fired[i] = 1;
         }
+        csc_mark(a, i, row);
     }
     if (a.rowstats) {
         sse_scaled = wave_sum(sse_scaled);
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(64 * NW) void decode_q_kernel(DecodeArgs a) {
         l1 = fabsf(raw_v);
         if (a.training && a.fired) a.fired[raw_i] = 1;
     }
+    csc_mark(a, raw_i, row);
     if (a.rowstats) {
         l0 = wave_sum(l0);
         l1 = wave_sum(l1);
@@ -375,6 +382,7 @@ __global__ __launch_bounds__(256) void decode_matry_kernel(DecodeArgs a, MatryAr
             l1 += fabsf(v);
             if (a.training && a.fired) a.fired[i] = 1;
         }
+        csc_mark(a, i, row);
     }
     if (a.rowstats) {
         sse_scaled = wave_sum(sse_scaled);
@@ -503,6 +511,7 @@ __global__ __launch_bounds__(64 * NW) void decode_matry_q_kernel(DecodeArgs a, M
         l1 = fabsf(raw_v);
         if (a.training && a.fired) a.fired[raw_i] = 1;
     }
+    csc_mark(a, raw_i, row);
     if (a.rowstats) {
         l0 = wave_sum(l0);
         l1 = wave_sum(l1);
@@ -1660,19 +1669,20 @@ hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStrea
     });
 }
 hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_clean, const float* colsum_m, int colsum_D,
-                            long colsum_row_stride, float* colsum_partials, float* colsum_out) {
+                            long colsum_row_stride, float* colsum_partials, float* colsum_out, bool prefilled) {
     if (a.n_rows <= 0) return hipSuccess;
     const long n = (long)a.n_rows * a.k;
-    const int blocks = (int)std::min<long>((n + 255) / 256, 4096);
+    // (prefilled: the bits of exactly these codes are set already -- no clear, and the first launch is the column sums alone)
+    const int blocks = prefilled ? 0 : (int)std::min<long>((n + 255) / 256, 4096);
     const int place_blocks = (int)std::min<long>((std::max<long>(n, a.S) + 255) / 256, 8192);
-    if (!bitmap_clean) hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
+    if (!bitmap_clean && !prefilled) hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
     if (colsum_m != nullptr) {  // out[d] = sum_b m[b][d] over the same n_rows rows, in the same two launches
         ColsumPlain c{colsum_m, a.n_rows, colsum_D, colsum_partials, colsum_row_stride > 0 ? colsum_row_stride : (long)colsum_D,
                       colsum_out, (a.n_rows + 63) / 64};
         hipLaunchKernelGGL(csc_fill_colsum_kernel, dim3(blocks + c.n_blocks), dim3(256), 0, stream, a, blocks, c);
         hipLaunchKernelGGL(csc_count_colsum_kernel, dim3((a.S + 3) / 4 + (colsum_D + 63) / 64), dim3(256), 0, stream, a, (a.S + 3) / 4, c);
     } else {
-        hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        if (blocks > 0) hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(csc_count_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
     }
     hipLaunchKernelGGL(csc_scan_block_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);

@@ -59,6 +59,7 @@ class EngineConfig:
     #   SAEV_AMD_ENC_WGS, SAEV_AMD_REFRESH_FIRST, SAEV_AMD_REFRESH_EVERY   encoder grid / bound-refresh cadence
     #   SAEV_AMD_AUX_SMALL_MAX    largest dead set of the few-dead-latents AuxK kernels (-1: always the dense algebra)
     #   SAEV_AMD_DEAD_LAG         age in steps of the tracker record that sizes a step's auxiliary work (default 4)
+    #   SAEV_AMD_CSC              1: the backward's pair-list build fills its bit map itself (default: the training decode does)
     dw_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_DW", "slices"))
     fwd_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_FWD", "default"))
     enc_mfma: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_ENC_MFMA", "0")))
@@ -69,6 +70,7 @@ class EngineConfig:
     refresh_every: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_REFRESH_EVERY", "0")))
     aux_small_max: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_SMALL_MAX", "0")))
     dead_lag: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_DEAD_LAG", "0")))
+    csc_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_CSC", "0")))
 
 
 @dataclasses.dataclass
@@ -150,7 +152,7 @@ class SaeEngine:
                 struct_size=C.sizeof(_lib.SaevDebugCfg), dw_route={"slices": 0, "rows": 1, "slices_a": 2, "slices_s": 4}[cfg.dw_route], enc_mfma=cfg.enc_mfma,
                 fused_chain=int(cfg.fused_chain), ngroups=cfg.ngroups, enc_wgs=cfg.enc_wgs, refresh_first=cfg.refresh_first,
                 refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route=int(cfg.fwd_route == "rows"),
-                dead_lag=cfg.dead_lag)
+                dead_lag=cfg.dead_lag, csc_route=cfg.csc_route)
             ctx = C.c_void_p()
             rc = self.lib.saev_create_ex(C.byref(ccfg), C.byref(dbg), self.device.index, C.byref(ctx))
             if rc != 0:

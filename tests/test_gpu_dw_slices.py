@@ -203,3 +203,28 @@ def test_gathered_backward_on_slices(d, s, k, n):
     a, c = out["rows"][2], out["slices"][2]
     assert (a - c).abs().max().item() <= 2e-6 * a.abs().max().item() + 1e-12
     assert not torch.equal(out["slices"][1], out["slices"][2])
+
+
+@pytest.mark.parametrize("d,s,k,b,prefixes", [(1024, 8192, 32, 2048, 1), (768, 6144, 32, 1000, 1), (512, 4096, 32, 1024, 4),
+                                               (1280, 5120, 64, 512, 1), (128, 1024, 8, 300, 1)])
+def test_decode_filled_bit_map_is_bit_identical_to_the_builds_own_fill(d, s, k, b, prefixes):
+    """saev_debug_cfg.csc_route: the training decode sets the (latent, row) bits of the backward's pair-list build (default) or the
+    build fills its bit map itself (1).  The pair list is the same list either way, so parameters and moments agree bit for bit --
+    also across the cases that decide whether the bit map can be trusted: a smaller batch, a forward without a backward (an
+    evaluation between two steps leaves the bits of ITS codes behind), and the batch growing back."""
+    from saev_amd.nn.objectives import sample_prefixes
+
+    engs = [_engine(d, s, k, b, "slices", seed=3, csc_route=r) for r in (0, 1)]
+    xs = [_data(d, b, n, "plain", seed=10 + i) for i, n in enumerate((b, b, max(1, b // 3), b, b))]
+    torch.manual_seed(0)
+    cuts = [sample_prefixes(s, prefixes) if prefixes > 1 else None for _ in xs]
+    for eng in engs:
+        for i, x in enumerate(xs):
+            if prefixes > 1:
+                eng.set_prefixes(cuts[i])
+            if i == 3:  # a training forward that no backward follows
+                eng.step_forward(x, training=True)
+            eng.train_step(x, 1e-3, 1.0)
+    torch.cuda.synchronize()
+    for name in ("params", "adam_m", "adam_v"):
+        assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), name

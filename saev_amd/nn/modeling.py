@@ -88,7 +88,7 @@ class TopK:
     aux: Aux = AuxK()
 
     def __post_init__(self):
-        assert self.top_k > 0, "top_k must be a positive integer."
+        assert self.top_k > 0, f"top_k = {self.top_k}: at least one latent must be kept"
 
 
 @dataclasses.dataclass(frozen=True)
@@ -100,7 +100,7 @@ class BatchTopK:
     aux: AuxK = AuxK()
 
     def __post_init__(self):
-        assert self.top_k > 0, "top_k must be a positive integer."
+        assert self.top_k > 0, f"top_k = {self.top_k}: at least one latent must be kept"
 
 
 ActivationConfig = tp.Union[Relu, TopK, BatchTopK]
@@ -368,7 +368,7 @@ def _cfg_kwargs(d: dict) -> dict:
     d.pop("seed", None)
     if "exp_factor" in d and "d_sae" not in d:
         if d.get("d_model") is None:
-            raise ValueError("Cannot infer d_sae from exp_factor without d_model in checkpoint.")
+            raise ValueError("legacy checkpoint gives exp_factor but no d_model: d_sae cannot be derived")
         d["d_sae"] = d["d_model"] * d.pop("exp_factor")
     return d
 
@@ -424,7 +424,7 @@ def load(fpath: pathlib.Path | str, *, device="cpu") -> SparseAutoencoder:
         cfg_dict["activation"] = _deser(cfg_dict["activation"], legacy=header["schema"] != 5)
         cfg = SparseAutoencoderConfig(**_cfg_kwargs(cfg_dict))
     else:
-        raise ValueError(f"Unknown schema version: {header['schema']}")
+        raise ValueError(f"checkpoint schema {header['schema']} is not one this loader knows (1-5)")
     model = SparseAutoencoder(cfg)
     model.load_state_dict(torch.load(buffer, weights_only=True, map_location="cpu"))
     return model.to(device)

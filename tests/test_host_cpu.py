@@ -182,7 +182,7 @@ def test_load_reads_legacy_schemas(tmp_path):
         assert got.cfg.d_sae == 16 and torch.equal(got.W_dec, sae.W_dec)
     assert isinstance(M.load(tmp_path / "v4l1.pt").cfg.activation.sparsity, M.L1Sparsity)
     (tmp_path / "bad.pt").write_bytes(json.dumps({"schema": 99, "cfg": {}}).encode() + b"\n")
-    with pytest.raises(ValueError, match="Unknown schema"):
+    with pytest.raises(ValueError, match="checkpoint schema 99"):
         M.load(tmp_path / "bad.pt")
 
 

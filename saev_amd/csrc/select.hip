@@ -890,6 +890,9 @@ __device__ __forceinline__ float f16r_margin(float xnorm_row, float xdelta_row, 
     const float acc = (1.05f * (float)D * 2.384185791015625e-07f + 7.62939453125e-06f) * xnorm_row * wmax;
     // elements of the x image below fp16's normal range (2^-14 after scaling; the scale follows the BATCH's largest element, so a
     // row far smaller than its batch can sit there whole): each is off by at most 2^-14 / x_scale, flushed or not
+    // (a batch that really holds such a row -- seven orders of magnitude below its largest element after centring -- sees this term
+    // dominate that row's margin, its list overflow, and the step take the exact dense route: tests/test_gpu_parity.py,
+    // tools/experiments/r4_tiny_rows_probe.py)
     const float sub = sqrtf((float)D) * 6.103515625e-05f / x_scale * wmax;
     return 2.0f * (rnd + acc + sub) + 2.0f * 1.1920929e-07f * bmax;
 }

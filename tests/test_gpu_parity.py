@@ -422,6 +422,47 @@ def test_f16r_refinement_resolves_near_ties_exactly(encoder_mode):
     assert (approx_sets != exact_sets).any(dim=1).float().mean() > 0.05
 
 
+@pytest.mark.parametrize("tiny", [1.0e-5, 1.0e-9, 1.0e-12])
+def test_f16r_rows_far_smaller_than_their_batch(encoder_mode, tiny):
+    """The power-of-two scale of the x images follows the BATCH's largest centred element, so a row that is many orders of
+    magnitude smaller than its batch sits below fp16's normal range as a whole: its image carries an absolute error the row's own
+    norm says nothing about (the `sub` term of f16r_margin).  Rows in +/- pairs keep the batch mean at zero, so the small rows stay
+    small after centring.  Their codes must be the exact-fp32 encoder's, up to what fp32 itself cannot separate -- whichever way
+    the step gets there: at 1e-5 the lists stay short; from ~1e-7 down the absolute term makes such a row's list overflow and the
+    step takes the exact dense route (tools/experiments/r4_tiny_rows_probe.py)."""
+    if encoder_mode != "f32":
+        pytest.skip("picks its own encoder modes; run once")
+    d, s, n, k = 256, 4096, 512, 32
+    g = torch.Generator().manual_seed(31)
+    p = rand_params(d, s, seed=32)
+    p["b_enc"] = torch.zeros(s)
+    big = torch.randn(224, d, generator=g)
+    small = tiny * torch.randn(32, d, generator=g)
+    x = torch.cat([big, -big, small, -small], dim=0).contiguous()
+    out = {}
+    for mode in ("f32", "f16r"):
+        eng = make_engine(d, s, k, k_aux=0, max_batch=n, encoder=mode)
+        eng.load_params(p)
+        idx, val = eng.encode_topk(x.cuda())
+        out[mode] = (idx.cpu(), val.cpu())
+    W = p["W_enc"].double()
+    h = x.double() @ W
+    habs = x.double().abs() @ W.abs()
+    kth = torch.topk(h, k, dim=-1).values[:, -1]
+    rows = list(range(448, n))
+    for mode in out:  # the values of the small rows are their exact pre-activations
+        idx, val = out[mode]
+        got, want = val[rows].double(), h.gather(1, idx.long())[rows]
+        assert ((got - want).abs() <= 4e-6 * habs.gather(1, idx.long())[rows] + 1e-37).all(), mode
+    n_diff = 0
+    for r in rows:
+        a, b = set(out["f32"][0][r].tolist()), set(out["f16r"][0][r].tolist())
+        n_diff += a != b
+        for i in a ^ b:  # only latents fp32 accumulation cannot tell from the k-th largest may differ
+            assert abs(h[r, i].item() - kth[r].item()) <= 4e-6 * habs[r, i].item(), (r, i, h[r, i].item(), kth[r].item())
+    assert n_diff <= 6, n_diff
+
+
 @pytest.mark.parametrize("scale", [3.0e5, 1.0e-6])
 def test_f16r_handles_any_activation_scale(encoder_mode, scale):
     """fp16 tops out at 65504 and flushes below 6e-8; the f16r images are pre-scaled by a power of two taken from

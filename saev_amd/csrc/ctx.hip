@@ -1484,6 +1484,8 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
         if (!ov && c->dval_fwd) { a.pv2 = c->pv2; a.dval = c->dval_rows; }
     }
     c->dval_pairs_ready = c->dws_pairs && a.pv2 != nullptr;
+    // (inside saev_train_step the column slices take the whole backward: the row kernels' pair list and work items are not built)
+    if (c->fused_step && c->dws_pairs) { a.pairs = nullptr; a.chunk_starts = nullptr; a.part_starts = nullptr; a.work_latent = nullptr; }
     // (the bit map row pitch depends on the batch: a map cleaned for a pitch covers every shorter one, S * words <= before)
     // db_dec = column sums of dL/dx_hat (Matryoshka: of the suffix sums C_0), formed in the grids of the CSC build's first two
     // launches; the AuxK contractions add theirs
@@ -1809,10 +1811,9 @@ int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_
     // (no saev_backward_end: the W_enc gradient stays in the transposed scratch the backward writes; the tail's single Adam
     // launch reads it there through LDS tiles.  The W_enc segment of the gradient buffer is NOT updated by this entry point
     // -- callers that want to look at gradients use the phases)
-    rc = saev_backward_begin(c, stream);
-    if (rc != SAEV_OK) return rc;
     c->fused_step = true;
-    rc = saev_backward_rows(c, 0, c->cfg.d_sae, stream);
+    rc = saev_backward_begin(c, stream);
+    if (rc == SAEV_OK) rc = saev_backward_rows(c, 0, c->cfg.d_sae, stream);
     c->fused_step = false;
     if (rc != SAEV_OK) return rc;
     c->wenc_t_pending = true;

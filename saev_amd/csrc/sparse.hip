@@ -676,7 +676,7 @@ __global__ void csc_place_kernel(CscArgs a) {
             rank += __popc(wd[e] & m);
         }
         const int slot = a.starts[i] + rank;
-        a.pairs[slot] = int2{b, (int)((size_t)b * a.code_stride + j)};
+        if (a.pairs != nullptr) a.pairs[slot] = int2{b, (int)((size_t)b * a.code_stride + j)};  // (read by dw_rows_kernel alone)
         if (a.pv != nullptr) {
             const int fl = (rank == 0 ? DWS_FIRST : 0) | (rank == a.counts[i] - 1 ? DWS_LAST : 0);
             int pblk = 0;  // Matryoshka: the latent's prefix block selects which suffix sum its pairs read

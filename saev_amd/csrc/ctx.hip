@@ -717,7 +717,7 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
                                      c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
         // (defer_margins: the caller's launch_pre_encode forms the margins together with the encoder's per-launch state)
         if (!defer_margins)
-            HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales + 1, pre_flag,
+            HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales, pre_flag,
                                          c->wmax_prev, c->row_margin, s));
         return SAEV_OK;
     }
@@ -902,7 +902,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
         } else {
             const int S_ = c->cfg.d_sae;
             HIPCHK(c, launch_pre_encode(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, f16r_mode ? c->xnorm_c : nullptr, c->cfg.d_model,
-                                        c->wnorm_scratch, (S_ + 255) / 256, f16r_mode ? c->f16r_scales + 1 : nullptr, const_cast<int32_t*>(pre_flag),
+                                        c->wnorm_scratch, (S_ + 255) / 256, f16r_mode ? c->f16r_scales : nullptr, const_cast<int32_t*>(pre_flag),
                                         c->wmax_prev, c->row_margin, c->flags + 1, s));
             timing_begin(c, s);  // the events bracket the encoder kernel alone
             int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);

@@ -107,8 +107,8 @@ hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int
 // encoder_init + (xnorm != NULL: row margins and scale check of launch_row_margins) + the list flags flags1[0..2] =
 // {need_dense = *pre_flag, n_overflow = 0, cand_max = 0} in one launch
 hipError_t launch_pre_encode(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, const float* xnorm, int D,
-                             const float* wg_part, int n_part, const float* w_scale, int32_t* pre_flag, float* wmax_prev,
-                             float* margin, int32_t* flags1, hipStream_t stream);
+                             const float* wg_part, int n_part, const float* scales, int32_t* pre_flag, float* wmax_prev,
+                             float* margin, int32_t* flags1, hipStream_t stream);  // scales: {x scale, W scale} (f16r_scales_kernel)
 hipError_t launch_heur_gate(float* state, const int32_t* pre_flag, int32_t* gate, hipStream_t stream);
 hipError_t launch_heur_update(float* state, const int32_t* bad, const float* cand_mean, int k, const int32_t* gate,
                               hipStream_t stream);
@@ -119,8 +119,8 @@ hipError_t launch_pow2_scale(const float* absmax, float* pair, hipStream_t strea
 hipError_t launch_center_stats(const float* x, const float* mu, int n, int D, float* xnorm, float* wg_absmax,
                                hipStream_t stream, const float* xmax = nullptr);  // ||x_b - mu|| per row (squares taken relative to
                                                                                   // *xmax when given), max |x - mu| per workgroup of 4 rows
-hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
-                              int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream);
+hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* scales,
+                              int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream);  // scales: {x scale, W scale}
 // see overflow_check_kernel (select.hip) for the two-stage use
 hipError_t launch_overflow_check(const int32_t* cand_cnt, int n_rows, int cap, const int32_t* pre_flag,
                                  int32_t* need_dense, int32_t* n_overflow, int32_t* cand_max, hipStream_t stream,

@@ -922,7 +922,7 @@ __device__ __forceinline__ bool f16r_scale_ok(float wmax, float w_scale) {
 // raise the dense-route flag -- the step then runs on the exact fp32 kernel -- and in any case remember the current
 // norm for the next call.
 __global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int n, int D, const float* wg_part, int n_part,
-                                                         const float* w_scale, int32_t* pre_flag, float* wmax_prev,
+                                                         const float* scales, int32_t* pre_flag, float* wmax_prev,
                                                          float* margin) {
     __shared__ float sh[3][4];
     float bm = 0.f, wm = 0.f, dm = 0.f;
@@ -934,12 +934,12 @@ __global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int
     const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
     const float dwmax = fmaxf(fmaxf(sh[2][0], sh[2][1]), fmaxf(sh[2][2], sh[2][3]));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (!f16r_scale_ok(wmax, *w_scale)) *pre_flag = 1;
+        if (!f16r_scale_ok(wmax, scales[1])) *pre_flag = 1;
         *wmax_prev = wmax;
     }
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    margin[r] = f16r_margin(xnorm[2 * r], xnorm[2 * r + 1], wmax, dwmax, bmax, D, w_scale[-1]);  // (f16r_scales: {x scale, W scale, ...})
+    margin[r] = f16r_margin(xnorm[2 * r], xnorm[2 * r + 1], wmax, dwmax, bmax, D, scales[0]);  // (scales = {x scale, W scale} of this step's images: f16r_scales_kernel)
 }
 // Everything the fused encoder launch needs zeroed or derived right before it, in one pass (three launches before):
 //   * the per-launch state of the encoder: candidate counters 0, shared group maxima "-inf";
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void row_margin_kernel(const float* xnorm, int
 //     flags1[1] n_overflow = 0, flags1[2] cand_max = 0 (select_cand_kernel raises them).
 __global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax,
                                                          const float* xnorm, int D, const float* wg_part, int n_part,
-                                                         const float* w_scale, int32_t* pre_flag, float* wmax_prev,
+                                                         const float* scales, int32_t* pre_flag, float* wmax_prev,
                                                          float* margin, int32_t* flags1) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_rows) cand_cnt[i] = 0;
@@ -969,12 +969,12 @@ __global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int 
     const float dwmax = fmaxf(fmaxf(sh[2][0], sh[2][1]), fmaxf(sh[2][2], sh[2][3]));
     if (i == 0) {
         int pre = *pre_flag != 0 ? 1 : 0;
-        if (!f16r_scale_ok(wmax, *w_scale)) { pre = 1; *pre_flag = 1; }
+        if (!f16r_scale_ok(wmax, scales[1])) { pre = 1; *pre_flag = 1; }
         *wmax_prev = wmax;
         flags1[0] = pre; flags1[1] = 0; flags1[2] = 0;
     }
     if (i >= n_rows) return;
-    margin[i] = f16r_margin(xnorm[2 * i], xnorm[2 * i + 1], wmax, dwmax, bmax, D, w_scale[-1]);  // (f16r_scales: {x scale, W scale, ...})
+    margin[i] = f16r_margin(xnorm[2 * i], xnorm[2 * i + 1], wmax, dwmax, bmax, D, scales[0]);  // (scales = {x scale, W scale} of this step's images: f16r_scales_kernel)
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)
@@ -1104,11 +1104,11 @@ hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int
     return hipGetLastError();
 }
 hipError_t launch_pre_encode(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, const float* xnorm, int D,
-                             const float* wg_part, int n_part, const float* w_scale, int32_t* pre_flag, float* wmax_prev,
+                             const float* wg_part, int n_part, const float* scales, int32_t* pre_flag, float* wmax_prev,
                              float* margin, int32_t* flags1, hipStream_t stream) {
     const int n = std::max(1, n_rows > n_gmax ? n_rows : n_gmax);
     hipLaunchKernelGGL(pre_encode_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cand_cnt, n_rows, gmax, n_gmax, xnorm, D,
-                       wg_part, n_part, w_scale, pre_flag, wmax_prev, margin, flags1);
+                       wg_part, n_part, scales, pre_flag, wmax_prev, margin, flags1);
     return hipGetLastError();
 }
 hipError_t launch_heur_gate(float* state, const int32_t* pre_flag, int32_t* gate, hipStream_t stream) {
@@ -1148,9 +1148,9 @@ hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stre
     hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, stream, v, n, out);
     return hipGetLastError();
 }
-hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* w_scale,
+hipError_t launch_row_margins(const float* xnorm, int n, int D, const float* wg_part, int n_part, const float* scales,
                               int32_t* pre_flag, float* wmax_prev, float* margin, hipStream_t stream) {
-    hipLaunchKernelGGL(row_margin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xnorm, n, D, wg_part, n_part, w_scale,
+    hipLaunchKernelGGL(row_margin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xnorm, n, D, wg_part, n_part, scales,
                        pre_flag, wmax_prev, margin);
     return hipGetLastError();
 }

@@ -451,6 +451,9 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     // truncated list and are overwritten there); this check used to be a launch of its own between the encoder and the
     // select.  (The list statistics come from stats_reduce: a per-row atomic here cost 30 us.)
     if (a.ovf != nullptr && (threadIdx.x & 63) == 0 && cnt > a.cand_cap) atomicOr(&a.ovf[0], 1);
+    // (so does a row without a finite margin: an inf / NaN element in the batch -- it poisons the column mean the first pass is
+    // centred on, every approximate value is NaN and no list holds anything; the exact route treats such input as torch does)
+    if (a.ovf != nullptr && a.row_margin != nullptr && (threadIdx.x & 63) == 0 && !(a.row_margin[row] < 3.0e38f)) atomicOr(&a.ovf[0], 1);
     const int n = min(cnt, a.cand_cap);  // wave-uniform
     const float* cv = a.cand_val + (size_t)row * a.cand_stride;
     const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256) void select_refine_kernel(SelectCandArgs a) {
     const int row = blockIdx.x * 4 + w;
     if (row >= a.n_rows) return;
     const int cnt = a.cand_cnt[row];
-    if (a.ovf != nullptr && lane == 0 && cnt > a.cand_cap) atomicOr(&a.ovf[0], 1);
+    if (a.ovf != nullptr && lane == 0 && (cnt > a.cand_cap || !(a.row_margin[row] < 3.0e38f))) atomicOr(&a.ovf[0], 1);
     const int n = min(cnt, a.cand_cap);
     const float* cv = a.cand_val + (size_t)row * a.cand_stride;
     const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
@@ -894,7 +897,10 @@ __device__ __forceinline__ float f16r_margin(float xnorm_row, float xdelta_row, 
     // dominate that row's margin, its list overflow, and the step take the exact dense route: tests/test_gpu_parity.py,
     // tools/experiments/r4_tiny_rows_probe.py)
     const float sub = sqrtf((float)D) * 6.103515625e-05f / x_scale * wmax;
-    return 2.0f * (rnd + acc + sub) + 2.0f * 1.1920929e-07f * bmax;
+    const float m = 2.0f * (rnd + acc + sub) + 2.0f * 1.1920929e-07f * bmax;
+    // (a row with an inf / NaN element has a NaN rounding-error norm: its margin must read as "keep everything" -- the list then
+    // overflows and the exact dense route treats the row as torch does -- not as a NaN that every comparison fails)
+    return m == m ? m : __builtin_inff();
 }
 __device__ __forceinline__ bool f16r_scale_ok(float wmax, float w_scale) {
     const float t = wmax * w_scale;

@@ -463,6 +463,30 @@ def test_f16r_rows_far_smaller_than_their_batch(encoder_mode, tiny):
     assert n_diff <= 6, n_diff
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_f16r_nonfinite_element_sends_the_batch_down_the_exact_route(encoder_mode, bad):
+    """One inf / NaN element poisons the column mean the f16r first pass is centred on, and with it every row's image.  The rows'
+    margins then read "keep everything", the lists overflow, and the step runs on the exact dense route (uncentred fp32): the
+    other rows get the codes the exact encoder gives them, as they do in the reference."""
+    if encoder_mode != "f32":
+        pytest.skip("picks its own encoder modes; run once")
+    d, s, n, k = 128, 2048, 300, 16
+    p = rand_params(d, s, seed=41)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(42))
+    x[7, 5] = bad
+    out = {}
+    for mode in ("f32", "f16r"):
+        eng = make_engine(d, s, k, k_aux=0, max_batch=n, encoder=mode)
+        eng.load_params(p)
+        eng.step_forward(x.cuda(), training=False)
+        idx, val, _ = eng.last_codes(n)
+        out[mode] = (idx.cpu(), val.cpu(), eng.read_stats().dense_route)
+    assert out["f16r"][2] == 1
+    rows = [r for r in range(n) if r != 7]
+    assert torch.equal(out["f32"][0][rows], out["f16r"][0][rows])
+    torch.testing.assert_close(out["f32"][1][rows], out["f16r"][1][rows], rtol=2e-6, atol=2e-6)
+
+
 @pytest.mark.parametrize("scale", [3.0e5, 1.0e-6])
 def test_f16r_handles_any_activation_scale(encoder_mode, scale):
     """fp16 tops out at 65504 and flushes below 6e-8; the f16r images are pre-scaled by a power of two taken from

@@ -17,7 +17,7 @@ saev_amd/libsaev_amd.so: $(OBJS)
 
 # the inline-asm staging of gemm_encode_f16x3.hip owns m0: prove on the assembly that the compiler never relies on it
 check-m0:
-	python3 tools/check_m0.py
+	HIPCC='$(HIPCC)' HIPFLAGS='$(FLAGS)' python3 tools/check_m0.py
 
 clean:
 	rm -rf build saev_amd/libsaev_amd.so

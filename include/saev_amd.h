@@ -92,10 +92,14 @@ int saev_layout(const saev_cfg* cfg, saev_layout_t* out);
 #define SAEV_ENCODER_F32 0
 #define SAEV_ENCODER_F16X3 1
 #define SAEV_ENCODER_BF16 2
-/*   F16R  : one v_mfma_f32_32x32x16_f16 per product on fp16-rounded operands as a FIRST PASS, run on activations
- *           centred on the batch mean (the bias absorbs mean * W_enc), whose error is bounded per row
- *           (|error| <= 1.05 * (2^-10 + d_model * 2^-22) * ||x_row - mean|| * max ||W_enc column|| + 2^-23 max |bias|);
- *           candidates are kept down to the running bound minus twice that, and the select stage recomputes every
+/*   F16R  : one v_mfma_f32_16x16x32_f16 per product on fp16-rounded operands as a FIRST PASS, run on activations
+ *           centred on the batch mean (the bias absorbs mean * W_enc) and pre-scaled by device-side powers of two.  Its
+ *           error is bounded per row b from the rounding errors the images ACTUALLY carry (their norms are measured by
+ *           the passes that write the images), by Cauchy-Schwarz:
+ *             E_b = 1.02 (||dx_b|| wmax + ||x_b - mean|| dwmax + ||dx_b|| dwmax)
+ *                   + (1.05 d_model 2^-22 + 2^-17) ||x_b - mean|| wmax + sqrt(d_model) 2^-14 wmax / scale_x + 2^-23 max |bias|,
+ *           wmax / dwmax = the largest column norm of W_enc / of its rounding error (select.hip: f16r_margin).
+ *           Candidates are kept down to the running bound minus 2 E_b, and the select stage recomputes every
  *           survivor exactly in fp32 (dot product of the uncentred row with the fp32 encoder column + b_enc) before the
  *           final cut.  Codes and values are those of exact fp32 arithmetic; a dense h (saev_encode_dense, overflow
  *           route) always comes from the exact fp32 kernel.  Default of the Python host. */
@@ -232,7 +236,7 @@ int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_r
  * forward (modeling.py:75-103).  Training mode only.  The reference reads n_dead back on every step
  * (`.item()`, modeling.py:92).  Here the update kernel leaves a record in pinned host memory each step; the
  * call looks at the record of four steps earlier, which bounds the current count from above, and while that
- * bound is <= min(16, k_aux) -- zero dead latents included -- it enqueues kernels that take the count from
+ * bound is <= min(40, k_aux) (saev_debug_cfg.aux_small_max) -- zero dead latents included -- it enqueues kernels that take the count from
  * the device: no read-back, no stream synchronisation.  Only when the bound is larger (or no valid record
  * exists yet: the first four steps after creation / saev_bind_tracker / saev_tracker_touched) does it read
  * n_dead back and size the dense AuxK algebra on the host.  saev_last_aux_route tells which happened:

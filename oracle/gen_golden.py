@@ -25,7 +25,6 @@ Fixture index:
   G13 matryoshka       objective fwd/bwd with 4 fixed prefixes (with and without dead latents)
   G9c train_c          the train_b run with grad_clip = 0.02: the clip coefficient is < 1 on every step
   G15 sample_prefixes  the reference's Matryoshka prefix draws under fixed seeds
-  G16 batch_entropy    the reference's loader-coverage metrics of the log block on seeded index batches
   G14 inference        the reference's framework/inference.worker_fn over a small protocol-2.1 cache (with and
                        without labels.bin / ignore_labels): CSR token_acts, mean_values, sparsity, distributions,
                        metrics.json; plus Metadata.hash and IndexMap known answers for the same cache
@@ -296,7 +295,7 @@ def g9_train(ref, tag, d, s, k, bsz, n_rows, n_train, thr, k_aux, lr, n_warm, gr
 
     sd.ShuffledDataLoader = fake_loader
     # the monitor/entropy helpers are loader-observability, not part of the path: stub to {}
-    # (both are put back after the run: g16_batch_entropy needs the real calc_batch_entropy of the same module)
+    # (both are put back after the run)
     orig_monitor, orig_entropy = T.DataloaderMonitor, T.statistics.calc_batch_entropy
     T.DataloaderMonitor = lambda dl: type("M", (), {"compute": lambda self, now=None: {}})()
     T.statistics.calc_batch_entropy = lambda *a, **kw: {}
@@ -366,24 +365,6 @@ def g15_sample_prefixes(ref):
     torch.manual_seed(7)
     out["s7_alt_1000_8"] = torch.stack([ref.objectives.sample_prefixes(1000, 8, pareto_power=1.5) for _ in range(3)])
     npz("g15_sample_prefixes", cases=np.array(cases), seeds=np.array([0, 1, 42, 1234]), **out)
-
-
-def g16_batch_entropy(ref):
-    """The reference's loader-coverage metrics (utils/statistics.py:57-122) on seeded index batches."""
-    import importlib
-
-    st = importlib.import_module("saev.utils.statistics")
-    g = torch.Generator().manual_seed(160)
-    out = {}
-    for tag, (n_ex, n_tok, b) in {"a": (1000, 256, 4096), "b": (37, 16, 64), "c": (5, 1, 200)}.items():
-        e = torch.randint(0, n_ex, (b,), generator=g, dtype=torch.int32)
-        t = torch.randint(0, n_tok, (b,), generator=g, dtype=torch.int32)
-        m = st.calc_batch_entropy(e, t, n_ex, n_tok)
-        out[f"{tag}_example_idx"], out[f"{tag}_token_idx"] = e, t
-        out[f"{tag}_support"] = np.array([n_ex, n_tok])
-        out[f"{tag}_keys"] = np.array(sorted(m))
-        out[f"{tag}_vals"] = np.array([m[k] for k in sorted(m)], dtype=np.float64)
-    npz("g16_batch_entropy", **out)
 
 
 def g10_make_saes(ref):
@@ -523,7 +504,6 @@ def main():
         g9_train(ref, "c", d=128, s=1024, k=16, bsz=256, n_rows=2048, n_train=6144, thr=512, k_aux=32, lr=2e-3, n_warm=4,
                  grad_clip=0.02)
         g15_sample_prefixes(ref)
-        g16_batch_entropy(ref)
         return
     g1_g2_g3(ref)
     g4_auxk(ref)
@@ -535,7 +515,6 @@ def main():
              grad_clip=0.02)
     g10_make_saes(ref)
     g15_sample_prefixes(ref)
-    g16_batch_entropy(ref)
     g11_schedule(ref)
     g12_checkpoint(ref)
     g13_matryoshka(ref)

@@ -94,6 +94,11 @@ struct saev_ctx {
     int dws_rows = 0;            // > 0: the copies describe the training forward in flight (that many rows)
     bool dws_pairs = false;      // the CSC build of this backward left pv / plat
     float *gS = nullptr, *xS = nullptr, *dvp = nullptr;
+    // A gathered backward (saev_backward_override) of a context that LENDS its x-derived buffers (saev_share_x) must not write
+    // the rows of all ranks over xS: its followers' forwards run after this backward and read xS as their own batch.  Such a
+    // context gets a second slice-major buffer for the gathered rows, allocated at the first backward that needs it.
+    float* xS_ov = nullptr;
+    float* xS_bwd = nullptr;  // the slice-major x the backward in flight reads when it runs over gathered rows (xS or xS_ov)
     // dval[b][j] = <g_b, W_dec[idx[b][j]]> left by the decode itself (decode_q_kernel; kernels.h: DecodeArgs::dval_out): pass A of
     // the slices then forms dW_dec only.  dval_fwd: the forward in flight has left it (same condition as dws_rows, plus the shape)
     float* dval_rows = nullptr;
@@ -410,9 +415,9 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (c->xs) hipMemset(c->xs, 0, (size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
     if (c->zero_bias) hipMemset(c->zero_bias, 0, std::max(S, D) * sizeof(float));
     if (KA > 0) {
-        // Every AuxK buffer is sized here, once, for the largest dead set the context accepts: no allocation ever happens
-        // inside a step.  Default min(d_sae, max(4096, 8 k_aux)) dead latents (2.3 GB at configs[1]; d_sae would be 11.5 GB
-        // there and 37 GB at configs[3]); a step that meets more fails loudly and names the field to raise.
+        // Every AuxK buffer is sized here for the dead set a healthy run meets: no allocation happens inside such a run's
+        // steps.  Default min(d_sae, max(4096, 8 k_aux)) dead latents (2.3 GB at configs[1]; d_sae would be 11.5 GB
+        // there and 37 GB at configs[3]); a step that meets more grows them (saev_step_dead, reported on stderr).
         const int s4 = (int)((S + 3) / 4 * 4);
         const int want = cfg->aux_dead_cap > 0 ? cfg->aux_dead_cap : std::max(4096, 8 * (int)KA);
         const int cap = std::min((want + 3) / 4 * 4, s4);
@@ -1444,6 +1449,8 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
                      std::to_string(cap) + " (out of device memory)";
             return rcg;
         }
+        std::fprintf(stderr, "[saev_amd] AuxK: %d dead latents exceeded the dead-set buffers; grown to %d inside the step "
+                             "(device-synchronising; saev_cfg.aux_dead_cap sizes them up front)\n", c->n_dead_host, cap);
     }
     if (c->n_dead_host <= small_max && c->cfg.d_model <= 2048) {
         c->aux_route = AUX_SMALL_HOST;
@@ -1474,7 +1481,15 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
     const bool ov_slices = ov && c->dws_ok && c->P_last == 1 && n <= c->back_rows;
     c->dws_pairs = ov ? ov_slices : c->dws_rows == n;
     if (ov_slices) {
-        HIPCHK(c, launch_slice_major_copy(c->ov_g, c->ov_x, n, D, c->gS, c->xS, s));
+        c->xS_bwd = c->xS;
+        if (!c->followers.empty()) {
+            if (c->xS_ov == nullptr) {  // (once per context: a device-wide allocation outside any steady-state step)
+                int rca = alloc(c, &c->xS_ov, (size_t)c->back_rows * D);
+                if (rca != SAEV_OK) return rca;
+            }
+            c->xS_bwd = c->xS_ov;
+        }
+        HIPCHK(c, launch_slice_major_copy(c->ov_g, c->ov_x, n, D, c->gS, c->xS_bwd, s));
         c->dws_rows = 0;  // (the copies no longer describe the forward's own rows)
     }
     if (c->dws_pairs) {
@@ -1542,7 +1557,8 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         // all latents of this context's own batch (in one pass or as the decoder / encoder halves of a two-pass backward): column slices out of the XCD L2s (kernels.h: DwSlicesArgs)
         DwSlicesArgs w{};
         w.starts = c->starts; w.pv = c->pv; w.pv2 = c->pv2; w.plat = c->plat; w.gS = c->P_last > 1 ? c->GS : c->gS; w.W_dec = a.W_dec; w.P = c->P_last;
-        w.xS = (!ov && c->fwd_step) ? c->xS_c : c->xS;  // (the forward's own slice-major x: split_f16r's -- possibly the leader's -- or the decode's)
+        // (the forward's own slice-major x: split_f16r's -- possibly the leader's -- or the decode's; gathered rows: the copy saev_backward_begin made)
+        w.xS = ov ? c->xS_bwd : (c->fwd_step ? c->xS_c : c->xS);
         w.n_rows = n; w.D = D; w.S = S; w.pair_cap = (int)((long)c->back_rows * K);
         w.dvp = c->dvp; w.dW_dec = a.dW_dec; w.dW_encT = a.dW_encT; w.db_enc = a.db_enc;
         const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;

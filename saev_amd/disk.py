@@ -37,13 +37,10 @@ class Run:
     def __init__(self, run_dir: pathlib.Path):
         self.run_dir = pathlib.Path(run_dir)
         if len(self.run_dir.parts) < 3 or self.run_dir.parts[-3:-1] != ("saev", "runs"):
-            raise ValueError("Run directory is invalid.")
-        if not self.run_dir.exists():
-            raise FileNotFoundError(f"Run directory does not exist: {self.run_dir}. Use Run.new() to create a new run.")
-        for sub in self.SUBDIRS:
-            if not (self.run_dir / sub).exists():
-                raise FileNotFoundError(
-                    f"{sub.capitalize()} directory does not exist: {self.run_dir / sub}. Use Run.new() to create a new run.")
+            raise ValueError(f"'{self.run_dir}' is not of the form <...>/saev/runs/<run id>")
+        missing = [p for p in (self.run_dir, *(self.run_dir / sub for sub in self.SUBDIRS)) if not p.exists()]
+        if missing:
+            raise FileNotFoundError(f"not a complete run on disk, missing: {', '.join(map(str, missing))} (Run.new(...) lays one out)")
 
     @classmethod
     def new(cls, run_id: str, *, train_shards_dir: pathlib.Path, val_shards_dir: pathlib.Path,

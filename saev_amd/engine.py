@@ -32,8 +32,9 @@ class EngineConfig:
     normalize_w_dec: bool = True
     remove_parallel_grads: bool = True
     max_batch: int = 16384
-    aux_dead_cap: int = 0      # largest dead set the dense AuxK buffers are sized for at creation; 0 = min(d_sae, max(4096,
-                               # 8 k_aux)); a step that meets more dead latents raises and names this field
+    aux_dead_cap: int = 0      # dead set the dense AuxK buffers are sized for at creation; 0 = min(d_sae, max(4096, 8 k_aux)).
+                               # A step that meets more dead latents GROWS them (a device-synchronising free + allocate inside
+                               # that step, reported on stderr; it fails only if the larger buffers do not fit the device)
     shard_world: int = 1       # > 1: flat buffers padded so that this many data-parallel ranks can each own 1/N of the tail
     max_backward_rows: int = 0  # 0 = max_batch; the GLOBAL batch for the sparse-state exchange (gathered backward over every
                                 # rank's rows): sizes the backward's scratch only, the forward's buffers stay at max_batch

@@ -138,30 +138,59 @@ class CollectiveWatchdog:
                 os._exit(13)
 
 
-def _selfcheck_steps(stepper_kw: dict, dist, world: int, rank: int, device, shard_world: int, global_rows: bool):
-    """Four steps of a 64 x 512 SAE (AuxK active from the third) through DataParallelStepper(**stepper_kw); returns the
-    parameters.  Every rank draws its own rows; ``global_rows``: the engine holds the global batch (sparse exchange)."""
-    from ..engine import EngineConfig, SaeEngine
+class _SelfCheck:
+    """The start-up self-check of choose_exchange in two phases, so that the ranks can agree between them: ``__init__`` only
+    allocates (engines of a 64 x 512 SAE pair that shares its batches, as train() links every SAE after the first to the
+    first; AuxK active from the third step) -- the one place a single rank can fail on its own (out of memory, a HIP error)
+    -- and ``run`` steps them through DataParallelStepper(**stepper_kw), which is where the collectives are."""
 
-    n = 128
-    e = SaeEngine(EngineConfig(d_model=64, d_sae=512, top_k=8, k_aux=16, dead_threshold_tokens=256, max_batch=n,
-                               max_backward_rows=n * world if global_rows else 0, shard_world=shard_world), device)
-    try:
-        gg = torch.Generator(device=device).manual_seed(3)
-        W0 = torch.randn(512, 64, device=device, generator=gg)
-        W0 /= W0.norm(dim=1, keepdim=True)
-        e.view("W_dec").copy_(W0)
-        e.view("W_enc").copy_(W0.t())
-        st = DataParallelStepper(e, dist, world, force=True, rank=rank, **stepper_kw)
-        gx = torch.Generator(device=device).manual_seed(100 + rank)
-        for i in range(4):
-            st.train_step(torch.randn(n, 64, device=device, generator=gx), 1e-3 * i, 0.05)
-        st.sync_params()
-        torch.cuda.synchronize(device)
-        st.close()
-        return {k: v.clone() for k, v in e.param_views().items()}
-    finally:
-        e.close()
+    N_ROWS = 128
+
+    def __init__(self, stepper_kw: dict, dist, world: int, rank: int, device, shard_world: int, global_rows: bool, n_saes: int = 2):
+        from ..engine import EngineConfig, SaeEngine
+
+        self.kw, self.dist, self.world, self.rank, self.device = stepper_kw, dist, world, rank, device
+        self.engines = []
+        try:
+            n = self.N_ROWS
+            gg = torch.Generator(device=device).manual_seed(3)
+            W0 = torch.randn(512, 64, device=device, generator=gg)
+            W0 /= W0.norm(dim=1, keepdim=True)
+            for j in range(n_saes):
+                e = SaeEngine(EngineConfig(d_model=64, d_sae=512, top_k=8, k_aux=16, dead_threshold_tokens=256, max_batch=n,
+                                           max_backward_rows=n * world if global_rows else 0, shard_world=shard_world), device)
+                self.engines.append(e)
+                Wj = W0.roll(5 * j, dims=0)
+                e.view("W_dec").copy_(Wj)
+                e.view("W_enc").copy_(Wj.t())
+                if j > 0:
+                    e.share_x(self.engines[0])
+        except Exception:
+            self.close()
+            raise
+
+    def run(self) -> dict:
+        """Four steps; returns the parameters of every SAE.  Every rank draws its own rows.  Errors propagate: a rank that
+        fails in here fails inside a sequence of collectives, and the only safe outcome is the process group's abort."""
+        steppers = [DataParallelStepper(e, self.dist, self.world, force=True, rank=self.rank, **self.kw) for e in self.engines]
+        try:
+            gx = torch.Generator(device=self.device).manual_seed(100 + self.rank)
+            for i in range(4):
+                x = torch.randn(self.N_ROWS, 64, device=self.device, generator=gx)
+                for st in steppers:
+                    st.train_step(x, 1e-3 * i, 0.05)
+            for st in steppers:
+                st.sync_params()
+            torch.cuda.synchronize(self.device)
+            return {f"{j}.{k}": v.clone() for j, e in enumerate(self.engines) for k, v in e.param_views().items()}
+        finally:
+            for st in steppers:
+                st.close()
+
+    def close(self) -> None:
+        for e in self.engines:
+            e.close()
+        self.engines = []
 
 
 def choose_exchange(dist, world: int, rank: int, device, local_batch: int, *, tail: str = "auto", exchange: str = "auto",
@@ -169,11 +198,17 @@ def choose_exchange(dist, world: int, rank: int, device, local_batch: int, *, ta
     """Resolve ("auto" | explicit) tail / exchange settings into what a run uses, identically on every rank.
 
       exchange  "auto": the sparse step state when a rank holds at most ``sparse_max_rows`` rows (strong scaling: the
-                268 MB gradient exchange would outlast the rank's compute), else the gradient ("dense");
+                268 MB gradient exchange would outlast the rank's compute), else the gradient ("dense"); with the tail pinned
+                to "sharded" it resolves to "dense" (the sparse exchange moves no gradient, there is nothing to shard);
       tail      "auto" (dense exchange only): "sharded" -- reduce-scatter, 1/world of the tail, all-gather -- when a
-                start-up self-check on a small SAE reproduces the all-reduce path's parameters on every rank and leaves all
-                ranks with identical parameters; "replicated" if anything differs or raises.  An automatically chosen sparse
+                start-up self-check on a small pair of SAEs reproduces the all-reduce path's parameters on every rank and
+                leaves all ranks with identical parameters; "replicated" if anything differs.  An automatically chosen sparse
                 exchange gets the same check against the all-reduce path.  Explicit settings are honoured unchecked.
+
+    The self-check is a fixed protocol every rank walks in step: (1) allocate -- errors caught locally, then one MIN
+    all-reduce of a status flag; (2) step the all-reduce path and the candidate -- errors in here are not caught: a rank that
+    fails between two collectives cannot be waited for, the process group's timeout / abort handling ends the job; (3) compare
+    -- again a local verdict and one MIN all-reduce.  No rank ever enters a collective its peers may skip.
     Returns (tail, exchange, report); the report says what was checked and why a fallback was taken."""
     report: dict = {"requested": {"tail": tail, "exchange": exchange}}
     if dist is None:
@@ -185,7 +220,7 @@ def choose_exchange(dist, world: int, rank: int, device, local_batch: int, *, ta
     if exchange == "sparse":  # pinned by the caller: honoured as it is
         return "replicated", "sparse", report
     if exchange == "auto":
-        exchange = "sparse" if local_batch <= sparse_max_rows else "dense"
+        exchange = "sparse" if (local_batch <= sparse_max_rows and tail != "sharded") else "dense"
     if exchange == "dense" and tail != "auto":
         return tail, exchange, report
 
@@ -195,26 +230,37 @@ def choose_exchange(dist, world: int, rank: int, device, local_batch: int, *, ta
         return bool(flag.item())
 
     candidate = {"tail": "sharded"} if exchange == "dense" else {"tail": "replicated", "exchange": "sparse"}
+    checks, why = [], None
+    try:  # phase 1: allocation only, no collective inside
+        checks.append(_SelfCheck({"tail": "replicated", "exchange": "dense"}, dist, world, rank, device, 1, False))
+        checks.append(_SelfCheck(dict({"exchange": "dense"}, **candidate), dist, world, rank, device,
+                                 world if candidate["tail"] == "sharded" else 1, exchange == "sparse"))
+        built = True
+    except Exception as exc:
+        built, why = False, f"allocation failed on rank {rank}: {type(exc).__name__}: {exc}"
+        print(f"[saev_amd.ddp] self-check of {candidate}: {why}", file=sys.stderr, flush=True)
     try:
-        ref = _selfcheck_steps({"tail": "replicated", "exchange": "dense"}, dist, world, rank, device, 1, False)
-        got = _selfcheck_steps(dict({"exchange": "dense"}, **candidate), dist, world, rank, device,
-                               world if candidate["tail"] == "sharded" else 1, exchange == "sparse")
-        # Against the all-reduce path a tolerance, not equality: the routes add in different orders, and Adam's m / sqrt(v)
-        # turns a noise-level gradient of either sign into a step of size lr -- so: nearly all elements within 1e-4
-        # relative, none further apart than a few learning rates
-        def close(a, b):
-            d = (a - b).abs()
-            return bool(((d > 1e-6 + 1e-4 * b.abs()).float().mean() < 1e-3) and d.max() < 0.02)
+        if not agree(built):
+            report["self_check"] = {"candidate": candidate, "passed": False, "why_not": why or "allocation failed on another rank"}
+            return "replicated", "dense", report
+        ref, got = checks[0].run(), checks[1].run()  # phase 2: every rank runs the same collectives or the job aborts
+    finally:
+        for ch in checks:
+            ch.close()
 
-        ok = all(close(got[k], ref[k]) for k in ref)
-        flat = torch.cat([v.reshape(-1) for v in got.values()]).clone()
-        mine = flat.clone()
-        dist.broadcast(flat, src=0)
-        ok = ok and torch.equal(flat, mine)  # every rank must hold rank 0's parameters, bit for bit
-        why = None if ok else "parameters differ from the all-reduce path or between ranks"
-    except Exception as exc:  # any failure of the candidate path means: use the plain one
-        ok, why = False, f"{type(exc).__name__}: {exc}"
-        print(f"[saev_amd.ddp] self-check of {candidate} failed on rank {rank}: {why}", file=sys.stderr, flush=True)
+    # phase 3.  Against the all-reduce path a tolerance, not equality: the routes add in different orders, and Adam's
+    # m / sqrt(v) turns a noise-level gradient of either sign into a step of size lr -- so: nearly all elements within 1e-4
+    # relative, none further apart than a few learning rates
+    def close(a, b):
+        d = (a - b).abs()
+        return bool(((d > 1e-6 + 1e-4 * b.abs()).float().mean() < 1e-3) and d.max() < 0.02)
+
+    ok = all(close(got[k], ref[k]) for k in ref)
+    flat = torch.cat([v.reshape(-1) for v in got.values()]).clone()
+    mine = flat.clone()
+    dist.broadcast(flat, src=0)
+    ok = ok and torch.equal(flat, mine)  # every rank must hold rank 0's parameters, bit for bit
+    why = None if ok else "parameters differ from the all-reduce path or between ranks"
     ok = agree(ok)
     report["self_check"] = {"candidate": candidate, "passed": ok, "why_not": why}
     if ok:

@@ -111,57 +111,65 @@ def _dist():
 # ------------------------------------------------------------------------------------------------
 
 
+def _datapoint_rows(dl, d_sae: int) -> tuple[Tensor, int]:
+    """The activation rows a datapoint initialisation is built from: whole batches off the loader until max(d_sae, 65 536)
+    rows -- or all the loader has, if that is fewer -- are in hand (train.py:141-157)."""
+    have = getattr(dl, "n_samples", None)
+    if have is not None and have < d_sae:
+        raise ValueError(f"datapoint initialisation of {d_sae} latents needs at least as many activation rows; the loader holds {have}")
+    want = max(d_sae, 65_536) if have is None else min(max(d_sae, 65_536), have)
+    chunks, n = [], 0
+    for batch in dl:
+        chunks.append(batch["act"])
+        n += len(batch["act"])
+        if n >= want:
+            break
+    if n < want:
+        raise RuntimeError(f"the loader ran dry after {n} of the {want} rows the datapoint initialisation asked for")
+    return torch.cat(chunks, dim=0), want
+
+
 def make_saes(
     cfgs: list[tuple[nn.SparseAutoencoderConfig, nn.ObjectiveConfig]], dl, device: torch.device | str = "cuda"
 ) -> tuple[torch.nn.ModuleList, torch.nn.ModuleList, list[dict[str, object]]]:
-    """Build SAEs + objectives; optional datapoint initialisation (train.py:108-189): rows of
-    (mean-centred, shuffled) activations blended with a Kaiming matrix become encoder columns, the
-    decoder is their transpose, decoder rows are unit-normalised and the encoder is re-synced to the
-    normalised decoder."""
-    saes, objs, param_groups = [], [], []
-    for sae_cfg, obj_cfg in cfgs:
-        sae = nn.SparseAutoencoder(sae_cfg)
-        saes.append(sae)
-        param_groups.append({"params": sae.parameters(), "lr": 0.0})
-        objs.append(nn.get_objective(obj_cfg))
-    if all(s.cfg.reinit_blend == 0 for s in saes):
-        logger.info("No datapoint initialization necessary; skipping.")
-        return torch.nn.ModuleList(saes), torch.nn.ModuleList(objs), param_groups
-    assert saes, "Need at least one SAE to initialize."
+    """SAEs, their objectives and Adam's parameter groups (lr 0.0: the first step only warms the moments up), with the
+    reference's optional datapoint initialisation (train.py:108-189): encoder columns are a blend
+    ``reinit_blend * (shuffled, mean-centred activation rows) + (1 - reinit_blend) * Kaiming``, the decoder is their
+    transpose with unit rows, and the encoder is set to the transpose of that normalised decoder.
+
+    The random draws come from torch's global CPU generator in the reference's order -- one permutation of the sampled rows,
+    one Kaiming matrix shared by all SAEs, one row permutation per SAE -- so seed + batches determine the initial weights
+    exactly as they do there (fixture G10); the arithmetic runs on whatever device the activations live on."""
+    saes = [nn.SparseAutoencoder(sae_cfg) for sae_cfg, _ in cfgs]
+    objs = [nn.get_objective(obj_cfg) for _, obj_cfg in cfgs]
+    param_groups = [{"params": sae.parameters(), "lr": 0.0} for sae in saes]
+    modules = torch.nn.ModuleList(saes), torch.nn.ModuleList(objs), param_groups
+    blends = [sae.cfg.reinit_blend for sae in saes]
+    for p in blends:
+        if not 0.0 <= p <= 1.0:
+            raise ValueError(f"reinit_blend = {p} is outside [0, 1]")
+    if not any(blends):
+        logger.info("every reinit_blend is 0: parameters keep their Kaiming / zero initialisation")
+        return modules
     d_sae = saes[0].cfg.d_sae
-    assert all(s.cfg.d_sae == d_sae for s in saes), "All SAEs must have same .d_sae"
-    if hasattr(dl, "n_samples"):
-        assert dl.n_samples >= d_sae, f"Need {d_sae} samples for datapoint init; dataloader has {dl.n_samples}."
-    n_samples = min(max(d_sae, 65_536), dl.n_samples)
+    if any(sae.cfg.d_sae != d_sae for sae in saes):
+        raise ValueError("datapoint initialisation shares one sample of rows: every SAE of the group needs the same d_sae")
     with torch.no_grad():
-        got, n_seen = [], 0
-        for batch in dl:
-            got.append(batch["act"])
-            n_seen += len(batch["act"])
-            if n_seen >= n_samples:
-                break
-        assert n_seen >= n_samples, f"Datapoint init requested {n_samples} samples but saw {n_seen}."
-        # Random draws come from torch's global CPU generator in the reference's call order (one permutation of the
-        # samples, one Kaiming matrix, one permutation per SAE), so the same seed and the same batches give the same
-        # initial weights as the reference (fixture G10); the arithmetic runs wherever the activations live.
-        acts = torch.cat(got, dim=0)
-        acts = acts[torch.randperm(n_samples).to(acts.device)]
+        acts, n_rows = _datapoint_rows(dl, d_sae)
+        acts = acts[torch.randperm(n_rows).to(acts.device)]
         centred = acts[:d_sae] - acts.mean(dim=0, keepdim=True)
         kaiming = torch.nn.init.kaiming_uniform_(torch.empty(centred.shape, dtype=centred.dtype)).to(acts.device)
-        for sae in saes:
-            p = sae.cfg.reinit_blend
-            assert 0.0 <= p <= 1.0, f"reinit_blend must be in [0, 1], got {p}."
+        for sae, p in zip(saes, blends):
             order = torch.randperm(d_sae).to(acts.device)
-            rows = (p * centred[order] + (1 - p) * kaiming[order]).to("cpu")
-            assert rows.shape == (sae.cfg.d_sae, sae.cfg.d_model), f"enc_rows has shape {tuple(rows.shape)}"
-            sae.W_enc.data.copy_(rows.T)
+            enc_cols = (p * centred[order] + (1 - p) * kaiming[order]).to("cpu")  # (d_sae, d_model): column s of W_enc
+            sae.W_enc.data.copy_(enc_cols.T)
             if sae.cfg.reinit_enc_dec_tranpose:
                 sae.W_dec.data.copy_(sae.W_enc.data.T)
             if sae.cfg.normalize_w_dec:
                 sae.W_dec.data /= torch.norm(sae.W_dec.data, dim=1, keepdim=True)
             sae.W_enc.data.copy_(sae.W_dec.data.T)
-    logger.info("Initialized %d SAEs with avg(p)=%.2f", len(saes), sum(s.cfg.reinit_blend for s in saes) / len(saes))
-    return torch.nn.ModuleList(saes), torch.nn.ModuleList(objs), param_groups
+    logger.info("datapoint initialisation done for %d SAE(s); mean blend %.2f", len(saes), sum(blends) / len(saes))
+    return modules
 
 
 # ------------------------------------------------------------------------------------------------
@@ -247,9 +255,6 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
                 pre = {}
                 st.train_step(x, lrs[i], c.grad_clip, pre_tail=lambda sae=sae, pre=pre, c=c: pre.update(_decoder_metrics(sae, c)))
                 m = _log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c, pre, dataloader, dist, world)
-                if "example_idx" in batch and getattr(dataloader, "metadata", None) is not None:
-                    md = dataloader.metadata
-                    m.update(batch_entropy(batch["example_idx"], batch["token_idx"], md.n_examples, md.content_tokens_per_example))
                 metrics.append(m)
             else:
                 st.train_step(x, lrs[i], c.grad_clip)
@@ -263,24 +268,6 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
         st.sync_params()  # (sharded tail: the last step's parameter gathers run on a side stream)
     logger.info("trained %d steps in %.1fs", global_step, time.time() - t_start)
     return saes, objs, run, global_step
-
-
-@torch.no_grad()
-def batch_entropy(example_idx: Tensor, token_idx: Tensor, n_examples: int, content_tokens_per_example: int) -> dict[str, float]:
-    """How well a batch covers the examples and the token positions (reference utils/statistics.py:57-122, logged next to
-    the loader metrics at train.py:371-377): entropy of the empirical distribution of the indices in natural-log units,
-    the same divided by log(support), and the share of the support that occurs at all."""
-    out = {}
-    for name, idx, support in (("loader/example", example_idx, n_examples), ("loader/token", token_idx, content_tokens_per_example)):
-        if support <= 0:
-            raise ValueError(f"{name}: support must be positive.")
-        counts = torch.unique(idx.to(torch.int64), return_counts=True)[1].to(torch.float64)
-        probs = counts / counts.sum()
-        ent = -(probs * probs.log()).sum().item()
-        out[f"{name}_entropy"] = ent
-        out[f"{name}_entropy_normalized"] = 0.0 if support <= 1 else ent / math.log(support)
-        out[f"{name}_coverage"] = counts.numel() / support
-    return out
 
 
 @torch.no_grad()

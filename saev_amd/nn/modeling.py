@@ -340,37 +340,17 @@ def _ser(value: tp.Any) -> tp.Any:
     return value
 
 
-def _deser(value: tp.Any, *, field: str = "", legacy: bool = False) -> tp.Any:
-    if isinstance(value, dict):
-        if "cls" in value and "params" in value:
-            cls = _CONFIG_CLASSES.get(value["cls"])
-            assert cls is not None, f"Unknown activation class '{value['cls']}' in payload."
-            kwargs = {}
-            for raw, v in value["params"].items():
-                key = "key" if raw == "kind" else raw
-                assert key not in kwargs, f"Duplicate key '{key}' after legacy normalization."
-                kwargs[key] = _deser(v, field=key, legacy=legacy)
-            return cls(**kwargs)
-        if legacy and field == "sparsity":
-            if not value:
-                return NoSparsity()
-            if set(value) <= {"coeff"}:
-                return L1Sparsity(**value)
-        return {k: _deser(v, field=field, legacy=legacy) for k, v in value.items()}
+def _deser(value: tp.Any) -> tp.Any:
+    """Inverse of ``_ser``: ``{"cls", "params"}`` nodes become instances of the named config class."""
     if isinstance(value, list):
-        return [_deser(v, field=field, legacy=legacy) for v in value]
-    return value
-
-
-def _cfg_kwargs(d: dict) -> dict:
-    d = dict(d)
-    d.pop("n_reinit_samples", None)
-    d.pop("seed", None)
-    if "exp_factor" in d and "d_sae" not in d:
-        if d.get("d_model") is None:
-            raise ValueError("legacy checkpoint gives exp_factor but no d_model: d_sae cannot be derived")
-        d["d_sae"] = d["d_model"] * d.pop("exp_factor")
-    return d
+        return [_deser(v) for v in value]
+    if not isinstance(value, dict):
+        return value
+    if set(value) == {"cls", "params"}:
+        if value["cls"] not in _CONFIG_CLASSES:
+            raise ValueError(f"checkpoint names a config class this package does not have: {value['cls']!r}")
+        return _CONFIG_CLASSES[value["cls"]](**{k: _deser(v) for k, v in value["params"].items()})
+    return {k: _deser(v) for k, v in value.items()}
 
 
 def _git_commit() -> str:
@@ -399,32 +379,18 @@ def dump(fpath: pathlib.Path | str, sae: SparseAutoencoder):
 
 
 def load(fpath: pathlib.Path | str, *, device="cpu") -> SparseAutoencoder:
-    """Read a checkpoint written by this package or by the reference (schemas 1-5 and pre-schema)."""
+    """Read an ``sae.pt`` of the current on-disk format -- schema 5, what ``dump`` here and the reference's ``nn.dump``
+    (modeling.py:548-574) write.  Older schemas belong to checkpoints that predate the TopK / AuxK config tree this package
+    trains; they are refused by number rather than guessed at (convert them with the reference's loader)."""
     with open(fpath, "rb") as fd:
-        header = json.loads(fd.readline())
-        buffer = io.BytesIO(fd.read())
-    if "schema" not in header:
-        for stale in ("sparsity_coeff", "ghost_grads", "l1_coeff", "use_ghost_grads", "seed"):
-            header.pop(stale, None)
-        header["d_model"] = header.pop("d_vit")
-        cfg = SparseAutoencoderConfig(**_cfg_kwargs(header), activation=Relu())
-    elif header["schema"] == 1:
-        cls_name = header.get("cls", "SparseAutoencoderConfig")
-        cfg_dict = dict(header["cfg"])
-        if cls_name in ("Relu", "TopK", "BatchTopK"):
-            act_cls = _CONFIG_CLASSES[cls_name]
-            act = act_cls(top_k=cfg_dict.pop("top_k", 32)) if cls_name != "Relu" else act_cls()
-            cfg = SparseAutoencoderConfig(**_cfg_kwargs(cfg_dict), activation=act)
-        else:
-            if "activation" in cfg_dict:
-                cfg_dict["activation"] = _deser(cfg_dict["activation"], legacy=True)
-            cfg = SparseAutoencoderConfig(**_cfg_kwargs(cfg_dict))
-    elif header["schema"] in (2, 3, 4, 5):
-        cfg_dict = dict(header["cfg"])
-        cfg_dict["activation"] = _deser(cfg_dict["activation"], legacy=header["schema"] != 5)
-        cfg = SparseAutoencoderConfig(**_cfg_kwargs(cfg_dict))
-    else:
-        raise ValueError(f"checkpoint schema {header['schema']} is not one this loader knows (1-5)")
-    model = SparseAutoencoder(cfg)
-    model.load_state_dict(torch.load(buffer, weights_only=True, map_location="cpu"))
+        first_line = fd.readline()
+        payload = io.BytesIO(fd.read())
+    header = json.loads(first_line)
+    schema = header.get("schema")
+    if schema != SCHEMA_VERSION:
+        raise ValueError(f"{fpath}: checkpoint schema {schema!r} is not supported (this loader reads schema {SCHEMA_VERSION})")
+    fields = dict(header["cfg"])
+    fields["activation"] = _deser(fields["activation"])
+    model = SparseAutoencoder(SparseAutoencoderConfig(**fields))
+    model.load_state_dict(torch.load(payload, weights_only=True, map_location="cpu"))
     return model.to(device)

@@ -221,6 +221,71 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
         assert bad.float().mean() <= 1e-4, f"{k}: {bad.sum().item()} of {bad.numel()} elements off"
 
 
+def _two_sae_worker(rank, world, port, out):
+    import os
+
+    import torch.distributed as dist
+
+    from saev_amd.framework.ddp import DataParallelStepper
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("g9_train_b")
+        bsz = int(g["bsz"])
+        engs = [_two_sae_engine(g, j, max_backward_rows=bsz)[0] for j in range(2)]
+        engs[1].share_x(engs[0])  # what train() does for every SAE after the first (framework/train.py)
+        steppers = [DataParallelStepper(e, dist, world, tail="replicated", exchange="sparse") for e in engs]
+        for i, xb in enumerate(g["acts"].split(bsz)[:5]):
+            x = xb[rank::world].contiguous().cuda()
+            for st in steppers:  # the leader's gathered backward runs BEFORE the follower's forward
+                st.train_step(x, 1e-3 * i, 0.05)
+        torch.cuda.synchronize()
+        torch.save([{k: v.cpu().clone() for k, v in e.param_views().items()} for e in engs], out.format(rank=rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_sae_engine(g, j, **kw):
+    """SAE j of the pair: the golden run's initial parameters, the second one with its latents rolled (a different model)."""
+    d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
+    eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz, **kw)
+    params = {key: g["init_" + key].clone() for key in R.PARAM_ORDER}
+    if j == 1:
+        params["W_enc"] = params["W_enc"].roll(7, dims=1) * 0.9
+        params["W_dec"] = params["W_dec"].roll(7, dims=0)
+        params["b_enc"] = params["b_enc"].roll(7, dims=0)
+    eng.load_params(params)
+    toks = torch.zeros(s, dtype=torch.int64)
+    toks[::9] = int(g["thr"])  # dead latents from the start: the auxiliary term's compact rows cross ranks too
+    eng.set_tracker(toks)
+    return eng, params
+
+
+def test_two_saes_sharing_x_under_the_sparse_exchange(tmp_path, encoder_mode):
+    """Round-4 advisor finding: the gathered backward of a context that lends its x-derived buffers (saev_share_x) wrote the
+    rows of ALL ranks over the slice-major x its follower's forward reads next.  Two ranks, two SAEs on the same batches,
+    sparse-state exchange, f16r: each SAE must end where one process training that SAE alone on the full batches ends."""
+    if encoder_mode != "f16r":
+        pytest.skip("the slice-major x only exists in the f16r mode")
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "rank{rank}.pt")
+    mp.spawn(_two_sae_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = (torch.load(out.format(rank=r)) for r in range(2))
+    g = load_golden("g9_train_b")
+    bsz = int(g["bsz"])
+    for j in range(2):
+        for k in R.PARAM_ORDER:
+            assert torch.equal(r0[j][k], r1[j][k]), (j, k)
+        eng, _ = _two_sae_engine(g, j)
+        for i, xb in enumerate(g["acts"].split(bsz)[:5]):
+            eng.train_step(xb.cuda(), 1e-3 * i, 0.05)
+        for k in R.PARAM_ORDER:
+            bad = ~torch.isclose(eng.view(k).cpu(), r0[j][k], rtol=2e-4, atol=2e-6)
+            assert bad.float().mean() <= 1e-4, f"SAE {j} {k}: {bad.sum().item()} of {bad.numel()} elements off"
+
+
 @pytest.mark.parametrize("prefixes", [None, (300, 900, 2048)])
 @pytest.mark.parametrize("n_dead", [0, 5, 80])
 def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes):

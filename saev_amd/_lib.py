@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class SaevCfg(C.Structure):
@@ -30,7 +30,7 @@ class SaevDebugCfg(C.Structure):
     """Route switches (include/saev_amd.h: saev_debug_cfg); all zero = shipped defaults."""
 
     _fields_ = [(n, C.c_int32) for n in ("struct_size", "dw_route", "enc_mfma", "fused_chain", "ngroups", "enc_wgs", "refresh_first",
-                                         "refresh_every", "aux_small_max", "fwd_route", "dead_lag", "csc_route")]
+                                         "refresh_every", "aux_small_max", "fwd_route", "dead_lag", "csc_route", "fin_route", "prep_route")]
 
 
 class SaevLayout(C.Structure):
@@ -100,6 +100,8 @@ _SIGNATURES = {
     "saev_wdec_ready_event": (C.c_int, [P, P]),
     "saev_wenc_ready_event": (C.c_int, [P, P]),
     "saev_train_step": (C.c_int, [P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
+    "saev_train_step_gather": (C.c_int, [P, P, P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
+    "saev_params_touched": (C.c_int, [P]),
     "saev_last_idx": (P, [P]),
     "saev_last_val": (P, [P]),
     "saev_last_x_hat": (P, [P]),

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
     const bool enc_unwritten = lat_unused != nullptr && lat_unused[i] != 0;  // (wave-uniform)
     for (int q = lane; q < (D >> 2); q += 64) {
         if (part != 2) {
-            const f32x4 g = oa[q] + a[q];
+            const f32x4 g = enc_unwritten ? a[q] : oa[q] + a[q];  // (a flagged latent: neither gradient row has been written)
             oa[q] = g;
             if (row_proj != nullptr) {  // the row changed: refresh its projection coefficient / projected squares (DwRowsArgs::row_proj)
                 const f32x4 w = project ? reinterpret_cast<const f32x4*>(W_dec + (size_t)i * D)[q] : f32x4{0.f, 0.f, 0.f, 0.f};

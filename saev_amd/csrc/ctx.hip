@@ -103,6 +103,9 @@ struct saev_ctx {
     // the slices then forms dW_dec only.  dval_fwd: the forward in flight has left it (same condition as dws_rows, plus the shape)
     float* dval_rows = nullptr;
     bool dval_fwd = false;
+    // the light finalize (kernels.h: DwSlicesArgs::wn2): ||w_i||^2 of the decoder rows as this step's normalize_rows wrote them
+    float* wn2 = nullptr;
+    bool wn2_fresh = false;  // wn2 describes W_dec as it is now (set by the training forward, cleared by whatever writes W_dec)
     // the decode out of 32-column slices (sparse.hip: decode_s_kernel): slice-major copy of the normalised W_dec left by the step's
     // normalize_rows, per (slice, row) loss terms; the dval shares go through dvp
     float* WdS = nullptr;
@@ -117,7 +120,7 @@ struct saev_ctx {
     float* rs_part = nullptr;
     float* xS_c = nullptr;       // the slice-major x of the step in flight (own xS, or the leader's: saev_share_x)
     int2 *pv = nullptr, *pv2 = nullptr;
-    int32_t *plat = nullptr, *cut_lat = nullptr;
+    int32_t *plat = nullptr, *cut_lat = nullptr, *cut_list = nullptr;
     // saev_train_step: latents without pairs are flagged instead of having their dW_enc^T row zeroed (DwSlicesArgs::lat_unused)
     int32_t* lat_unused = nullptr;
     bool fused_step = false;     // inside saev_train_step: the transposed W_enc gradient is read by the fused Adam alone
@@ -167,6 +170,20 @@ struct saev_ctx {
           *sq_part = nullptr, *wmax_prev = nullptr;
     bool wmax_known = false;
     bool mu_ready = false;  // the step already put the column means of x into mu
+    // ---- the streamed f16r step: what a forward derives from x comes from ONE pass (xprep_kernel) centred, scaled
+    // and normalised with what the previous batch left; what it derives from W_enc was left by the fused Adam of the previous step
+    // (AdamImageArgs) -- or by this context's last full preparation, while W_enc has not moved since.
+    bool stream_ok = false;       // mode and geometry allow it (f16r, slice route of the refinement, guaranteed bounds)
+    float *WeS = nullptr;         // slice-major fp32 W_enc^T of its own (the gradient scratch dW_encT no longer doubles as it)
+    float *xn_part = nullptr, *amax_part = nullptr, *cmax_part = nullptr;
+    int scale_par = 0;            // which half of f16r_scales (2 x 8 floats) belongs to the step in flight
+    bool prep_valid = false;      // mu and scales[par][0, 4] describe a previous batch of this context
+    bool wimg_fresh = false;      // ws / WeS / dot_part / sq_part / b_shift / wnorm_scratch describe W_enc AS IT IS NOW ...
+    int64_t mu_serial = 0, wimg_mu_serial = -1;  // ... centred on the mu of this version (mu_serial: bumped whenever mu is rewritten)
+    bool stream_step = false;     // the forward in flight took the streamed preparation
+    bool train_fused = false;     // inside saev_train_step: the forward moves mu, the tail's Adam leaves the next images
+    const float* gather_pool = nullptr;   // saev_train_step_gather: the batch is rows[0..n) of this pool, x is where it is written
+    const int64_t* gather_rows = nullptr;
     // Where the step in flight finds what was derived from x alone: max|x|, the column means, the centred row norms, the
     // per-workgroup maxima behind the x scale, and the fp16 / bf16 images.  Its own buffers -- or those of the context it
     // shares a batch with (saev_share_x: several SAEs trained on the same batches form them once).
@@ -242,6 +259,10 @@ int alloc(saev_ctx* c, T** p, size_t count) {
 // largest of the group maxima for 32 < top_k <= 64.  saev_debug_cfg.ngroups = 64 forces the second variant for small k as well: it
 // cuts the candidates per row from ~980 to ~360 at config 2, but its bound phase (32 published maxima per lane, a
 // bisection over packed 16-bit keys) costs more than the shorter lists save (encoder 1.43-1.51 vs 1.35-1.38 ms).
+// {x scale, W scale, x scale, 1, square normaliser, -, -, -} of the step in flight / of the next one (streamed f16r step)
+float* scl(const saev_ctx* c) { return c->f16r_scales + 8 * c->scale_par; }
+float* scl_next(const saev_ctx* c) { return c->f16r_scales + 8 * (c->scale_par ^ 1); }
+
 int f16_ngroups(const saev_ctx* c) {
     if (c->cfg.top_k > 32 || c->dbg.ngroups == 64) return 64;
     return 32;
@@ -373,7 +394,8 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
         if (c->dval_rows != nullptr && c->dbg.dw_route == 4 && decode_slices_supported((int)D, (int)S, (int)K, (int)K) && c->cfg.normalize_w_dec) {
             A(WdS, S * D); A(dec_part, (size_t)(D / 32) * MB * 3);
         }
-        A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
+        A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(cut_list, 1 + (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
+        if (c->dval_rows != nullptr && c->dbg.fin_route == 0) { A(wn2, S); }
     }
     A(colsum_partials, ((MBB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
@@ -386,10 +408,15 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
         A(ws, (size_t)c->S_pad * 2 * c->Dp);
-        A(row_margin, MB); A(wnorm_scratch, std::max((S + 3) / 4, 3 * ((S + 255) / 256))); A(f16r_scales, 4); A(mu, D); A(xnorm, 2 * MB); A(b_shift, S);
+        A(row_margin, MB); A(wnorm_scratch, std::max((S + 3) / 4, 3 * ((S + 255) / 256))); A(f16r_scales, 16); A(mu, D); A(xnorm, 2 * MB); A(b_shift, S);
         A(xabs_part, (MB + 3) / 4);
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(dot_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(sq_part, (size_t)2 * (c->Dp / 32) * c->S_pad); A(wmax_prev, 1); }
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16R) { A(surv_idx, MB * REFINE_CAP); A(surv_val, MB * REFINE_CAP); A(surv_cnt, MB); }
+    }
+    c->stream_ok = c->fwd_slices && c->cfg.bound_mode == 0 && c->dbg.prep_route == 0 && D % 32 == 0 && c->Dp == (int)D;
+    if (c->stream_ok) {
+        A(WeS, S * D); A(xn_part, (size_t)(D / 32) * c->MB_pad * 2);
+        A(amax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(cmax_part, (size_t)(c->MB_pad / 256) * (D / 32));
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
     A(tau_max, MB); A(heur_state, 8); A(stats_scratch, STATS_SCRATCH_DOUBLES); A(tickets, 8); A(db_aux, D);
@@ -414,6 +441,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     hipMemset(c->rowstats, 0, MB * sizeof(RowStats));
     if (c->xs) hipMemset(c->xs, 0, (size_t)c->MB_pad * 2 * c->Dp * sizeof(_Float16));
     if (c->zero_bias) hipMemset(c->zero_bias, 0, std::max(S, D) * sizeof(float));
+    if (c->f16r_scales) hipMemset(c->f16r_scales, 0, 16 * sizeof(float));
     if (KA > 0) {
         // Every AuxK buffer is sized here for the dead set a healthy run meets: no allocation happens inside such a run's
         // steps.  Default min(d_sae, max(4096, 8 k_aux)) dead latents (2.3 GB at configs[1]; d_sae would be 11.5 GB
@@ -484,6 +512,8 @@ int saev_bind(saev_ctx* c, float* params, float* grads, float* adam_m, float* ad
     REQUIRE(c, params != nullptr, SAEV_INVALID_ARG, "saev_bind: params is NULL");
     REQUIRE(c, ((uintptr_t)params % 16) == 0, SAEV_INVALID_ARG, "saev_bind: params must be 16-byte aligned");
     c->params = params;
+    c->wn2_fresh = false;
+    c->wimg_fresh = false;
     c->grads = grads;
     c->adam_m = adam_m;
     c->adam_v = adam_v;
@@ -699,30 +729,37 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // centre the first pass on the batch's column mean: h = (x - mu) W + (mu W + b)
         // (mu = column sums / n, scaled in the same kernel so that every consumer sees the same fp32 values)
         if (!x_borrowed) {
-            if (!c->mu_ready) HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n));
+            if (!c->mu_ready) { HIPCHK(c, launch_colsum(x, n, D, c->colsum_partials, c->mu, 0, nullptr, s, 0, 1.0f / (float)n)); c->mu_serial++; }
             HIPCHK(c, launch_center_stats(x, c->mu, n, D, c->xnorm, c->xabs_part, s, xmax_dev));
         }
         c->mu_ready = false;
         // (the x scale depends on x alone: a borrowing context recomputes the same value from the leader's maxima, next
         // to its own W scale.  Folding this reduction into center_stats_kernel's last workgroup was tried: a release fence
         // per workgroup of four rows took that kernel from 12 to 115 us)
-        HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, c->f16r_scales, s));
+        HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, scl(c), s));
+        // (the slice-major W_enc^T: in the gradient scratch, free until the backward -- or, where the streamed step may follow, in a
+        // buffer of its own, so that it survives the backward)
+        float* const wt_out = (c->fwd_step && c->stream_ok) ? c->WeS : c->dW_encT;
         if (!x_borrowed && c->wenc_ready == nullptr) {
             // the usual case: nobody's parameter all-gather to wait for in between -- both image passes in one launch
-            HIPCHK(c, launch_split_f16r(x, n, D, c->Dp, c->xs, c->f16r_scales, c->mu, c->params + c->off_W_enc, S, c->S_pad, c->ws,
-                                        reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT, s, c->fwd_step ? c->xS : nullptr,
+            HIPCHK(c, launch_split_f16r(x, n, D, c->Dp, c->xs, scl(c), c->mu, c->params + c->off_W_enc, S, c->S_pad, c->ws,
+                                        reinterpret_cast<double*>(c->dot_part), c->sq_part, wt_out, s, c->fwd_step ? c->xS : nullptr,
                                         c->fwd_step ? 1 : 0));
         } else {
-            if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, c->f16r_scales, c->mu, c->fwd_step ? c->xS : nullptr));
+            if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, 2, s, 1.0f, scl(c), c->mu, c->fwd_step ? c->xS : nullptr));
             { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }  // x is prepared; from here on W_enc / b_enc are read
-            HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, c->f16r_scales + 1,
-                                      c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, c->dW_encT, c->fwd_step ? 1 : 0));
+            HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, 1.0f, c->ws, 2, s, scl(c) + 1,
+                                      c->mu_c, reinterpret_cast<double*>(c->dot_part), c->sq_part, wt_out, c->fwd_step ? 1 : 0));
         }
+        // what this pass leaves describes W_enc as it is now, centred on this context's current mu: a streamed forward may follow
+        // while neither moves (a borrowed centre belongs to the leader: no streamed step there)
+        c->wimg_fresh = c->stream_ok && c->fwd_step && !x_borrowed && c->leader == nullptr;
+        c->wimg_mu_serial = c->mu_serial;
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
-                                     c->f16r_scales + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
+                                     scl(c) + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
         // (defer_margins: the caller's launch_pre_encode forms the margins together with the encoder's per-launch state)
         if (!defer_margins)
-            HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, c->f16r_scales, pre_flag,
+            HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, scl(c), pre_flag,
                                          c->wmax_prev, c->row_margin, s));
         return SAEV_OK;
     }
@@ -742,7 +779,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         a.xs = c->xs_c; a.ws = c->ws;
         a.b_enc = f16r ? c->b_shift : c->params + c->off_b_enc;  // f16r: images are centred, the bias carries mu W
         a.n_rows = n; a.Dp = c->Dp; a.S = c->cfg.d_sae; a.w_scale = (bf || f16r) ? 1.0f : 256.0f;
-        a.scale_dev = f16r ? c->f16r_scales : nullptr;
+        a.scale_dev = f16r ? scl(c) : nullptr;
         a.arith = bf ? 1 : (f16r ? 2 : 0);
         a.row_margin = f16r ? c->row_margin : nullptr;
         const int enc_wgs = c->dbg.enc_wgs > 0 ? c->dbg.enc_wgs : 256;
@@ -823,7 +860,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     const bool predict_mode = fused_supported(c->cfg) && c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 &&
                               f16_ngroups(c) == 32;
     const bool one_launch_pre = fused_supported(c->cfg) && !predict_mode;  // margins + encoder state + list flags in one launch
-    {
+    if (!c->stream_step) {
         int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev, x_borrowed, one_launch_pre);
         if (rc0 != SAEV_OK) return rc0;
         rc0 = wait_wenc(c, s);  // (the f32 encoder has no preparation: it reads W_enc from here on)
@@ -865,7 +902,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 if (c->fwd_step) {  // exact values from 32-column slices of W_enc^T that the XCD L2s hold (select.hip)
                     RefineSlicesArgs rs{};
                     rs.surv_idx = c->surv_idx; rs.surv_cnt = c->surv_cnt; rs.surv_val = c->surv_val; rs.surv_rng = c->surv_rng;
-                    rs.xS = c->xS_c; rs.WeS = c->dW_encT; rs.b_enc = sc.b_enc; rs.part = c->rs_part;
+                    rs.xS = c->xS_c; rs.WeS = c->stream_ok ? c->WeS : c->dW_encT; rs.b_enc = sc.b_enc; rs.part = c->rs_part;
                     rs.n_rows = n; rs.S = c->cfg.d_sae; rs.D = c->cfg.d_model;
                     rs.lat_range = c->rs_lat_range; rs.n_ranges = c->rs_n_ranges;
                     rs.enable_flag = flag; rs.enable_when = when;
@@ -906,8 +943,29 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
             if (rc != SAEV_OK) return rc;
         } else {
             const int S_ = c->cfg.d_sae;
+            if (c->stream_step) {
+                // the streamed preparation: one pass over x (gathered from the pool on the way in, if the caller handed a pool),
+                // then one small launch; W_enc is not read at all (its images were left by the previous step's Adam)
+                const int D_ = c->cfg.d_model;
+                XprepArgs xp{};
+                xp.x = c->gather_pool != nullptr ? c->gather_pool : x; xp.rows = c->gather_rows; xp.x_out = c->gather_pool != nullptr ? const_cast<float*>(x) : nullptr;
+                xp.n = n; xp.D = D_; xp.nks = D_ / 32; xp.n_pad = c->MB_pad; xp.scales = scl(c); xp.mu = c->mu; xp.xs = c->xs; xp.xS = c->xS;
+                xp.xn_part = c->xn_part; xp.col_part = c->colsum_partials; xp.amax_part = c->amax_part; xp.cmax_part = c->cmax_part;
+                HIPCHK(c, launch_xprep(xp, s));
+                PreEncode2Args pe{};
+                pe.cand_cnt = c->cand_cnt; pe.n_rows = n; pe.gmax = c->gmax; pe.n_gmax = ng * c->gmax_stride;
+                pe.xn_part = c->xn_part; pe.nks = D_ / 32; pe.n_pad = c->MB_pad; pe.D = D_;
+                pe.wg_part = c->wnorm_scratch; pe.n_part = (S_ + 255) / 256; pe.scales = scl(c); pe.scales_next = scl_next(c);
+                pe.pre_flag = const_cast<int32_t*>(pre_flag); pe.wmax_prev = c->wmax_prev; pe.margin = c->row_margin; pe.xnorm = c->xnorm;
+                pe.flags1 = c->flags + 1; pe.col_part = c->colsum_partials; pe.n_rowblk = (n + 255) / 256; pe.mu = c->mu;
+                pe.inv_n = 1.0f / (float)n; pe.update_mu = c->train_fused ? 1 : 0;
+                pe.amax_part = c->amax_part; pe.cmax_part = c->cmax_part; pe.n_img = ((n + 255) / 256) * (D_ / 32);
+                pe.upper = c->upper; pe.stats = c->stats;
+                HIPCHK(c, launch_pre_encode2(pe, s));
+                if (c->train_fused) c->mu_serial++;
+            } else
             HIPCHK(c, launch_pre_encode(c->cand_cnt, n, c->gmax, ng * c->gmax_stride, f16r_mode ? c->xnorm_c : nullptr, c->cfg.d_model,
-                                        c->wnorm_scratch, (S_ + 255) / 256, f16r_mode ? c->f16r_scales : nullptr, const_cast<int32_t*>(pre_flag),
+                                        c->wnorm_scratch, (S_ + 255) / 256, f16r_mode ? scl(c) : nullptr, const_cast<int32_t*>(pre_flag),
                                         c->wmax_prev, c->row_margin, c->flags + 1, s));
             timing_begin(c, s);  // the events bracket the encoder kernel alone
             int rc = run_encoder(c, x, n, EPI_TOPK, nullptr, pre_flag, 0, s);
@@ -1030,12 +1088,21 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     // everything that depends on x alone comes from the context this one shares its batches with, if that one has just
     // built it for this very batch (saev_share_x); otherwise it is built here
     const bool borrowed = bind_x_sources(c, x, n, true);
-    if (!borrowed && c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
+    // The streamed preparation: this context neither lends nor borrows, a previous batch has left a centre, a scale
+    // and a normaliser, and the operand images of W_enc describe the parameters as they are, centred on that very centre.
+    c->stream_step = c->stream_ok && c->prep_valid && c->wimg_fresh && c->wimg_mu_serial == c->mu_serial && c->leader == nullptr &&
+                     c->followers.empty() && c->wenc_ready == nullptr && c->fwd_step;
+    if (c->gather_pool != nullptr && !c->stream_step)  // (the batch as a contiguous matrix first: every other route reads x itself)
+        HIPCHK(c, launch_gather_rows(c->gather_pool, c->gather_rows, n, D, const_cast<float*>(x), s));
+    if (c->stream_step) {
+        c->xprep_x = nullptr;  // (xprep_kernel / pre_encode2_kernel, enqueued by encode_topk_impl, do all of the below)
+    } else if (!borrowed && c->cfg.encoder_mode == SAEV_ENCODER_F16R) {
         // one pass: max|x| for the MSE and the column sums the encoder centres on; the launch that finishes them also clears
         // the step's statistics and the force-dense flag (flags[0])
         c->xprep_x = nullptr;
         HIPCHK(c, launch_colsum_absmax(x, n, D, c->colsum_partials, c->mu, c->xabs_part, c->upper, s, 1.0f / (float)n, c->stats, c->flags));
         c->mu_ready = true;
+        c->mu_serial++;
     } else {
         HIPCHK(c, launch_step_zero(c->stats, c->upper, c->flags, s));
         if (!borrowed) {
@@ -1047,17 +1114,24 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     int rc = encode_topk_impl(c, x, n, c->idx, c->val, c->flags, s, c->upper_c, borrowed);
     if (rc != SAEV_OK) return rc;
     if (!borrowed) { c->xprep_x = x; c->xprep_n = n; c->xprep_serial++; }
+    if (!borrowed && c->stream_ok && !c->stream_step && c->fwd_step) {
+        // a full preparation seeds the streamed one: this batch's x scale is in scl(c)[0] already, its max |x| becomes the normaliser
+        HIPCHK(c, hipMemcpyAsync(scl(c) + 4, c->upper, sizeof(float), hipMemcpyDeviceToDevice, s));
+        c->prep_valid = true;
+    }
     if (wdec_ev != nullptr) HIPCHK(c, hipStreamWaitEvent(s, wdec_ev, 0));
     c->wds_fresh = false;
     if (training) {
         // (a training step whose decode can take the slices: normalize_rows leaves the slice-major copy on its way)
         const bool want_slices = c->WdS != nullptr && c->cfg.normalize_w_dec && c->P == 1 && c->dws_ok;
+        c->wn2_fresh = false;
         if (want_slices) {
-            HIPCHK(c, launch_normalize_rows(c->params + c->off_W_dec, S, D, s, c->WdS));
+            HIPCHK(c, launch_normalize_rows(c->params + c->off_W_dec, S, D, s, c->WdS, c->wn2));
             c->wds_fresh = true;
-        } else {
-            rc = saev_normalize_w_dec(c, stream);
-            if (rc != SAEV_OK) return rc;
+            c->wn2_fresh = c->wn2 != nullptr;
+        } else if (c->cfg.normalize_w_dec) {
+            HIPCHK(c, launch_normalize_rows(c->params + c->off_W_dec, S, D, s, nullptr, c->wn2));
+            c->wn2_fresh = c->wn2 != nullptr;
         }
     }
 
@@ -1493,6 +1567,7 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
         c->dws_rows = 0;  // (the copies no longer describe the forward's own rows)
     }
     if (c->dws_pairs) {
+        a.zero_word = c->cut_list;
         a.pv = c->pv; a.plat = c->plat; a.val = ov ? c->ov_val : c->val;
         a.P = c->P_last;
         for (int p = 0; p < c->P_last; ++p) a.cuts[p] = c->cuts_last[p];
@@ -1563,12 +1638,13 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         w.dvp = c->dvp; w.dW_dec = a.dW_dec; w.dW_encT = a.dW_encT; w.db_enc = a.db_enc;
         const size_t runs_cap = ((size_t)w.pair_cap + DWS_RUN - 1) / DWS_RUN;
         w.part_dec = c->partials; w.part_enc = c->partials + 2 * runs_cap * D;  // (max_part * 2 rows hold 4 * runs_cap)
-        w.cut_lat = c->cut_lat;
+        w.cut_lat = c->cut_lat; w.cut_list = c->cut_list;
         w.lat_unused = (all_rows && c->fused_step) ? c->lat_unused : nullptr;
         c->unused_valid = w.lat_unused != nullptr;
         w.row_proj = a.row_proj; w.project = a.project; w.enc_sq = a.enc_sq;
         w.clear_bitmap = a.clear_bitmap; w.clear_words = a.clear_words;
         w.have_dval = c->dval_pairs_ready ? 1 : 0;
+        if (c->dval_pairs_ready && c->wn2_fresh && part == 0) w.wn2 = c->wn2;
         HIPCHK(c, launch_dw_slices(w, (int)((long)n * K), part, s));
     } else {
         c->unused_valid = false;
@@ -1772,6 +1848,10 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     int rc = tail_ranges(c, shard_rank, &r);
     if (rc != SAEV_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    c->wn2_fresh = false;  // (W_dec moves)
+    const bool emit = c->train_fused && c->stream_ok && c->prep_valid && c->leader == nullptr && c->followers.empty() && shard_rank < 0 &&
+                      c->tail_proj_in_adam && c->wenc_t_pending;
+    c->wimg_fresh = false;  // (W_enc moves: only the fused Adam below leaves images of what it writes)
     AdamArgs a{};
     a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
     a.omb1 = (float)(1.0 - 0.9); a.omb2 = (float)(1.0 - 0.999);
@@ -1783,9 +1863,26 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
         c->tail_proj_in_adam = false; c->wenc_t_pending = false;
         const long S = c->cfg.d_sae, D = c->cfg.d_model;
         a.p = c->params; a.g = c->grads; a.m = c->adam_m; a.v = c->adam_v; a.n = c->n_params;
+        AdamImageArgs im{};
+        if (emit) {
+            // this step's images were built (or found) with scl(c); a step that took the full preparation hands its x scale and
+            // normaliser on to the next one (a streamed step's second launch has written them already)
+            if (!c->stream_step) HIPCHK(c, hipMemcpyAsync(scl_next(c), scl(c), 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            im.ws = c->ws; im.WeS = c->WeS; im.dot_part = reinterpret_cast<double*>(c->dot_part); im.sq_part = c->sq_part;
+            im.mu = c->mu; im.wmax_prev = c->wmax_prev; im.scales_next = scl_next(c); im.nks = c->Dp / 32; im.S_pad = c->S_pad;
+        }
         HIPCHK(c, launch_adam_fused(a, c->row_proj, c->dW_encT, (int)S, (int)D, S * D, c->off_W_enc - S * D, c->off_W_enc,
-                                    c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr));
+                                    c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr,
+                                    emit ? &im : nullptr));
         c->unused_valid = false;
+        if (emit) {
+            // the bias of the next centred first pass and the column-norm maxima its margins need: W-only, so they are finished here
+            HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, (int)S, c->S_pad, scl_next(c) + 1,
+                                         c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
+            c->scale_par ^= 1;
+            c->wimg_fresh = true;
+            c->wimg_mu_serial = c->mu_serial;
+        }
         return SAEV_OK;
     }
     if (shard_rank < 0 && c->tail_proj_in_adam) {  // decoder rows with the projection applied on the way in, then the rest
@@ -1816,14 +1913,33 @@ int saev_step_tail(saev_ctx* c, float lr, float max_norm, float grad_scale, int6
     return saev_tail_apply(c, lr, max_norm, grad_scale, adam_step, -1, stream);
 }
 
+int saev_train_step_gather(saev_ctx* c, const float* pool, const int64_t* rows, float* x_out, int32_t n, float lr, float max_norm,
+                           int64_t adam_step, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, pool && rows && x_out, SAEV_INVALID_ARG, "saev_train_step_gather: NULL buffer");
+    c->gather_pool = pool; c->gather_rows = rows;
+    const int rc = saev_train_step(c, x_out, n, lr, max_norm, adam_step, stream);
+    c->gather_pool = nullptr; c->gather_rows = nullptr;
+    return rc;
+}
+
+int saev_params_touched(saev_ctx* c) {
+    if (!c) return SAEV_INVALID_ARG;
+    c->wimg_fresh = false;
+    c->wn2_fresh = false;
+    return SAEV_OK;
+}
+
 int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_norm, int64_t adam_step,
                     void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
     c->fused_forward = c->dws_ok && c->GS != nullptr;  // (the backward below takes the column slices: nothing reads G's blocks 1..P-1)
+    c->train_fused = true;
     int rc = saev_step_forward(c, x, n, n, 1, stream);
     c->fused_forward = false;
-    if (rc != SAEV_OK) return rc;
+    if (rc != SAEV_OK) { c->train_fused = false; return rc; }
     rc = saev_step_dead(c, n, stream);
-    if (rc != SAEV_OK) return rc;
+    if (rc != SAEV_OK) { c->train_fused = false; return rc; }
     // (no saev_backward_end: the W_enc gradient stays in the transposed scratch the backward writes; the tail's single Adam
     // launch reads it there through LDS tiles.  The W_enc segment of the gradient buffer is NOT updated by this entry point
     // -- callers that want to look at gradients use the phases)
@@ -1831,10 +1947,11 @@ int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_
     rc = saev_backward_begin(c, stream);
     if (rc == SAEV_OK) rc = saev_backward_rows(c, 0, c->cfg.d_sae, stream);
     c->fused_step = false;
-    if (rc != SAEV_OK) return rc;
+    if (rc != SAEV_OK) { c->train_fused = false; return rc; }
     c->wenc_t_pending = true;
     rc = saev_step_tail(c, lr, max_norm, 1.0f, adam_step, stream);
     c->wenc_t_pending = false;
+    c->train_fused = false;
     return rc;
 }
 

@@ -220,6 +220,7 @@ struct CscArgs {
     const float* dval;
     int P;                  // (with pv) Matryoshka: the pair word carries the virtual row p(latent) * n_rows + row; <= 1: plain
     int32_t cuts[16];       // MAX_PREFIXES
+    int32_t* zero_word;     // optional: set to 0 by the build (DwSlicesArgs::cut_list's counter)
 };
 // bitmap_clean: the whole bit map is known to be zero (dw_combine_kernel cleared it after the previous build)
 // colsum_*: optional column sums out[d] = sum_b m[b][d] (b < a.n_rows; partials: ceil(n_rows / 64) * D floats) computed in the
@@ -297,6 +298,8 @@ struct DwSlicesArgs {
     float* part_dec;         // (2 * ceil(pair_cap / DWS_RUN), D) head / tail partial of every run
     float* part_enc;
     int32_t* cut_lat;        // (ceil(pair_cap / DWS_RUN)) per run: the latent that begins in it and is cut at its end, or -1
+    int32_t* cut_list;       // optional (1 + ceil(pair_cap / DWS_RUN)): [0] = how many runs have cut_lat >= 0 (zeroed by the CSC build:
+                             // CscArgs::zero_word), then those runs in arrival order -- the light finalize walks this list
     float2* row_proj;        // optional, as DwRowsArgs
     int project;
     float* enc_sq;           // optional
@@ -307,6 +310,11 @@ struct DwSlicesArgs {
     int32_t* lat_unused;
     // pv2 already holds dval (CscArgs::pv2): pass A forms dW_dec only, no dval shares, no dw_dval_sum_kernel
     int have_dval;
+    // optional (the "light" finalize: a one-pass backward whose decode left dval): wn2[i] = ||w_i||^2 as normalize_rows left it.
+    // The finalize is then ONE launch that reads the two gradient rows of a latent once for their squares and takes
+    // <dW_dec[i], w_i> = sum over the latent's pairs of val * dval (dW_dec[i] = sum val g_b and dval = <g_b, w_i>) from the pair
+    // lists: the decoder rows are not read (134 MB per step at configs[1]), dw_finalize_cut / dw_clear_bitmap ride in the launch.
+    const float* wn2;
 };
 // part as in DwRowsArgs (0 both gradients; 1 decoder half: passes A + dval sums; 2 encoder half: pass B, after part 1)
 hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream);
@@ -329,7 +337,8 @@ hipError_t launch_colsum_absmax(const float* m, int n_rows, int D, float* partia
 
 // ---- tail.hip: HBM-bound streaming kernels over the parameter-sized buffers -------------------
 // WS: optional slice-major copy [D / 32][S][32] of the normalised rows (d_model % 32 == 0)
-hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream, float* WS = nullptr);
+// wn2 (optional): ||row||^2 of every row as written (1 up to rounding; what remove_parallel_grads divides by)
+hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream, float* WS = nullptr, float* wn2 = nullptr);
 // rows [0, S) of gW projected orthogonal to the rows of W (project != 0); with sq_partials, ceil(S / 4) doubles: the sums
 // of squares of the rows as written (the clip norm's share of W_dec, from the same pass)
 hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream, double* sq_partials = nullptr,
@@ -361,8 +370,18 @@ hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* r
 // decoder rows projected through row_proj, W_enc's gradient read from the transposed scratch gT (S, D) through LDS tiles,
 // the two bias segments [off, off + n) element-wise (adam_fused_kernel)
 // lat_unused (optional): latents whose gradient rows are zero and not to be read (DwSlicesArgs::lat_unused)
+// optional: the W_enc tiles of the fused Adam also write what the NEXT forward of the f16r encoder needs of W_enc -- its fp16
+// images, the slice-major fp32 W_enc^T, the per-image shares of <mu, w>, ||w||^2 and the rounding-error norm (split_wT_body<2>'s
+// outputs, same layout) -- scaled with the power of two derived from *wmax_prev (written to scales_next[1]).  The forward then
+// never reads W_enc.
+struct AdamImageArgs {
+    _Float16* ws; float* WeS; double* dot_part; float* sq_part;
+    const float* mu; const float* wmax_prev; float* scales_next;
+    int nks, S_pad;
+};
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
-                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused = nullptr);
+                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused = nullptr,
+                             const AdamImageArgs* img = nullptr);
 constexpr int SUMSQ_EX_BLOCKS = 32;  // blk_part: this many doubles of scratch; ticket: an int, zero between launches
 
 // what the host learns about the dead set of a step without waiting for it (saev_step_dead reads the record of an
@@ -461,6 +480,45 @@ hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, floa
                            float* W_T = nullptr,
                            int wt_slices = 0);  // W_T written slice-major: [D / 32][S][32]
 // launch_split_rows(mode 2, scale_dev = scales, mu) and launch_split_wT(mode 2, scale_dev = scales + 1, mu, ...) in ONE launch
+// The streamed f16r step (split.hip: xprep_kernel): the fp16 images of x - mu, the slice-major copy of x, the pieces of the row
+// norms, of the next centring vector and of the batch maxima -- one pass over x (optionally gathered from a pool by row index),
+// centred / scaled / normalised with what the PREVIOUS batch left (mu, scales[0], *up_prev).
+struct XprepArgs {
+    const float* x;        // (n, D) row-major -- or the pool the rows are drawn from
+    const int64_t* rows;   // optional (n): row r of the batch is pool row rows[r]
+    float* x_out;          // optional (with rows): the batch, contiguous (n, D)
+    int n, D, nks, n_pad;  // nks = D / 32 images per row block; n_pad = row pitch of xn_part (multiple of 256)
+    const float* scales;   // scales[0]: x scale of this step's images (a power of two); scales[4]: the squares are taken of (x - mu) / scales[4]
+    const float* mu;       // (D) centring vector
+    _Float16* xs;          // images
+    float* xS;             // [D / 32][n][32]
+    float* xn_part;        // [nks][n_pad][2]
+    float* col_part;       // [row blocks][D]
+    float* amax_part;      // [row blocks * nks]
+    float* cmax_part;      // [row blocks * nks]
+};
+hipError_t launch_xprep(const XprepArgs& a, hipStream_t stream);
+// ... and its second launch (select.hip: pre_encode2_kernel): row norms / margins, encoder state, batch maxima, flags, next mu.
+struct PreEncode2Args {
+    int32_t* cand_cnt; int n_rows;
+    int32_t* gmax; int n_gmax;
+    const float* xn_part; int nks, n_pad, D;
+    const float* wg_part; int n_part;        // bias_finish_kernel's per-workgroup maxima (|b_shift|, column norms, rounding-error norms)
+    const float* scales;                     // {x scale, W scale, x scale, 1, square normaliser} of this step
+    float* scales_next;                      // [0], [2] receive the next step's x scale, [4] its normaliser (this batch's max |x|)
+    int32_t* pre_flag;                       // the step's force-dense flag (written)
+    float* wmax_prev;
+    float* margin;                           // (n_rows)
+    float* xnorm;                            // optional (2 n_rows)
+    int32_t* flags1;                         // need_dense, n_overflow, cand_max
+    const float* col_part; int n_rowblk;     // xprep's column sums per row block
+    float* mu; float inv_n; int update_mu;
+    const float* amax_part; const float* cmax_part; int n_img;
+    float* upper;                            // max |x| of this batch
+    saev_step_stats* stats;                  // zeroed
+    int nb_rows;                             // (set by the launcher)
+};
+hipError_t launch_pre_encode2(PreEncode2Args a, hipStream_t stream);
 hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, const float* scales, const float* mu, const float* W,
                              int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream,
                              float* xS = nullptr, int wt_slices = 0);

@@ -982,6 +982,66 @@ __global__ __launch_bounds__(256) void pre_encode_kernel(int32_t* cand_cnt, int 
     if (i >= n_rows) return;
     margin[i] = f16r_margin(xnorm[2 * i], xnorm[2 * i + 1], wmax, dwmax, bmax, D, scales[0]);  // (scales = {x scale, W scale} of this step's images: f16r_scales_kernel)
 }
+// The streamed f16r step's second (and last) preparation launch, behind xprep_kernel (kernels.h: PreEncode2Args):
+//   * rows: the two norms of x_b - mu from their 32-column pieces, the margin, the candidate counter; the shared group maxima;
+//   * workgroup 0: the batch maxima (max |x| for the MSE's rescale; max |x - mu| -> the NEXT step's x scale, and the check that
+//     THIS step's images, scaled with the previous batch's maximum, stayed inside fp16: otherwise the dense route), the W scale
+//     check of pre_encode_kernel, the step's flags and statistics block;
+//   * workgroups past the rows: the next centring vector mu = column sums / n (only a step whose Adam will rebuild the W images
+//     with it moves mu: `update_mu`).
+__global__ __launch_bounds__(256) void pre_encode2_kernel(PreEncode2Args a) {
+    __shared__ float sh[5][4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.x >= a.nb_rows) {  // ---- mu ----
+        const int d = ((int)blockIdx.x - a.nb_rows) * 256 + threadIdx.x;
+        if (d >= a.D || !a.update_mu) return;
+        float t = 0.f;
+        for (int b = 0; b < a.n_rowblk; ++b) t += a.col_part[(size_t)b * a.D + d];
+        t *= a.inv_n;
+        if (t - t == 0.f) a.mu[d] = t;  // (a non-finite column sum -- an inf / NaN in the batch -- keeps the old centre: any vector is valid)
+        return;
+    }
+    if (i < a.n_rows) a.cand_cnt[i] = 0;
+    if (i < a.n_gmax) a.gmax[i] = INT32_MIN;
+    float bm = 0.f, wm = 0.f, dm = 0.f, am = 0.f, cm = 0.f;
+    for (int j = threadIdx.x; j < a.n_part; j += 256) { bm = fmaxf(bm, a.wg_part[j]); wm = fmaxf(wm, a.wg_part[a.n_part + j]); dm = fmaxf(dm, a.wg_part[2 * a.n_part + j]); }
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; j < a.n_img; j += 256) { am = fmaxf(am, a.amax_part[j]); cm = fmaxf(cm, a.cmax_part[j]); }
+    bm = wave_max(bm); wm = wave_max(wm); dm = wave_max(dm); am = wave_max(am); cm = wave_max(cm);
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[0][w] = bm; sh[1][w] = wm; sh[2][w] = dm; sh[3][w] = am; sh[4][w] = cm; }
+    __syncthreads();
+    const float bmax = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
+    const float wmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
+    const float dwmax = fmaxf(fmaxf(sh[2][0], sh[2][1]), fmaxf(sh[2][2], sh[2][3]));
+    const float x_scale = a.scales[0];
+    if (i == 0) {
+        const float amax = fmaxf(fmaxf(sh[3][0], sh[3][1]), fmaxf(sh[3][2], sh[3][3]));
+        const float cmax = fmaxf(fmaxf(sh[4][0], sh[4][1]), fmaxf(sh[4][2], sh[4][3]));
+        int pre = 0;
+        if (!f16r_scale_ok(wmax, a.scales[1])) pre = 1;
+        if (!(cmax * x_scale < 60000.0f)) pre = 1;  // an element of this step's x image left fp16's range (or is not finite)
+        *a.pre_flag = pre;
+        *a.wmax_prev = wmax;
+        a.flags1[0] = pre; a.flags1[1] = 0; a.flags1[2] = 0;
+        *a.upper = amax;
+        *a.stats = saev_step_stats{};
+        const float xs_next = (cmax > 0.f && cmax < 3.0e38f) ? exp2f(13.0f - floorf(log2f(cmax))) : x_scale;
+        a.scales_next[0] = xs_next;
+        a.scales_next[2] = xs_next;
+        a.scales_next[4] = (amax > 0.f && amax < 3.0e38f) ? amax : a.scales[4];
+    }
+    if (i >= a.n_rows) return;
+    const float up = a.scales[4];  // (the normaliser xprep_kernel used)
+    const float back = (up > 0.f && up < 3.0e38f) ? up : 1.0f;
+    float s2 = 0.f, d2 = 0.f;
+    for (int ks = 0; ks < a.nks; ++ks) {  // (image order: fixed)
+        const float2 t = reinterpret_cast<const float2*>(a.xn_part)[(size_t)ks * a.n_pad + i];
+        s2 += t.x; d2 += t.y;
+    }
+    const float xn = back * sqrtf(s2) * 1.000001f, xd = back * sqrtf(d2) * 1.000002f;  // (rounded up: they bound errors)
+    if (a.xnorm != nullptr) { a.xnorm[2 * i] = xn; a.xnorm[2 * i + 1] = xd; }
+    a.margin[i] = f16r_margin(xn, xd, wmax, dwmax, bmax, a.D, x_scale);
+}
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)
 __global__ void pow2_scale_kernel(const float* absmax, float* pair) {
@@ -1115,6 +1175,11 @@ hipError_t launch_pre_encode(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n
     const int n = std::max(1, n_rows > n_gmax ? n_rows : n_gmax);
     hipLaunchKernelGGL(pre_encode_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cand_cnt, n_rows, gmax, n_gmax, xnorm, D,
                        wg_part, n_part, scales, pre_flag, wmax_prev, margin, flags1);
+    return hipGetLastError();
+}
+hipError_t launch_pre_encode2(PreEncode2Args a, hipStream_t stream) {
+    a.nb_rows = (std::max(1, std::max(a.n_rows, a.n_gmax)) + 255) / 256;
+    hipLaunchKernelGGL(pre_encode2_kernel, dim3(a.nb_rows + (a.D + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_heur_gate(float* state, const int32_t* pre_flag, int32_t* gate, hipStream_t stream) {

@@ -642,6 +642,7 @@ __global__ __launch_bounds__(1024) void csc_scan_offset_kernel(CscArgs a) {
         if (a.chunk_starts) { a.chunk_starts[i] += base[1]; a.part_starts[i] += base[2]; }
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        if (a.zero_word != nullptr) *a.zero_word = 0;
         a.starts[a.S] = base[0] + a.scan_totals[blockIdx.x * 3 + 0];
         if (a.chunk_starts) a.chunk_starts[a.S] = base[1] + a.scan_totals[blockIdx.x * 3 + 1];
     }
@@ -1055,8 +1056,11 @@ __global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : (DEC ? 5 : 6)) void dw_sli
                 *reinterpret_cast<f32x4*>(o) = acc;
                 // every run leaves word of whether a latent BEGINS in it and continues past its end (its tail partial):
                 // dw_finalize_cut_kernel starts from these
-                if (DEC && slice == 0 && li == 0 && (xc[j] & DWS_END))
-                    a.cut_lat[run] = (!head_open && !(xc[j] & DWS_LAST)) ? lc[j] : -1;
+                if (DEC && slice == 0 && li == 0 && (xc[j] & DWS_END)) {
+                    const int cl = (!head_open && !(xc[j] & DWS_LAST)) ? lc[j] : -1;
+                    a.cut_lat[run] = cl;
+                    if (cl >= 0 && a.cut_list != nullptr) a.cut_list[1 + atomicAdd(&a.cut_list[0], 1)] = run;
+                }
                 head_open = false;
                 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (PASS_A) w4 = j + 1 < PB ? wc[j + 1 < PB ? j + 1 : 0] : wnext0;  // (the next pair is the first of its latent)
@@ -1237,6 +1241,184 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a, int ki
         }
     } else if (proj) {
         write_row_proj<NV>(a.row_proj, i, acc, wv, a.project, lane);
+    }
+}
+
+// The light finalize (DwSlicesArgs::wn2): ONE launch of 1 024-thread workgroups.
+//   * Workgroups [0, 2 (n_runs - 1)): a latent cut by run boundaries (L or more pairs), one gradient row of it -- the workgroup at
+//     the FIRST boundary the latent crosses owns it.  Sixteen waves = four column quarters x four groups of partial rows (a latent
+//     that fires on every row -- 256 partials at 16 384 rows, the critical path of this launch -- has 64 partial rows per group,
+//     a quarter of a row per wave).  Same order of additions as dw_finalize_cut_kernel: bit-identical rows and db_enc.
+//   * The rest: sixteen latents each, one wave per latent.  The two gradient rows are read once for their squares; the decoder row
+//     is not: <dW_dec[i], w_i> = sum over the latent's pairs of val * dval, ||w_i||^2 comes from normalize_rows (wn2).
+//   (Squares from per-slice pieces left by the passes -- no row read at all -- were measured: the extra store per finished latent
+//   cost the two passes 13 us each, more than the 268 MB of row reads they saved here.)
+// Both also zero the CSC bit map words of the pairs they walk (dw_clear_bitmap_kernel's job).
+template <int NVQ>  // float4 columns per lane of a column quarter: ceil(D / 4 / 256)
+__global__ __launch_bounds__(1024) void dw_finalize_light_kernel(DwSlicesArgs a, int n_cut_blocks) {
+    constexpr int L = DWS_RUN;
+    __shared__ f32x4 sh[3][NVQ * 256];
+    __shared__ float shs[16], shst[4][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int D = a.D, D4 = D >> 2;
+    if ((int)blockIdx.x < n_cut_blocks) {
+      const int n_items = 2 * a.cut_list[0];
+      for (int item = blockIdx.x; item < n_items; item += n_cut_blocks) {  // (block-uniform loop: the barriers inside are reached by all)
+        const int r0 = a.cut_list[1 + (item >> 1)], enc = item & 1;
+        const int i = a.cut_lat[r0];
+        const int s = a.starts[i], e = a.starts[i + 1];
+        const int r1 = (e - 1) / L;
+        const float* const part = enc ? a.part_enc : a.part_dec;
+        const int colq = w & 3, rg = w >> 2;
+        const int nh = r1 - r0, ch = (nh + 3) / 4;
+        const int ra = r0 + 1 + rg * ch, rb = min(r1 + 1, ra + ch);
+        int col[NVQ];
+        bool ok[NVQ];
+        f32x4 acc[NVQ];
+#pragma unroll
+        for (int n = 0; n < NVQ; ++n) { col[n] = (n * 4 + colq) * 64 + lane; ok[n] = col[n] < D4; acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // (trips of four rows added pairwise, or of two: what dw_finalize_cut_kernel<NV> does for this d_model; two trips in flight)
+        const int TRIP = D4 <= 256 ? 4 : 2;
+        int r = ra;
+        for (; r + 2 * TRIP <= rb && TRIP == 4; r += 8) {
+            f32x4 t[8][NVQ];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)(r + u) * 2 * D);
+#pragma unroll
+                for (int n = 0; n < NVQ; ++n) t[u][n] = ok[n] ? p[col[n]] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int n = 0; n < NVQ; ++n) {
+                acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
+                acc[n] += (t[4][n] + t[5][n]) + (t[6][n] + t[7][n]);
+            }
+        }
+        for (; r + TRIP <= rb; r += TRIP) {
+            f32x4 t[4][NVQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)(r + min(u, TRIP - 1)) * 2 * D);
+#pragma unroll
+                for (int n = 0; n < NVQ; ++n) t[u][n] = (ok[n] && u < TRIP) ? p[col[n]] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int n = 0; n < NVQ; ++n) {
+                if (TRIP == 4) acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
+                else acc[n] += t[0][n] + t[1][n];
+            }
+        }
+        for (; r < rb; ++r) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)r * 2 * D);
+#pragma unroll
+            for (int n = 0; n < NVQ; ++n)
+                if (ok[n]) acc[n] += p[col[n]];
+        }
+        float dbs = 0.f;
+        if (enc && colq == 0) {  // db_enc: a quarter of the latent's pairs per row group's first wave (and their bit map words)
+            const int cnt = e - s, q4 = (cnt + 3) / 4;
+            for (int p = s + rg * q4 + lane; p < min(e, s + (rg + 1) * q4); p += 64) {
+                const int2 pe = a.pv2[p];
+                dbs += __int_as_float(pe.y);
+                if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (pe.x >> 12)] = 0u;
+            }
+            dbs = wave_sum(dbs);
+        }
+        if (rg != 0) {
+#pragma unroll
+            for (int n = 0; n < NVQ; ++n) sh[rg - 1][(n * 4 + colq) * 64 + lane] = acc[n];
+        }
+        if (lane == 0) shs[w] = dbs;
+        __syncthreads();
+        float dot = 0.f, gsq = 0.f;
+        if (rg == 0) {
+            // (a latent that begins exactly at a run boundary has its first piece stored as that run's tail partial as well)
+            const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)r0 * 2 + 1) * D);
+            float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
+            const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+#pragma unroll
+            for (int n = 0; n < NVQ; ++n) {
+                if (!ok[n]) continue;
+                const int c = (n * 4 + colq) * 64 + lane;
+                const f32x4 g = (((p[col[n]] + acc[n]) + sh[0][c]) + sh[1][c]) + sh[2][c];
+                reinterpret_cast<f32x4*>(row)[col[n]] = g;
+                gsq = __builtin_fmaf(g[3], g[3], __builtin_fmaf(g[2], g[2], __builtin_fmaf(g[1], g[1], __builtin_fmaf(g[0], g[0], gsq))));
+                if (!enc && a.row_proj != nullptr && a.project) {
+                    const f32x4 wv = wr[col[n]];
+                    dot = __builtin_fmaf(g[3], wv[3], __builtin_fmaf(g[2], wv[2], __builtin_fmaf(g[1], wv[1], __builtin_fmaf(g[0], wv[0], dot))));
+                }
+            }
+            gsq = wave_sum(gsq);
+            dot = wave_sum(dot);
+        }
+        if (rg == 0 && lane == 0) { shst[colq][0] = gsq; shst[colq][1] = dot; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float dbt = ((shs[0] + shs[4]) + shs[8]) + shs[12];
+            const float g2 = ((shst[0][0] + shst[1][0]) + shst[2][0]) + shst[3][0];
+            const float dt = ((shst[0][1] + shst[1][1]) + shst[2][1]) + shst[3][1];
+            if (enc) {
+                a.db_enc[i] = dbt;
+                if (a.enc_sq != nullptr) a.enc_sq[i] = g2;
+            } else if (a.row_proj != nullptr) {
+                const float nsq = a.wn2[i];
+                const float sc = (a.project && nsq > 0.f) ? dt / nsq : 0.f;
+                a.row_proj[i] = float2{sc, fmaxf(__builtin_fmaf(-sc, dt, g2), 0.f)};
+            }
+        }
+        __syncthreads();  // (the LDS arrays are reused by the next item)
+      }
+      return;
+    }
+    // ---- every other latent: one wave ----
+    const int i = ((int)blockIdx.x - n_cut_blocks) * 16 + w;
+    if (i >= a.S) return;
+    const int s = a.starts[i], e = a.starts[i + 1];
+    if (a.lat_unused != nullptr && lane == 0) a.lat_unused[i] = e == s ? 1 : 0;
+    if (e - s >= L && s / L != (e - 1) / L) return;  // (a cut latent)
+    if (e == s) {  // unused: statistics zero; rows zeroed only for callers that read the gradient buffers (no lat_unused flag)
+        if (a.lat_unused == nullptr) {
+            for (int q = lane; q < D4; q += 64) {
+                reinterpret_cast<f32x4*>(a.dW_dec + (size_t)i * D)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                reinterpret_cast<f32x4*>(a.dW_encT + (size_t)i * D)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (lane == 0) {
+            a.db_enc[i] = 0.f;
+            if (a.enc_sq != nullptr) a.enc_sq[i] = 0.f;
+            if (a.row_proj != nullptr) a.row_proj[i] = float2{0.f, 0.f};
+        }
+        return;
+    }
+    float gsq = 0.f, esq = 0.f;
+    {
+        const f32x4* gd = reinterpret_cast<const f32x4*>(a.dW_dec + (size_t)i * D);
+        const f32x4* ge = reinterpret_cast<const f32x4*>(a.dW_encT + (size_t)i * D);
+#pragma unroll 4
+        for (int q = lane; q < D4; q += 64) {
+            const f32x4 u = gd[q], v = ge[q];
+            gsq = __builtin_fmaf(u[3], u[3], __builtin_fmaf(u[2], u[2], __builtin_fmaf(u[1], u[1], __builtin_fmaf(u[0], u[0], gsq))));
+            esq = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], esq))));
+        }
+    }
+    float dot = 0.f, dbs = 0.f;
+    for (int p = s + lane; p < e; p += 64) {
+        const int2 pd = a.pv2[p];
+        const float dv = __int_as_float(pd.y);
+        dbs += dv;
+        dot = __builtin_fmaf(__int_as_float(a.pv[p].y), dv, dot);
+        if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (pd.x >> 12)] = 0u;
+    }
+    gsq = wave_sum(gsq); esq = wave_sum(esq); dot = wave_sum(dot); dbs = wave_sum(dbs);
+    if (lane == 0) {
+        a.db_enc[i] = dbs;
+        if (a.enc_sq != nullptr) a.enc_sq[i] = esq;
+        if (a.row_proj != nullptr) {
+            // ||g - sc w||^2 = ||g||^2 - sc <g, w> with sc = <g, w> / ||w||^2 (modeling.py:419-445); never negative in exact arithmetic
+            const float nsq = a.wn2[i];
+            const float sc = (a.project && nsq > 0.f) ? dot / nsq : 0.f;
+            a.row_proj[i] = float2{sc, fmaxf(__builtin_fmaf(-sc, dot, gsq), 0.f)};
+        }
     }
 }
 
@@ -1701,21 +1883,34 @@ hipError_t launch_slice_major_copy(const float* g, const float* x, int n, int D,
     hipLaunchKernelGGL(slice_major_copy_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, g, x, n, D, gS, xS);
     return hipGetLastError();
 }
-hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream) {
+hipError_t launch_dw_slices(const DwSlicesArgs& a_in, int max_pairs, int part, hipStream_t stream) {
+    DwSlicesArgs a = a_in;
     if (a.D % DWS_SLICE != 0 || max_pairs <= 0) return hipErrorInvalidValue;
     const int n_runs = (max_pairs + DWS_RUN - 1) / DWS_RUN;
     const int wg_per_slice = (n_runs + 31) / 32;
     const int grid = ((a.D / DWS_SLICE + 7) / 8) * 8 * wg_per_slice;
     // part 1: the decoder's half (pass A leaves the dval the encoder's half needs); part 2: the encoder's; 0: both
+    // light finalize: both halves in one call, dval from the decode, and the three buffers it needs
+    const bool light = part == 0 && a.have_dval && a.wn2 != nullptr;
     if (part != 2 && a.have_dval) {
         hipLaunchKernelGGL((dw_slices_kernel<true, false>), dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
-        if (a.clear_bitmap != nullptr) hipLaunchKernelGGL(dw_clear_bitmap_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
+        if (a.clear_bitmap != nullptr && !light) hipLaunchKernelGGL(dw_clear_bitmap_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
     } else if (part != 2) {
         hipLaunchKernelGGL(dw_slices_kernel<true>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
         hipLaunchKernelGGL(dw_dval_sum_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
     }
     if (part != 1) hipLaunchKernelGGL(dw_slices_kernel<false>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
     const int kinds = part == 0 ? 2 : 1, kind0 = part == 2 ? 1 : 0;
+    if (light) {  // one launch: cut latents first, then a wave per latent that reads no row back (and clears the bit map words)
+        const int n_cut = a.cut_list != nullptr ? std::min(2 * (n_runs - 1), 1024) : 0;  // workgroups that walk the list of cut latents
+        if (a.cut_list == nullptr && n_runs > 1) return hipErrorInvalidValue;
+        const dim3 grid_f(n_cut + (a.S + 15) / 16);
+        const int nvq = (a.D / 4 + 255) / 256;
+        if (nvq <= 1) hipLaunchKernelGGL(dw_finalize_light_kernel<1>, grid_f, dim3(1024), 0, stream, a, n_cut);
+        else if (nvq == 2) hipLaunchKernelGGL(dw_finalize_light_kernel<2>, grid_f, dim3(1024), 0, stream, a, n_cut);
+        else hipLaunchKernelGGL(dw_finalize_light_kernel<4>, grid_f, dim3(1024), 0, stream, a, n_cut);
+        return hipGetLastError();
+    }
     return dispatch_nv(a.D, [&](auto nv) {
         if (n_runs > 1) hipLaunchKernelGGL(dw_finalize_cut_kernel<decltype(nv)::value>, dim3(n_runs - 1, kinds), dim3(256), 0, stream, a, kind0);
         hipLaunchKernelGGL(dw_finalize_kernel<decltype(nv)::value>, dim3((a.S + 3) / 4, kinds), dim3(256), 0, stream, a, kind0);

@@ -187,6 +187,93 @@ __global__ __launch_bounds__(1024) void split_f16r_kernel(SplitF16rArgs a) {
                           a.sq_part, a.W_T, a.wt_slices);
 }
 
+// ---- the streamed f16r step: everything derived from x in ONE pass (kernels.h: XprepArgs) ------------------------------------
+// Centring vector, x scale and the square normaliser are those of the PREVIOUS batch (any fixed vector / power of two / positive
+// number is valid for the margin; the batch's own would need a pass before this one).  A workgroup = one image (256 rows x 32
+// columns), as split_rows_body<2>; on top of the image and the slice-major copy it leaves
+//   * xn_part[ks][row] = {sum ((x - mu) / up)^2, sum (delta / up)^2} over the image's 32 columns (delta = the rounding error the
+//     fp16 image of the row carries: center_stats_kernel's two norms, in 32-column pieces),
+//   * col_part[blk][32 columns] = column sums of x over the image's rows (the NEXT centring vector),
+//   * amax_part / cmax_part[image] = max |x|, max |x - mu| (the MSE's rescale; the NEXT x scale and this image's overflow check),
+//   * with `rows`: the batch is gathered from a pool on the way in, and written out contiguously (x_out).
+__device__ __forceinline__ float xprep_round_f16_sig(float v) {  // (= select.hip: round_f16_sig)
+    const uint32_t b = __float_as_uint(v);
+    return __uint_as_float((b + 0x0FFFu + ((b >> 13) & 1u)) & 0xFFFFE000u);
+}
+__global__ __launch_bounds__(1024) void xprep_kernel(XprepArgs a) {
+    __shared__ float cs[256][33];
+    __shared__ float cs2[32][33];
+    __shared__ float shm[2][16];
+    const int nks = a.nks;
+    const int bid = blockIdx.x, blk = bid / nks, ks = bid % nks;
+    const int i = threadIdx.x, lane = i & 63, w = i >> 6;
+    const int rl = i >> 2, p = i & 3;
+    const int c = p ^ ((4 - ((rl >> 2) & 3)) & 3);
+    const int r = blk * 256 + rl, k = ks * 32 + c * 8;
+    const float scale = a.scales[0];
+    const float up = a.scales[4];
+    const float back = (up > 0.f && up < 3.0e38f) ? up : 1.0f, inv = 1.0f / back;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float raw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float am = 0.f, cm = 0.f, s2 = 0.f, d2 = 0.f;
+    if (r < a.n) {  // (D % 32 == 0 on this route: the chunk's eight values exist)
+        const size_t src = a.rows != nullptr ? (size_t)a.rows[r] : (size_t)r;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + src * a.D + k);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + src * a.D + k + 4);
+        if (a.x_out != nullptr) {
+            f32x4* o = reinterpret_cast<f32x4*>(a.x_out + (size_t)r * a.D + k);
+            o[0] = x0; o[1] = x1;
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(a.xS + ((size_t)ks * a.n + r) * 32 + c * 8);
+        o[0] = x0; o[1] = x1;
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.mu + k), m1 = *reinterpret_cast<const f32x4*>(a.mu + k + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            raw[e] = e < 4 ? x0[e] : x1[e - 4];
+            const float ce = raw[e] - (e < 4 ? m0[e] : m1[e - 4]);
+            am = fmaxf(am, fabsf(raw[e]));
+            cm = fmaxf(cm, fabsf(ce));
+            const float d = (ce - xprep_round_f16_sig(ce)) * inv, q = ce * inv;
+            s2 = __builtin_fmaf(q, q, s2);
+            d2 = __builtin_fmaf(d, d, d2);
+            v[e] = ce * scale;
+        }
+        // (a non-finite element: NaN maxima would be dropped by fmaxf -- carry them as inf so that the step sees them)
+        if (!(s2 < 3.0e38f)) { cm = __builtin_inff(); }
+    }
+    reinterpret_cast<half8*>(a.xs + (size_t)bid * 256 * 32)[i] = pack8<2>(v, 0);
+    // the row's two norm pieces: its four chunks sit in four neighbouring lanes
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    d2 += __shfl_xor(d2, 1, 64); d2 += __shfl_xor(d2, 2, 64);
+    if (p == 0 && r < a.n) reinterpret_cast<float2*>(a.xn_part)[(size_t)ks * a.n_pad + r] = float2{s2, d2};
+    // column sums over the image's 256 rows: through LDS, eight-row segments then the 32 segments, fixed order
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[rl][c * 8 + e] = raw[e];
+    am = wave_max(am); cm = wave_max(cm);
+    if (lane == 0) { shm[0][w] = am; shm[1][w] = cm; }
+    __syncthreads();
+    {
+        const int col = i & 31, seg = i >> 5;
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += cs[seg * 8 + j][col];
+        cs2[seg][col] = t;
+    }
+    __syncthreads();
+    if (i < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) t += cs2[j][i];
+        a.col_part[(size_t)blk * a.D + ks * 32 + i] = t;
+    }
+    if (i == 32) {
+        float m0 = 0.f, m1 = 0.f;
+        for (int j = 0; j < 16; ++j) { m0 = fmaxf(m0, shm[0][j]); m1 = fmaxf(m1, shm[1][j]); }
+        a.amax_part[bid] = m0;
+        a.cmax_part[bid] = m1;
+    }
+}
+
 // b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]), ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale and
 // ||dW[:, s]|| from the second plane of sq_part; per workgroup one maximum of |b_shift| (wg_max[0..nwg)), one of the norms
 // (wg_max[nwg..2 nwg)) and one of the rounding-error norms (wg_max[2 nwg..3 nwg))
@@ -263,5 +350,12 @@ hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int 
     const int nwg = (S + 255) / 256;
     hipLaunchKernelGGL(bias_finish_kernel, dim3(nwg), dim3(256), 0, stream, dot_part, sq_part, Dp / 32, S, S_pad, w_scale,
                        b_enc, b_shift, wg_part);
+    return hipGetLastError();
+}
+
+hipError_t launch_xprep(const XprepArgs& a, hipStream_t stream) {
+    const int nblk = (a.n + 255) / 256;
+    if (nblk <= 0 || a.D % 32 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(xprep_kernel, dim3(nblk * a.nks), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }

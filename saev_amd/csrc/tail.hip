@@ -8,7 +8,7 @@
 namespace {
 
 template <int NV>
-__global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, int D, float* WS) {
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, int D, float* WS, float* wn2) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= S) return;
@@ -24,17 +24,22 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, in
     }
     ss = wave_sum(ss);
     const float nrm = sqrtf(ss);
+    float s2 = 0.f;
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int q = lane + 64 * n;
         if (q < D4) {
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = v[n][e] / nrm;
+            for (int e = 0; e < 4; ++e) { o[e] = v[n][e] / nrm; s2 = __builtin_fmaf(o[e], o[e], s2); }
             r[q] = o;
             // slice-major copy [D / 32][S][32] for the slice decode (sparse.hip: decode_s_kernel), 128 bytes per (row, slice)
             if (WS != nullptr) reinterpret_cast<f32x4*>(WS)[((size_t)(q >> 3) * S + i) * 8 + (q & 7)] = o;
         }
+    }
+    if (wn2 != nullptr) {  // (same fma chain and lane order as rpg_row_stats forms ||w||^2 with)
+        s2 = wave_sum(s2);
+        if (lane == 0) wn2[i] = s2;
     }
 }
 
@@ -255,7 +260,9 @@ struct AdamFusedArgs {
     int S, D;
     long off_b_dec, n_b_dec, off_W_enc, off_b_enc, n_b_enc;
     int nb_rows, nb_tiles, tiles_s;
+    AdamImageArgs img;     // img.ws != NULL: the W_enc tiles also leave the NEXT step's f16r operand images (kernels.h)
 };
+typedef _Float16 half8t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const AdamArgs& a, float gs, float step_size, int t) {
     const int S = f.S, D = f.D;
     {
@@ -281,11 +288,14 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
         float* const V = a.v + f.off_W_enc;
         const int sl = (threadIdx.x & 63) * 4, dr = threadIdx.x >> 6;
         const int sidx = s0 + sl;
-        if (sidx >= S) return;
+        const bool emit = f.img.ws != nullptr;
+        if (sidx >= S && !emit) return;
+        f32x4 pn[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int dl = dr + 4 * i, d = d0 + dl;
-            if (d >= D) continue;
+            pn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (d >= D || sidx >= S) continue;
             const size_t o = (size_t)d * S + sidx;
             f32x4 p = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(P + o));
             f32x4 m = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(M + o));
@@ -299,6 +309,58 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
             __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(P + o));
             __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(M + o));
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(V + o));
+            pn[i] = p;
+        }
+        if (!emit) return;
+        // ---- the next step's operand images of this tile (= image (s0 / 256, d0 / 32) of split_wT_body<2>, same arithmetic):
+        // the updated values go back through the LDS tile, then thread rl owns latent s0 + rl: its 32 k as four fp16 chunks in the
+        // encoder's image order, the slice-major fp32 row for the exact refinement, and the image's shares of <mu, w>, ||w||^2
+        // and ||w - fp16(w)||^2 (bias_finish_kernel adds the shares of the D / 32 images)
+        __syncthreads();  // (every thread has taken its gradient out of the tile)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&tile[dr + 4 * i][sl]) = pn[i];
+        __shared__ float mu_s[TD];
+        if (threadIdx.x < TD) mu_s[threadIdx.x] = f.img.mu[d0 + threadIdx.x];
+        __syncthreads();
+        const float wm = *f.img.wmax_prev;
+        const float scale = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
+        if (t == 0 && threadIdx.x == 0) { f.img.scales_next[1] = scale; f.img.scales_next[3] = 1.0f; }
+        const int rl = threadIdx.x, ks = d0 / TD;
+        const int swz = (4 - ((rl >> 2) & 3)) & 3;
+        double accp[4];
+        float sqp[4], dsp[4];
+        half8t* const img = reinterpret_cast<half8t*>(f.img.ws + ((size_t)(s0 / TS) * f.img.nks + ks) * 256 * 32);
+        f32x4* const wes = reinterpret_cast<f32x4*>(f.img.WeS + ((size_t)ks * S + s0 + rl) * 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[8];
+            half8t h;
+            double acc = 0.0;
+            float sq = 0.f, dsq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = tile[c * 8 + e][rl] * scale;
+                h[e] = (_Float16)v[e];
+                acc += (double)mu_s[c * 8 + e] * (double)v[e];
+                sq += v[e] * v[e];
+                const float d = v[e] - (float)h[e];
+                dsq += d * d;
+            }
+            img[rl * 4 + (c ^ swz)] = h;
+            if (s0 + rl < S) {
+                const float inv = 1.0f / scale;  // power of two
+                wes[2 * c] = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+                wes[2 * c + 1] = f32x4{v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv};
+            }
+            accp[c] = acc; sqp[c] = sq; dsp[c] = dsq;
+        }
+        {
+            // (the order in which split_wT_body's four lanes of a latent -- positions 0..3 holding chunks 0^swz .. 3^swz -- add up)
+            const int c0 = swz, c1 = 1 ^ swz, c2 = 2 ^ swz, c3 = 3 ^ swz;
+            const size_t o = (size_t)ks * f.img.S_pad + s0 + rl;
+            f.img.dot_part[o] = (accp[c0] + accp[c1]) + (accp[c2] + accp[c3]);
+            f.img.sq_part[o] = (sqp[c0] + sqp[c1]) + (sqp[c2] + sqp[c3]);
+            f.img.sq_part[(size_t)f.img.nks * f.img.S_pad + o] = (dsp[c0] + dsp[c1]) + (dsp[c2] + dsp[c3]);
         }
         return;
     }
@@ -573,9 +635,9 @@ hipError_t dispatch_nv(int D, F&& f) {
 
 }  // namespace
 
-hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream, float* WS) {
+hipError_t launch_normalize_rows(float* W, int S, int D, hipStream_t stream, float* WS, float* wn2) {
     return dispatch_nv(D, [&](auto nv) {
-        hipLaunchKernelGGL(normalize_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, W, S, D, WS);
+        hipLaunchKernelGGL(normalize_rows_kernel<decltype(nv)::value>, dim3((S + 3) / 4), dim3(256), 0, stream, W, S, D, WS, wn2);
     });
 }
 hipError_t launch_rpg(float* gW, const float* W, int S, int D, hipStream_t stream, double* sq_partials, int project) {
@@ -613,8 +675,10 @@ hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, in
     });
 }
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
-                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused) {
+                             long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused,
+                             const AdamImageArgs* img) {
     AdamFusedArgs f{};
+    if (img != nullptr && D % 32 == 0) f.img = *img;
     f.a = a; f.row_proj = row_proj; f.gT = gT; f.S = S; f.D = D; f.lat_unused = lat_unused;
     f.off_b_dec = off_b_dec; f.n_b_dec = n_b_dec; f.off_W_enc = off_W_enc; f.off_b_enc = off_b_enc; f.n_b_enc = n_b_enc;
     f.nb_rows = (S + 3) / 4;

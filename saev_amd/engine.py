@@ -61,6 +61,8 @@ class EngineConfig:
     #   SAEV_AMD_AUX_SMALL_MAX    largest dead set of the few-dead-latents AuxK kernels (-1: always the dense algebra)
     #   SAEV_AMD_DEAD_LAG         age in steps of the tracker record that sizes a step's auxiliary work (default 4)
     #   SAEV_AMD_CSC              1: the backward's pair-list build fills its bit map itself (default: the training decode does)
+    #   SAEV_AMD_FIN              1: the backward's finalize re-reads the gradient rows for their statistics (round-4 kernels)
+    #   SAEV_AMD_PREP             1: every f16r forward prepares its operands from x and W_enc itself (no streamed preparation)
     dw_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_DW", "slices"))
     fwd_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_FWD", "default"))
     enc_mfma: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_ENC_MFMA", "0")))
@@ -72,6 +74,8 @@ class EngineConfig:
     aux_small_max: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_SMALL_MAX", "0")))
     dead_lag: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_DEAD_LAG", "0")))
     csc_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_CSC", "0")))
+    fin_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_FIN", "0")))
+    prep_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_PREP", "0")))
 
 
 @dataclasses.dataclass
@@ -153,13 +157,14 @@ class SaeEngine:
                 struct_size=C.sizeof(_lib.SaevDebugCfg), dw_route={"slices": 0, "rows": 1, "slices_a": 2, "slices_s": 4}[cfg.dw_route], enc_mfma=cfg.enc_mfma,
                 fused_chain=int(cfg.fused_chain), ngroups=cfg.ngroups, enc_wgs=cfg.enc_wgs, refresh_first=cfg.refresh_first,
                 refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route=int(cfg.fwd_route == "rows"),
-                dead_lag=cfg.dead_lag, csc_route=cfg.csc_route)
+                dead_lag=cfg.dead_lag, csc_route=cfg.csc_route, fin_route=cfg.fin_route, prep_route=cfg.prep_route)
             ctx = C.c_void_p()
             rc = self.lib.saev_create_ex(C.byref(ccfg), C.byref(dbg), self.device.index, C.byref(ctx))
             if rc != 0:
                 raise _lib.SaevError(f"saev_create failed with status {rc} for {cfg}")
             self.ctx = ctx
             self._chk(self.lib.saev_bind(ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v)), "saev_bind")
+            self._params_version = self.params._version
             self._chk(self.lib.saev_bind_tracker(ctx, _ptr(self.toks_since_active), _ptr(self.fired)), "saev_bind_tracker")
             # the tail's sum of squares lives in a torch tensor from the start, so that a collective can reach it
             self.sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
@@ -224,6 +229,19 @@ class SaeEngine:
     def load_params(self, params: dict[str, torch.Tensor]) -> None:
         for k in self.offsets:
             self.view(k).copy_(params[k].to(self.device, torch.float32))
+        self.params_touched()
+
+    def params_touched(self) -> None:
+        """Tell the context that the parameter buffer was written from outside the library (include/saev_amd.h: PARAMETER
+        OWNERSHIP): it drops what it keeps of W_enc / W_dec between calls.  In-place torch operations on ``params`` or on views of
+        it are noticed by themselves (torch's version counter, checked before every forward); writes that bypass it -- ``.data``,
+        raw pointers, another library -- need this call."""
+        self._chk(self.lib.saev_params_touched(self.ctx), "saev_params_touched")
+        self._params_version = self.params._version
+
+    def _note_param_writes(self) -> None:
+        if self.params._version != self._params_version:
+            self.params_touched()
 
     def _check_x(self, x: torch.Tensor) -> torch.Tensor:
         if x.device != self.device or x.dtype != torch.float32:
@@ -254,6 +272,7 @@ class SaeEngine:
 
     def encode_topk(self, x: torch.Tensor):
         x = self._check_x(x)
+        self._note_param_writes()
         n, k = x.shape[0], min(self.cfg.top_k, self.cfg.d_sae)
         idx = torch.empty(n, k, device=self.device, dtype=torch.int32)
         val = torch.empty(n, k, device=self.device, dtype=torch.float32)
@@ -291,6 +310,7 @@ class SaeEngine:
     def step_forward(self, x: torch.Tensor, *, training: bool = True, n_rows_global: int | None = None):
         x = self._check_x(x)
         self._x_keepalive = x
+        self._note_param_writes()
         n = x.shape[0]
         self._chk(self.lib.saev_step_forward(self.ctx, _ptr(x), n, n_rows_global or n, int(training), _stream()), "saev_step_forward")
 
@@ -407,8 +427,26 @@ class SaeEngine:
         (``step_forward`` / ``step_dead`` / ``step_backward`` / ``step_tail``), as the log steps of ``train()`` do."""
         x = self._check_x(x)
         self._x_keepalive = x
+        self._note_param_writes()
         self.adam_steps += 1
         self._chk(self.lib.saev_train_step(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps, _stream()), "saev_train_step")
+
+    def train_step_gather(self, pool: torch.Tensor, rows: torch.Tensor, lr: float, max_norm: float = 1.0, out: torch.Tensor | None = None) -> torch.Tensor:
+        """``train_step`` on the batch ``pool[rows]``, drawn inside the step (saev_train_step_gather): the step's first kernel reads
+        the pool rows and leaves the batch as a contiguous matrix -- returned -- on its way."""
+        n = rows.shape[0]
+        if pool.device != self.device or pool.dtype != torch.float32 or pool.ndim != 2 or pool.shape[1] != self.cfg.d_model or not pool.is_contiguous():
+            raise _lib.SaevError(f"the pool must be a contiguous float32 (rows, {self.cfg.d_model}) matrix on {self.device}")
+        if rows.device != self.device or rows.dtype != torch.int64 or not rows.is_contiguous():
+            raise _lib.SaevError(f"rows must be contiguous int64 on {self.device}")
+        if out is None:
+            out = torch.empty(n, self.cfg.d_model, device=self.device, dtype=torch.float32)
+        self._x_keepalive = (pool, rows, out)
+        self._note_param_writes()
+        self.adam_steps += 1
+        self._chk(self.lib.saev_train_step_gather(self.ctx, _ptr(pool), _ptr(rows), _ptr(out), n, lr, max_norm, self.adam_steps, _stream()),
+                  "saev_train_step_gather")
+        return out
 
     def read_stats(self) -> StepStats:
         st = _lib.SaevStepStats()

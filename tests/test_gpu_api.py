@@ -410,10 +410,19 @@ def test_train_on_the_device_with_the_default_datapoint_init(tmp_path, monkeypat
     saes, objs, run, steps = T.train([cfg])
     assert steps >= 10 and set(started) == set(R.PARAM_ORDER)
     # what the same seed and the same delivered batches give on the CPU (test_host_cpu.py pins that arithmetic to G10)
-    batches = [b["act"].cpu() for b in data.ShuffledDataLoader(dc, device="cuda")]
+    # (make_saes is handed the step limiter, whose n_samples is n_train -- as in the reference, train.py:260-262 -- so the
+    # sample is min(max(d_sae, 65 536), n_train) rows, drawn over as many epochs of the loader as that takes)
+    from saev_amd.utils import scheduling
+
+    n_want = min(max(s, 65_536), cfg.n_train)
+    batches = []
+    for b in scheduling.BatchLimiter(data.ShuffledDataLoader(dc, device="cuda"), cfg.n_train):
+        batches.append(b["act"].cpu())
+        if sum(len(t) for t in batches) >= n_want:
+            break
 
     class Loader:
-        n_samples = sum(len(b) for b in batches)
+        n_samples = cfg.n_train
 
         def __iter__(self):
             return iter({"act": b} for b in batches)

@@ -123,16 +123,28 @@ def _tie_restatement_to_the_oracle(eng, x, x_hat, dead, k_aux, alpha, diff, A, n
     mask = torch.zeros(s, dtype=torch.bool)
     mask[dead.cpu()] = True
     h = R.encode_pre(xs, W_enc, b_enc)
+    h.retain_grad()
     loss = R.auxk_loss(x=xs, h=h, x_hat_last=xh, dead_mask=mask, W_dec=W_dec, b_dec=b_dec, k_aux=k_aux, alpha=alpha)
     loss.backward()
     sub = diff[:n_sub]
     mine = alpha * (sub * sub).mean().item()
     assert math.isclose(loss.item(), mine, rel_tol=2e-5), (loss.item(), mine)
-    b = x.shape[0]
-    # the restatement's gradient formulas on the subset (its factor is 2 alpha / (B d); the subset's own is 2 alpha / (n_sub d))
     dc = dead.cpu()
-    g_sub = (2.0 * alpha / (n_sub * d)) * sub
+    # The restatement selects on fp64 pre-activations, the oracle (like the reference) on fp32 ones: with more dead latents than
+    # k_aux a near-tie at the cut can fall either way, which moves one (row, latent) term of the gradients.  The selections must
+    # agree almost everywhere; the FORMULAS are then tied on the oracle's own selection.
+    # (the oracle's selection, exact ties included, read off autograd: dL/dh is non-zero exactly at the kept entries)
     As = A[:n_sub]
+    hd = h.detach()[:, dc].double()
+    kept = h.grad[:, dc] != 0
+    assert (kept.sum(dim=1) == min(k_aux, dc.numel())).all()
+    A_or = torch.where(kept, hd, torch.zeros_like(hd)).to(As.device)
+    assert ((A_or != 0) != (As != 0)).float().mean().item() <= 1e-4, "restatement and oracle select different dead latents"
+    As = A_or
+    W_dd, b_dd = eng.view("W_dec")[dead].double(), eng.view("b_dec").double()
+    sub = As @ W_dd + b_dd - (x[:n_sub].double() - x_hat[:n_sub].double())
+    # the restatement's gradient formulas on the subset (its factor is 2 alpha / (B d); the subset's own is 2 alpha / (n_sub d))
+    g_sub = (2.0 * alpha / (n_sub * d)) * sub
     mine_Wdec = (As.t() @ g_sub).cpu()
     dA = (g_sub @ eng.view("W_dec")[dead].double().t()) * (As != 0)
     mine_WencT = (dA.t() @ x[:n_sub].double()).cpu()

@@ -228,3 +228,38 @@ def test_decode_filled_bit_map_is_bit_identical_to_the_builds_own_fill(d, s, k, 
     torch.cuda.synchronize()
     for name in ("params", "adam_m", "adam_v"):
         assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), name
+
+
+@pytest.mark.parametrize("d,s,k,b,n,kind,prefixes", [(1024, 32768, 32, 16384, 16384, "dense_latent", 1), (1024, 8192, 32, 4096, 4096, "few_latents", 1),
+                                                      (768, 6144, 32, 4096, 4096, "plain", 1), (512, 4096, 32, 1024, 1000, "plain", 4),
+                                                      (128, 1024, 8, 512, 300, "plain", 1), (64, 256, 4, 64, 3, "plain", 1)])
+def test_light_finalize_agrees_with_the_row_reading_one(d, s, k, b, n, kind, prefixes):
+    """saev_debug_cfg.fin_route: the one-launch finalize forms the projection coefficient <g_i, w_i> / ||w_i||^2, the squares of the
+    projected row and of the W_enc^T gradient row and db_enc from per-slice squares, the pair lists (<dW_dec[i], w_i> = sum of
+    val * dval over the latent's pairs) and ||w_i||^2 left by normalize_rows; route 1 re-reads every gradient and decoder row, as
+    round 4 did.  Same quantities, other summation orders: clip norms agree to fp32 rounding, and so do the parameters after steps
+    with the clip active -- including latents cut by run boundaries, unused latents, AuxK rows added behind the finalize."""
+    from saev_amd.nn.objectives import sample_prefixes
+
+    thr = 3 * n
+    engs = [_engine(d, s, k, b, "slices", seed=5, fin_route=r, k_aux=16, dead_threshold_tokens=thr) for r in (0, 1)]
+    xs = [_data(d, b, n, kind, seed=20 + i) for i in range(5)]
+    torch.manual_seed(0)
+    cuts = [sample_prefixes(s, prefixes) if prefixes > 1 else None for _ in xs]
+    norms = [[], []]
+    for e, eng in enumerate(engs):
+        for i, x in enumerate(xs):
+            if prefixes > 1:
+                eng.set_prefixes(cuts[i])
+            eng.train_step(x, 1e-3, 0.05 if i % 2 else 1.0)
+            norms[e].append(eng.read_stats().grad_norm)
+    torch.cuda.synchronize()
+    # (the routes round differently, so a near-tie of a later step's TopK may fall the other way: the first steps to fp32
+    # rounding, the later ones to the size of a flipped code)
+    for i, (a, c) in enumerate(zip(*norms)):
+        assert math.isclose(a, c, rel_tol=2e-6 if i < 3 else 2e-4), (norms[0], norms[1])
+    assert engs[0].read_stats().n_dead == engs[1].read_stats().n_dead
+    for name in ("params", "adam_m", "adam_v"):
+        p0, p1 = getattr(engs[0], name), getattr(engs[1], name)
+        bad = ~torch.isclose(p0, p1, rtol=1e-4, atol=1e-7 * p1.abs().max().item())
+        assert bad.float().mean().item() <= 1e-3, f"{name}: {bad.sum().item()} of {bad.numel()} elements apart"

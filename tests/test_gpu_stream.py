@@ -1,0 +1,167 @@
+"""The streamed f16r step (saev_debug_cfg.prep_route): one pass over x centred / scaled / normalised with what the
+PREVIOUS batch left, W_enc operand images left by the previous step's Adam -- against the full preparation of every step
+(prep_route = 1: statistics, centring and both image passes from this batch and the current W_enc).  The first pass is only a
+filter; the exact refinement makes the codes those of fp32 arithmetic on either route, so whole training runs must agree BIT FOR
+BIT -- through batches whose statistics jump, evaluation forwards in between, parameter writes from outside, non-finite input."""
+
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _once(encoder_mode):
+    if encoder_mode != "f16r":
+        pytest.skip("the streamed preparation belongs to the f16r encoder")
+
+
+def _engine(d, s, k, b, prep_route, seed=0, **kw):
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    eng = SaeEngine(EngineConfig(d_model=d, d_sae=s, top_k=k, max_batch=b, prep_route=prep_route, **kw))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = (torch.rand(s, d, device="cuda", generator=g) * 2 - 1) * math.sqrt(6.0 / d)
+    W /= W.norm(dim=1, keepdim=True)
+    eng.view("W_dec").copy_(W)
+    eng.view("W_enc").copy_(W.t() + 0.01 * torch.randn(d, s, device="cuda", generator=g))
+    eng.view("b_enc").copy_(0.05 * torch.randn(s, device="cuda", generator=g))
+    eng.view("b_dec").copy_(0.05 * torch.randn(d, device="cuda", generator=g))
+    return eng
+
+
+def _batches(d, n, count, seed=1):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    mu = torch.randn(d, device="cuda", generator=g)
+    return [torch.randn(n, d, device="cuda", generator=g) + mu for _ in range(count)]
+
+
+def _same(e0, e1, what=""):
+    for name in ("params", "adam_m", "adam_v"):
+        assert torch.equal(getattr(e0, name), getattr(e1, name)), f"{what}: {name} differ"
+    assert torch.equal(e0.toks_since_active, e1.toks_since_active)
+
+
+@pytest.mark.parametrize("d,s,k,b,n", [(1024, 32768, 32, 16384, 16384), (768, 6144, 32, 4096, 4096), (256, 2048, 16, 1024, 1000),
+                                        (64, 512, 8, 256, 200)])
+def test_streamed_steps_equal_fully_prepared_steps_bit_for_bit(d, s, k, b, n):
+    engs = [_engine(d, s, k, b, r, seed=3, k_aux=32, dead_threshold_tokens=3 * n) for r in (0, 1)]
+    xs = _batches(d, n, 7)
+    for i, x in enumerate(xs):
+        for eng in engs:
+            eng.train_step(x, 1e-3, 0.05 if i % 2 else 1.0)
+            st = eng.read_stats()
+            assert st.dense_route == 0 and st.n_overflow_rows == 0, (i, st)
+        a, c = (e.read_stats() for e in engs)
+        assert a.mse == c.mse and a.l1 == c.l1 and a.grad_norm == c.grad_norm and a.n_dead == c.n_dead, (i, a, c)
+    torch.cuda.synchronize()
+    _same(*engs)
+
+
+def test_streamed_step_survives_what_happens_between_steps():
+    """Evaluation forwards, API encodes, a smaller batch, parameter writes through torch (noticed by the version counter) and through
+    a raw .data write announced with params_touched(): after each, the streamed route must still agree with the full preparation."""
+    d, s, k, b = 256, 2048, 16, 1024
+    engs = [_engine(d, s, k, b, r, seed=4) for r in (0, 1)]
+    xs = _batches(d, b, 12, seed=5)
+    other = _batches(d, 300, 3, seed=6)
+    for i, x in enumerate(xs):
+        for eng in engs:
+            if i == 2:
+                eng.step_forward(other[0], training=False)       # an evaluation batch with other statistics
+                eng.step_forward(other[1], training=False)
+            if i == 4:
+                eng.encode_topk(other[2])                        # the API op rebuilds the images itself
+            if i == 5:
+                x_used = x[:700].contiguous()                    # a smaller batch
+            else:
+                x_used = x
+            if i == 6:
+                eng.view("W_enc").mul_(1.01)                     # torch in-place: the version counter moves
+            if i == 8:
+                eng.view("b_enc").data.add_(0.01)                # a raw write ...
+                eng.params_touched()                             # ... announced
+            if i == 9:  # the phases instead of the fused step: their Adam leaves no images
+                eng.step_forward(x_used, training=True)
+                eng.step_dead(x_used.shape[0])
+                eng.step_backward()
+                eng.tail_prepare()
+                eng.tail_apply(1e-3, 1.0)
+            else:
+                eng.train_step(x_used, 1e-3, 1.0)
+        a, c = (e.read_stats() for e in engs)
+        assert a.mse == c.mse and a.dense_route == c.dense_route == 0, (i, a, c)
+        idx0, val0, _ = engs[0].last_codes(x_used.shape[0])
+        idx1, val1, _ = engs[1].last_codes(x_used.shape[0])
+        assert torch.equal(idx0, idx1) and torch.equal(val0, val1), i
+    torch.cuda.synchronize()
+    _same(*engs)
+
+
+def test_a_jump_in_the_data_takes_the_exact_route_and_recovers():
+    """The x images of a streamed step are scaled with the previous batch's maximum and centred on its mean.  A batch a thousand
+    times larger leaves fp16's range: the step must notice and take the exact dense route; so does the first small batch after
+    the large ones (centred on THEIR mean, its margins keep every candidate).  Each costs one slow step, never a wrong code: the
+    run agrees with the fully prepared one to the rounding of the dense route's own fp32 summation order, and is back on the
+    fused route afterwards."""
+    d, s, k, b = 256, 2048, 16, 512
+    engs = [_engine(d, s, k, b, r, seed=7) for r in (0, 1)]
+    xs = _batches(d, b, 9, seed=8)
+    xs[3] = xs[3] * 1000.0 + 50.0
+    xs[4] = xs[4] * 1000.0 + 50.0
+    routes = []
+    for i, x in enumerate(xs):
+        for eng in engs:
+            eng.train_step(x, 1e-4, 1.0)
+        a, c = (e.read_stats() for e in engs)
+        routes.append(a.dense_route)
+        assert c.dense_route == 0 and math.isclose(a.mse, c.mse, rel_tol=1e-5), (i, a, c)
+        (i0, v0, _), (i1, v1, _) = (e.last_codes(b) for e in engs)
+        assert (i0 != i1).float().mean().item() <= 1e-3, i
+    assert routes[:3] == [0, 0, 0] and routes[3] == 1 and routes[-2:] == [0, 0] and sum(routes) <= 3, routes
+    torch.cuda.synchronize()
+    for name in ("params", "adam_m"):
+        p0, p1 = getattr(engs[0], name), getattr(engs[1], name)
+        bad = ~torch.isclose(p0, p1, rtol=1e-3, atol=1e-6 * p1.abs().max().item())
+        assert bad.float().mean().item() <= 1e-3, f"{name}: {bad.sum().item()} of {bad.numel()} elements apart"
+
+
+def test_streamed_step_with_non_finite_input_matches_the_full_preparation():
+    d, s, k, b = 128, 1024, 8, 256
+    engs = [_engine(d, s, k, b, r, seed=9) for r in (0, 1)]
+    xs = _batches(d, b, 6, seed=10)
+    xs[2] = xs[2].clone()
+    xs[2][5, 7] = float("inf")
+    for i, x in enumerate(xs[:3]):
+        for eng in engs:
+            eng.step_forward(x, training=False) if i == 2 else eng.train_step(x, 1e-3, 1.0)
+        a, c = (e.read_stats() for e in engs)
+        assert a.dense_route == c.dense_route, (i, a, c)
+        for u, v in zip(engs[0].last_codes(b)[:2], engs[1].last_codes(b)[:2]):
+            assert torch.equal(u, v), i
+    for x in xs[3:]:  # and finite batches after it run fused again, identically
+        for eng in engs:
+            eng.train_step(x, 1e-3, 1.0)
+    a, c = (e.read_stats() for e in engs)
+    assert a.dense_route == c.dense_route == 0 and a.mse == c.mse
+    _same(*engs)
+
+
+def test_train_step_gather_equals_gather_then_train_step():
+    """saev_train_step_gather: the batch is drawn from the pool by the step's first kernel (which leaves it as a contiguous
+    matrix on its way) -- same parameters as saev_gather_rows followed by saev_train_step, on the streamed and the full route."""
+    d, s, k, b = 256, 2048, 16, 1024
+    pool = torch.cat(_batches(d, b, 6, seed=11))
+    g = torch.Generator().manual_seed(12)
+    for route in (0, 1):
+        e0, e1 = (_engine(d, s, k, b, route, seed=13) for _ in range(2))
+        for i in range(6):
+            rows = torch.randperm(pool.shape[0], generator=g)[:b].cuda()
+            x = e0.train_step_gather(pool, rows, 1e-3, 1.0)
+            assert torch.equal(x, pool[rows])
+            e1.train_step(e1.gather_rows(pool, rows), 1e-3, 1.0)
+            assert e0.read_stats().mse == e1.read_stats().mse
+        torch.cuda.synchronize()
+        _same(e0, e1, f"route {route}")

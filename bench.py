@@ -152,6 +152,151 @@ def other_config_record(dev, *, name, d, s, k, b, encoder, n_prefixes=1, steps=1
     return rec
 
 
+def vendor_gemm_record(dev, b=BATCH, d=D_MODEL, s=D_SAE, launches=200):
+    """Anchor for the encoder's first pass (measurement only -- nothing in the product path calls a library GEMM): what the vendor
+    fp16 GEMM (torch.matmul -> hipBLASLt) reaches on THIS box for the encoder's own contraction, `launches` back-to-back launches
+    timed with HIP events so that the power controller has settled; random operands at the scale of the encoder's images, both
+    layouts of W, and all-zero operands (same instruction stream, clock not power-limited: the gap is the power limit)."""
+    out = {"shape": [b, d, s], "launches": launches, "dtype": "fp16 operands, fp32 accumulate, fp16 output (1 GB written; the encoder's fused "
+                                                              "TopK epilogue writes ~8 KB of candidates per row instead)"}
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = (torch.randn(b, d, device=dev, generator=g) * 4096).half()
+    w = (torch.randn(d, s, device=dev, generator=g) * 256).half()
+    y = torch.empty(b, s, device=dev, dtype=torch.float16)
+    for name, xo, wo in (("random_nn", x, w), ("random_nt", x, w.t().contiguous().t()), ("zeros_nt", torch.zeros_like(x), torch.zeros_like(w).t().contiguous().t())):
+        for _ in range(20):
+            torch.matmul(xo, wo, out=y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(launches):
+            torch.matmul(xo, wo, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / launches
+        out[name] = {"ms": ms, "tflops": 2.0 * b * d * s / ms / 1e9}
+    del x, w, y
+    torch.cuda.empty_cache()
+    out["tflops"] = max(out["random_nn"]["tflops"], out["random_nt"]["tflops"])
+    return out
+
+
+def synthetic_pool(dev, kind, n_rows, d, seed=17):
+    """Activation pools of the three data regimes of SURVEY.md 8d.  "mean": x = z + mu with a per-dimension mean (the throughput
+    data: the headline); "isotropic": x = z; "lowrank": x = A s + 0.1 eps with A (d x 4d) unit columns and s 16-sparse with exp(1)
+    magnitudes (the parity data: TopK is meaningful, some latents die)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    if kind == "mean":
+        return torch.randn(n_rows, d, device=dev, generator=g) + torch.randn(d, device=dev, generator=torch.Generator(device=dev).manual_seed(17))
+    if kind == "isotropic":
+        return torch.randn(n_rows, d, device=dev, generator=g)
+    assert kind == "lowrank"
+    A = torch.randn(4 * d, d, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    A /= A.norm(dim=1, keepdim=True)
+    out = torch.empty(n_rows, d, device=dev)
+    for lo in range(0, n_rows, 8192):
+        n = min(8192, n_rows - lo)
+        idx = torch.randint(0, 4 * d, (n, 16), device=dev, generator=g)
+        mag = -torch.log(torch.rand(n, 16, device=dev, generator=g).clamp_min(1e-12))
+        out[lo:lo + n] = torch.einsum("nk,nkd->nd", mag, A[idx]) + 0.1 * torch.randn(n, d, device=dev, generator=g)
+    return out
+
+
+def data_regime_record(dev, kind, *, pretrain=1500, steps=40, pool_batches=16):
+    """configs[1] on another data regime: the same loop as the headline (draw from a pool + train step), steady state."""
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    eng = SaeEngine(EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=BATCH, aux_dead_cap=4096), dev)
+    g = torch.Generator(device=dev).manual_seed(42)
+    W = (torch.rand(D_SAE, D_MODEL, device=dev, generator=g) * 2 - 1) * math.sqrt(6.0 / D_MODEL)
+    W /= W.norm(dim=1, keepdim=True)
+    eng.view("W_dec").copy_(W)
+    eng.view("W_enc").copy_(W.t())
+    del W
+    pool = synthetic_pool(dev, kind, pool_batches * BATCH, D_MODEL)
+    perm = torch.randperm(pool.shape[0], device=dev, generator=g)
+    x = torch.empty(BATCH, D_MODEL, device=dev)
+
+    def one(i):
+        eng.train_step_gather(pool, perm[(i % pool_batches) * BATCH:(i % pool_batches + 1) * BATCH], 4e-4 * min(1.0, i / 500), 1.0, out=x)
+
+    for i in range(pretrain):
+        one(i)
+    eng.enable_kernel_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(pretrain, pretrain + steps):
+        one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.read_stats()
+    rec = {"data": kind, "pretrain_steps": pretrain, "steps": steps, "ms_per_step": dt / steps * 1e3, "activations_per_sec": BATCH * steps / dt,
+           "encoder_kernel_ms": eng.encoder_ms(), "mse_last": st.mse, "n_dead_last": st.n_dead, "aux_route_last": eng.aux_route(),
+           "dense_route": st.dense_route, "cand_max": st.cand_max}
+    eng.close()
+    del eng, pool
+    torch.cuda.empty_cache()
+    return rec
+
+
+def train_e2e_record(dev, *, steps=400, pool_batches=32):
+    """What a USER of the package gets: framework.train.train() (loader, limiter, lr schedule, per-step Python) on a resident pool
+    at configs[1]'s shape against the bare engine loop on the same pool from the same initial weights, both from random init."""
+    import saev_amd.utils.scheduling as sched
+    from saev_amd import data, nn
+    from saev_amd.engine import EngineConfig, SaeEngine
+    from saev_amd.framework import train as T
+    from saev_amd.nn import modeling, objectives
+
+    pool = synthetic_pool(dev, "mean", pool_batches * BATCH, D_MODEL)
+    dcfg = data.ShuffledConfig(batch_size=BATCH, seed=17)
+    cfg = T.Config(train_data=dcfg, val_data=dcfg, n_train=steps * BATCH, n_val=BATCH,
+                   sae=nn.SparseAutoencoderConfig(d_model=D_MODEL, d_sae=D_SAE, reinit_blend=0.0, activation=modeling.TopK(top_k=TOP_K)),
+                   objective=objectives.Matryoshka(n_prefixes=1), log_every=10**9, track=False, runs_root=pathlib.Path("/tmp/saev_bench_runs"))
+    t_loop = {}
+    orig_iter = sched.BatchLimiter.__iter__
+
+    def timed_iter(self, _orig=orig_iter, _t=t_loop):
+        torch.cuda.synchronize()
+        _t["t0"] = time.perf_counter()
+        yield from _orig(self)
+
+    sched.BatchLimiter.__iter__ = timed_iter
+    try:
+        saes, objs, run, n_steps = T.train([cfg], train_pool=pool)
+    finally:
+        sched.BatchLimiter.__iter__ = orig_iter
+    torch.cuda.synchronize()
+    dt_train = time.perf_counter() - t_loop["t0"]
+    del saes, objs
+    torch.cuda.empty_cache()
+    # the bare loop: same shapes, same lr ramp, same pool
+    eng = SaeEngine(EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=BATCH), dev)
+    torch.manual_seed(cfg.seed)
+    ref = nn.SparseAutoencoder(cfg.sae)
+    eng.load_params({k: v.detach() for k, v in ref.state_dict().items()})
+    g = torch.Generator(device=dev).manual_seed(1)
+    perm = torch.randperm(pool.shape[0], device=dev, generator=g)
+    x = torch.empty(BATCH, D_MODEL, device=dev)
+    sched_lr = sched.WarmupCosine(0.0, cfg.n_lr_warmup, cfg.lr, n_steps, 0.0)
+    lr = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        eng.train_step_gather(pool, perm[(i % pool_batches) * BATCH:(i % pool_batches + 1) * BATCH], lr, cfg.grad_clip, out=x)
+        lr = sched_lr.step()
+    torch.cuda.synchronize()
+    dt_loop = time.perf_counter() - t0
+    eng.close()
+    del eng, pool
+    torch.cuda.empty_cache()
+    return {"steps": n_steps, "train_ms_per_step": dt_train / n_steps * 1e3, "train_activations_per_sec": BATCH * n_steps / dt_train,
+            "engine_loop_ms_per_step": dt_loop / n_steps * 1e3, "train_over_engine_loop": dt_loop / dt_train,
+            "feed": "resident pool of 32 batches, seeded permutation per epoch (data.ShuffledDataLoader), batch drawn inside the step",
+            "note": "framework.train.train() end to end (first steps from random init, no log step in the window) against the bare "
+                    "SaeEngine.train_step_gather loop on the same pool; tools/bench_train_e2e.py has the streaming feed from a shard directory"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,11 +338,22 @@ def main():
     ap.add_argument("--extract-e2e", action="store_true",
                     help="add the `extract_e2e` sub-record: configs[4] on one GPU -- ViT-L/14-shaped transformer forward (random init, "
                          "bf16 autocast) -> hooks -> device reservoir -> SAE train steps, no disk in between")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `vendor_gemm`, `data_regimes` and `train_e2e` sub-records (profiling runs)")
     ap.add_argument("--no-busbw", action="store_true", help="skip the `collectives` sub-record (RCCL bus bandwidth of the step's collectives)")
     ap.add_argument("--n-saes", type=int, default=1,
                     help="train this many SAEs on every batch (the reference's parallel groups); the extra ones differ in "
                          "parameters only and share the first one's x statistics / operand images.  value still counts each batch once")
+    ap.add_argument("--shape", default=None,
+                    help="d_model,d_sae,top_k of a TOY run (rehearsals of the multi-rank code path on one device, e.g. "
+                         "--shape 256,2048,16 --batch 256 --backend gloo --same-device): the line then says so in config.workload "
+                         "and carries none of the sub-records that are sized for configs[1]")
     args = ap.parse_args()
+    global D_MODEL, D_SAE, TOP_K
+    toy = args.shape is not None
+    if toy:
+        D_MODEL, D_SAE, TOP_K = (int(v) for v in args.shape.split(","))
+        args.no_other_configs = args.no_extras = args.no_auxk_probe = args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -393,6 +549,11 @@ def main():
                                        sparse_bytes_per_rank=sparse_rows * (8 * D_MODEL + 8 * TOP_K))
         collectives["note"] = ("RCCL on the live communicator, mean of 5 after 2 warm-up calls, max over ranks; busbw = algbw x 2(n-1)/n (all-reduce) "
                                "or x (n-1)/n (reduce-scatter / all-gather); the sparse step state is sized for 2 048 rows per rank")
+    vendor_gemm = data_regimes = train_e2e = None
+    if world == 1 and not args.no_extras and B == BATCH:
+        vendor_gemm = vendor_gemm_record(dev)
+        data_regimes = [data_regime_record(dev, kind) for kind in ("isotropic", "lowrank")]
+        train_e2e = train_e2e_record(dev)
     extract_e2e = None
     if world == 1 and args.extract_e2e:
         from tools.bench_extract_e2e import run as extract_run
@@ -449,7 +610,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": dtype_name,
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: d_in={D_MODEL}, d_sae={D_SAE} (32x), k={TOP_K}, batch={B}/GPU, "
+            "config": {"workload": ("TOY SHAPE (rehearsal, not BASELINE's workload): " if toy else "configs[1]: ") +
+                                   f"d_in={D_MODEL}, d_sae={D_SAE} ({D_SAE // D_MODEL}x), k={TOP_K}, batch={B}/GPU, "
                                    "TopK SAE train step incl. AuxK bookkeeping + Adam, pool of 64 batches",
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder": eng.cfg.encoder, "n_saes": args.n_saes,
                        "weight_gradients": ("whole-row gathers (dw_rows)" if os.environ.get("SAEV_AMD_DW") == "rows" or D_MODEL % 32 != 0
@@ -486,6 +648,13 @@ def main():
             out["auxk_active"] = auxk_active
         if other_configs is not None:
             out["other_configs"] = other_configs
+        if vendor_gemm is not None:
+            roof["vendor_gemm_tflops"] = vendor_gemm["tflops"]
+            roof["vendor_gemm"] = vendor_gemm
+        if data_regimes is not None:
+            out["data_regimes"] = data_regimes
+        if train_e2e is not None:
+            out["train_e2e"] = train_e2e
         if extract_e2e is not None:
             out["extract_e2e"] = extract_e2e
         if collectives is not None:

@@ -149,7 +149,8 @@ typedef struct {
     int32_t dead_lag;      /* saev_step_dead sizes the auxiliary work from the tracker record of this many steps ago
                               (0 = 4, at most 8): shorter = tighter bound of the dead count, longer = more host run-ahead  */
     int32_t csc_route;     /* latent-major pair list of the backward: 0 = the training decode sets the (latent, row) bits of the
-                              build's bit map while it holds the codes, 1 = the build's own fill pass always                 */
+                              build's bit map while it holds the codes, 1 = the build's own fill pass always, 2 = as 0 with the
+                              round-4 scan (two launches) instead of the single look-back scan                               */
     int32_t fin_route;     /* end of the column-slice backward: 0 = one launch; the projection coefficient comes from the pair lists
                               (<dW_dec[i], w_i> = sum val * dval) and ||w||^2 from normalize_rows, the decoder rows are not read,
                               1 = the round-4 kernels (dw_finalize, dw_finalize_cut, dw_clear_bitmap: three launches, every

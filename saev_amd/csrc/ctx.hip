@@ -62,6 +62,7 @@ struct saev_ctx {
     uint32_t* bitmap = nullptr;
     int32_t* grp_prefix = nullptr;
     int32_t* scan_totals = nullptr;
+    int32_t csc_epoch = 0;  // CscArgs::epoch of the last build
     int bitmap_words = 0;
     int back_rows = 0;  // max(max_batch, max_backward_rows): rows a (gathered) backward may cover
     int bitmap_words_last = 0;
@@ -364,7 +365,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     c->bitmap_words = (int)(((MBB + 31) / 32 + 7) / 8 * 8);
     A(bitmap, S * c->bitmap_words);
     A(grp_prefix, S * (c->bitmap_words / 8));
-    A(scan_totals, ((S + 1023) / 1024) * 3);
+    A(scan_totals, ((S + 1023) / 1024) * 4);
     A(counts, S); A(starts, S + 1); A(pairs, MBB * K); A(dval_pairs, MBB * (size_t)cfg->top_k);
     {
         const long max_pairs = MBB * K;
@@ -431,6 +432,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     hipMemset(c->fired, 0, S * sizeof(int32_t));
     hipMemset(c->dead, 0, S * sizeof(int32_t));
     hipMemset(c->flags, 0, 16 * sizeof(int32_t));
+    hipMemset(c->scan_totals, 0, ((S + 1023) / 1024) * 4 * sizeof(int32_t));  // (no workgroup's "ready" word equals a build's epoch)
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
     hipMemset(c->stats_scratch, 0, STATS_SCRATCH_DOUBLES * sizeof(double));
     hipMemset(c->tickets, 0, 8 * sizeof(int));
@@ -1148,7 +1150,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     // (slice-major copies for the weight gradients: dL/dx_hat always from the decode, x only when split_f16r has not left one)
     if (training && c->dws_ok && (c->P == 1 || c->GS != nullptr)) { a.gS = c->P == 1 ? c->gS : c->GS; a.xS = c->fwd_step ? nullptr : c->xS; c->dws_rows = n; }
     // (... and the products dval, from the decoder rows while the decode holds them in registers)
-    if (c->dws_rows == n && c->dval_rows != nullptr) { a.dval_out = c->dval_rows; c->dval_fwd = true; }
+    if (c->dws_rows == n && c->dval_rows != nullptr && (c->P == 1 || decode_matry_forms_dval(D, K))) { a.dval_out = c->dval_rows; c->dval_fwd = true; }
     // The decode reads every code anyway: it sets the (latent, row) bits of the backward's pair-list build (0.5 M scattered atomics
     // that csc_fill paid 35 us for on their own), provided the bit map is clean at this row pitch -- the previous full backward
     // cleared it behind itself -- and this context's backwards run over its own rows.
@@ -1566,6 +1568,8 @@ int saev_backward_begin(saev_ctx* c, void* stream) {
         HIPCHK(c, launch_slice_major_copy(c->ov_g, c->ov_x, n, D, c->gS, c->xS_bwd, s));
         c->dws_rows = 0;  // (the copies no longer describe the forward's own rows)
     }
+    c->csc_epoch = c->csc_epoch == 0x7fffffff ? 1 : c->csc_epoch + 1;
+    a.epoch = c->dbg.csc_route == 2 ? 0 : c->csc_epoch;  // (csc_route 2: the two-launch scan)
     if (c->dws_pairs) {
         a.zero_word = c->cut_list;
         a.pv = c->pv; a.plat = c->plat; a.val = ov ? c->ov_val : c->val;

@@ -167,7 +167,8 @@ struct DecodeArgs {
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 // whether launch_decode forms dval_out for this shape (otherwise the pointer is ignored and pass A forms the products)
-bool decode_forms_dval(int D, int k);
+bool decode_forms_dval(int D, int k);        // plain decode: top_k <= 64 (two register halves above 32), d_model 256 .. 1280
+bool decode_matry_forms_dval(int D, int k);  // Matryoshka decode: top_k <= 32, d_model <= 1024
 // The same decode out of 32-column slices of W_dec that an XCD's L2 holds (decode_s_kernel + decode_s_finish_kernel): the route of a
 // training step whose normalize_rows has just left the slice-major copy WdS.  part: per (slice, row) {sse_scaled, pad, sse64, sumsq64}
 // (n_slices x n_rows x 3 doubles), dvp: per slice the 32 dval shares of every row (pitch dvp_pitch floats per slice, >= n_rows * 32).
@@ -221,6 +222,8 @@ struct CscArgs {
     int P;                  // (with pv) Matryoshka: the pair word carries the virtual row p(latent) * n_rows + row; <= 1: plain
     int32_t cuts[16];       // MAX_PREFIXES
     int32_t* zero_word;     // optional: set to 0 by the build (DwSlicesArgs::cut_list's counter)
+    int32_t epoch;          // != 0: one scan launch with look-back; scan_totals then holds 4 words per 1 024 latents, the last the
+                            // epoch of the build that wrote them (a value no earlier build of this context used)
 };
 // bitmap_clean: the whole bit map is known to be zero (dw_combine_kernel cleared it after the previous build)
 // colsum_*: optional column sums out[d] = sum_b m[b][d] (b < a.n_rows; partials: ceil(n_rows / 64) * D floats) computed in the

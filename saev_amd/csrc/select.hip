@@ -996,7 +996,15 @@ __global__ __launch_bounds__(256) void pre_encode2_kernel(PreEncode2Args a) {
         const int d = ((int)blockIdx.x - a.nb_rows) * 256 + threadIdx.x;
         if (d >= a.D || !a.update_mu) return;
         float t = 0.f;
-        for (int b = 0; b < a.n_rowblk; ++b) t += a.col_part[(size_t)b * a.D + d];
+        int b = 0;
+        for (; b + 8 <= a.n_rowblk; b += 8) {  // (eight loads in flight, added in block order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.col_part[(size_t)(b + u) * a.D + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; b < a.n_rowblk; ++b) t += a.col_part[(size_t)b * a.D + d];
         t *= a.inv_n;
         if (t - t == 0.f) a.mu[d] = t;  // (a non-finite column sum -- an inf / NaN in the batch -- keeps the old centre: any vector is valid)
         return;
@@ -1034,7 +1042,15 @@ __global__ __launch_bounds__(256) void pre_encode2_kernel(PreEncode2Args a) {
     const float up = a.scales[4];  // (the normaliser xprep_kernel used)
     const float back = (up > 0.f && up < 3.0e38f) ? up : 1.0f;
     float s2 = 0.f, d2 = 0.f;
-    for (int ks = 0; ks < a.nks; ++ks) {  // (image order: fixed)
+    int ks = 0;
+    for (; ks + 8 <= a.nks; ks += 8) {  // (image order: fixed; eight loads in flight)
+        float2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const float2*>(a.xn_part)[(size_t)(ks + u) * a.n_pad + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s2 += t[u].x; d2 += t[u].y; }
+    }
+    for (; ks < a.nks; ++ks) {
         const float2 t = reinterpret_cast<const float2*>(a.xn_part)[(size_t)ks * a.n_pad + i];
         s2 += t.x; d2 += t.y;
     }

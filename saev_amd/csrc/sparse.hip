@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
 // decode_kernel with the row spread over NW = D / 256 waves (one float4 of the row per lane) and ALL k <= 32 decoder rows of the
 // codes held in registers (32 float4 per lane) until dL/dx_hat is known: dval_j = <g, W_dec[idx_j]> then costs no second gather
 // and no W_dec slices in the backward's pass A (DwSlicesArgs::have_dval).  x_hat is accumulated in code order, as decode_kernel does.
-template <int NW>
+template <int NW, int KH>  // KH = 1: k <= 32 codes; 2: k <= 64, in two halves of 32 decoder rows
 __global__ __launch_bounds__(64 * NW) void decode_q_kernel(DecodeArgs a) {
-    __shared__ float sh_dv[NW][32];
+    __shared__ float sh_dv[NW][32 * KH];
     __shared__ float sh_f[NW];
     __shared__ double sh_d[NW][2];
     const int lane = threadIdx.x & 63;
@@ -200,25 +200,29 @@ __global__ __launch_bounds__(64 * NW) void decode_q_kernel(DecodeArgs a) {
     f32x4 acc = reinterpret_cast<const f32x4*>(a.b_dec)[q];
     const f32x4 xv = reinterpret_cast<const f32x4*>(a.x + (size_t)row * a.D)[q];
     __builtin_amdgcn_sched_barrier(0);
-    // all 32 gathers in flight together (an absent code reads row 0 and is not used): buffer loads with the row offset in an SGPR
-    // and one lane offset -- written as address arithmetic hipcc forms 64-bit VGPR addresses and sinks the loads into the sum
+    // all 32 gathers of a half in flight together (an absent code reads row 0 and is not used): buffer loads with the row offset in
+    // an SGPR and one lane offset -- written as address arithmetic hipcc forms 64-bit VGPR addresses and sinks the loads into the sum
     // below, eight in flight
     typedef int i32x4_ __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W_dec), 0, (uint32_t)a.S * (uint32_t)(D4 * 16), 0x00020000);
     const uint32_t voff = (uint32_t)q * 16u;
     f32x4 wv[32];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const int i = __builtin_amdgcn_readlane(my_i, j);
-        const i32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(wres, voff, (uint32_t)max(i, 0) * (uint32_t)(D4 * 16), 0);
-        wv[j] = f32x4{__int_as_float(t[0]), __int_as_float(t[1]), __int_as_float(t[2]), __int_as_float(t[3])};
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int h = 0; h < KH; ++h) {  // x_hat in code order: half 0, then half 1
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const int i = __builtin_amdgcn_readlane(my_i, j);
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw_v), j));
-        if (i >= 0) acc += v * wv[j];
+        for (int j = 0; j < 32; ++j) {
+            const int i = __builtin_amdgcn_readlane(my_i, 32 * h + j);
+            const i32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(wres, voff, (uint32_t)max(i, 0) * (uint32_t)(D4 * 16), 0);
+            wv[j] = f32x4{__int_as_float(t[0]), __int_as_float(t[1]), __int_as_float(t[2]), __int_as_float(t[3])};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int i = __builtin_amdgcn_readlane(my_i, 32 * h + j);
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw_v), 32 * h + j));
+            if (i >= 0) acc += v * wv[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (a.x_hat) reinterpret_cast<f32x4*>(a.x_hat + (size_t)row * a.D)[q] = acc;
     const float u = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
@@ -242,12 +246,25 @@ __global__ __launch_bounds__(64 * NW) void decode_q_kernel(DecodeArgs a) {
             if (a.xS != nullptr) reinterpret_cast<f32x4*>(a.xS)[o] = xv;
         }
     }
-    {
+    // dval_j = <g, W_dec[idx_j]>: the rows of the LAST half are still in registers; an earlier half (k > 32) is gathered once more
+    // (96 row gathers per activation row instead of the 128 of a decode that forgets the rows plus a backward pass that re-reads them)
+#pragma unroll
+    for (int hh = 0; hh < KH; ++hh) {
+        const int h = KH - 1 - hh;
+        if (hh > 0) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int i = __builtin_amdgcn_readlane(my_i, 32 * h + j);
+                const i32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(wres, voff, (uint32_t)max(i, 0) * (uint32_t)(D4 * 16), 0);
+                wv[j] = f32x4{__int_as_float(t[0]), __int_as_float(t[1]), __int_as_float(t[2]), __int_as_float(t[3])};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float pd[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) pd[j] = (g[0] * wv[j][0] + g[1] * wv[j][1]) + (g[2] * wv[j][2] + g[3] * wv[j][3]);
         const float r = wave_reduce_scatter32(pd, lane);  // lane l: the wave's sum of pd[(l >> 1) & 31]
-        if ((lane & 1) == 0) sh_dv[w][lane >> 1] = r;
+        if ((lane & 1) == 0) sh_dv[w][32 * h + (lane >> 1)] = r;
     }
     sse_scaled = wave_sum(sse_scaled);
     sse64 = wave_sum_d(sse64);
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void decode_q_kernel(DecodeArgs a) {
     if (lane == 0) { sh_f[w] = sse_scaled; sh_d[w][0] = sse64; sh_d[w][1] = sumsq64; }
     __syncthreads();
     if (w != 0) return;
-    if (lane < 32) {
+    if (lane < 32 * KH) {
         float s = sh_dv[0][lane];
 #pragma unroll
         for (int v = 1; v < NW; ++v) s += sh_dv[v][lane];
@@ -1562,7 +1579,7 @@ __device__ __forceinline__ void colsum_final_plain(const ColsumPlain& c, int bid
     const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int d = bid * 64 + col;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (d < c.D) {
+    if (d < c.D && slice < 4) {
         int b = slice;
         for (; b + 12 < c.n_blocks; b += 16) {
             s0 += c.partials[(size_t)b * c.D + d];
@@ -1572,13 +1589,84 @@ __device__ __forceinline__ void colsum_final_plain(const ColsumPlain& c, int bid
         }
         for (; b < c.n_blocks; b += 4) s0 += c.partials[(size_t)b * c.D + d];
     }
-    part[slice][col] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
+    if (slice < 4) part[slice][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();  // (every thread of the workgroup comes through here: in a wider workgroup, waves past the fourth idle along)
     if (slice == 0 && d < c.D) c.out[d] = ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col])) * 1.0f;
+}
+// The two scan launches in one (decoupled look-back): a workgroup scans its 1 024 latents, publishes its three totals and then the
+// build's epoch as the "ready" word, and adds up the totals of the workgroups before it as they appear -- at most 80 workgroups of
+// 1 024 threads (d_sae <= 81 920), all resident at once, so the wait cannot deadlock.  Same sums in the same order as
+// csc_scan_block_kernel + csc_scan_offset_kernel.  Workgroups past the scan finish the build's column sums (colsum_final_plain).
+__global__ __launch_bounds__(1024) void csc_scan_fused_kernel(CscArgs a, int n_scan, ColsumPlain c, int have_colsum) {
+    __shared__ int wave_tot[16][3];
+    __shared__ int base[3];
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if ((int)blockIdx.x >= n_scan) {
+        if (have_colsum) colsum_final_plain(c, (int)blockIdx.x - n_scan, part);  // (block-uniform: all 1 024 threads reach its barrier)
+        return;
+    }
+    const int blk = blockIdx.x;
+    const int i = blk * 1024 + tid;
+    int v[3] = {0, 0, 0};
+    if (i < a.S) {
+        const int cn = a.counts[i];
+        const int nch = (cn + DW_CHUNK - 1) / DW_CHUNK;
+        v[0] = cn; v[1] = max(1, nch); v[2] = nch > 1 ? nch : 0;
+    }
+    int incl[3] = {v[0], v[1], v[2]};
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int n = __shfl_up(incl[q], o, 64);
+            if (lane >= o) incl[q] += n;
+        }
+    }
+    if (lane == 63)
+        for (int q = 0; q < 3; ++q) wave_tot[w][q] = incl[q];
+    __syncthreads();
+    int off[3] = {0, 0, 0};
+    for (int j = 0; j < w; ++j)
+        for (int q = 0; q < 3; ++q) off[q] += wave_tot[j][q];
+    int32_t* const agg = a.scan_totals;  // [workgroup][4]: three totals, then the epoch of the build that wrote them
+    if (tid == 1023) {
+        for (int q = 0; q < 3; ++q) __hip_atomic_store(&agg[blk * 4 + q], off[q] + incl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&agg[blk * 4 + 3], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {  // first wave: the totals of the workgroups before this one, each as soon as it is there
+        int s3[3] = {0, 0, 0};
+        for (int b = lane; b < blk; b += 64) {
+            while (__hip_atomic_load(&agg[b * 4 + 3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) __builtin_amdgcn_s_sleep(1);
+            for (int q = 0; q < 3; ++q) s3[q] += __hip_atomic_load(&agg[b * 4 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int q = 0; q < 3; ++q) s3[q] = wave_sum_i(s3[q]);
+        if (lane == 0)
+            for (int q = 0; q < 3; ++q) base[q] = s3[q];
+    }
+    __syncthreads();
+    if (i < a.S) {
+        a.starts[i] = base[0] + off[0] + incl[0] - v[0];
+        if (a.chunk_starts) {
+            a.chunk_starts[i] = base[1] + off[1] + incl[1] - v[1];
+            a.part_starts[i] = base[2] + off[2] + incl[2] - v[2];
+        }
+    }
+    if (blk == n_scan - 1 && tid == 1023) {
+        if (a.zero_word != nullptr) *a.zero_word = 0;
+        a.starts[a.S] = base[0] + off[0] + incl[0];
+        if (a.chunk_starts) a.chunk_starts[a.S] = base[1] + off[1] + incl[1];
+    }
 }
 __global__ __launch_bounds__(256) void csc_fill_colsum_kernel(CscArgs a, int n_fill, ColsumPlain c) {
     if ((int)blockIdx.x < n_fill) csc_fill_body(a, blockIdx.x, n_fill);
     else colsum_partial_plain(c, blockIdx.x - n_fill);
+}
+// (prefilled builds: nothing to fill, so the column sums' FIRST stage rides here and their second in the scan launch)
+__global__ __launch_bounds__(256) void csc_count_colpart_kernel(CscArgs a, int n_count, ColsumPlain c) {
+    // (the few long-running column-sum workgroups first: behind the 8 192 short count workgroups they ran alone at the end, 50 us)
+    if ((int)blockIdx.x < c.n_blocks) colsum_partial_plain(c, blockIdx.x);
+    else csc_count_body(a, blockIdx.x - c.n_blocks);
 }
 __global__ __launch_bounds__(256) void csc_count_colsum_kernel(CscArgs a, int n_count, ColsumPlain c) {
     __shared__ float part[4][64];
@@ -1795,16 +1883,22 @@ __global__ __launch_bounds__(256) void decode_s_finish_kernel(DecodeSliceArgs s)
 
 }  // namespace
 
-bool decode_forms_dval(int D, int k) { return k <= 32 && D % 256 == 0 && D >= 256 && D <= 1024; }
+bool decode_forms_dval(int D, int k) { return k <= 64 && D % 256 == 0 && D >= 256 && D <= 1280; }
+bool decode_matry_forms_dval(int D, int k) { return k <= 32 && D % 256 == 0 && D >= 256 && D <= 1024; }
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
     if (a.dval_out != nullptr && a.x != nullptr && decode_forms_dval(a.D, a.k)) {
+#define DQ(NW)                                                                                                             \
+    if (a.k <= 32) hipLaunchKernelGGL((decode_q_kernel<NW, 1>), dim3(a.n_rows), dim3(64 * NW), 0, stream, a);              \
+    else hipLaunchKernelGGL((decode_q_kernel<NW, 2>), dim3(a.n_rows), dim3(64 * NW), 0, stream, a)
         switch (a.D / 256) {
-            case 1: hipLaunchKernelGGL(decode_q_kernel<1>, dim3(a.n_rows), dim3(64), 0, stream, a); break;
-            case 2: hipLaunchKernelGGL(decode_q_kernel<2>, dim3(a.n_rows), dim3(128), 0, stream, a); break;
-            case 3: hipLaunchKernelGGL(decode_q_kernel<3>, dim3(a.n_rows), dim3(192), 0, stream, a); break;
-            default: hipLaunchKernelGGL(decode_q_kernel<4>, dim3(a.n_rows), dim3(256), 0, stream, a); break;
+            case 1: DQ(1); break;
+            case 2: DQ(2); break;
+            case 3: DQ(3); break;
+            case 4: DQ(4); break;
+            default: DQ(5); break;
         }
+#undef DQ
         return hipGetLastError();
     }
     return dispatch_nv(a.D, [&](auto nv) {
@@ -1826,7 +1920,7 @@ hipError_t launch_decode_slices(const DecodeSliceArgs& a, hipStream_t stream) {
 }
 hipError_t launch_decode_matry(const DecodeArgs& a, const MatryArgs& m, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
-    if (a.dval_out != nullptr && a.x != nullptr && a.training && decode_forms_dval(a.D, a.k)) {
+    if (a.dval_out != nullptr && a.x != nullptr && a.training && decode_matry_forms_dval(a.D, a.k)) {
         const size_t smem = (size_t)m.P * a.D * sizeof(float);  // <= 64 KB (P <= 16, D <= 1024), next to < 1 KB of static LDS
         static bool attr_set = false;
         if (!attr_set) {
@@ -1858,17 +1952,28 @@ hipError_t launch_csc_build(const CscArgs& a, hipStream_t stream, bool bitmap_cl
     const int blocks = prefilled ? 0 : (int)std::min<long>((n + 255) / 256, 4096);
     const int place_blocks = (int)std::min<long>((std::max<long>(n, a.S) + 255) / 256, 8192);
     if (!bitmap_clean && !prefilled) hipLaunchKernelGGL(csc_clear_kernel, dim3(2048), dim3(256), 0, stream, a);
-    if (colsum_m != nullptr) {  // out[d] = sum_b m[b][d] over the same n_rows rows, in the same two launches
-        ColsumPlain c{colsum_m, a.n_rows, colsum_D, colsum_partials, colsum_row_stride > 0 ? colsum_row_stride : (long)colsum_D,
-                      colsum_out, (a.n_rows + 63) / 64};
+    const int n_scan = (a.S + 1023) / 1024;
+    ColsumPlain c{colsum_m, a.n_rows, colsum_D, colsum_partials, colsum_row_stride > 0 ? colsum_row_stride : (long)colsum_D,
+                  colsum_out, (a.n_rows + 63) / 64};
+    int colsum_in_scan = 0;
+    if (colsum_m != nullptr && prefilled && a.epoch != 0) {
+        // the bits are there already: count + first stage of the column sums, then scan + their second stage -- three launches in all
+        hipLaunchKernelGGL(csc_count_colpart_kernel, dim3((a.S + 3) / 4 + c.n_blocks), dim3(256), 0, stream, a, (a.S + 3) / 4, c);
+        colsum_in_scan = 1;
+    } else if (colsum_m != nullptr) {  // out[d] = sum_b m[b][d] over the same n_rows rows, in the same two launches
         hipLaunchKernelGGL(csc_fill_colsum_kernel, dim3(blocks + c.n_blocks), dim3(256), 0, stream, a, blocks, c);
         hipLaunchKernelGGL(csc_count_colsum_kernel, dim3((a.S + 3) / 4 + (colsum_D + 63) / 64), dim3(256), 0, stream, a, (a.S + 3) / 4, c);
     } else {
         if (blocks > 0) hipLaunchKernelGGL(csc_fill_kernel, dim3(blocks), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(csc_count_kernel, dim3((a.S + 3) / 4), dim3(256), 0, stream, a);
     }
-    hipLaunchKernelGGL(csc_scan_block_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);
-    hipLaunchKernelGGL(csc_scan_offset_kernel, dim3((a.S + 1023) / 1024), dim3(1024), 0, stream, a);
+    if (a.epoch != 0 && n_scan <= 128) {
+        hipLaunchKernelGGL(csc_scan_fused_kernel, dim3(n_scan + (colsum_in_scan ? (colsum_D + 63) / 64 : 0)), dim3(1024), 0, stream, a, n_scan, c,
+                           colsum_in_scan);
+    } else {
+        hipLaunchKernelGGL(csc_scan_block_kernel, dim3(n_scan), dim3(1024), 0, stream, a);
+        hipLaunchKernelGGL(csc_scan_offset_kernel, dim3(n_scan), dim3(1024), 0, stream, a);
+    }
     hipLaunchKernelGGL(csc_place_kernel, dim3(place_blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -71,6 +71,7 @@ class DataLoader:
         self.drop_last = cfg.drop_last
         self.manager_pid = -1
         self.engine = engine
+        self.defer_gather = False  # resident mode: yield (pool, rows) and leave the row gather to the consumer's train step
         self._epoch = 0
         self._fds: dict[str, int] = {}
         self._fd_lock = threading.Lock()
@@ -310,6 +311,10 @@ class DataLoader:
             rows = perm[lo : lo + B]
             if rows.shape[0] < B and self.drop_last:
                 return
+            if self.defer_gather and self.engine is not None:
+                # the consumer draws the rows itself, inside its train step (SaeEngine.train_step_gather): "act" is what it gets back
+                yield {"act": None, "rows": rows, "pool": self.pool, "example_idx": self.example_idx[rows], "token_idx": self.token_idx[rows]}
+                continue
             if self.engine is not None:
                 act = self.engine.gather_rows(self.pool, rows)
             else:

@@ -164,7 +164,7 @@ class SaeEngine:
                 raise _lib.SaevError(f"saev_create failed with status {rc} for {cfg}")
             self.ctx = ctx
             self._chk(self.lib.saev_bind(ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v)), "saev_bind")
-            self._params_version = self.params._version
+            self._params_version = self._pversion()
             self._chk(self.lib.saev_bind_tracker(ctx, _ptr(self.toks_since_active), _ptr(self.fired)), "saev_bind_tracker")
             # the tail's sum of squares lives in a torch tensor from the start, so that a collective can reach it
             self.sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
@@ -237,10 +237,17 @@ class SaeEngine:
         it are noticed by themselves (torch's version counter, checked before every forward); writes that bypass it -- ``.data``,
         raw pointers, another library -- need this call."""
         self._chk(self.lib.saev_params_touched(self.ctx), "saev_params_touched")
-        self._params_version = self.params._version
+        self._params_version = self._pversion()
+
+    def _pversion(self):
+        try:
+            return self.params._version
+        except RuntimeError:  # a buffer created under torch.inference_mode() has no version counter: nothing to go by
+            return None
 
     def _note_param_writes(self) -> None:
-        if self.params._version != self._params_version:
+        v = self._pversion()
+        if v is None or v != self._params_version:
             self.params_touched()
 
     def _check_x(self, x: torch.Tensor) -> torch.Tensor:

@@ -238,19 +238,33 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
         scheds.append(scheduling.WarmupCosine(0.0, c.n_lr_warmup, c.lr, len(limiter), 0.0))
         lrs.append(0.0)  # first optimizer step is pure warm-up (train.py:118)
     dataloader.engine = steppers[0].engine
+    # One rank, a resident pool: the loader hands over (pool, row indices) and the first SAE's step draws the batch in its own
+    # first kernel (SaeEngine.train_step_gather) -- no gather pass, and for a single SAE the streamed preparation of the step.
+    if world == 1 and hasattr(dataloader, "defer_gather"):
+        dataloader.defer_gather = True
 
     global_step, n_patches_seen = 0, 0
     t_start = time.time()
     for batch in limiter:
         x = batch["act"]
-        n_patches_seen += len(x) * world
         log_now = (global_step + 1) % cfg.log_every == 0
+        drawn_by_step = False
+        if x is None:  # (deferred gather)
+            if log_now:
+                x = steppers[0].engine.gather_rows(batch["pool"], batch["rows"])
+            else:
+                drawn_by_step = True
+        n_patches_seen += (len(batch["rows"]) if x is None else len(x)) * world
         metrics = []
         for i, (sae, st, c) in enumerate(zip(saes, steppers, cfgs)):
             # Matryoshka cut points: sampled per SAE per step from torch's global CPU RNG, like the reference
             # (objectives.py:125); every rank draws the same sequence (same seed, same call order)
             if c.objective.n_prefixes > 1:
                 st.engine.set_prefixes(objectives.sample_prefixes(c.sae.d_sae, c.objective.n_prefixes))
+            if drawn_by_step and i == 0:
+                x = st.engine.train_step_gather(batch["pool"], batch["rows"], lrs[i], c.grad_clip)
+                lrs[i] = scheds[i].step()
+                continue
             if log_now:
                 pre = {}
                 st.train_step(x, lrs[i], c.grad_clip, pre_tail=lambda sae=sae, pre=pre, c=c: pre.update(_decoder_metrics(sae, c)))

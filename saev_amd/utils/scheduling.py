@@ -73,7 +73,7 @@ def rows_of(batch, nominal: int) -> int:
     tensors), else ``len(batch)``; ``nominal`` when neither gives a positive integer."""
     probe = batch
     if isinstance(batch, Mapping):
-        probe = next(iter(batch.values()), None)
+        probe = next((v for v in batch.values() if v is not None), None)  # (a deferred draw carries "act": None, then its row indices)
     if isinstance(probe, Sized):
         n = len(probe)
         if n > 0:

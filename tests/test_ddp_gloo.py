@@ -281,9 +281,10 @@ def _free_port():
 @pytest.mark.parametrize("world,overlap,tail,exchange", [(2, False, "replicated", "dense"), (2, True, "replicated", "dense"),
                                                          (2, False, "sharded", "dense"), (4, False, "sharded", "dense"),
                                                          (4, False, "replicated", "dense"), (2, False, "replicated", "sparse"),
-                                                         (4, False, "replicated", "sparse")])
+                                                         (4, False, "replicated", "sparse"), (8, False, "sharded", "dense"),
+                                                         (8, False, "replicated", "dense"), (8, False, "replicated", "sparse")])
 def test_ranks_reproduce_single_process_step(tmp_path, world, overlap, tail, exchange):
-    """2 (4) ranks x B/2 (B/4) rows == one process on B rows, for the all-reduce exchange (flat and bucketed / overlapped),
+    """2 (4, 8 -- the node size north_star names) ranks x B/2 (B/4, B/8) rows == one process on B rows, for the all-reduce exchange (flat and bucketed / overlapped),
     for the sharded tail (reduce-scatter -> tail on 1/world of the elements -> all-gather) and for the sparse-state exchange
     (all-gather of x / dL/dx_hat / codes, full backward on every rank, the auxiliary term's compact rows summed)."""
     out = str(tmp_path / "rank{rank}.pt")

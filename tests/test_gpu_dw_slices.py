@@ -259,7 +259,10 @@ def test_light_finalize_agrees_with_the_row_reading_one(d, s, k, b, n, kind, pre
     for i, (a, c) in enumerate(zip(*norms)):
         assert math.isclose(a, c, rel_tol=2e-6 if i < 3 else 2e-4), (norms[0], norms[1])
     assert engs[0].read_stats().n_dead == engs[1].read_stats().n_dead
+    # (the parameters after five free-running steps: a code that flipped in a later step moves its latent's rows by a whole
+    # Adam step of either sign, so the bulk must agree closely and the rest stay within a few learning rates)
     for name in ("params", "adam_m", "adam_v"):
         p0, p1 = getattr(engs[0], name), getattr(engs[1], name)
         bad = ~torch.isclose(p0, p1, rtol=1e-4, atol=1e-7 * p1.abs().max().item())
-        assert bad.float().mean().item() <= 1e-3, f"{name}: {bad.sum().item()} of {bad.numel()} elements apart"
+        assert bad.float().mean().item() <= 2e-2, f"{name}: {bad.sum().item()} of {bad.numel()} elements apart"
+    assert (engs[0].params - engs[1].params).abs().max().item() <= 5 * 1e-3

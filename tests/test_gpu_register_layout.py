@@ -47,6 +47,13 @@ def _teacher_forced_step(eng, cfg, x, lr, prefixes=None, seed=None):
     return state, ref, eng.read_stats()
 
 
+@pytest.mark.parametrize("d,k", [(1280, 64), (1280, 32), (512, 64), (1024, 48), (256, 33), (768, 64)])
+def test_steps_match_the_oracle_at_the_wide_shapes(d, k):
+    """decode_q_kernel<NW, 2>: more than 32 codes per row are decoded in two halves of 32 decoder rows (the first half gathered once
+    more for dval), and d_model 1280 (configs[3]: five waves per activation row) -- the same three teacher-forced steps."""
+    test_steps_match_the_oracle_at_every_width(d, k, 1)
+
+
 @pytest.mark.parametrize("d", [256, 512, 768, 1024])
 @pytest.mark.parametrize("k,n_pre", [(8, 1), (32, 1), (32, 4), (17, 10)])
 def test_steps_match_the_oracle_at_every_width(d, k, n_pre):
@@ -77,14 +84,19 @@ def test_steps_match_the_oracle_at_every_width(d, k, n_pre):
     assert flips <= 1
 
 
+@pytest.mark.parametrize("d,k", [(1280, 64), (512, 64), (1280, 17)])
+def test_gradients_agree_with_dval_formed_in_the_backward_wide(d, k, encoder_mode):
+    test_gradients_agree_with_dval_formed_in_the_backward(d, 1, encoder_mode, k=k)
+
+
 @pytest.mark.parametrize("d", [256, 512, 768, 1024])
 @pytest.mark.parametrize("n_pre", [1, 5])
-def test_gradients_agree_with_dval_formed_in_the_backward(d, n_pre, encoder_mode):
+def test_gradients_agree_with_dval_formed_in_the_backward(d, n_pre, encoder_mode, k=32):
     """The same forward + backward with dval = <dL/dx_hat row (or the prefix block's suffix sum), decoder row> taken from the decode
     and formed by the first pass of the column slices: the four gradients agree to rounding, codes and loss bit for bit."""
     if encoder_mode != "f16r":
         pytest.skip("the decode does not depend on the encoder arithmetic: run once")
-    s, k, n = 8 * d, 32, 1000
+    s, n = 8 * d, 1000
     p = rand_params(d, s, seed=400 + d)
     x = (torch.randn(n, d, generator=torch.Generator().manual_seed(401 + d)) + 0.2).cuda()
     torch.manual_seed(77)

@@ -18,6 +18,6 @@ for grp in \
   "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES" \
   "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES"; do
   i=$((i + 1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $W/pmc_g$i -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0 "$@" > $W.g$i.log 2>&1 || tail -5 $W.g$i.log
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $W/pmc_g$i -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras --sustained-steps 0 "$@" > $W.g$i.log 2>&1 || tail -5 $W.g$i.log
 done
 python tools/stall_summary.py $W "$OUT/${TAG}_stalls.txt" "$TAG"

@@ -5,7 +5,7 @@ TAG=${1:-r3_passA}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 export PYTHONPATH=$PWD
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-value -Iinclude"
-OPTS="--steps 30 --warmup 5 --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0"
+OPTS="--steps 30 --warmup 5 --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras --sustained-steps 0"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 run() {
   echo "== $1" >> $OUT/${TAG}.txt

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 ( time timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 ) 2>&1 | grep -E "passed|failed|error|real"
 for i in 1 2 3; do
   for R in 1 0; do
-    SAEV_AMD_CSC=$R timeout 300 python bench.py --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0 --steps 100 2>/dev/null | tail -1 | python -c "
+    SAEV_AMD_CSC=$R timeout 300 python bench.py --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras --sustained-steps 0 --steps 100 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('csc_route $R', 'steady %.4f ms' % d['ms_per_step'], 'early %.4f' % d['from_random_init']['ms_per_step'], 'enc %.4f' % d['roofline']['kernel_ms'])"

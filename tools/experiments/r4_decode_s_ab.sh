@@ -3,7 +3,7 @@
 export PYTHONPATH=$PWD
 python -m pytest tests/test_gpu_dw_slices.py tests/test_gpu_register_layout.py -x -q -m gpu -k "f16r" 2>&1 | grep -E "passed|failed|Error" | tail -3
 for r in slices slices_s slices slices_s; do
-  SAEV_AMD_DW=$r python bench.py --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0 --steps 100 2>/dev/null | tail -1 | python -c "
+  SAEV_AMD_DW=$r python bench.py --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras --sustained-steps 0 --steps 100 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$r', 'steady %.4f ms' % d['ms_per_step'], 'early %.4f' % d['from_random_init']['ms_per_step'], 'enc %.4f' % d['roofline']['kernel_ms'])"

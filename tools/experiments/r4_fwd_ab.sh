@@ -14,7 +14,7 @@ done > gpurun_out/${TAG}_ab.txt
 cat gpurun_out/${TAG}_ab.txt
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rm -rf /tmp/prof_fwd
-rocprofv3 --kernel-trace -d /tmp/prof_fwd -o run -- python bench.py --steps 100 --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0 > /tmp/prof_fwd.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/prof_fwd -o run -- python bench.py --steps 100 --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras --sustained-steps 0 > /tmp/prof_fwd.log 2>&1
 DB=$(find /tmp/prof_fwd -name '*.db' | head -1)
 python tools/rocpd_stats.py "$DB" --last 100 > gpurun_out/${TAG}_kernel_stats_steady.txt
 head -32 gpurun_out/${TAG}_kernel_stats_steady.txt

@@ -3,7 +3,7 @@
 export PYTHONPATH=$PWD
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rm -rf /tmp/l2p
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/l2p -o run -- python bench.py --pretrain-steps 300 --steps 3 --warmup 1 --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0 > /tmp/l2p.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/l2p -o run -- python bench.py --pretrain-steps 300 --steps 3 --warmup 1 --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras --sustained-steps 0 > /tmp/l2p.log 2>&1
 python3 - "$(find /tmp/l2p -name '*counter_collection.csv' | head -1)" <<'PY'
 import csv, sys, collections
 acc = collections.OrderedDict()

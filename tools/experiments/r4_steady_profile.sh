@@ -5,9 +5,9 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 TAG=${1:-r04e}
 rm -rf /tmp/prof_st
-rocprofv3 --kernel-trace -d /tmp/prof_st -o run -- python bench.py --steps 100 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-auxk-probe --no-other-configs > /tmp/prof_st.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/prof_st -o run -- python bench.py --steps 100 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras > /tmp/prof_st.log 2>&1
 DB=$(find /tmp/prof_st -name '*.db' | head -1)
 python tools/rocpd_stats.py "$DB" --last 100 > gpurun_out/${TAG}_kernel_stats_steady.txt
 python tools/rocpd_gaps.py "$DB" --last 100 > gpurun_out/${TAG}_gaps_steady.txt
-tail -1 /tmp/prof_st.log > gpurun_out/${TAG}_steady_bench_line.json
+grep '^{' /tmp/prof_st.log | tail -1 > gpurun_out/${TAG}_steady_bench_line.json
 head -32 gpurun_out/${TAG}_kernel_stats_steady.txt; head -8 gpurun_out/${TAG}_gaps_steady.txt

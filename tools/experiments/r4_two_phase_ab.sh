@@ -9,7 +9,7 @@ for i in 1 2; do
 done
 for i in 1 2; do
   for ph in 1 2; do
-    SAEV_AMD_ENC_PHASES=$ph python bench.py --no-cpu-baseline --no-auxk-probe --no-other-configs --sustained-steps 0 --steps 100 2>/dev/null | tail -1 | python -c "
+    SAEV_AMD_ENC_PHASES=$ph python bench.py --no-cpu-baseline --no-auxk-probe --no-other-configs --no-extras --sustained-steps 0 --steps 100 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('phases $ph', 'steady %.4f ms' % d['ms_per_step'], 'early %.4f' % d['from_random_init']['ms_per_step'], 'enc %.4f' % d['roofline']['kernel_ms'])"

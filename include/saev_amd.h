@@ -145,7 +145,8 @@ typedef struct {
     int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 40; -1 = never (dense algebra
                               whatever the count); values above 64 are clamped                                           */
     int32_t fwd_route;     /* exact refinement of the f16r encoder: 0 = from 32-column slices of W_enc^T that the XCD L2s hold
-                              where the geometry allows, 1 = whole-row gathers always                                   */
+                              where the geometry allows (their D / 32 shares per survivor added by the final select), 1 = whole-row
+                              gathers always, 2 = slices with a separate pass that adds the shares (round 4)              */
     int32_t dead_lag;      /* saev_step_dead sizes the auxiliary work from the tracker record of this many steps ago
                               (0 = 4, at most 8): shorter = tighter bound of the dead count, longer = more host run-ahead  */
     int32_t csc_route;     /* latent-major pair list of the backward: 0 = the training decode sets the (latent, row) bits of the

@@ -782,7 +782,8 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
                                                                const float* dWe, const float* dbe, float* gW_dec,
                                                                float* gW_encT, float* gb_enc, int lat_lo, int lat_hi,
                                                                const int32_t* nd_dev, int part, float2* row_proj,
-                                                               const float* W_dec, int project, float* enc_sq, int32_t* lat_unused) {
+                                                               const float* W_dec, int project, float* enc_sq, int32_t* lat_unused,
+                                                               const int32_t* starts) {
     // part: 0 = all three gradients; 1 = the decoder rows only; 2 = the encoder rows and bias only (saev_backward_rows_part)
     if (nd_dev != nullptr) nd = min(nd, *nd_dev);
     const int lane = threadIdx.x & 63;
@@ -794,11 +795,20 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
     const f32x4* e = reinterpret_cast<const f32x4*>(dWe + (size_t)j * D);
     f32x4* oa = reinterpret_cast<f32x4*>(gW_dec + (size_t)i * D);
     f32x4* oe = reinterpret_cast<f32x4*>(gW_encT + (size_t)i * D);
-    float dot = 0.f, nsq = 0.f, esq = 0.f;
+    float dot = 0.f, nsq = 0.f, esq = 0.f, old_d = 0.f, old_e = 0.f;
     const bool enc_unwritten = lat_unused != nullptr && lat_unused[i] != 0;  // (wave-uniform)
+    // (the clip norm already holds the squares of this row's main-path part -- the backward's passes add them up per wave -- unless
+    // the latent was cut by run boundaries, whose statistics are per row like the ones written here)
+    bool counted = false;
+    if (starts != nullptr && !enc_unwritten) {
+        const int s0 = starts[i], e0 = starts[i + 1];
+        counted = e0 > s0 && !(e0 - s0 >= DWS_RUN && s0 / DWS_RUN != (e0 - 1) / DWS_RUN);
+    }
     for (int q = lane; q < (D >> 2); q += 64) {
         if (part != 2) {
-            const f32x4 g = enc_unwritten ? a[q] : oa[q] + a[q];  // (a flagged latent: neither gradient row has been written)
+            const f32x4 o = enc_unwritten ? f32x4{0.f, 0.f, 0.f, 0.f} : oa[q];  // (a flagged latent: neither gradient row has been written)
+            if (counted) old_d = __builtin_fmaf(o[3], o[3], __builtin_fmaf(o[2], o[2], __builtin_fmaf(o[1], o[1], __builtin_fmaf(o[0], o[0], old_d))));
+            const f32x4 g = o + a[q];
             oa[q] = g;
             if (row_proj != nullptr) {  // the row changed: refresh its projection coefficient / projected squares (DwRowsArgs::row_proj)
                 const f32x4 w = project ? reinterpret_cast<const f32x4*>(W_dec + (size_t)i * D)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -807,7 +817,9 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
             }
         }
         if (part != 1) {
-            const f32x4 ge = enc_unwritten ? e[q] : oe[q] + e[q];
+            const f32x4 o = enc_unwritten ? f32x4{0.f, 0.f, 0.f, 0.f} : oe[q];
+            if (counted) old_e = __builtin_fmaf(o[3], o[3], __builtin_fmaf(o[2], o[2], __builtin_fmaf(o[1], o[1], __builtin_fmaf(o[0], o[0], old_e))));
+            const f32x4 ge = o + e[q];
             oe[q] = ge;
 #pragma unroll
             for (int c = 0; c < 4; ++c) esq = __builtin_fmaf(ge[c], ge[c], esq);
@@ -817,6 +829,7 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
     if (enc_unwritten && lane == 0) lat_unused[i] = 0;
     if (enc_sq != nullptr && part != 1) {  // the row changed: its squares again (DwRowsArgs::enc_sq)
         esq = wave_sum(esq);
+        if (counted) esq -= wave_sum(old_e);
         if (lane == 0) enc_sq[i] = esq;
     }
     if (row_proj != nullptr && part != 2) {  // same arithmetic, in the same order, as rpg_row_stats (common.h)
@@ -830,6 +843,7 @@ __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl
             for (int c = 0; c < 4; ++c) { const float t = rpg_apply(g[c], sc, w[c]); sq = __builtin_fmaf(t, t, sq); }
         }
         sq = wave_sum(sq);
+        if (counted) sq -= wave_sum(old_d);
         if (lane == 0) row_proj[i] = float2{sc, sq};
     }
 }
@@ -1001,9 +1015,9 @@ hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStre
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,
                                    const int32_t* nd_dev, int part, float2* row_proj, const float* W_dec, int project,
-                                   float* enc_sq, int32_t* lat_unused) {
+                                   float* enc_sq, int32_t* lat_unused, const int32_t* starts) {
     if (nd <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_add_dead_kernel, dim3((nd + 3) / 4), dim3(256), 0, s, dl, nd, D, dWd, dWe, dbe, gW_dec,
-                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev, part, row_proj, W_dec, project, enc_sq, lat_unused);
+                       gW_encT, gb_enc, lat_lo, lat_hi, nd_dev, part, row_proj, W_dec, project, enc_sq, lat_unused, starts);
     return hipGetLastError();
 }

@@ -106,6 +106,8 @@ struct saev_ctx {
     bool dval_fwd = false;
     // the light finalize (kernels.h: DwSlicesArgs::wn2): ||w_i||^2 of the decoder rows as this step's normalize_rows wrote them
     float* wn2 = nullptr;
+    float* sq_wave = nullptr;  // per-wave squares of the two passes (DwSlicesArgs::sq_wave_dec, then _enc: contiguous)
+    int sq_wave_n = 0;         // > 0: the backward in flight left 2 x this many of them (the tail adds them to the clip norm)
     bool wn2_fresh = false;  // wn2 describes W_dec as it is now (set by the training forward, cleared by whatever writes W_dec)
     // the decode out of 32-column slices (sparse.hip: decode_s_kernel): slice-major copy of the normalised W_dec left by the step's
     // normalize_rows, per (slice, row) loss terms; the dval shares go through dvp
@@ -379,7 +381,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
         c->dws_ok = !rows_only && D % DWS_SLICE == 0 && (uint64_t)S * D * 4ull < (1ull << 32) && MBB < (1l << 24) &&
                     (uint64_t)MBB * K < (1ull << 31);
     }
-    c->fwd_slices = c->cfg.encoder_mode == SAEV_ENCODER_F16R && c->dbg.fwd_route == 0 && c->dbg.fused_chain == 0 && D % RS_SLICE == 0 &&
+    c->fwd_slices = c->cfg.encoder_mode == SAEV_ENCODER_F16R && (c->dbg.fwd_route == 0 || c->dbg.fwd_route == 2) && c->dbg.fused_chain == 0 && D % RS_SLICE == 0 &&
                     (uint64_t)S * 128ull < (1ull << 32) - 256ull && fused_supported(c->cfg);
     if (c->fwd_slices) {
         A(rs_part, (size_t)(D / RS_SLICE) * MB * REFINE_CAP); A(surv_rng, MB * RS_MAX_RANGES);
@@ -396,7 +398,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
             A(WdS, S * D); A(dec_part, (size_t)(D / 32) * MB * 3);
         }
         A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(cut_list, 1 + (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
-        if (c->dval_rows != nullptr && c->dbg.fin_route == 0) { A(wn2, S); }
+        if (c->dval_rows != nullptr && c->dbg.fin_route == 0) { A(wn2, S); A(sq_wave, (size_t)2 * dw_slices_waves((int)D, (int)(MBB * K))); }
     }
     A(colsum_partials, ((MBB + 63) / 64) * D);
     A(sumsq_partials, 2 * 1024 + (S + 3) / 4 + 8 + transpose_blocks((int)S, (int)D)); A(sumsq_total, 1);
@@ -908,7 +910,11 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                     rs.n_rows = n; rs.S = c->cfg.d_sae; rs.D = c->cfg.d_model;
                     rs.lat_range = c->rs_lat_range; rs.n_ranges = c->rs_n_ranges;
                     rs.enable_flag = flag; rs.enable_when = when;
-                    HIPCHK(c, launch_refine_slices(rs, s));
+                    // (the D / 32 shares of a survivor are added by the final select itself: refine_sum_kernel's launch and its
+                    // round trip through surv_val are gone; saev_debug_cfg.fwd_route = 2 keeps the separate pass)
+                    const bool fold = c->dbg.fwd_route != 2;
+                    HIPCHK(c, launch_refine_slices(rs, s, !fold));
+                    if (fold) { sc.sum_part = c->rs_part; sc.sum_bias = sc.b_enc; sc.sum_n = c->cfg.d_model / RS_SLICE; sc.sum_plane = (size_t)n * REFINE_CAP; }
                 } else {
                     HIPCHK(c, launch_refine_exact(sc, s));
                 }
@@ -1648,7 +1654,14 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         w.row_proj = a.row_proj; w.project = a.project; w.enc_sq = a.enc_sq;
         w.clear_bitmap = a.clear_bitmap; w.clear_words = a.clear_words;
         w.have_dval = c->dval_pairs_ready ? 1 : 0;
-        if (c->dval_pairs_ready && c->wn2_fresh && part == 0) w.wn2 = c->wn2;
+        c->sq_wave_n = 0;
+        if (c->dval_pairs_ready && c->wn2_fresh && part == 0) {
+            w.wn2 = c->wn2;
+            if (c->fused_step && all_rows && c->sq_wave != nullptr && c->dbg.fin_route != 2) {  // (fin_route 2: the finalize reads the rows for their squares)
+                c->sq_wave_n = dw_slices_waves(D, (int)((long)n * K));
+                w.sq_wave_dec = c->sq_wave; w.sq_wave_enc = c->sq_wave + c->sq_wave_n;
+            }
+        }
         HIPCHK(c, launch_dw_slices(w, (int)((long)n * K), part, s));
     } else {
         c->unused_valid = false;
@@ -1658,11 +1671,12 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->n_dead_host, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s,
                                           c->aux_dev_count ? c->flags + 4 : nullptr, part, a.row_proj, a.W_dec, a.project, a.enc_sq,
-                                          c->unused_valid ? c->lat_unused : nullptr));
+                                          c->unused_valid ? c->lat_unused : nullptr, c->sq_wave_n > 0 ? c->starts : nullptr));
     else if (c->aux_route != AUX_NONE)  // few dead latents: the device knows how many
         HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part,
-                                          a.row_proj, a.W_dec, a.project, a.enc_sq, c->unused_valid ? c->lat_unused : nullptr));
+                                          a.row_proj, a.W_dec, a.project, a.enc_sq, c->unused_valid ? c->lat_unused : nullptr,
+                                          c->sq_wave_n > 0 ? c->starts : nullptr));
     // gathered backward: the auxiliary term's share of db_dec (summed over the ranks by the caller, like the compact rows)
     if (ov && c->aux_route != AUX_NONE && part != 2 && lat_lo == 0)
         HIPCHK(c, launch_colsum(c->db_aux, 1, D, c->colsum_partials, c->grads + c->off_b_dec, 1, nullptr, s));
@@ -1809,7 +1823,8 @@ int saev_tail_prepare(saev_ctx* c, int32_t shard_rank, void* stream) {
         c->row_proj_valid = false;
         HIPCHK(c, launch_sumsq_final_ex(nullptr, 0, c->row_proj, (int)S, c->grads + S * D, r.a_hi - S * D,
                                         c->grads + c->off_b_enc, r.b_hi - c->off_b_enc, saev_sumsq_device(c), c->sumsq_partials,
-                                        c->tickets + 1, s, c->enc_sq));
+                                        c->tickets + 1, s, c->enc_sq, c->sq_wave_n > 0 ? c->sq_wave : nullptr, 2l * c->sq_wave_n));
+        c->sq_wave_n = 0;
         c->tail_proj_in_adam = true;
         return SAEV_OK;
     }

@@ -81,6 +81,13 @@ struct SelectCandArgs {
     // lat_range latents, n_ranges <= RS_MAX_RANGES of them; NULL = one list in candidate order
     int32_t* surv_rng;
     int lat_range, n_ranges;
+    // optional (the final cut behind refine_slices_kernel): cand_val is not read; the value of candidate j of a row is
+    // sum_bias[cand_idx[j]] + the sum_n shares sum_part[c][row][j] (c = 0 .. sum_n - 1, plane pitch sum_plane floats, row pitch
+    // cand_stride) added in slice order -- refine_sum_kernel's pass folded into the select that consumes it
+    const float* sum_part;
+    const float* sum_bias;
+    int sum_n;
+    size_t sum_plane;
 };
 hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream);
 // survivors -> exact values -> final cut in one launch (f16r with guaranteed bounds); a.row_margin, x, W_encT, b_enc set
@@ -99,7 +106,8 @@ struct RefineSlicesArgs {
     int n_rows, S, D, lat_range, n_ranges;
     const int32_t* enable_flag; int enable_when;
 };
-hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream);
+// sum_shares = false: the caller's final select adds the shares itself (SelectCandArgs::sum_part)
+hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream, bool sum_shares = true);
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream);
 hipError_t launch_init_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 hipError_t launch_encoder_init(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n_gmax, hipStream_t stream,
@@ -318,9 +326,17 @@ struct DwSlicesArgs {
     // <dW_dec[i], w_i> = sum over the latent's pairs of val * dval (dW_dec[i] = sum val g_b and dval = <g_b, w_i>) from the pair
     // lists: the decoder rows are not read (134 MB per step at configs[1]), dw_finalize_cut / dw_clear_bitmap ride in the launch.
     const float* wn2;
+    // optional (with wn2): the passes add up the squares of every piece they store WHOLE, per wave -- sq_wave_dec / sq_wave_enc
+    // [grid x 4] -- and the finalize then reads no gradient row at all: the clip norm needs the squares of all rows, not of each,
+    // and only the projection correction -sc_i <g_i, w_i> is per latent (row_proj[i].y; enc_sq[i] = 0).  Latents cut by run
+    // boundaries keep their full per-row statistics (their pieces are partial sums); scatter_add_dead_kernel, which replaces the
+    // statistics of the rows it adds to, takes out what the waves counted for them (its `starts` argument).
+    float* sq_wave_dec;
+    float* sq_wave_enc;
 };
 // part as in DwRowsArgs (0 both gradients; 1 decoder half: passes A + dval sums; 2 encoder half: pass B, after part 1)
 hipError_t launch_dw_slices(const DwSlicesArgs& a, int max_pairs, int part, hipStream_t stream);
+int dw_slices_waves(int D, int max_pairs);
 // [D / 32][n][32] copies of two row-major (n, D) matrices (the gathered rows of a sparse-state exchange)
 hipError_t launch_slice_major_copy(const float* g, const float* x, int n, int D, float* gS, float* xS, hipStream_t stream);
 // sq_part: optional, transpose_blocks(S, D) doubles = per-tile sums of squares of `in`
@@ -366,9 +382,11 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
 // the decoder rows [0, S) of a.p / a.g / a.m / a.v with the projection coefficient row_proj[i].x applied to the gradient
 hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream);
 // total = sum(partials[0..nb)) + sum_i row_proj[i].y + |e1|^2 + |e2|^2 (see sumsq_final_ex_kernel)
+// plain (optional): n_plain floats added as they are (DwSlicesArgs::sq_wave_dec / _enc, contiguous)
 hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
                                  const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream,
-                                 const float* enc_sq = nullptr);  // + sum_i enc_sq[i] (squares of the rows of the transposed dW_enc)
+                                 const float* enc_sq = nullptr,  // + sum_i enc_sq[i] (squares of the rows of the transposed dW_enc)
+                                 const float* plain = nullptr, long n_plain = 0);
 // Adam over everything in one launch with the gradients where the backward left them: a.{p,g,m,v} = the flat buffers, the
 // decoder rows projected through row_proj, W_enc's gradient read from the transposed scratch gT (S, D) through LDS tiles,
 // the two bias segments [off, off + n) element-wise (adam_fused_kernel)
@@ -599,4 +617,8 @@ hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float
                                    float* enc_sq = nullptr,
                                    // optional (DwSlicesArgs::lat_unused): a flagged latent's dW_enc^T row was not written -- it is
                                    // taken as zeros here and the flag cleared (both its rows are gradients now)
-                                   int32_t* lat_unused = nullptr);
+                                   int32_t* lat_unused = nullptr,
+                                   // optional (DwSlicesArgs::sq_wave_dec): the clip norm holds the squares of a row's main-path
+                                   // part already, unless the latent was cut by run boundaries (starts: the CSC offsets):
+                                   // the statistics left here are then those of the row as it is now MINUS that part
+                                   const int32_t* starts = nullptr);

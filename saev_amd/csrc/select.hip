@@ -457,6 +457,28 @@ __global__ __launch_bounds__(256) void select_cand_kernel(SelectCandArgs a) {
     const int n = min(cnt, a.cand_cap);  // wave-uniform
     const float* cv = a.cand_val + (size_t)row * a.cand_stride;
     const int32_t* ci = a.cand_idx + (size_t)row * a.cand_stride;
+    __shared__ float l_sum[4][REFINE_CAP];
+    if (a.sum_part != nullptr) {
+        // the exact values of the survivors from their per-slice shares (refine_slices_kernel), eight loads in flight, added in
+        // slice order; they stay in LDS for the cut below (LDS operations of one wave execute in order)
+        float* const lv = l_sum[threadIdx.x >> 6];
+        for (int j = threadIdx.x & 63; j < n; j += 64) {
+            const size_t o = (size_t)row * a.cand_stride + j;
+            float sv = 0.f;
+            int c = 0;
+            for (; c + 8 <= a.sum_n; c += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = a.sum_part[(size_t)(c + u) * a.sum_plane + o];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv += v[u];
+            }
+            for (; c < a.sum_n; ++c) sv += a.sum_part[(size_t)c * a.sum_plane + o];
+            lv[j] = sv + a.sum_bias[ci[j]];
+        }
+        __asm__ volatile("" ::: "memory");
+        cv = lv;
+    }
     if (n <= 64 && a.row_margin == nullptr) select_small_row(a, row, n, cv, ci);
     else if (n <= 512) select_cand_row<8>(a, row, n, s_idx, s_val, cv, ci);
     else if (n <= 1024) select_cand_row<16>(a, row, n, s_idx, s_val, cv, ci);
@@ -1165,7 +1187,7 @@ hipError_t launch_select_dense(const SelectDenseArgs& a, hipStream_t stream) {
 
 hipError_t launch_select_cand(const SelectCandArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
-    if (a.cand_cap > 4096) return hipErrorInvalidValue;
+    if (a.cand_cap > 4096 || (a.sum_part != nullptr && a.cand_cap > REFINE_CAP)) return hipErrorInvalidValue;
     if (a.k > 32) hipLaunchKernelGGL(select_cand_kernel<true>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(select_cand_kernel<false>, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
@@ -1254,7 +1276,7 @@ hipError_t launch_refine_exact(const SelectCandArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream) {
+hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream, bool sum_shares) {
     if (a.n_rows <= 0) return hipSuccess;
     if (a.D % RS_SLICE != 0 || (uint64_t)a.S * 128ull >= (1ull << 32) - 256ull || a.n_ranges <= 0) return hipErrorInvalidValue;
     // rows per eight-lane group: 8 evens out the survivor lists of a group's rows (283 -> 257 us at 16 384 rows); a small batch
@@ -1267,7 +1289,7 @@ hipError_t launch_refine_slices(const RefineSlicesArgs& a, hipStream_t stream) {
     else hipLaunchKernelGGL(refine_slices_kernel<RS_ROWS_MAX>, grid, dim3(256), 0, stream, a, wg_per_combo);
     // (adding the shares inside the final select instead -- 32 dependent loads per lane of a kernel that lives on its bit
     // search -- took that select from 20 to 80 us against 42 for this pass)
-    hipLaunchKernelGGL(refine_sum_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
+    if (sum_shares) hipLaunchKernelGGL(refine_sum_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -992,16 +992,21 @@ __global__ __launch_bounds__(256) void slice_major_copy_kernel(const float* __re
 // DEC (pass A): m = gS, out = dW_dec, coefficients pv[].y = val, W slices for the dval shares (DVAL).  Otherwise m = xS, out = dW_enc^T,
 // coefficients pv2[].y = dval.  A workgroup = 4 waves x 8 lane groups = 32 runs of one slice.
 template <bool DEC, bool DVAL = true>
-__global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : (DEC ? 5 : 6)) void dw_slices_kernel(DwSlicesArgs a, int wg_per_slice) {
+__global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : 5) void dw_slices_kernel(DwSlicesArgs a, int wg_per_slice) {  // (pass B at six waves spilled once it kept its squares)
     constexpr bool PASS_A = DEC && DVAL;  // the dval shares are formed here (DVAL = false: the decode has left them, DwSlicesArgs::have_dval)
     constexpr int L = DWS_RUN;
     const int lane = threadIdx.x & 63, gi = lane >> 3, li = lane & 7;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int slice = xcd + 8 * (q / wg_per_slice);
-    if (slice * DWS_SLICE >= a.D) return;
+    // (the wave's slot of DwSlicesArgs::sq_wave_dec / _enc: an SGPR pair, formed where it is used -- registers are what this kernel lives on)
+    const bool sq_on = (DEC ? a.sq_wave_dec : a.sq_wave_enc) != nullptr;
+    auto sq_slot = [&]() -> float* {
+        return (DEC ? a.sq_wave_dec : a.sq_wave_enc) + ((size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+    };
+    if (slice * DWS_SLICE >= a.D) { if (sq_on && lane == 0) *sq_slot() = 0.f; return; }
     const int NP = a.starts[a.S];
     const int run0 = ((q % wg_per_slice) * 4 + (threadIdx.x >> 6)) * 8;
-    if (run0 * L >= NP) return;  // (wave-uniform)
+    if (run0 * L >= NP) { if (sq_on && lane == 0) *sq_slot() = 0.f; return; }  // (wave-uniform)
     const int run = run0 + gi;
     const int col = slice * DWS_SLICE + li * 4;
     const uint32_t colb = (uint32_t)col * 4u, rowb = (uint32_t)a.D * 4u, li16 = (uint32_t)li * 16u;
@@ -1022,6 +1027,10 @@ __global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : (DEC ? 5 : 6)) void dw_sli
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
     float* const dvp = PASS_A ? a.dvp + (size_t)slice * a.pair_cap : nullptr;
+    // (squares of the pieces this lane stores whole, DwSlicesArgs::sq_wave_dec: kept in LDS -- one more live register made pass B
+    // spill at its six waves per SIMD, 170 -> 224 us)
+    __shared__ float sh_sq[256];
+    sh_sq[threadIdx.x] = 0.f;
     const int sel = (lane & 56) << 2;  // byte address of the group's lane 0 for ds_bpermute
     const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(DEC ? a.gS : a.xS) + (size_t)slice * a.n_rows * DWS_SLICE * (DEC && a.P > 1 ? a.P : 1), 0,
@@ -1069,7 +1078,11 @@ __global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : (DEC ? 5 : 6)) void dw_sli
                 float* o;
                 if (head_open) o = part + ((size_t)run * 2 + 0) * a.D + col;                   // began in an earlier run
                 else if (!(xc[j] & DWS_LAST)) o = part + ((size_t)run * 2 + 1) * a.D + col;    // continues in the next run
-                else o = out + (size_t)lc[j] * a.D + col;                                      // the whole latent lies in this run
+                else {                                                                         // the whole latent lies in this run
+                    o = out + (size_t)lc[j] * a.D + col;
+                    if (sq_on)
+                        sh_sq[threadIdx.x] += __builtin_fmaf(acc[3], acc[3], __builtin_fmaf(acc[2], acc[2], __builtin_fmaf(acc[1], acc[1], acc[0] * acc[0])));
+                }
                 *reinterpret_cast<f32x4*>(o) = acc;
                 // every run leaves word of whether a latent BEGINS in it and continues past its end (its tail partial):
                 // dw_finalize_cut_kernel starts from these
@@ -1106,6 +1119,10 @@ __global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : (DEC ? 5 : 6)) void dw_sli
         if (PASS_A && p0 + 8 * t + li < p1) dvp[p0 + 8 * t + li] = dmine;
         e_c = e_n; lat_c = lat_n;
         load_info(t + 2, e_n, lat_n);
+    }
+    if (sq_on) {
+        const float sq = wave_sum(sh_sq[threadIdx.x]);
+        if (lane == 0) *sq_slot() = sq;
     }
 }
 
@@ -1408,7 +1425,8 @@ __global__ __launch_bounds__(1024) void dw_finalize_light_kernel(DwSlicesArgs a,
         return;
     }
     float gsq = 0.f, esq = 0.f;
-    {
+    const bool waves_hold_squares = a.sq_wave_dec != nullptr;  // (the passes added up the squares of both rows: nothing to read here)
+    if (!waves_hold_squares) {
         const f32x4* gd = reinterpret_cast<const f32x4*>(a.dW_dec + (size_t)i * D);
         const f32x4* ge = reinterpret_cast<const f32x4*>(a.dW_encT + (size_t)i * D);
 #pragma unroll 4
@@ -1434,7 +1452,8 @@ __global__ __launch_bounds__(1024) void dw_finalize_light_kernel(DwSlicesArgs a,
             // ||g - sc w||^2 = ||g||^2 - sc <g, w> with sc = <g, w> / ||w||^2 (modeling.py:419-445); never negative in exact arithmetic
             const float nsq = a.wn2[i];
             const float sc = (a.project && nsq > 0.f) ? dot / nsq : 0.f;
-            a.row_proj[i] = float2{sc, fmaxf(__builtin_fmaf(-sc, dot, gsq), 0.f)};
+            // (waves_hold_squares: only the projection's correction is per latent; the total cannot go negative, a term may)
+            a.row_proj[i] = float2{sc, waves_hold_squares ? -sc * dot : fmaxf(__builtin_fmaf(-sc, dot, gsq), 0.f)};
         }
     }
 }
@@ -1988,6 +2007,10 @@ hipError_t launch_slice_major_copy(const float* g, const float* x, int n, int D,
     hipLaunchKernelGGL(slice_major_copy_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, g, x, n, D, gS, xS);
     return hipGetLastError();
 }
+int dw_slices_waves(int D, int max_pairs) {  // waves of one pass of launch_dw_slices (the length of DwSlicesArgs::sq_wave_dec)
+    const int n_runs = (max_pairs + DWS_RUN - 1) / DWS_RUN;
+    return ((D / DWS_SLICE + 7) / 8) * 8 * ((n_runs + 31) / 32) * 4;
+}
 hipError_t launch_dw_slices(const DwSlicesArgs& a_in, int max_pairs, int part, hipStream_t stream) {
     DwSlicesArgs a = a_in;
     if (a.D % DWS_SLICE != 0 || max_pairs <= 0) return hipErrorInvalidValue;
@@ -1997,6 +2020,7 @@ hipError_t launch_dw_slices(const DwSlicesArgs& a_in, int max_pairs, int part, h
     // part 1: the decoder's half (pass A leaves the dval the encoder's half needs); part 2: the encoder's; 0: both
     // light finalize: both halves in one call, dval from the decode, and the three buffers it needs
     const bool light = part == 0 && a.have_dval && a.wn2 != nullptr;
+    if (!light) { a.sq_wave_dec = nullptr; a.sq_wave_enc = nullptr; }
     if (part != 2 && a.have_dval) {
         hipLaunchKernelGGL((dw_slices_kernel<true, false>), dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
         if (a.clear_bitmap != nullptr && !light) hipLaunchKernelGGL(dw_clear_bitmap_kernel, dim3((max_pairs + 255) / 256), dim3(256), 0, stream, a);
@@ -2007,7 +2031,7 @@ hipError_t launch_dw_slices(const DwSlicesArgs& a_in, int max_pairs, int part, h
     if (part != 1) hipLaunchKernelGGL(dw_slices_kernel<false>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
     const int kinds = part == 0 ? 2 : 1, kind0 = part == 2 ? 1 : 0;
     if (light) {  // one launch: cut latents first, then a wave per latent that reads no row back (and clears the bit map words)
-        const int n_cut = a.cut_list != nullptr ? std::min(2 * (n_runs - 1), 1024) : 0;  // workgroups that walk the list of cut latents
+        const int n_cut = a.cut_list != nullptr ? std::min(2 * (n_runs - 1), 4096) : 0;  // workgroups that walk the list of cut latents
         if (a.cut_list == nullptr && n_runs > 1) return hipErrorInvalidValue;
         const dim3 grid_f(n_cut + (a.S + 15) / 16);
         const int nvq = (a.D / 4 + 255) / 256;

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* partial
 // every thread adding its strided share in index order, then a fixed tree: deterministic.
 __global__ __launch_bounds__(1024) void sumsq_final_ex_kernel(const double* partials, int nb, const float2* row_proj, int n_rows,
                                                               const float* e1, long n1, const float* e2, long n2, double* total,
-                                                              double* blk_part, int* ticket, const float* enc_sq) {
+                                                              double* blk_part, int* ticket, const float* enc_sq, const float* plain,
+                                                              long n_plain) {
     // (one workgroup alone needed 32 us for the 0.4 MB: latency.  gridDim.x workgroups take contiguous slices of each
     // range, the last one to arrive -- a ticket -- adds the slices in index order)
     __shared__ double sh[16];
@@ -140,6 +141,8 @@ __global__ __launch_bounds__(1024) void sumsq_final_ex_kernel(const double* part
     for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)e1[i] * (double)e1[i];
     slice(n2, lo, hi);
     for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)e2[i] * (double)e2[i];
+    slice(n_plain, lo, hi);
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) s += (double)plain[i];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -663,9 +666,9 @@ hipError_t launch_sumsq(const float* g, long n, double* partials, double* total,
 }
 hipError_t launch_sumsq_final_ex(const double* partials, int nb, const float2* row_proj, int n_rows, const float* e1, long n1,
                                  const float* e2, long n2, double* total, double* blk_part, int* ticket, hipStream_t stream,
-                                 const float* enc_sq) {
+                                 const float* enc_sq, const float* plain, long n_plain) {
     hipLaunchKernelGGL(sumsq_final_ex_kernel, dim3(SUMSQ_EX_BLOCKS), dim3(1024), 0, stream, partials, nb, row_proj, n_rows, e1, n1, e2,
-                       n2, total, blk_part, ticket, enc_sq);
+                       n2, total, blk_part, ticket, enc_sq, plain, n_plain);
     return hipGetLastError();
 }
 hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, int D, hipStream_t stream) {

@@ -54,6 +54,7 @@ class EngineConfig:
     #   SAEV_AMD_DW=slices_a      column slices, but dval = <dL/dx_hat row, decoder row> formed by their first pass instead of by the decode
     #   SAEV_AMD_DW=slices_s      as the default, but the decode itself gathers 32-column slices of W_dec out of the XCD L2s (decode_s_kernel; a wash)
     #   SAEV_AMD_FWD=rows         exact refinement of the f16r encoder by whole-row gathers instead of 32-column slices
+    #   SAEV_AMD_FWD=sum_pass     slices, with the shares of a survivor added by a pass of their own (round 4) instead of by the final select
     #   SAEV_AMD_ENC_MFMA=32      single-product encoders on the 32x32x16 MFMA kernel
     #   SAEV_AMD_FUSED_CHAIN=1    f16r select -> refine -> select as one launch
     #   SAEV_AMD_NGROUPS=64       64-group TopK bound also for top_k <= 32
@@ -151,12 +152,12 @@ class SaeEngine:
                 aux_dead_cap=cfg.aux_dead_cap, shard_world=cfg.shard_world,
                 bound_mode={"guaranteed": 0, "predicted": 1}[cfg.bounds], max_backward_rows=cfg.max_backward_rows,
             )
-            if cfg.dw_route not in ("slices", "rows", "slices_a", "slices_s") or cfg.fwd_route not in ("default", "rows"):
-                raise ValueError(f"EngineConfig.dw_route must be 'slices', 'slices_a', 'slices_s' or 'rows' and fwd_route 'default' or 'rows', got {cfg.dw_route!r} / {cfg.fwd_route!r}")
+            if cfg.dw_route not in ("slices", "rows", "slices_a", "slices_s") or cfg.fwd_route not in ("default", "rows", "sum_pass"):
+                raise ValueError(f"EngineConfig.dw_route must be 'slices', 'slices_a', 'slices_s' or 'rows' and fwd_route 'default', 'rows' or 'sum_pass', got {cfg.dw_route!r} / {cfg.fwd_route!r}")
             dbg = _lib.SaevDebugCfg(
                 struct_size=C.sizeof(_lib.SaevDebugCfg), dw_route={"slices": 0, "rows": 1, "slices_a": 2, "slices_s": 4}[cfg.dw_route], enc_mfma=cfg.enc_mfma,
                 fused_chain=int(cfg.fused_chain), ngroups=cfg.ngroups, enc_wgs=cfg.enc_wgs, refresh_first=cfg.refresh_first,
-                refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route=int(cfg.fwd_route == "rows"),
+                refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route={"default": 0, "rows": 1, "sum_pass": 2}[cfg.fwd_route],
                 dead_lag=cfg.dead_lag, csc_route=cfg.csc_route, fin_route=cfg.fin_route, prep_route=cfg.prep_route)
             ctx = C.c_void_p()
             rc = self.lib.saev_create_ex(C.byref(ccfg), C.byref(dbg), self.device.index, C.byref(ctx))

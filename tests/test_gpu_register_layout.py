@@ -50,13 +50,15 @@ def _teacher_forced_step(eng, cfg, x, lr, prefixes=None, seed=None):
 @pytest.mark.parametrize("d,k", [(1280, 64), (1280, 32), (512, 64), (1024, 48), (256, 33), (768, 64)])
 def test_steps_match_the_oracle_at_the_wide_shapes(d, k):
     """decode_q_kernel<NW, 2>: more than 32 codes per row are decoded in two halves of 32 decoder rows (the first half gathered once
-    more for dval), and d_model 1280 (configs[3]: five waves per activation row) -- the same three teacher-forced steps."""
-    test_steps_match_the_oracle_at_every_width(d, k, 1)
+    more for dval), and d_model 1280 (configs[3]: five waves per activation row) -- the same three teacher-forced steps.  The clip norm
+    at SURVEY 8c's 1e-3: the ORACLE's fp32 norm of these larger gradients is itself 1-2e-4 off its own fp64 value (every route of the
+    HIP path agrees with the fp64 norm of its gradient to 1e-8: tools/experiments/r5_diag_wide.py)."""
+    test_steps_match_the_oracle_at_every_width(d, k, 1, norm_tol=1e-3)
 
 
 @pytest.mark.parametrize("d", [256, 512, 768, 1024])
 @pytest.mark.parametrize("k,n_pre", [(8, 1), (32, 1), (32, 4), (17, 10)])
-def test_steps_match_the_oracle_at_every_width(d, k, n_pre):
+def test_steps_match_the_oracle_at_every_width(d, k, n_pre, norm_tol=1e-4):
     """Three teacher-forced train steps (lr 0 first, as the reference's scheduler gives) with 1 / 4 / 10 Matryoshka prefixes: losses,
     gradient norm and every parameter against the oracle; n = 300 rows is not a multiple of anything the kernels tile by."""
     s, n = 4 * d, 300
@@ -77,7 +79,7 @@ def test_steps_match_the_oracle_at_every_width(d, k, n_pre):
         flips += flipped
         assert math.isclose(st.mse, ref["mse"], rel_tol=4.0 / (n * k)), (i, st.mse, ref["mse"])
         if not flipped:
-            assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=1e-4), (i, st.grad_norm, ref["grad_norm"])
+            assert math.isclose(st.grad_norm, ref["grad_norm"], rel_tol=norm_tol), (i, st.grad_norm, ref["grad_norm"])
             for key in R.PARAM_ORDER:
                 bad = ~torch.isclose(eng.view(key).cpu(), state.params[key], rtol=1e-4, atol=2e-6)
                 assert bad.float().mean() <= 1e-4, f"step {i} {key}: {bad.sum().item()} of {bad.numel()} elements off"

@@ -165,3 +165,18 @@ def test_train_step_gather_equals_gather_then_train_step():
             assert e0.read_stats().mse == e1.read_stats().mse
         torch.cuda.synchronize()
         _same(e0, e1, f"route {route}")
+
+
+@pytest.mark.parametrize("d,s,k,b", [(1024, 8192, 32, 2048), (768, 6144, 32, 1000), (256, 2048, 16, 300)])
+def test_shares_added_by_the_final_select_equal_the_separate_pass(d, s, k, b):
+    """saev_debug_cfg.fwd_route = 2 keeps refine_sum_kernel; the default lets the final select add a survivor's D / 32 shares itself,
+    in the same order: codes, values and therefore whole runs are bit-identical."""
+    from saev_amd.engine import EngineConfig, SaeEngine  # noqa: F401
+
+    engs = [_engine(d, s, k, b, 0, seed=21, fwd_route=r) for r in ("default", "sum_pass")]
+    for i, x in enumerate(_batches(d, b, 4, seed=22)):
+        for eng in engs:
+            eng.train_step(x, 1e-3, 1.0)
+        (i0, v0, _), (i1, v1, _) = (e.last_codes(b) for e in engs)
+        assert torch.equal(i0, i1) and torch.equal(v0, v1), i
+    _same(*engs)

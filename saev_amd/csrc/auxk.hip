@@ -730,11 +730,27 @@ __global__ __launch_bounds__(256) void aux_small_wsum_kernel(const float* part, 
 // latent -- 256 lanes walking 1 024 blocks four loads at a time).
 __global__ __launch_bounds__(1024) void aux_fused_wsum_kernel(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd,
                                                               float* dWe, const float* partb, float* db_out, int db_accumulate,
-                                                              const float* partbe, float* dbe) {
+                                                              const float* partbe, float* dbe, const RowStats* rs, int n_rows,
+                                                              float alpha, saev_step_stats* stats) {
     const int nd = *nd_dev;
     if (nd <= 0 || nd > AUX_FUSED_MAX) return;
     __shared__ f32x4 sh[16][64];
     const int D4 = D >> 2;
+    if (blockIdx.y == 4) {  // the auxiliary loss of the step from the rows' shares (stats_reduce_kernel's with_aux = 2 launch)
+        if (blockIdx.x != 0 || rs == nullptr) return;
+        __shared__ double shd[16];
+        double t = 0.0;
+        for (int r = threadIdx.x; r < n_rows; r += 1024) t += (double)rs[r].aux_sse;
+        t = wave_sum_d(t);
+        if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tt = 0.0;
+            for (int w = 0; w < 16; ++w) tt += shd[w];
+            stats->aux = (float)((double)alpha * tt / ((double)n_rows * (double)D));
+        }
+        return;
+    }
     // blockIdx.y: 0 decoder rows, 1 encoder rows (nd x D out of [blk][2][AUX_FUSED_MAX][D]); 2 db_dec's share (D out of [blk][D]);
     // 3 db_enc[dl] (AUX_FUSED_MAX out of [blk][AUX_FUSED_MAX]) -- the last two used to be two column-sum launches each
     const int kind = blockIdx.y;
@@ -947,9 +963,10 @@ hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int3
     return hipGetLastError();
 }
 hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,
-                                 const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe) {
-    hipLaunchKernelGGL(aux_fused_wsum_kernel, dim3((AUX_FUSED_MAX * (D >> 2) + 63) / 64, 4), dim3(1024), 0, s, part, n_blk, D, nd_dev, dWd, dWe,
-                       partb, db_out, db_accumulate, partbe, dbe);
+                                 const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe,
+                                 const RowStats* rs, int n_rows, float alpha, saev_step_stats* stats) {
+    hipLaunchKernelGGL(aux_fused_wsum_kernel, dim3((AUX_FUSED_MAX * (D >> 2) + 63) / 64, rs != nullptr ? 5 : 4), dim3(1024), 0, s, part, n_blk, D,
+                       nd_dev, dWd, dWe, partb, db_out, db_accumulate, partbe, dbe, rs, n_rows, alpha, stats);
     return hipGetLastError();
 }
 bool aux_fused_supported(int D) { return D % 256 == 0 && D >= 256 && D <= 1024; }

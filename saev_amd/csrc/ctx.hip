@@ -183,7 +183,11 @@ struct saev_ctx {
     bool prep_valid = false;      // mu and scales[par][0, 4] describe a previous batch of this context
     bool wimg_fresh = false;      // ws / WeS / dot_part / sq_part / b_shift / wnorm_scratch describe W_enc AS IT IS NOW ...
     int64_t mu_serial = 0, wimg_mu_serial = -1;  // ... centred on the mu of this version (mu_serial: bumped whenever mu is rewritten)
+    bool wimg_bf16_fresh = false; // bf16 encoder: ws describes W_enc as it is now
     bool stream_step = false;     // the forward in flight took the streamed preparation
+    bool stats_pending = false, stats_lists = false;  // the forward of a fused train step left its statistics to saev_step_dead's launch
+    bool aux_stats_pending = false;  // ... and its one-pass AuxK forward left the auxiliary loss to the backward's ordered-sum launch
+    bool dead_list_ready = false; // ... which also left the list of dead latents (if any are dead)
     bool train_fused = false;     // inside saev_train_step: the forward moves mu, the tail's Adam leaves the next images
     const float* gather_pool = nullptr;   // saev_train_step_gather: the batch is rows[0..n) of this pool, x is where it is written
     const int64_t* gather_rows = nullptr;
@@ -518,6 +522,7 @@ int saev_bind(saev_ctx* c, float* params, float* grads, float* adam_m, float* ad
     c->params = params;
     c->wn2_fresh = false;
     c->wimg_fresh = false;
+    c->wimg_bf16_fresh = false;
     c->grads = grads;
     c->adam_m = adam_m;
     c->adam_v = adam_v;
@@ -769,7 +774,11 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
     }
     if (!x_borrowed) HIPCHK(c, launch_split_rows(x, n, D, c->Dp, c->xs, bf ? 1 : 0, s));
     { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }
-    HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, bf ? 1.0f : 256.0f, c->ws, bf ? 1 : 0, s));
+    // (bf16: the fused Adam of the previous step has left the images of the W_enc it wrote -- AdamImageArgs::mode 1 -- and nothing
+    // has written the parameters since: include/saev_amd.h, PARAMETER OWNERSHIP)
+    if (!(bf && c->wimg_bf16_fresh))
+        HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, bf ? 1.0f : 256.0f, c->ws, bf ? 1 : 0, s));
+    if (bf && c->dbg.prep_route == 0 && c->Dp == D && D % 32 == 0) c->wimg_bf16_fresh = true;  // (the images describe W_enc as it is)
     return SAEV_OK;
 }
 
@@ -1189,6 +1198,12 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     // (list statistics from the candidate counters themselves unless the fused encoder is out of play or predicts bounds,
     // where overflow_check_kernel leaves them in flags[2..3])
     const bool lists = fused_supported(c->cfg) && !(c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 && f16_ngroups(c) == 32);
+    c->stats_pending = false;
+    if (c->train_fused && training) {  // (saev_train_step: the tracker update that follows takes this reduction into its launch)
+        c->stats_pending = true;
+        c->stats_lists = lists;
+        return SAEV_OK;
+    }
     HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P, c->cfg.alpha, 0, c->upper_c, c->flags + 2, c->stats, s, nullptr, c->stats_scratch,
                                   lists ? c->cand_cnt : nullptr, CAND_CAP));
     return SAEV_OK;
@@ -1296,7 +1311,7 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
     c->aux_small = true;
     c->aux_all = false;
     c->aux_fused = false;
-    HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s, nd_dev));
+    if (!c->dead_list_ready) HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s, nd_dev));
     HIPCHK(c, launch_gather_dead_small(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd_dev, D, S,
                                        c->WencT_dead, c->Wdec_dead, s));
     if (bound <= AUX_FUSED_MAX && aux_fused_supported(D) && c->dbg.aux_small_max != AUX_SMALL_MAX) {
@@ -1306,7 +1321,10 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
         HIPCHK(c, launch_aux_small_fused(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                          c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
                                          c->cfg.alpha * 2.0f / ((float)n * (float)D), c->aux_small_part, c->g_aux, c->A_dead, c->rowstats, s, bound));
-        HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, nullptr, c->stats, s, nd_dev, c->stats_scratch));
+        // (inside saev_train_step the backward's ordered-sum launch also forms the step's auxiliary loss: aux_stats_pending)
+        c->aux_stats_pending = c->train_fused;
+        if (!c->aux_stats_pending)
+            HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, nullptr, c->stats, s, nd_dev, c->stats_scratch));
         return SAEV_OK;
     }
     HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
@@ -1334,7 +1352,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     // so every product below has its usual shape and nothing is read back.
     const int32_t* nd_dev = c->aux_dev_count ? c->flags + 4 : nullptr;
     const int32_t* ku_dev = c->aux_dev_count ? c->flags + 5 : nullptr;
-    HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
+    if (!c->dead_list_ready) HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
     HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
                                  c->Wenc_dead, c->Wdec_dead, s, nd_dev));
     c->aux_small = false;
@@ -1400,7 +1418,9 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
             // kernel leaves at once in that case, hence the memset)
             if (c->ov_x != nullptr) HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));
             HIPCHK(c, launch_aux_fused_wsum(c->aux_small_part, blocks, D, nd_dev, c->dWd, c->dWe, s, c->g_aux,
-                                            c->ov_x != nullptr ? c->db_aux : c->grads + c->off_b_dec, c->ov_x != nullptr ? 0 : 1, c->A_dead, c->dbe));
+                                            c->ov_x != nullptr ? c->db_aux : c->grads + c->off_b_dec, c->ov_x != nullptr ? 0 : 1, c->A_dead, c->dbe,
+                                            c->aux_stats_pending ? c->rowstats : nullptr, n, c->cfg.alpha, c->stats));
+            c->aux_stats_pending = false;
             return SAEV_OK;
         }
         HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
@@ -1464,7 +1484,16 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     d.horizon_tokens = (int64_t)lag * n_rows_global;
     d.step = step; d.cum_tokens = c->tokens_seen;
     d.rec = c->rec_dev ? c->rec_dev + step % DEAD_RING : nullptr;
-    HIPCHK(c, launch_dead_update(d, s));
+    c->dead_list_ready = false;
+    if (c->stats_pending) {
+        c->stats_pending = false;
+        d.dead_list = c->cfg.k_aux > 0 ? c->dead_list : nullptr;
+        HIPCHK(c, launch_stats_dead(c->rowstats, c->n_last, c->cfg.d_model, c->P_last, c->cfg.alpha, c->upper_c, c->flags + 2, c->stats,
+                                    c->stats_scratch, c->stats_lists ? c->cand_cnt : nullptr, CAND_CAP, d, s));
+        c->dead_list_ready = d.dead_list != nullptr;
+    } else {
+        HIPCHK(c, launch_dead_update(d, s));
+    }
     c->n_dead_host = 0;
     c->k_use_host = 0;
     c->aux_route = AUX_NONE;
@@ -1871,6 +1900,9 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     const bool emit = c->train_fused && c->stream_ok && c->prep_valid && c->leader == nullptr && c->followers.empty() && shard_rank < 0 &&
                       c->tail_proj_in_adam && c->wenc_t_pending;
     c->wimg_fresh = false;  // (W_enc moves: only the fused Adam below leaves images of what it writes)
+    const bool emit_bf16 = c->train_fused && c->cfg.encoder_mode == SAEV_ENCODER_BF16 && c->wimg_bf16_fresh && shard_rank < 0 &&
+                           c->tail_proj_in_adam && c->wenc_t_pending;
+    c->wimg_bf16_fresh = false;
     AdamArgs a{};
     a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
     a.omb1 = (float)(1.0 - 0.9); a.omb2 = (float)(1.0 - 0.999);
@@ -1890,10 +1922,12 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
             im.ws = c->ws; im.WeS = c->WeS; im.dot_part = reinterpret_cast<double*>(c->dot_part); im.sq_part = c->sq_part;
             im.mu = c->mu; im.wmax_prev = c->wmax_prev; im.scales_next = scl_next(c); im.nks = c->Dp / 32; im.S_pad = c->S_pad;
         }
+        if (emit_bf16) { im.ws = c->ws; im.nks = c->Dp / 32; im.S_pad = c->S_pad; im.mode = 1; }
         HIPCHK(c, launch_adam_fused(a, c->row_proj, c->dW_encT, (int)S, (int)D, S * D, c->off_W_enc - S * D, c->off_W_enc,
                                     c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr,
-                                    emit ? &im : nullptr));
+                                    (emit || emit_bf16) ? &im : nullptr));
         c->unused_valid = false;
+        c->wimg_bf16_fresh = emit_bf16;
         if (emit) {
             // the bias of the next centred first pass and the column-norm maxima its margins need: W-only, so they are finished here
             HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, (int)S, c->S_pad, scl_next(c) + 1,
@@ -1945,6 +1979,7 @@ int saev_train_step_gather(saev_ctx* c, const float* pool, const int64_t* rows, 
 int saev_params_touched(saev_ctx* c) {
     if (!c) return SAEV_INVALID_ARG;
     c->wimg_fresh = false;
+    c->wimg_bf16_fresh = false;
     c->wn2_fresh = false;
     return SAEV_OK;
 }

@@ -399,6 +399,7 @@ struct AdamImageArgs {
     _Float16* ws; float* WeS; double* dot_part; float* sq_part;
     const float* mu; const float* wmax_prev; float* scales_next;
     int nks, S_pad;
+    int mode;  // 0: the f16r set described above; 1: the bf16 encoder -- only ws, W_enc^T rounded to bf16 (nothing else is read)
 };
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
                              long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused = nullptr,
@@ -429,8 +430,13 @@ struct DeadArgs {
     int64_t horizon_tokens; // see DeadRecord
     int64_t step, cum_tokens;
     DeadRecord* rec;        // device-visible pointer into pinned host memory, or NULL
+    int32_t* dead_list;     // optional (launch_stats_dead only): the ascending list of dead latents, written when any are dead
 };
 hipError_t launch_dead_update(const DeadArgs& a, hipStream_t stream);
+// launch_stats_reduce (with_aux = 0) and launch_dead_update in one launch (a fused train step: the two meet nowhere)
+hipError_t launch_stats_dead(const RowStats* rs, int n_rows, int D, int P, float alpha, const float* upper, const int32_t* n_overflow,
+                             saev_step_stats* stats, double* scratch, const int32_t* cand_cnt, int cand_cap, const DeadArgs& d,
+                             hipStream_t stream);
 hipError_t launch_absmax(const float* x, long n, float* out_zeroed, hipStream_t stream);
 hipError_t launch_gather_rows(const float* pool, const int64_t* rows, int n_rows, int D, float* out, hipStream_t stream);
 hipError_t launch_scatter_dense(const int32_t* idx, const float* val, int n_rows, int k, int stride, int S, float* f,
@@ -598,7 +604,9 @@ bool aux_fused_supported(int D);
 // the ordered sums of all four partial sets in one launch: dWd / dWe rows, db_dec's share (db_out, added to what is there when
 // db_accumulate) and db_enc[dl] (dbe)
 hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,
-                                 const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe);
+                                 const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe,
+                                 // optional: the step's auxiliary loss from the rows' shares as well (stats->aux; a fused train step)
+                                 const RowStats* rs = nullptr, int n_rows = 0, float alpha = 0.f, saev_step_stats* stats = nullptr);
 int aux_fused_blocks(int n_rows);
 hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                   const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale,

@@ -1278,21 +1278,21 @@ __global__ __launch_bounds__(256) void dw_finalize_kernel(DwSlicesArgs a, int ki
     }
 }
 
-// The light finalize (DwSlicesArgs::wn2): ONE launch of 1 024-thread workgroups.
-//   * Workgroups [0, 2 (n_runs - 1)): a latent cut by run boundaries (L or more pairs), one gradient row of it -- the workgroup at
-//     the FIRST boundary the latent crosses owns it.  Sixteen waves = four column quarters x four groups of partial rows (a latent
-//     that fires on every row -- 256 partials at 16 384 rows, the critical path of this launch -- has 64 partial rows per group,
-//     a quarter of a row per wave).  Same order of additions as dw_finalize_cut_kernel: bit-identical rows and db_enc.
-//   * The rest: sixteen latents each, one wave per latent.  The two gradient rows are read once for their squares; the decoder row
-//     is not: <dW_dec[i], w_i> = sum over the latent's pairs of val * dval, ||w_i||^2 comes from normalize_rows (wn2).
-//   (Squares from per-slice pieces left by the passes -- no row read at all -- were measured: the extra store per finished latent
-//   cost the two passes 13 us each, more than the 268 MB of row reads they saved here.)
+// The light finalize (DwSlicesArgs::wn2): ONE launch of 256-thread workgroups.
+//   * Workgroups [0, n_cut_blocks) walk the list of latents cut by run boundaries (DwSlicesArgs::cut_list: L or more pairs, spanning
+//     a boundary; most runs have none), one (latent, gradient row) item at a time: dw_finalize_cut_kernel's sums in the same order
+//     -- bit-identical rows and db_enc -- with eight partial rows in flight per wave instead of four (a latent that fires on every
+//     row has 64 partial rows per wave: the critical path of this launch).  256 threads per item: most cut latents have a handful
+//     of partials, and four times as many items are resident as with the 1 024-thread form (45 us for ~6 000 items).
+//   * The rest: four latents each, one wave per latent.  No decoder row is read: <dW_dec[i], w_i> = sum over the latent's pairs of
+//     val * dval, ||w_i||^2 comes from normalize_rows (wn2).  The squares of the two gradient rows: kept per wave by the passes
+//     (sq_wave_dec / _enc: only their total matters to the clip norm), or read here when the passes did not keep them.
 // Both also zero the CSC bit map words of the pairs they walk (dw_clear_bitmap_kernel's job).
-template <int NVQ>  // float4 columns per lane of a column quarter: ceil(D / 4 / 256)
-__global__ __launch_bounds__(1024) void dw_finalize_light_kernel(DwSlicesArgs a, int n_cut_blocks) {
+template <int NV>
+__global__ __launch_bounds__(256) void dw_finalize_light_kernel(DwSlicesArgs a, int n_cut_blocks) {
     constexpr int L = DWS_RUN;
-    __shared__ f32x4 sh[3][NVQ * 256];
-    __shared__ float shs[16], shst[4][2];
+    __shared__ f32x4 sh[3][NV * 64];  // (waves 1-3; wave 0 keeps its sum in registers)
+    __shared__ float shdb[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int D = a.D, D4 = D >> 2;
     if ((int)blockIdx.x < n_cut_blocks) {
@@ -1303,101 +1303,92 @@ __global__ __launch_bounds__(1024) void dw_finalize_light_kernel(DwSlicesArgs a,
         const int s = a.starts[i], e = a.starts[i + 1];
         const int r1 = (e - 1) / L;
         const float* const part = enc ? a.part_enc : a.part_dec;
-        const int colq = w & 3, rg = w >> 2;
         const int nh = r1 - r0, ch = (nh + 3) / 4;
-        const int ra = r0 + 1 + rg * ch, rb = min(r1 + 1, ra + ch);
-        int col[NVQ];
-        bool ok[NVQ];
-        f32x4 acc[NVQ];
+        const int ra = r0 + 1 + w * ch, rb = min(r1 + 1, ra + ch);
+        f32x4 acc[NV];
 #pragma unroll
-        for (int n = 0; n < NVQ; ++n) { col[n] = (n * 4 + colq) * 64 + lane; ok[n] = col[n] < D4; acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // (trips of four rows added pairwise, or of two: what dw_finalize_cut_kernel<NV> does for this d_model; two trips in flight)
-        const int TRIP = D4 <= 256 ? 4 : 2;
+        for (int n = 0; n < NV; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int TRIP = NV <= 4 ? 4 : 2;  // (the unit dw_finalize_cut_kernel adds pairwise: kept, two of them in flight)
         int r = ra;
-        for (; r + 2 * TRIP <= rb && TRIP == 4; r += 8) {
-            f32x4 t[8][NVQ];
+        for (; r + 2 * TRIP <= rb; r += 2 * TRIP) {
+            f32x4 t[2 * TRIP][NV];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 2 * TRIP; ++u) {
                 const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)(r + u) * 2 * D);
 #pragma unroll
-                for (int n = 0; n < NVQ; ++n) t[u][n] = ok[n] ? p[col[n]] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int n = 0; n < NV; ++n) t[u][n] = (lane + 64 * n < D4) ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int n = 0; n < NVQ; ++n) {
-                acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
-                acc[n] += (t[4][n] + t[5][n]) + (t[6][n] + t[7][n]);
+            for (int n = 0; n < NV; ++n) {
+                if constexpr (TRIP == 4) {
+                    acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
+                    acc[n] += (t[4][n] + t[5][n]) + (t[6][n] + t[7][n]);
+                } else {
+                    acc[n] += t[0][n] + t[1][n];
+                    acc[n] += t[2][n] + t[3][n];
+                }
             }
         }
         for (; r + TRIP <= rb; r += TRIP) {
-            f32x4 t[4][NVQ];
+            f32x4 t[TRIP][NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)(r + min(u, TRIP - 1)) * 2 * D);
+            for (int u = 0; u < TRIP; ++u) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)(r + u) * 2 * D);
 #pragma unroll
-                for (int n = 0; n < NVQ; ++n) t[u][n] = (ok[n] && u < TRIP) ? p[col[n]] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int n = 0; n < NV; ++n) t[u][n] = (lane + 64 * n < D4) ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int n = 0; n < NVQ; ++n) {
-                if (TRIP == 4) acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
+            for (int n = 0; n < NV; ++n) {
+                if constexpr (TRIP == 4) acc[n] += (t[0][n] + t[1][n]) + (t[2][n] + t[3][n]);
                 else acc[n] += t[0][n] + t[1][n];
             }
         }
         for (; r < rb; ++r) {
             const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)r * 2 * D);
 #pragma unroll
-            for (int n = 0; n < NVQ; ++n)
-                if (ok[n]) acc[n] += p[col[n]];
+            for (int n = 0; n < NV; ++n)
+                if (lane + 64 * n < D4) acc[n] += p[lane + 64 * n];
         }
         float dbs = 0.f;
-        if (enc && colq == 0) {  // db_enc: a quarter of the latent's pairs per row group's first wave (and their bit map words)
+        if (enc) {  // db_enc: a quarter of the latent's pairs per wave (and their bit map words)
             const int cnt = e - s, q4 = (cnt + 3) / 4;
-            for (int p = s + rg * q4 + lane; p < min(e, s + (rg + 1) * q4); p += 64) {
+            for (int p = s + w * q4 + lane; p < min(e, s + (w + 1) * q4); p += 64) {
                 const int2 pe = a.pv2[p];
                 dbs += __int_as_float(pe.y);
                 if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (pe.x >> 12)] = 0u;
             }
             dbs = wave_sum(dbs);
         }
-        if (rg != 0) {
+        if (w != 0) {
 #pragma unroll
-            for (int n = 0; n < NVQ; ++n) sh[rg - 1][(n * 4 + colq) * 64 + lane] = acc[n];
+            for (int n = 0; n < NV; ++n) sh[w - 1][lane + 64 * n] = acc[n];
         }
-        if (lane == 0) shs[w] = dbs;
+        if (lane == 0) shdb[w] = dbs;
         __syncthreads();
-        float dot = 0.f, gsq = 0.f;
-        if (rg == 0) {
+        if (w == 0) {
             // (a latent that begins exactly at a run boundary has its first piece stored as that run's tail partial as well)
             const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)r0 * 2 + 1) * D);
-            float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
-            const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
 #pragma unroll
-            for (int n = 0; n < NVQ; ++n) {
-                if (!ok[n]) continue;
-                const int c = (n * 4 + colq) * 64 + lane;
-                const f32x4 g = (((p[col[n]] + acc[n]) + sh[0][c]) + sh[1][c]) + sh[2][c];
-                reinterpret_cast<f32x4*>(row)[col[n]] = g;
-                gsq = __builtin_fmaf(g[3], g[3], __builtin_fmaf(g[2], g[2], __builtin_fmaf(g[1], g[1], __builtin_fmaf(g[0], g[0], gsq))));
-                if (!enc && a.row_proj != nullptr && a.project) {
-                    const f32x4 wv = wr[col[n]];
-                    dot = __builtin_fmaf(g[3], wv[3], __builtin_fmaf(g[2], wv[2], __builtin_fmaf(g[1], wv[1], __builtin_fmaf(g[0], wv[0], dot))));
-                }
+            for (int n = 0; n < NV; ++n) {
+                const f32x4 t = (lane + 64 * n < D4) ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[n] = (((t + acc[n]) + sh[0][lane + 64 * n]) + sh[1][lane + 64 * n]) + sh[2][lane + 64 * n];
             }
-            gsq = wave_sum(gsq);
-            dot = wave_sum(dot);
-        }
-        if (rg == 0 && lane == 0) { shst[colq][0] = gsq; shst[colq][1] = dot; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float dbt = ((shs[0] + shs[4]) + shs[8]) + shs[12];
-            const float g2 = ((shst[0][0] + shst[1][0]) + shst[2][0]) + shst[3][0];
-            const float dt = ((shst[0][1] + shst[1][1]) + shst[2][1]) + shst[3][1];
+            float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+                if (lane + 64 * n < D4) reinterpret_cast<f32x4*>(row)[lane + 64 * n] = acc[n];
             if (enc) {
-                a.db_enc[i] = dbt;
-                if (a.enc_sq != nullptr) a.enc_sq[i] = g2;
+                if (lane == 0) a.db_enc[i] = ((shdb[0] + shdb[1]) + shdb[2]) + shdb[3];
+                if (a.enc_sq != nullptr) {
+                    const float sq = row_sumsq<NV>(acc);
+                    if (lane == 0) a.enc_sq[i] = sq;
+                }
             } else if (a.row_proj != nullptr) {
-                const float nsq = a.wn2[i];
-                const float sc = (a.project && nsq > 0.f) ? dt / nsq : 0.f;
-                a.row_proj[i] = float2{sc, fmaxf(__builtin_fmaf(-sc, dt, g2), 0.f)};
+                f32x4 wv[NV];
+                const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+#pragma unroll
+                for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+                write_row_proj<NV>(a.row_proj, i, acc, wv, a.project, lane);
             }
         }
         __syncthreads();  // (the LDS arrays are reused by the next item)
@@ -1405,7 +1396,7 @@ __global__ __launch_bounds__(1024) void dw_finalize_light_kernel(DwSlicesArgs a,
       return;
     }
     // ---- every other latent: one wave ----
-    const int i = ((int)blockIdx.x - n_cut_blocks) * 16 + w;
+    const int i = ((int)blockIdx.x - n_cut_blocks) * 4 + w;
     if (i >= a.S) return;
     const int s = a.starts[i], e = a.starts[i + 1];
     if (a.lat_unused != nullptr && lane == 0) a.lat_unused[i] = e == s ? 1 : 0;
@@ -2031,14 +2022,11 @@ hipError_t launch_dw_slices(const DwSlicesArgs& a_in, int max_pairs, int part, h
     if (part != 1) hipLaunchKernelGGL(dw_slices_kernel<false>, dim3(grid), dim3(256), 0, stream, a, wg_per_slice);
     const int kinds = part == 0 ? 2 : 1, kind0 = part == 2 ? 1 : 0;
     if (light) {  // one launch: cut latents first, then a wave per latent that reads no row back (and clears the bit map words)
-        const int n_cut = a.cut_list != nullptr ? std::min(2 * (n_runs - 1), 4096) : 0;  // workgroups that walk the list of cut latents
+        const int n_cut = a.cut_list != nullptr ? std::min(2 * (n_runs - 1), 8192) : 0;  // workgroups that walk the list of cut latents
         if (a.cut_list == nullptr && n_runs > 1) return hipErrorInvalidValue;
-        const dim3 grid_f(n_cut + (a.S + 15) / 16);
-        const int nvq = (a.D / 4 + 255) / 256;
-        if (nvq <= 1) hipLaunchKernelGGL(dw_finalize_light_kernel<1>, grid_f, dim3(1024), 0, stream, a, n_cut);
-        else if (nvq == 2) hipLaunchKernelGGL(dw_finalize_light_kernel<2>, grid_f, dim3(1024), 0, stream, a, n_cut);
-        else hipLaunchKernelGGL(dw_finalize_light_kernel<4>, grid_f, dim3(1024), 0, stream, a, n_cut);
-        return hipGetLastError();
+        return dispatch_nv(a.D, [&](auto nv) {
+            hipLaunchKernelGGL(dw_finalize_light_kernel<decltype(nv)::value>, dim3(n_cut + (a.S + 3) / 4), dim3(256), 0, stream, a, n_cut);
+        });
     }
     return dispatch_nv(a.D, [&](auto nv) {
         if (n_runs > 1) hipLaunchKernelGGL(dw_finalize_cut_kernel<decltype(nv)::value>, dim3(n_runs - 1, kinds), dim3(256), 0, stream, a, kind0);

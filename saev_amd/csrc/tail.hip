@@ -322,14 +322,27 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
         __syncthreads();  // (every thread has taken its gradient out of the tile)
 #pragma unroll
         for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&tile[dr + 4 * i][sl]) = pn[i];
+        const int rl = threadIdx.x, ks = d0 / TD;
+        const int swz = (4 - ((rl >> 2) & 3)) & 3;
+        if (f.img.mode == 1) {  // the bf16 encoder: its images are W_enc^T rounded to bf16, nothing else (split_wT_body<1>)
+            __syncthreads();
+            typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
+            half8t* const imgb = reinterpret_cast<half8t*>(f.img.ws + ((size_t)(s0 / TS) * f.img.nks + ks) * 256 * 32);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x8t h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (__bf16)tile[c * 8 + e][rl];
+                imgb[rl * 4 + (c ^ swz)] = __builtin_bit_cast(half8t, h);
+            }
+            return;
+        }
         __shared__ float mu_s[TD];
         if (threadIdx.x < TD) mu_s[threadIdx.x] = f.img.mu[d0 + threadIdx.x];
         __syncthreads();
         const float wm = *f.img.wmax_prev;
         const float scale = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
         if (t == 0 && threadIdx.x == 0) { f.img.scales_next[1] = scale; f.img.scales_next[3] = 1.0f; }
-        const int rl = threadIdx.x, ks = d0 / TD;
-        const int swz = (4 - ((rl >> 2) & 3)) & 3;
         double accp[4];
         float sqp[4], dsp[4];
         half8t* const img = reinterpret_cast<half8t*>(f.img.ws + ((size_t)(s0 / TS) * f.img.nks + ks) * 256 * 32);
@@ -459,9 +472,38 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void dead_update_kernel(DeadArgs a) {
-    __shared__ int sh[2][4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// dead mask (S) -> ascending list of dead latents by ONE 1 024-thread workgroup, every thread a contiguous chunk (auxk.hip's
+// dead_compact_kernel; here for the workgroup that finishes the tracker update)
+__device__ __forceinline__ void dead_compact_block(const int32_t* dead, int S, int32_t* list, int (&wave_tot)[16]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (S + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(S, i0 + per);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += dead[i] ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int pos = incl - cnt;
+    for (int j = 0; j < w; ++j) pos += wave_tot[j];
+    if (cnt > 0)
+        for (int i = i0; i < i1; ++i)
+            if (dead[i]) list[pos++] = i;
+}
+
+// tracker update (objectives.py:107-120) on latents [bid * blockDim.x, ...); the last of `n_blocks` workgroups publishes the counts
+// and the host-visible record; with a.dead_list (1 024-thread workgroups only) it also leaves the ascending list of dead latents
+// whenever any are dead (dead_compact_kernel's launch)
+__device__ __forceinline__ void dead_update_body(const DeadArgs& a, int bid, int n_blocks) {
+    __shared__ int sh[2][16];
+    __shared__ int wave_tot[16];
+    __shared__ int last_n;
+    const int i = bid * blockDim.x + threadIdx.x;
+    const int nw = blockDim.x >> 6;
     int d = 0, near = 0;
     if (i < a.S) {
         int64_t t = a.toks[i] + a.add_tokens;
@@ -474,12 +516,15 @@ __global__ __launch_bounds__(256) void dead_update_kernel(DeadArgs a) {
     }
     const int c = wave_sum_i(d), cn = wave_sum_i(near);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = c; sh[1][threadIdx.x >> 6] = cn; }
+    if (threadIdx.x == 0) last_n = -1;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&a.scratch[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);  // integer sums: order does not matter
-        atomicAdd(&a.scratch[2], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+        int s0 = 0, s1 = 0;
+        for (int w = 0; w < nw; ++w) { s0 += sh[0][w]; s1 += sh[1][w]; }
+        atomicAdd(&a.scratch[0], s0);  // integer sums: order does not matter
+        atomicAdd(&a.scratch[2], s1);
         __threadfence();
-        if (atomicAdd(&a.scratch[1], 1) == (int)gridDim.x - 1) {  // last block: publish and reset
+        if (atomicAdd(&a.scratch[1], 1) == n_blocks - 1) {  // last block: publish and reset
             __threadfence();
             const int t = atomicExch(&a.scratch[0], 0);
             const int tn = atomicExch(&a.scratch[2], 0);
@@ -495,8 +540,16 @@ __global__ __launch_bounds__(256) void dead_update_kernel(DeadArgs a) {
                 a.rec->cum_tokens = a.cum_tokens;
                 a.rec->step = a.step;
             }
+            last_n = t;
         }
     }
+    if (a.dead_list == nullptr) return;
+    __syncthreads();
+    if (last_n > 0) dead_compact_block(a.dead, a.S, a.dead_list, wave_tot);  // (block-uniform: only the last workgroup sees last_n >= 0)
+}
+__global__ __launch_bounds__(256) void dead_update_kernel(DeadArgs a) {
+    a.dead_list = nullptr;  // (the list needs 1 024-thread workgroups: stats_dead_kernel)
+    dead_update_body(a, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, float* out) {
@@ -541,11 +594,14 @@ __global__ __launch_bounds__(256) void scatter_dense_kernel(const int32_t* idx, 
 // not bytes); the last one to finish -- a ticket -- adds the slices in index order and writes the step's statistics.
 // scratch: 16 x 8 doubles followed by the ticket counter (an int, zero between launches).  With cand_cnt the same pass
 // also gives the list statistics of the fused encoder (rows whose list overflowed, longest list).
-__global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, int n_rows, int D, int P, float alpha,
-                                                            int with_aux, const float* upper,
-                                                            const int32_t* n_overflow, saev_step_stats* stats,
-                                                            const int32_t* n_dead_dev, double* scratch,
-                                                            const int32_t* cand_cnt, int cand_cap) {
+struct StatsArgs {
+    const RowStats* rs; int n_rows, D, P; float alpha; int with_aux; const float* upper; const int32_t* n_overflow;
+    saev_step_stats* stats; const int32_t* n_dead_dev; double* scratch; const int32_t* cand_cnt; int cand_cap;
+};
+__device__ __forceinline__ void stats_reduce_body(const StatsArgs& A, int bid, int n_blocks) {
+    const RowStats* rs = A.rs; const int n_rows = A.n_rows, D = A.D, P = A.P; const float alpha = A.alpha; const int with_aux = A.with_aux;
+    const float* upper = A.upper; const int32_t* n_overflow = A.n_overflow; saev_step_stats* stats = A.stats;
+    const int32_t* n_dead_dev = A.n_dead_dev; double* scratch = A.scratch; const int32_t* cand_cnt = A.cand_cnt; const int cand_cap = A.cand_cap;
     // with_aux == 2: the AuxK pass of a step whose dead count only the device knows -- nothing to add when it is zero
     // (the forward's call has already written every other field)
     if (with_aux == 2 && *n_dead_dev <= 0) return;
@@ -553,8 +609,8 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
     __shared__ double sh[16][NS];
     __shared__ int last;
     double s[NS] = {0, 0, 0, 0, 0, 0, 0, 0};  // [6] rows with cand_cnt > cap, [7] max cand_cnt
-    const int per = (n_rows + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    const int per = (n_rows + n_blocks - 1) / n_blocks;
+    const int r0 = bid * per, r1 = min(n_rows, r0 + per);
     for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
         const RowStats v = rs[r];
         s[0] += v.sse_scaled; s[1] += v.l0; s[2] += v.l1; s[3] += with_aux ? v.aux_sse : 0.f;
@@ -577,13 +633,13 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
         const int i = threadIdx.x;
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t = i < 7 ? t + sh[w][i] : fmax(t, sh[w][i]);
-        __hip_atomic_store(&scratch[blockIdx.x * NS + i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&scratch[bid * NS + i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+        last = (atomicAdd(ticket, 1) == n_blocks - 1) ? 1 : 0;
         if (last) __threadfence();
     }
     __syncthreads();
@@ -593,13 +649,13 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const RowStats* rs, 
     __shared__ double part[16][NS];
     if (threadIdx.x < 16 * NS) {
         const int b = threadIdx.x / NS, i = threadIdx.x % NS;
-        part[b][i] = b < (int)gridDim.x ? __hip_atomic_load(&scratch[b * NS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        part[b][i] = b < n_blocks ? __hip_atomic_load(&scratch[b * NS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
     {
         double t[NS] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int b = 0; b < (int)gridDim.x; ++b) {
+        for (int b = 0; b < n_blocks; ++b) {
             for (int i = 0; i < 7; ++i) t[i] += part[b][i];
             t[7] = fmax(t[7], part[b][7]);
         }
@@ -634,6 +690,13 @@ hipError_t dispatch_nv(int D, F&& f) {
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+__global__ __launch_bounds__(1024) void stats_reduce_kernel(StatsArgs A) { stats_reduce_body(A, blockIdx.x, gridDim.x); }
+// the forward's statistics and the tracker update of a fused train step in one launch (they meet nowhere)
+__global__ __launch_bounds__(1024) void stats_dead_kernel(StatsArgs A, int n_stat, DeadArgs d) {
+    if ((int)blockIdx.x < n_stat) stats_reduce_body(A, blockIdx.x, n_stat);
+    else dead_update_body(d, (int)blockIdx.x - n_stat, (int)gridDim.x - n_stat);
 }
 
 }  // namespace
@@ -726,7 +789,15 @@ hipError_t launch_stats_reduce(const RowStats* rs, int n_rows, int D, int P, flo
                                const int32_t* n_overflow, saev_step_stats* stats, hipStream_t stream,
                                const int32_t* n_dead_dev, double* scratch, const int32_t* cand_cnt, int cand_cap) {
     const int nb = std::max(1, std::min(16, (n_rows + 1023) / 1024));
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3(nb), dim3(1024), 0, stream, rs, n_rows, D, P, alpha, with_aux, upper,
-                       n_overflow, stats, n_dead_dev, scratch, cand_cnt, cand_cap);
+    const StatsArgs A{rs, n_rows, D, P, alpha, with_aux, upper, n_overflow, stats, n_dead_dev, scratch, cand_cnt, cand_cap};
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(nb), dim3(1024), 0, stream, A);
+    return hipGetLastError();
+}
+hipError_t launch_stats_dead(const RowStats* rs, int n_rows, int D, int P, float alpha, const float* upper, const int32_t* n_overflow,
+                             saev_step_stats* stats, double* scratch, const int32_t* cand_cnt, int cand_cap, const DeadArgs& d,
+                             hipStream_t stream) {
+    const int nb = std::max(1, std::min(16, (n_rows + 1023) / 1024));
+    const StatsArgs A{rs, n_rows, D, P, alpha, 0, upper, n_overflow, stats, nullptr, scratch, cand_cnt, cand_cap};
+    hipLaunchKernelGGL(stats_dead_kernel, dim3(nb + (d.S + 1023) / 1024), dim3(1024), 0, stream, A, nb, d);
     return hipGetLastError();
 }

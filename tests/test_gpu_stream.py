@@ -180,3 +180,22 @@ def test_shares_added_by_the_final_select_equal_the_separate_pass(d, s, k, b):
         (i0, v0, _), (i1, v1, _) = (e.last_codes(b) for e in engs)
         assert torch.equal(i0, i1) and torch.equal(v0, v1), i
     _same(*engs)
+
+
+def test_bf16_images_left_by_adam_equal_a_fresh_split():
+    """The bf16 encoder (configs[3]): the fused Adam leaves the bf16 images of the W_enc it writes (AdamImageArgs::mode 1), the next
+    forward skips its pass over W_enc.  Rounding is rounding: runs with and without (prep_route = 1) agree bit for bit, across an
+    evaluation forward and a parameter write in between."""
+    d, s, k, b = 256, 2048, 16, 512
+    engs = [_engine(d, s, k, b, r, seed=31, encoder="bf16") for r in (0, 1)]
+    xs = _batches(d, b, 7, seed=32)
+    for i, x in enumerate(xs):
+        for eng in engs:
+            if i == 3:
+                eng.step_forward(xs[0], training=False)
+            if i == 5:
+                eng.view("W_enc").mul_(0.99)
+            eng.train_step(x, 1e-3, 1.0)
+        a, c = (e.read_stats() for e in engs)
+        assert a.mse == c.mse and a.dense_route == c.dense_route == 0, (i, a, c)
+    _same(*engs)

@@ -401,7 +401,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
         if (c->dval_rows != nullptr && c->dbg.dw_route == 4 && decode_slices_supported((int)D, (int)S, (int)K, (int)K) && c->cfg.normalize_w_dec) {
             A(WdS, S * D); A(dec_part, (size_t)(D / 32) * MB * 3);
         }
-        A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(cut_list, 1 + (MBB * K + DWS_RUN - 1) / DWS_RUN); A(lat_unused, S);
+        A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(cut_list, 4 * (1 + (MBB * K + DWS_RUN - 1) / DWS_RUN)); A(lat_unused, S);
         if (c->dval_rows != nullptr && c->dbg.fin_route == 0) { A(wn2, S); A(sq_wave, (size_t)2 * dw_slices_waves((int)D, (int)(MBB * K))); }
     }
     A(colsum_partials, ((MBB + 63) / 64) * D);

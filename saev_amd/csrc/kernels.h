@@ -309,8 +309,9 @@ struct DwSlicesArgs {
     float* part_dec;         // (2 * ceil(pair_cap / DWS_RUN), D) head / tail partial of every run
     float* part_enc;
     int32_t* cut_lat;        // (ceil(pair_cap / DWS_RUN)) per run: the latent that begins in it and is cut at its end, or -1
-    int32_t* cut_list;       // optional (1 + ceil(pair_cap / DWS_RUN)): [0] = how many runs have cut_lat >= 0 (zeroed by the CSC build:
-                             // CscArgs::zero_word), then those runs in arrival order -- the light finalize walks this list
+    int32_t* cut_list;       // optional, 4 x (1 + ceil(pair_cap / DWS_RUN)) ints: [0] = how many runs have cut_lat >= 0 (zeroed by the CSC
+                             // build: CscArgs::zero_word), then from [4] on one {run, latent, starts[latent], starts[latent + 1]} per such
+                             // run, in arrival order -- the light finalize walks this list
     float2* row_proj;        // optional, as DwRowsArgs
     int project;
     float* enc_sq;           // optional

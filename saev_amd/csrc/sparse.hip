@@ -1089,7 +1089,8 @@ __global__ __launch_bounds__(256, (DEC && DVAL) ? 4 : 5) void dw_slices_kernel(D
                 if (DEC && slice == 0 && li == 0 && (xc[j] & DWS_END)) {
                     const int cl = (!head_open && !(xc[j] & DWS_LAST)) ? lc[j] : -1;
                     a.cut_lat[run] = cl;
-                    if (cl >= 0 && a.cut_list != nullptr) a.cut_list[1 + atomicAdd(&a.cut_list[0], 1)] = run;
+                    if (cl >= 0 && a.cut_list != nullptr)  // {run, latent, its pair range}: the finalize needs no further look-up
+                        reinterpret_cast<i32x4*>(a.cut_list)[1 + atomicAdd(&a.cut_list[0], 1)] = i32x4{run, cl, a.starts[cl], a.starts[cl + 1]};
                 }
                 head_open = false;
                 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1197,9 +1198,17 @@ __global__ __launch_bounds__(256) void dw_finalize_cut_kernel(DwSlicesArgs a, in
             if (lane + 64 * n < D4) acc[n] += p[lane + 64 * n];
     }
     float dbs = 0.f;
-    if (enc) {  // db_enc: a quarter of the latent's pairs per wave
+    if (enc) {  // db_enc: a quarter of the latent's pairs per wave (eight loads in flight, added in pair order)
         const int cnt = e - s, q4 = (cnt + 3) / 4;
-        for (int p = s + w * q4 + lane; p < min(e, s + (w + 1) * q4); p += 64) dbs += __int_as_float(a.pv2[p].y);
+        const int pend = min(e, s + (w + 1) * q4);
+        for (int p0 = s + w * q4 + lane; p0 < pend; p0 += 64 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (p0 + 64 * u < pend) ? __int_as_float(a.pv2[p0 + 64 * u].y) : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + 64 * u < pend) dbs += t[u];
+        }
         dbs = wave_sum(dbs);
     }
     if (w != 0) {
@@ -1296,13 +1305,27 @@ __global__ __launch_bounds__(256) void dw_finalize_light_kernel(DwSlicesArgs a, 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int D = a.D, D4 = D >> 2;
     if ((int)blockIdx.x < n_cut_blocks) {
+      // (the list's length and this workgroup's first entry are requested together: the array is sized for every run)
+      const i32x4 first = reinterpret_cast<const i32x4*>(a.cut_list)[1 + (blockIdx.x >> 1)];
       const int n_items = 2 * a.cut_list[0];
       for (int item = blockIdx.x; item < n_items; item += n_cut_blocks) {  // (block-uniform loop: the barriers inside are reached by all)
-        const int r0 = a.cut_list[1 + (item >> 1)], enc = item & 1;
-        const int i = a.cut_lat[r0];
-        const int s = a.starts[i], e = a.starts[i + 1];
+        const i32x4 ent = item == (int)blockIdx.x ? first : reinterpret_cast<const i32x4*>(a.cut_list)[1 + (item >> 1)];
+        const int r0 = ent[0], i = ent[1], s = ent[2], e = ent[3], enc = item & 1;
         const int r1 = (e - 1) / L;
         const float* const part = enc ? a.part_enc : a.part_dec;
+        // (what wave 0 needs at the end is requested now, next to the partial rows: the first run's tail partial, the decoder row)
+        f32x4 tp[NV], wv[NV];
+        if (w == 0) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)r0 * 2 + 1) * D);
+            const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
+            const bool need_w = !enc && a.row_proj != nullptr;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const bool ok = lane + 64 * n < D4;
+                tp[n] = ok ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+                wv[n] = (ok && need_w) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         const int nh = r1 - r0, ch = (nh + 3) / 4;
         const int ra = r0 + 1 + w * ch, rb = min(r1 + 1, ra + ch);
         f32x4 acc[NV];
@@ -1351,11 +1374,22 @@ __global__ __launch_bounds__(256) void dw_finalize_light_kernel(DwSlicesArgs a, 
         }
         float dbs = 0.f;
         if (enc) {  // db_enc: a quarter of the latent's pairs per wave (and their bit map words)
+            // (eight pair words in flight per lane: a latent that fires on every row has 64 of them per lane, and the bit map stores
+            // -- which the compiler must assume to alias the list -- kept the loop at one load per trip: 38 us for that one latent,
+            // the critical path of the whole launch.  Same order of additions.)
             const int cnt = e - s, q4 = (cnt + 3) / 4;
-            for (int p = s + w * q4 + lane; p < min(e, s + (w + 1) * q4); p += 64) {
-                const int2 pe = a.pv2[p];
-                dbs += __int_as_float(pe.y);
-                if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (pe.x >> 12)] = 0u;
+            const int pend = min(e, s + (w + 1) * q4);
+            for (int p0 = s + w * q4 + lane; p0 < pend; p0 += 64 * 8) {
+                int2 pe[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pe[u] = (p0 + 64 * u < pend) ? a.pv2[p0 + 64 * u] : int2{0, 0};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (p0 + 64 * u < pend) {
+                        dbs += __int_as_float(pe[u].y);
+                        if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (pe[u].x >> 12)] = 0u;
+                    }
+                }
             }
             dbs = wave_sum(dbs);
         }
@@ -1367,12 +1401,8 @@ __global__ __launch_bounds__(256) void dw_finalize_light_kernel(DwSlicesArgs a, 
         __syncthreads();
         if (w == 0) {
             // (a latent that begins exactly at a run boundary has its first piece stored as that run's tail partial as well)
-            const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)r0 * 2 + 1) * D);
 #pragma unroll
-            for (int n = 0; n < NV; ++n) {
-                const f32x4 t = (lane + 64 * n < D4) ? p[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[n] = (((t + acc[n]) + sh[0][lane + 64 * n]) + sh[1][lane + 64 * n]) + sh[2][lane + 64 * n];
-            }
+            for (int n = 0; n < NV; ++n) acc[n] = (((tp[n] + acc[n]) + sh[0][lane + 64 * n]) + sh[1][lane + 64 * n]) + sh[2][lane + 64 * n];
             float* const row = (enc ? a.dW_encT : a.dW_dec) + (size_t)i * D;
 #pragma unroll
             for (int n = 0; n < NV; ++n)
@@ -1384,10 +1414,6 @@ __global__ __launch_bounds__(256) void dw_finalize_light_kernel(DwSlicesArgs a, 
                     if (lane == 0) a.enc_sq[i] = sq;
                 }
             } else if (a.row_proj != nullptr) {
-                f32x4 wv[NV];
-                const f32x4* wr = reinterpret_cast<const f32x4*>(a.W_dec + (size_t)i * D);
-#pragma unroll
-                for (int n = 0; n < NV; ++n) wv[n] = (lane + 64 * n < D4) ? wr[lane + 64 * n] : f32x4{0.f, 0.f, 0.f, 0.f};
                 write_row_proj<NV>(a.row_proj, i, acc, wv, a.project, lane);
             }
         }
@@ -1395,48 +1421,71 @@ __global__ __launch_bounds__(256) void dw_finalize_light_kernel(DwSlicesArgs a, 
       }
       return;
     }
-    // ---- every other latent: one wave ----
-    const int i = ((int)blockIdx.x - n_cut_blocks) * 4 + w;
+    // ---- every other latent: an eight-lane group (32 latents per workgroup; a wave per latent left this part latency-bound: 31 us
+    // for a few loads and stores per latent).  A latent that is not cut has fewer than 2 L = 128 pairs: lane li of the group plays
+    // the lanes li, li + 8, ..., li + 56 of the wave that dw_finalize_kernel gives a latent, two terms each at most, and the sums
+    // go through that wave's tree (xor 32, 16, 8 in registers, 4, 2, 1 across the group): db_enc comes out bit-identical. ----
+    const int li = lane & 7;
+    const int i = ((int)blockIdx.x - n_cut_blocks) * 32 + (int)(threadIdx.x >> 3);
     if (i >= a.S) return;
     const int s = a.starts[i], e = a.starts[i + 1];
-    if (a.lat_unused != nullptr && lane == 0) a.lat_unused[i] = e == s ? 1 : 0;
+    if (a.lat_unused != nullptr && li == 0) a.lat_unused[i] = e == s ? 1 : 0;
     if (e - s >= L && s / L != (e - 1) / L) return;  // (a cut latent)
     if (e == s) {  // unused: statistics zero; rows zeroed only for callers that read the gradient buffers (no lat_unused flag)
         if (a.lat_unused == nullptr) {
-            for (int q = lane; q < D4; q += 64) {
+            for (int q = li; q < D4; q += 8) {
                 reinterpret_cast<f32x4*>(a.dW_dec + (size_t)i * D)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 reinterpret_cast<f32x4*>(a.dW_encT + (size_t)i * D)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (lane == 0) {
+        if (li == 0) {
             a.db_enc[i] = 0.f;
             if (a.enc_sq != nullptr) a.enc_sq[i] = 0.f;
             if (a.row_proj != nullptr) a.row_proj[i] = float2{0.f, 0.f};
         }
         return;
     }
+    auto group_tree = [&](float (&v)[8]) -> float {  // = wave_sum over the 64 lanes this group stands for (lane l = li + 8 j)
+        float r = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+        r += __shfl_xor(r, 4, 64);
+        r += __shfl_xor(r, 2, 64);
+        r += __shfl_xor(r, 1, 64);
+        return r;
+    };
     float gsq = 0.f, esq = 0.f;
     const bool waves_hold_squares = a.sq_wave_dec != nullptr;  // (the passes added up the squares of both rows: nothing to read here)
     if (!waves_hold_squares) {
         const f32x4* gd = reinterpret_cast<const f32x4*>(a.dW_dec + (size_t)i * D);
         const f32x4* ge = reinterpret_cast<const f32x4*>(a.dW_encT + (size_t)i * D);
 #pragma unroll 4
-        for (int q = lane; q < D4; q += 64) {
+        for (int q = li; q < D4; q += 8) {
             const f32x4 u = gd[q], v = ge[q];
             gsq = __builtin_fmaf(u[3], u[3], __builtin_fmaf(u[2], u[2], __builtin_fmaf(u[1], u[1], __builtin_fmaf(u[0], u[0], gsq))));
             esq = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], esq))));
         }
+        gsq += __shfl_xor(gsq, 4, 64); gsq += __shfl_xor(gsq, 2, 64); gsq += __shfl_xor(gsq, 1, 64);
+        esq += __shfl_xor(esq, 4, 64); esq += __shfl_xor(esq, 2, 64); esq += __shfl_xor(esq, 1, 64);
     }
-    float dot = 0.f, dbs = 0.f;
-    for (int p = s + lane; p < e; p += 64) {
-        const int2 pd = a.pv2[p];
-        const float dv = __int_as_float(pd.y);
-        dbs += dv;
-        dot = __builtin_fmaf(__int_as_float(a.pv[p].y), dv, dot);
-        if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (pd.x >> 12)] = 0u;
+    float dv8[8], dt8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float dbs = 0.f, dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {  // (the wave lane's loop: p = s + l, s + l + 64)
+            const int p = s + li + 8 * j + 64 * t;
+            if (p < e) {
+                const int2 pd = a.pv2[p];
+                const float dv = __int_as_float(pd.y);
+                dbs += dv;
+                dot = __builtin_fmaf(__int_as_float(a.pv[p].y), dv, dot);
+                if (a.clear_bitmap != nullptr) a.clear_bitmap[(size_t)i * a.clear_words + (pd.x >> 12)] = 0u;
+            }
+        }
+        dv8[j] = dbs; dt8[j] = dot;
     }
-    gsq = wave_sum(gsq); esq = wave_sum(esq); dot = wave_sum(dot); dbs = wave_sum(dbs);
-    if (lane == 0) {
+    // (wave_sum's tree: xor 32 pairs j with j + 4, xor 16 j with j + 2, xor 8 j with j + 1)
+    const float dbs = group_tree(dv8), dot = group_tree(dt8);
+    if (li == 0) {
         a.db_enc[i] = dbs;
         if (a.enc_sq != nullptr) a.enc_sq[i] = esq;
         if (a.row_proj != nullptr) {
@@ -2025,7 +2074,7 @@ hipError_t launch_dw_slices(const DwSlicesArgs& a_in, int max_pairs, int part, h
         const int n_cut = a.cut_list != nullptr ? std::min(2 * (n_runs - 1), 8192) : 0;  // workgroups that walk the list of cut latents
         if (a.cut_list == nullptr && n_runs > 1) return hipErrorInvalidValue;
         return dispatch_nv(a.D, [&](auto nv) {
-            hipLaunchKernelGGL(dw_finalize_light_kernel<decltype(nv)::value>, dim3(n_cut + (a.S + 3) / 4), dim3(256), 0, stream, a, n_cut);
+            hipLaunchKernelGGL(dw_finalize_light_kernel<decltype(nv)::value>, dim3(n_cut + (a.S + 31) / 32), dim3(256), 0, stream, a, n_cut);
         });
     }
     return dispatch_nv(a.D, [&](auto nv) {

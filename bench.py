@@ -580,7 +580,9 @@ def main():
         # HBM/fabric bytes per launch of that kernel come from rocprofv3 PMC passes (they cannot be collected inside the
         # timed run); the committed summaries are the source, and they only apply to the shape/encoder they were taken on
         tfile = {"f16x3": ROOT / "profiles" / "r01_d_encoder_traffic.json",
-                 "f16r": ROOT / "profiles" / "r04_encoder_traffic.json"}.get(eng.cfg.encoder)
+                 "f16r": ROOT / "profiles" / "r05_encoder_traffic.json"}.get(eng.cfg.encoder)
+        if tfile is not None and not tfile.exists() and eng.cfg.encoder == "f16r":
+            tfile = ROOT / "profiles" / "r04_encoder_traffic.json"
         if tfile is not None and not tfile.exists() and eng.cfg.encoder == "f16r":
             tfile = ROOT / "profiles" / "r03_encoder_traffic.json"
         if tfile is not None and not tfile.exists() and eng.cfg.encoder == "f16r":

@@ -272,6 +272,16 @@ class SparseAutoencoder(torch.nn.Module):
                 getattr(self, n).data = eng.view(n)
             self.__dict__["_engine"] = eng
             self.__dict__["_engine_max_batch"] = eng.cfg.max_batch
+        # The engine keeps what its forward needs of W_enc / W_dec between calls (include/saev_amd.h, PARAMETER OWNERSHIP).  The four
+        # Parameters are views of its buffer with version counters of their own: an in-place write through them (load_state_dict,
+        # an initialiser, a user's sae.W_enc.mul_()) shows here and drops what the engine kept.  Writes through .data show nowhere.
+        try:
+            vers = tuple(getattr(self, n)._version for n in ("W_dec", "b_dec", "W_enc", "b_enc"))
+        except RuntimeError:  # inference tensors carry no version counter
+            vers = None
+        if vers is None or vers != self.__dict__.get("_param_versions"):
+            eng.params_touched()
+            self.__dict__["_param_versions"] = vers
         return eng
 
     # ---- reference API ----------------------------------------------------------------------

@@ -199,3 +199,26 @@ def test_bf16_images_left_by_adam_equal_a_fresh_split():
         a, c = (e.read_stats() for e in engs)
         assert a.mse == c.mse and a.dense_route == c.dense_route == 0, (i, a, c)
     _same(*engs)
+
+
+def test_a_write_through_a_module_parameter_drops_what_the_engine_kept():
+    """The four Parameters of nn.SparseAutoencoder are views of the engine's buffer with version counters of their own.  An
+    in-place write through one of them between two forwards must reach the engine (SparseAutoencoder._eng compares the counters):
+    the second forward's codes are those of the new weights."""
+    from saev_amd.nn import modeling as M
+
+    torch.manual_seed(0)
+    cfg = M.SparseAutoencoderConfig(d_model=256, d_sae=2048, reinit_blend=0.0, activation=M.TopK(top_k=16))
+    sae = M.SparseAutoencoder(cfg).cuda().eval()
+    x = _batches(256, 300, 2, seed=41)
+    with torch.no_grad():
+        a0, a1 = sae(x[0]), sae(x[1])   # (the second forward of unchanged weights may reuse the images of the first)
+        keep = (a1.idx.clone(), a1.val.clone())  # (the engine's buffers are overwritten by the next forward)
+        sae.W_enc.mul_(-1.0)            # every pre-activation changes sign
+        sae.b_enc.add_(0.25)
+        got = sae(x[1])
+        fresh = M.SparseAutoencoder(cfg).cuda().eval()
+        fresh.load_state_dict(sae.state_dict())
+        want = fresh(x[1])
+    assert torch.equal(got.idx, want.idx) and torch.equal(got.val, want.val) and torch.equal(got.x_hats, want.x_hats)
+    assert not torch.equal(keep[0], got.idx.to(keep[0].device))

@@ -349,7 +349,10 @@ int saev_train_step_gather(saev_ctx* ctx, const float* pool, const int64_t* rows
  * (fp16 operand images, a slice-major fp32 transpose, bias and norm shares: written by the Adam launch of saev_train_step, or by
  * the last forward that prepared them itself) and uses it for as long as only the library has written the parameter buffer.  A
  * caller that writes W_enc / b_enc / W_dec itself -- loads a checkpoint, broadcasts, pokes a value -- must say so before the
- * next call; saev_bind does it implicitly.  (The Python host calls it whenever torch's version counter of the buffer moved.) */
+ * next call; saev_bind does it implicitly.  (The Python host calls it whenever torch's version counter of the buffer moved.)
+ * Safety net, not a substitute: every streamed step compares a few thousand pseudo-random elements of W_enc / b_enc with the
+ * copies its images came with; a difference sends that step down the exact dense route (correct codes, a slow step) and makes
+ * the next forward prepare from scratch.  A bulk write is caught with certainty, a poke at a few elements is not. */
 int saev_params_touched(saev_ctx* ctx);
 
 /* Codes / reconstruction of the last saev_step_forward (device pointers into context scratch):

@@ -179,6 +179,9 @@ struct saev_ctx {
     bool stream_ok = false;       // mode and geometry allow it (f16r, slice route of the refinement, guaranteed bounds)
     float *WeS = nullptr;         // slice-major fp32 W_enc^T of its own (the gradient scratch dW_encT no longer doubles as it)
     float *xn_part = nullptr, *amax_part = nullptr, *cmax_part = nullptr;
+    float* b_seen = nullptr;      // b_enc as bias_finish read it (the staleness samples of xprep_kernel compare against it)
+    int32_t *stale_host = nullptr, *stale_dev = nullptr;  // pinned word: a streamed step found the parameters changed behind its back
+    uint32_t stale_salt = 0;
     int scale_par = 0;            // which half of f16r_scales (2 x 8 floats) belongs to the step in flight
     bool prep_valid = false;      // mu and scales[par][0, 4] describe a previous batch of this context
     bool wimg_fresh = false;      // ws / WeS / dot_part / sq_part / b_shift / wnorm_scratch describe W_enc AS IT IS NOW ...
@@ -423,7 +426,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     c->stream_ok = c->fwd_slices && c->cfg.bound_mode == 0 && c->dbg.prep_route == 0 && D % 32 == 0 && c->Dp == (int)D;
     if (c->stream_ok) {
         A(WeS, S * D); A(xn_part, (size_t)(D / 32) * c->MB_pad * 2);
-        A(amax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(cmax_part, (size_t)(c->MB_pad / 256) * (D / 32));
+        A(amax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(cmax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(b_seen, S);
     }
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
     A(tau_max, MB); A(heur_state, 8); A(stats_scratch, STATS_SCRATCH_DOUBLES); A(tickets, 8); A(db_aux, D);
@@ -438,6 +441,17 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     hipMemset(c->fired, 0, S * sizeof(int32_t));
     hipMemset(c->dead, 0, S * sizeof(int32_t));
     hipMemset(c->flags, 0, 16 * sizeof(int32_t));
+    if (c->stream_ok) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&c->stale_dev), hp, 0) == hipSuccess) {
+            c->stale_host = static_cast<int32_t*>(hp);
+            *c->stale_host = 0;
+        } else {
+            if (hp) hipHostFree(hp);
+            c->stale_host = nullptr; c->stale_dev = nullptr;  // (the device-side part of the check still works)
+        }
+    }
     hipMemset(c->scan_totals, 0, ((S + 1023) / 1024) * 4 * sizeof(int32_t));  // (no workgroup's "ready" word equals a build's epoch)
     hipMemset(c->stats, 0, sizeof(saev_step_stats));
     hipMemset(c->stats_scratch, 0, STATS_SCRATCH_DOUBLES * sizeof(double));
@@ -505,6 +519,7 @@ void saev_destroy(saev_ctx* c) {
     if (c->G) hipFree(c->G);
     if (c->GS) hipFree(c->GS);
     if (c->rec_host) hipHostFree(c->rec_host);
+    if (c->stale_host) hipHostFree(c->stale_host);
     if (c->dead_ev_created)
         for (int i = 0; i < DEAD_RING; ++i) hipEventDestroy(c->dead_ev[i]);
     if (c->ev_created)
@@ -765,7 +780,7 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         c->wimg_fresh = c->stream_ok && c->fwd_step && !x_borrowed && c->leader == nullptr;
         c->wimg_mu_serial = c->mu_serial;
         HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, S, c->S_pad,
-                                     scl(c) + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
+                                     scl(c) + 1, c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s, c->b_seen));
         // (defer_margins: the caller's launch_pre_encode forms the margins together with the encoder's per-launch state)
         if (!defer_margins)
             HIPCHK(c, launch_row_margins(c->xnorm_c, n, D, c->wnorm_scratch, (S + 255) / 256, scl(c), pre_flag,
@@ -968,6 +983,8 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 xp.x = c->gather_pool != nullptr ? c->gather_pool : x; xp.rows = c->gather_rows; xp.x_out = c->gather_pool != nullptr ? const_cast<float*>(x) : nullptr;
                 xp.n = n; xp.D = D_; xp.nks = D_ / 32; xp.n_pad = c->MB_pad; xp.scales = scl(c); xp.mu = c->mu; xp.xs = c->xs; xp.xS = c->xS;
                 xp.xn_part = c->xn_part; xp.col_part = c->colsum_partials; xp.amax_part = c->amax_part; xp.cmax_part = c->cmax_part;
+                xp.W_enc = c->params + c->off_W_enc; xp.WeS = c->WeS; xp.b_enc = c->params + c->off_b_enc; xp.b_seen = c->b_seen;
+                xp.S = S_; xp.salt = ++c->stale_salt; xp.stale = c->flags + 12;
                 HIPCHK(c, launch_xprep(xp, s));
                 PreEncode2Args pe{};
                 pe.cand_cnt = c->cand_cnt; pe.n_rows = n; pe.gmax = c->gmax; pe.n_gmax = ng * c->gmax_stride;
@@ -977,7 +994,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 pe.flags1 = c->flags + 1; pe.col_part = c->colsum_partials; pe.n_rowblk = (n + 255) / 256; pe.mu = c->mu;
                 pe.inv_n = 1.0f / (float)n; pe.update_mu = c->train_fused ? 1 : 0;
                 pe.amax_part = c->amax_part; pe.cmax_part = c->cmax_part; pe.n_img = ((n + 255) / 256) * (D_ / 32);
-                pe.upper = c->upper; pe.stats = c->stats;
+                pe.upper = c->upper; pe.stats = c->stats; pe.stale = c->flags + 12; pe.stale_host = c->stale_dev;
                 HIPCHK(c, launch_pre_encode2(pe, s));
                 if (c->train_fused) c->mu_serial++;
             } else
@@ -1107,6 +1124,12 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     const bool borrowed = bind_x_sources(c, x, n, true);
     // The streamed preparation: this context neither lends nor borrows, a previous batch has left a centre, a scale
     // and a normaliser, and the operand images of W_enc describe the parameters as they are, centred on that very centre.
+    if (c->stale_host != nullptr && *reinterpret_cast<volatile int32_t*>(c->stale_host) != 0) {
+        // a streamed step found W_enc / b_enc changed behind its back (it took the exact route itself): prepare from scratch
+        *reinterpret_cast<volatile int32_t*>(c->stale_host) = 0;
+        c->wimg_fresh = false;
+        c->wn2_fresh = false;
+    }
     c->stream_step = c->stream_ok && c->prep_valid && c->wimg_fresh && c->wimg_mu_serial == c->mu_serial && c->leader == nullptr &&
                      c->followers.empty() && c->wenc_ready == nullptr && c->fwd_step;
     if (c->gather_pool != nullptr && !c->stream_step)  // (the batch as a contiguous matrix first: every other route reads x itself)
@@ -1931,7 +1954,7 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
         if (emit) {
             // the bias of the next centred first pass and the column-norm maxima its margins need: W-only, so they are finished here
             HIPCHK(c, launch_bias_finish(reinterpret_cast<const double*>(c->dot_part), c->sq_part, c->Dp, (int)S, c->S_pad, scl_next(c) + 1,
-                                         c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s));
+                                         c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s, c->b_seen));
             c->scale_par ^= 1;
             c->wimg_fresh = true;
             c->wimg_mu_serial = c->mu_serial;

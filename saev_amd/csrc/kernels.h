@@ -524,6 +524,13 @@ struct XprepArgs {
     float* col_part;       // [row blocks][D]
     float* amax_part;      // [row blocks * nks]
     float* cmax_part;      // [row blocks * nks]
+    // Safety net behind the parameter-ownership contract (include/saev_amd.h): every workgroup compares two pseudo-random elements
+    // of W_enc with the slice-major copy the images came with, and one of b_enc with the copy bias_finish kept -- equal bit for bit
+    // unless somebody wrote the parameters without saying so.  A difference raises *stale: pre_encode2_kernel then sends the step
+    // down the exact dense route and tells the host (a bulk write -- a copy, an optimizer step, a broadcast -- is caught with
+    // certainty; a poke at a handful of elements is not: that is what saev_params_touched is for).
+    const float* W_enc; const float* WeS; const float* b_enc; const float* b_seen;
+    int S; uint32_t salt; int32_t* stale;
 };
 hipError_t launch_xprep(const XprepArgs& a, hipStream_t stream);
 // ... and its second launch (select.hip: pre_encode2_kernel): row norms / margins, encoder state, batch maxima, flags, next mu.
@@ -543,6 +550,7 @@ struct PreEncode2Args {
     float* mu; float inv_n; int update_mu;
     const float* amax_part; const float* cmax_part; int n_img;
     float* upper;                            // max |x| of this batch
+    int32_t* stale; int32_t* stale_host;     // XprepArgs::stale (consumed and cleared here); optional pinned word the host polls
     saev_step_stats* stats;                  // zeroed
     int nb_rows;                             // (set by the launcher)
 };
@@ -553,8 +561,9 @@ hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, con
 // f16r: b_shift = float(sum_ks dot_part / *w_scale + b_enc); wg_part[0..nwg) = per-workgroup max |b_shift|,
 // wg_part[nwg..2 nwg) = per-workgroup max column norm of W_enc (nwg = ceil(S/256)); launch_row_margins reduces them and
 // raises *pre_flag when the largest norm times *w_scale is outside the safe fp16 window, then wmax_prev = that norm
+// b_seen (optional): a copy of b_enc as it was read here (XprepArgs::b_seen)
 hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int Dp, int S, int S_pad, const float* w_scale,
-                              const float* b_enc, float* b_shift, float* wg_part, hipStream_t stream);
+                              const float* b_enc, float* b_shift, float* wg_part, hipStream_t stream, float* b_seen = nullptr);
 hipError_t launch_max_reduce(const float* v, int n, float* out, hipStream_t stream);
 
 // ---- auxk.hip: AuxK as dense algebra over the compacted dead set -----------------------------------

@@ -272,6 +272,20 @@ __global__ __launch_bounds__(1024) void xprep_kernel(XprepArgs a) {
         a.amax_part[bid] = m0;
         a.cmax_part[bid] = m1;
     }
+    if (a.stale != nullptr && i >= 64 && i < 67) {  // the samples of XprepArgs::stale (a wave that has nothing else left to do)
+        uint32_t h = ((uint32_t)bid * 3u + (uint32_t)(i - 64)) * 2654435761u + a.salt * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        bool differs;
+        if (i < 66) {
+            const uint32_t d = h % (uint32_t)a.D, sidx = (h >> 8) % (uint32_t)a.S;
+            const float w = a.W_enc[(size_t)d * a.S + sidx], c = a.WeS[((size_t)(d >> 5) * a.S + sidx) * 32 + (d & 31)];
+            differs = __float_as_uint(w) != __float_as_uint(c);
+        } else {
+            const uint32_t sidx = h % (uint32_t)a.S;
+            differs = __float_as_uint(a.b_enc[sidx]) != __float_as_uint(a.b_seen[sidx]);
+        }
+        if (differs) atomicOr(a.stale, 1);
+    }
 }
 
 // b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]), ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale and
@@ -280,7 +294,8 @@ __global__ __launch_bounds__(1024) void xprep_kernel(XprepArgs a) {
 __global__ __launch_bounds__(256) void bias_finish_kernel(const double* __restrict__ dot_part,
                                                           const float* __restrict__ sq_part, int nks, int S, int S_pad,
                                                           const float* __restrict__ w_scale, const float* __restrict__ b_enc,
-                                                          float* __restrict__ b_shift, float* __restrict__ wg_max) {
+                                                          float* __restrict__ b_shift, float* __restrict__ wg_max,
+                                                          float* __restrict__ b_seen) {
     __shared__ float sh[3][4];
     const int sidx = blockIdx.x * 256 + threadIdx.x;
     float out = 0.f, nrm = 0.f, dnrm = 0.f;
@@ -292,8 +307,10 @@ __global__ __launch_bounds__(256) void bias_finish_kernel(const double* __restri
             dsq += (double)sq_part[(size_t)(nks + ks) * S_pad + sidx];
         }
         const double sc = (double)(*w_scale);
-        out = (float)(acc / sc + (double)b_enc[sidx]);
+        const float be = b_enc[sidx];
+        out = (float)(acc / sc + (double)be);
         b_shift[sidx] = out;
+        if (b_seen != nullptr) b_seen[sidx] = be;
         nrm = (float)(sqrt(sq) / sc) * 1.000001f;  // (rounded up: it bounds an error)
         dnrm = (float)(sqrt(dsq) / sc) * 1.00001f;  // (the shares are fp32 sums of 32 squares: rounded up a little further)
     }
@@ -346,10 +363,10 @@ hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, con
 }
 
 hipError_t launch_bias_finish(const double* dot_part, const float* sq_part, int Dp, int S, int S_pad, const float* w_scale,
-                              const float* b_enc, float* b_shift, float* wg_part, hipStream_t stream) {
+                              const float* b_enc, float* b_shift, float* wg_part, hipStream_t stream, float* b_seen) {
     const int nwg = (S + 255) / 256;
     hipLaunchKernelGGL(bias_finish_kernel, dim3(nwg), dim3(256), 0, stream, dot_part, sq_part, Dp / 32, S, S_pad, w_scale,
-                       b_enc, b_shift, wg_part);
+                       b_enc, b_shift, wg_part, b_seen);
     return hipGetLastError();
 }
 

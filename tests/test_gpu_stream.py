@@ -222,3 +222,31 @@ def test_a_write_through_a_module_parameter_drops_what_the_engine_kept():
         want = fresh(x[1])
     assert torch.equal(got.idx, want.idx) and torch.equal(got.val, want.val) and torch.equal(got.x_hats, want.x_hats)
     assert not torch.equal(keep[0], got.idx.to(keep[0].device))
+
+
+def test_an_unannounced_parameter_write_is_caught_on_the_device():
+    """The safety net behind the ownership contract: a bulk write to W_enc through .data (torch's version counter does not move, nobody
+    calls params_touched) between two steps.  The streamed step's first kernel compares samples of W_enc / b_enc with the copies its
+    images came with, finds them changed, and the step takes the exact dense route: same codes as an engine that was told; the host
+    learns of it and the run is back on the fused route afterwards."""
+    d, s, k, b = 256, 2048, 16, 512
+    told, untold = (_engine(d, s, k, b, 0, seed=51) for _ in range(2))
+    xs = _batches(d, b, 8, seed=52)
+    routes = []
+    for i, x in enumerate(xs):
+        for eng in (told, untold):
+            if i == 3:
+                eng.view("W_enc").data.mul_(-1.0)       # (a raw write: invisible to the version counter)
+                if eng is told:
+                    eng.params_touched()
+            if i == 5:
+                eng.view("b_enc").data.add_(0.5)
+                if eng is told:
+                    eng.params_touched()
+            eng.train_step(x, 1e-4, 1.0)
+        a, c = told.read_stats(), untold.read_stats()
+        routes.append(c.dense_route)
+        assert a.dense_route == 0 and math.isclose(a.mse, c.mse, rel_tol=1e-5), (i, a, c)
+        (i0, v0, _), (i1, v1, _) = (e.last_codes(b) for e in (told, untold))
+        assert (i0 != i1).float().mean().item() <= 1e-3, i
+    assert routes[3] == 1 and routes[5] == 1 and routes[:3] == [0, 0, 0] and routes[-1] == 0, routes

@@ -106,13 +106,6 @@ struct saev_ctx {
     bool dval_fwd = false;
     // the light finalize (kernels.h: DwSlicesArgs::wn2): ||w_i||^2 of the decoder rows as this step's normalize_rows wrote them
     float* wn2 = nullptr;
-    // The decoder rows as the NEXT training step needs them -- normalised (train.py:334-335) -- left by the fused Adam while it holds the
-    // updated row (AdamFusedArgs::wdn_out): the parameter buffer keeps Adam's output, as the reference does, and the step's own
-    // kernels (decode, finalize, AuxK gathers, Adam's read) take the rows from here; normalize_rows runs only when this is not fresh
-    float* WdN = nullptr;
-    float* wnrm = nullptr;       // the norms Adam divided by (the staleness samples of xprep_kernel re-do one division per workgroup)
-    bool wdn_fresh = false;      // WdN = normalize(W_dec as it is now), wn2 its squares
-    const float* wdec_use = nullptr;  // the decoder rows of the training step in flight (WdN, or the parameter rows normalised in place)
     float* sq_wave = nullptr;  // per-wave squares of the two passes (DwSlicesArgs::sq_wave_dec, then _enc: contiguous)
     int sq_wave_n = 0;         // > 0: the backward in flight left 2 x this many of them (the tail adds them to the clip norm)
     bool wn2_fresh = false;  // wn2 describes W_dec as it is now (set by the training forward, cleared by whatever writes W_dec)
@@ -412,7 +405,6 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
             A(WdS, S * D); A(dec_part, (size_t)(D / 32) * MB * 3);
         }
         A(pv, MBB * K); A(pv2, MBB * K); A(plat, MBB * K); A(cut_lat, (MBB * K + DWS_RUN - 1) / DWS_RUN); A(cut_list, 4 * (1 + (MBB * K + DWS_RUN - 1) / DWS_RUN)); A(lat_unused, S);
-        if (c->dval_rows != nullptr && c->dbg.fin_route == 0 && c->cfg.normalize_w_dec && c->dbg.prep_route == 0) { A(WdN, S * D); A(wnrm, S); }
         if (c->dval_rows != nullptr && c->dbg.fin_route == 0) { A(wn2, S); A(sq_wave, (size_t)2 * dw_slices_waves((int)D, (int)(MBB * K))); }
     }
     A(colsum_partials, ((MBB + 63) / 64) * D);
@@ -546,7 +538,6 @@ int saev_bind(saev_ctx* c, float* params, float* grads, float* adam_m, float* ad
     c->wn2_fresh = false;
     c->wimg_fresh = false;
     c->wimg_bf16_fresh = false;
-    c->wdn_fresh = false;
     c->grads = grads;
     c->adam_m = adam_m;
     c->adam_v = adam_v;
@@ -711,7 +702,6 @@ int saev_normalize_w_dec(saev_ctx* c, void* stream) {
     if (!c) return SAEV_INVALID_ARG;
     REQUIRE(c, c->params, SAEV_NOT_BOUND, "parameters not bound");
     if (!c->cfg.normalize_w_dec) return SAEV_OK;
-    c->wdn_fresh = false;  // (the parameter rows change: the copy Adam left describes what they were)
     HIPCHK(c, launch_normalize_rows(c->params + c->off_W_dec, c->cfg.d_sae, c->cfg.d_model, (hipStream_t)stream));
     return SAEV_OK;
 }
@@ -995,7 +985,6 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 xp.xn_part = c->xn_part; xp.col_part = c->colsum_partials; xp.amax_part = c->amax_part; xp.cmax_part = c->cmax_part;
                 xp.W_enc = c->params + c->off_W_enc; xp.WeS = c->WeS; xp.b_enc = c->params + c->off_b_enc; xp.b_seen = c->b_seen;
                 xp.S = S_; xp.salt = ++c->stale_salt; xp.stale = c->flags + 12;
-                if (c->train_fused && c->wdn_fresh && c->WdN != nullptr) { xp.W_dec = c->params + c->off_W_dec; xp.WdN = c->WdN; xp.wnrm = c->wnrm; }
                 HIPCHK(c, launch_xprep(xp, s));
                 PreEncode2Args pe{};
                 pe.cand_cnt = c->cand_cnt; pe.n_rows = n; pe.gmax = c->gmax; pe.n_gmax = ng * c->gmax_stride;
@@ -1140,7 +1129,6 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
         *reinterpret_cast<volatile int32_t*>(c->stale_host) = 0;
         c->wimg_fresh = false;
         c->wn2_fresh = false;
-        c->wdn_fresh = false;
     }
     c->stream_step = c->stream_ok && c->prep_valid && c->wimg_fresh && c->wimg_mu_serial == c->mu_serial && c->leader == nullptr &&
                      c->followers.empty() && c->wenc_ready == nullptr && c->fwd_step;
@@ -1177,12 +1165,6 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
         // (a training step whose decode can take the slices: normalize_rows leaves the slice-major copy on its way)
         const bool want_slices = c->WdS != nullptr && c->cfg.normalize_w_dec && c->P == 1 && c->dws_ok;
         c->wn2_fresh = false;
-        c->wdec_use = c->params + c->off_W_dec;
-        if (c->train_fused && c->wdn_fresh && c->WdN != nullptr && !want_slices) {
-            // the previous step's Adam has left these rows normalised (and their squares): nothing to do, the step reads them there
-            c->wdec_use = c->WdN;
-            c->wn2_fresh = true;
-        } else
         if (want_slices) {
             HIPCHK(c, launch_normalize_rows(c->params + c->off_W_dec, S, D, s, c->WdS, c->wn2));
             c->wds_fresh = true;
@@ -1195,7 +1177,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
 
     DecodeArgs a{};
     a.x = x; a.idx = c->idx; a.val = c->val; a.code_stride = K; a.k = K;
-    a.W_dec = (training && c->wdec_use != nullptr) ? c->wdec_use : c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
+    a.W_dec = c->params + c->off_W_dec; a.b_dec = c->params + c->off_b_dec;
     a.n_rows = n; a.D = D; a.S = S; a.idx_limit = S;
     a.upper = c->upper_c;
     a.gscale = 2.0f / ((float)n * (float)D * (float)c->P);
@@ -1353,7 +1335,7 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
     c->aux_all = false;
     c->aux_fused = false;
     if (!c->dead_list_ready) HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s, nd_dev));
-    HIPCHK(c, launch_gather_dead_small(c->params + c->off_W_enc, c->wdec_use, c->dead_list, nd_dev, D, S,
+    HIPCHK(c, launch_gather_dead_small(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd_dev, D, S,
                                        c->WencT_dead, c->Wdec_dead, s));
     if (bound <= AUX_FUSED_MAX && aux_fused_supported(D) && c->dbg.aux_small_max != AUX_SMALL_MAX) {
         // a handful of dead latents: one pass over x and x_hat leaves the block partials of every gradient of the auxiliary term
@@ -1394,7 +1376,7 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     const int32_t* nd_dev = c->aux_dev_count ? c->flags + 4 : nullptr;
     const int32_t* ku_dev = c->aux_dev_count ? c->flags + 5 : nullptr;
     if (!c->dead_list_ready) HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s));
-    HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->wdec_use, c->dead_list, nd, ndp, D, S,
+    HIPCHK(c, launch_gather_dead(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd, ndp, D, S,
                                  c->Wenc_dead, c->Wdec_dead, s, nd_dev));
     c->aux_small = false;
     c->aux_all = false;
@@ -1690,7 +1672,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
     hipStream_t s = (hipStream_t)stream;
     DwRowsArgs a{};
     a.starts = c->starts; a.chunk_starts = c->chunk_starts; a.work_latent = c->work_latent;
-    a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = ov ? c->ov_val : c->val; a.W_dec = c->wdec_use != nullptr ? c->wdec_use : c->params + c->off_W_dec;
+    a.part_starts = c->part_starts; a.pairs = c->pairs; a.val = ov ? c->ov_val : c->val; a.W_dec = c->params + c->off_W_dec;
     a.g = ov ? c->ov_g : (c->P_last > 1 ? c->G : c->g);  // Matryoshka: rows receive the suffix-summed gradients C_p
     a.x = ov ? c->ov_x : c->x_last;
     a.D = D; a.S = S; a.k_dev = nullptr; a.accumulate = 0;
@@ -1938,7 +1920,6 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     if (rc != SAEV_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     c->wn2_fresh = false;  // (W_dec moves)
-    c->wdn_fresh = false;
     const bool emit = c->train_fused && c->stream_ok && c->prep_valid && c->leader == nullptr && c->followers.empty() && shard_rank < 0 &&
                       c->tail_proj_in_adam && c->wenc_t_pending;
     c->wimg_fresh = false;  // (W_enc moves: only the fused Adam below leaves images of what it writes)
@@ -1965,14 +1946,10 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
             im.mu = c->mu; im.wmax_prev = c->wmax_prev; im.scales_next = scl_next(c); im.nks = c->Dp / 32; im.S_pad = c->S_pad;
         }
         if (emit_bf16) { im.ws = c->ws; im.nks = c->Dp / 32; im.S_pad = c->S_pad; im.mode = 1; }
-        // (the decoder rows: read where this step's kernels read them, left normalised for the next one)
-        const bool emit_wdn = c->train_fused && c->WdN != nullptr && c->cfg.normalize_w_dec;
         HIPCHK(c, launch_adam_fused(a, c->row_proj, c->dW_encT, (int)S, (int)D, S * D, c->off_W_enc - S * D, c->off_W_enc,
                                     c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr,
-                                    (emit || emit_bf16) ? &im : nullptr, c->wdec_use == c->WdN ? c->WdN : nullptr,
-                                    emit_wdn ? c->WdN : nullptr, emit_wdn ? c->wn2 : nullptr, emit_wdn ? c->wnrm : nullptr));
+                                    (emit || emit_bf16) ? &im : nullptr));
         c->unused_valid = false;
-        c->wdn_fresh = emit_wdn;
         c->wimg_bf16_fresh = emit_bf16;
         if (emit) {
             // the bias of the next centred first pass and the column-norm maxima its margins need: W-only, so they are finished here
@@ -2027,7 +2004,6 @@ int saev_params_touched(saev_ctx* c) {
     c->wimg_fresh = false;
     c->wimg_bf16_fresh = false;
     c->wn2_fresh = false;
-    c->wdn_fresh = false;
     return SAEV_OK;
 }
 

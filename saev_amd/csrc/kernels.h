@@ -404,11 +404,7 @@ struct AdamImageArgs {
 };
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
                              long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused = nullptr,
-                             const AdamImageArgs* img = nullptr,
-                             // optional: decoder rows read from p_dec_in (S x D, the normalised copy) instead of from a.p; the
-                             // updated rows also written normalised to wdn_out with their squares in wn2_out (tail.hip: adam_row)
-                             const float* p_dec_in = nullptr, float* wdn_out = nullptr, float* wn2_out = nullptr,
-                             float* wnrm_out = nullptr);
+                             const AdamImageArgs* img = nullptr);
 constexpr int SUMSQ_EX_BLOCKS = 32;  // blk_part: this many doubles of scratch; ticket: an int, zero between launches
 
 // what the host learns about the dead set of a step without waiting for it (saev_step_dead reads the record of an
@@ -535,7 +531,6 @@ struct XprepArgs {
     // certainty; a poke at a handful of elements is not: that is what saev_params_touched is for).
     const float* W_enc; const float* WeS; const float* b_enc; const float* b_seen;
     int S; uint32_t salt; int32_t* stale;
-    const float* W_dec; const float* WdN; const float* wnrm;  // optional: the normalised decoder rows Adam left and the norms it divided by
 };
 hipError_t launch_xprep(const XprepArgs& a, hipStream_t stream);
 // ... and its second launch (select.hip: pre_encode2_kernel): row norms / margins, encoder state, batch maxima, flags, next mu.

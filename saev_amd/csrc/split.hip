@@ -286,13 +286,6 @@ __global__ __launch_bounds__(1024) void xprep_kernel(XprepArgs a) {
         }
         if (differs) atomicOr(a.stale, 1);
     }
-    if (a.stale != nullptr && a.WdN != nullptr && i == 67) {  // ... and one element of W_dec against its normalised copy
-        uint32_t h = ((uint32_t)bid * 7u + 5u) * 2654435761u + a.salt * 40503u;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        const uint32_t lat = h % (uint32_t)a.S, d = (h >> 10) % (uint32_t)a.D;
-        const float want = a.W_dec[(size_t)lat * a.D + d] / a.wnrm[lat];
-        if (__float_as_uint(want) != __float_as_uint(a.WdN[(size_t)lat * a.D + d])) atomicOr(a.stale, 1);
-    }
 }
 
 // b_shift[s] = float(sum_ks dot_part[ks][s] / w_scale + b_enc[s]), ||W[:, s]|| = sqrt(sum_ks sq_part[ks][s]) / w_scale and

@@ -7,11 +7,6 @@
 
 namespace {
 
-// the lane's share of a row's sum of squares, with every rounding spelled out: normalize_rows_kernel and the fused Adam (which
-// leaves the NEXT step's normalised rows, AdamFusedArgs::wdn_out) must form the same norm from the same values, bit for bit
-__device__ __forceinline__ float row_ss_acc(float ss, const f32x4& v) {
-    return __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ss))));
-}
 template <int NV>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, int D, float* WS, float* wn2) {
     const int lane = threadIdx.x & 63;
@@ -25,7 +20,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* W, int S, in
     for (int n = 0; n < NV; ++n) {
         const int q = lane + 64 * n;
         v[n] = (q < D4) ? r[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-        ss = row_ss_acc(ss, v[n]);
+        ss += v[n][0] * v[n][0] + v[n][1] * v[n][1] + v[n][2] * v[n][2] + v[n][3] * v[n][3];
     }
     ss = wave_sum(ss);
     const float nrm = sqrtf(ss);
@@ -203,18 +198,11 @@ __device__ __forceinline__ float clip_coef(const AdamArgs& a, float* norm_out) {
 // read.  The row is walked in chunks of four float4 per stream (16 loads in flight per lane) with the scheduler fenced
 // between chunks: left alone the compiler interleaves all NV x 4 division / square-root sequences and takes 178 (NV = 4),
 // 256 (NV = 5) or -- spilling thousands of dwords -- more than 256 (NV = 8) VGPRs for a kernel that lives on occupancy.
-// p_in (optional): where the row's CURRENT value is read (the normalised copy the previous step's Adam left: AdamFusedArgs::p_dec_in);
-// wdn / wn2 (optional): the updated row divided by its norm, and the squares of that -- exactly what normalize_rows_kernel would
-// make of the row at the top of the next step (same values, same order of operations), so that the next step starts without it
 template <int NV>
-__device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float sc, float gs, float step_size, int lane, bool g_zero = false,
-                                         const float* p_in = nullptr, float* wdn = nullptr, float* wn2 = nullptr, float* wnrm = nullptr) {
+__device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float sc, float gs, float step_size, int lane, bool g_zero = false) {
     const int D4 = D >> 2;
     const size_t base = (size_t)i * D4;
     constexpr int CH = 4;
-    const f32x4* const pin = p_in != nullptr ? reinterpret_cast<const f32x4*>(p_in) : reinterpret_cast<const f32x4*>(a.p);
-    float ss = 0.f;
-    f32x4 keep[NV <= CH ? CH : 1];  // (rows of at most four float4 per lane stay in registers for the normalised copy)
 #pragma unroll 1  // (a real loop: unrolled, the address arithmetic of all chunks is hoisted and spills)
     for (int n0 = 0; n0 < NV; n0 += CH) {
         f32x4 p[CH], g[CH], m[CH], v[CH];
@@ -222,7 +210,7 @@ __device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float 
         for (int c = 0; c < CH; ++c) {
             const int q = lane + 64 * (n0 + c);
             if (n0 + c < NV && q < D4) {
-                p[c] = __builtin_nontemporal_load(pin + base + q);
+                p[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + base + q);
                 g[c] = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + base + q);
                 m[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + base + q);
                 v[c] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + base + q);
@@ -237,37 +225,12 @@ __device__ __forceinline__ void adam_row(const AdamArgs& a, int i, int D, float 
                 const AdamElem r = adam_elem(p[c][e], scaled_grad(rpg_apply(g[c][e], sc, p[c][e]), gs), m[c][e], v[c][e], a, step_size);
                 p[c][e] = r.p; m[c][e] = r.m; v[c][e] = r.v;
             }
-            if (wdn != nullptr && NV > CH) reinterpret_cast<f32x4*>(a.p)[base + q] = p[c];  // (read back below: keep it near)
-            else __builtin_nontemporal_store(p[c], reinterpret_cast<f32x4*>(a.p) + base + q);
+            __builtin_nontemporal_store(p[c], reinterpret_cast<f32x4*>(a.p) + base + q);
             __builtin_nontemporal_store(m[c], reinterpret_cast<f32x4*>(a.m) + base + q);
             __builtin_nontemporal_store(v[c], reinterpret_cast<f32x4*>(a.v) + base + q);
-            if (wdn != nullptr) {
-                ss = row_ss_acc(ss, p[c]);
-                if constexpr (NV <= CH) keep[c] = p[c];
-            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (wdn == nullptr) return;
-    // (lanes past the row's end added nothing; same per-lane order n = 0 .. NV - 1, same wave tree as normalize_rows_kernel)
-    ss = wave_sum(ss);
-    const float nrm = sqrtf(ss);
-    float s2 = 0.f;
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const int q = lane + 64 * n;
-        if (q >= D4) continue;
-        f32x4 pv;
-        if constexpr (NV <= CH) pv = keep[n];
-        else pv = reinterpret_cast<const f32x4*>(a.p)[base + q];
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = pv[e] / nrm; s2 = __builtin_fmaf(o[e], o[e], s2); }
-        reinterpret_cast<f32x4*>(wdn)[base + q] = o;
-    }
-    s2 = wave_sum(s2);
-    if (lane == 0 && wn2 != nullptr) wn2[i] = s2;
-    if (lane == 0 && wnrm != nullptr) wnrm[i] = nrm;
 }
 
 // Adam over the S decoder rows with remove_parallel_grads applied on the way in: g' = g - sc_i * W_dec[i] with sc_i =
@@ -301,10 +264,6 @@ struct AdamFusedArgs {
     long off_b_dec, n_b_dec, off_W_enc, off_b_enc, n_b_enc;
     int nb_rows, nb_tiles, tiles_s;
     AdamImageArgs img;     // img.ws != NULL: the W_enc tiles also leave the NEXT step's f16r operand images (kernels.h)
-    const float* p_dec_in; // optional: the decoder rows are read here (the normalised copy of the previous step) instead of in a.p
-    float* wdn_out;        // optional: the updated decoder rows, normalised (what the next step's normalize_rows would write)
-    float* wn2_out;        // ... and their squares (DwSlicesArgs::wn2)
-    float* wnrm_out;       // ... and the norms divided by
 };
 typedef _Float16 half8t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const AdamArgs& a, float gs, float step_size, int t) {
@@ -448,8 +407,7 @@ __global__ __launch_bounds__(256, (PART == 2 ? 3 : 4)) void adam_fused_kernel(Ad
         const int lane = threadIdx.x & 63;
         const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (i >= S) return;
-        adam_row<NV>(a, i, D, f.row_proj[i].x, gs, step_size, lane, f.lat_unused != nullptr && f.lat_unused[i] != 0, f.p_dec_in, f.wdn_out,
-                     f.wn2_out, f.wnrm_out);
+        adam_row<NV>(a, i, D, f.row_proj[i].x, gs, step_size, lane, f.lat_unused != nullptr && f.lat_unused[i] != 0);
         return;
     }
     // the two bias segments
@@ -784,10 +742,9 @@ hipError_t launch_adam_rows(const AdamArgs& a, const float2* row_proj, int S, in
 }
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
                              long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused,
-                             const AdamImageArgs* img, const float* p_dec_in, float* wdn_out, float* wn2_out, float* wnrm_out) {
+                             const AdamImageArgs* img) {
     AdamFusedArgs f{};
     if (img != nullptr && D % 32 == 0) f.img = *img;
-    f.p_dec_in = p_dec_in; f.wdn_out = wdn_out; f.wn2_out = wn2_out; f.wnrm_out = wnrm_out;
     f.a = a; f.row_proj = row_proj; f.gT = gT; f.S = S; f.D = D; f.lat_unused = lat_unused;
     f.off_b_dec = off_b_dec; f.n_b_dec = n_b_dec; f.off_W_enc = off_W_enc; f.off_b_enc = off_b_enc; f.n_b_enc = n_b_enc;
     f.nb_rows = (S + 3) / 4;

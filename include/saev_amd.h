@@ -159,6 +159,9 @@ typedef struct {
     int32_t prep_route;    /* f16r forward preparation: 0 = streamed where possible (one pass over x centred / scaled with what the
                               previous batch left, W_enc images left by the previous step's Adam), 1 = the full preparation on
                               every step (statistics, centring and both image passes from x and W_enc: the round-4 sequence)    */
+    int32_t aux_dense_route; /* selection of the dense AuxK algebra: 0 = one launch leaves the code matrix, its mask, its maximum and its
+                              operand scale (dead sets up to 4 096 columns), 1 = the round-4 sequence (radix select, two fills, scatter,
+                              absmax, scale: six launches)                                                                    */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

@@ -99,6 +99,139 @@ __global__ void dead_bias_vec_kernel(const float* b_enc, const int32_t* dl, int 
     if (j < ndp) out[j] = (j < nd) ? b_enc[dl[j]] : pad;
 }
 
+// ---- max |.| of a matrix as a by-product of the kernel that writes it, and the power-of-two operand scale that follows from it ----
+// Every workgroup of the producing grid stores its maximum (part[blockIdx.x]: a plain store -- one returning device-scope atomic
+// per workgroup on a shared counter, the "last workgroup finishes" pattern, made aux_resid_kernel 42 -> 316 us: the XCDs' L2s
+// are not coherent with one another and each such atomic is a round trip to the fabric behind a write-back); pow2_parts_kernel,
+// one small workgroup, turns the maxima into {2^e, 1} with 2^e * absmax in [2^13, 2^14) (what pow2_scale_kernel makes of
+// absmax_kernel's word).
+__device__ __forceinline__ float pow2_operand_scale(float m) { return (m > 0.f && m < 3.0e38f) ? exp2f(13.0f - floorf(log2f(m))) : 1.0f; }
+__global__ __launch_bounds__(256) void pow2_parts_kernel(const float* part, int n, float* pair) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pair[0] = pow2_operand_scale(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])));
+        pair[1] = 1.0f;
+    }
+}
+// the workgroup's maximum from its (up to four) waves' values; returns it in thread 0
+__device__ __forceinline__ float block_max4(float m, float* sh) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// max |x| over n floats (n % 4 == 0) per workgroup (no word to zero, no atomics)
+__global__ __launch_bounds__(256) void absmax_parts_kernel(const float* x, long n4, float* part) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[q];
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = block_max4(m, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+
+// The AuxK selection as the dense code matrix it is used as: A[b][j] = H[b][j] where j is one of the row's k largest
+// pre-activations over the dead set (ties on the k-th value: lowest columns first, as select_dense_kernel), 0 elsewhere;
+// mask[b][j] = selected; the workgroup's max |A| (part[blockIdx.x], for pow2_parts_kernel).  One launch instead of
+// select_dense (four passes over the row through an LDS histogram) + two fills + aux_scatter + absmax.
+// One wave per row, the row's keys in registers (NV float4 per lane: ndp <= 256 NV), the k-th largest key by a bit-wise
+// search that stops as soon as exactly k keys pass (usually after the exponent and a few mantissa bits).
+template <int NV>
+__global__ __launch_bounds__(256) void aux_select_kernel(const float* __restrict__ H, int n_rows, int ndp, int k_host, const int32_t* k_dev,
+                                                         float* __restrict__ A, uint8_t* __restrict__ mask, float* __restrict__ part) {
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = k_dev != nullptr ? min(*k_dev, k_host) : k_host;
+    const int q4 = ndp >> 2;
+    float m = 0.f;
+    for (int row = blockIdx.x * 4 + w; row < n_rows; row += gridDim.x * 4) {
+        const f32x4* hr = reinterpret_cast<const f32x4*>(H + (size_t)row * ndp);
+        uint32_t key[NV][4];  // 0 = no column (below every key a real value has, NaNs with the sign bit aside)
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q < q4) v = hr[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) key[n][e] = q < q4 ? f2ukey(v[e]) : 0u;
+        }
+        uint32_t T = 0u;
+        int cnt = 256 * NV;
+        if (k > 0) {
+#pragma unroll 1
+            for (int bit = 31; bit >= 0 && cnt != k; --bit) {
+                const uint32_t cand = T | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int n = 0; n < NV; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c += key[n][e] >= cand ? 1 : 0;
+                c = wave_sum_i(c);
+                if (c >= k) { T = cand; cnt = c; }
+            }
+        }
+        // cnt == k: the keys >= T are the selection.  Otherwise T is the k-th largest key itself and more than one column holds it:
+        // the keys > T and the first `need` columns, in ascending order, of those that equal it
+        int need = 0, eq_before[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) eq_before[n] = 0;
+        const bool ties = k > 0 && cnt != k;
+        if (ties) {
+            int gt = 0;
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gt += key[n][e] > T ? 1 : 0;
+            need = k - wave_sum_i(gt);
+            int base = 0;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                int eq = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) eq += key[n][e] == T ? 1 : 0;
+                int incl = eq;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
+                }
+                eq_before[n] = base + incl - eq;
+                base += __shfl(incl, 63, 64);
+            }
+        }
+        f32x4* ar = reinterpret_cast<f32x4*>(A + (size_t)row * ndp);
+        uint32_t* mr = reinterpret_cast<uint32_t*>(mask + (size_t)row * ndp);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = lane + 64 * n;
+            if (q >= q4) continue;
+            f32x4 o;
+            uint32_t mw = 0u;
+            int eqs = eq_before[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool sel = k > 0 && (ties ? key[n][e] > T : key[n][e] >= T);
+                if (ties && key[n][e] == T) { sel = eqs < need; ++eqs; }
+                o[e] = sel ? ukey2f(key[n][e]) : 0.f;
+                mw |= sel ? (1u << (8 * e)) : 0u;
+                m = fmaxf(m, fabsf(o[e]));
+            }
+            ar[q] = o;
+            mr[q] = mw;
+        }
+    }
+    m = block_max4(m, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+
 // A[b][idx] = val, mask[b][idx] = 1 for the selected codes (A and mask are zeroed by the caller)
 __global__ __launch_bounds__(256) void aux_scatter_kernel(const int32_t* idx, const float* val, long n_rows, int k,
                                                           int stride, int ndp, float* A, uint8_t* mask, const int32_t* k_dev) {
@@ -119,19 +252,20 @@ __global__ __launch_bounds__(256) void aux_scatter_kernel(const int32_t* idx, co
 template <int NV>
 __global__ __launch_bounds__(256) void aux_resid_kernel(float* E, const float* x, const float* x_hat, const float* b_dec,
                                                         int n_rows, int D, float gscale, RowStats* rowstats,
-                                                        const int32_t* nd_dev) {
+                                                        const int32_t* nd_dev, float* part) {
+    __shared__ float sh[4];
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
     const int D4 = D >> 2;
+    float gmax = 0.f;  // max |g_aux| of the rows of this workgroup (part[blockIdx.x]: for pow2_parts_kernel, the scale of g_aux's fp16 split)
+    if (row < n_rows) {
     f32x4* er = reinterpret_cast<f32x4*>(E + (size_t)row * D);
     if (nd_dev != nullptr && *nd_dev <= 0) {  // sized by a bound, but nothing is dead: the auxiliary term is exactly zero (modeling.py:92-94)
 #pragma unroll
         for (int n = 0; n < NV; ++n)
             if (lane + 64 * n < D4) er[lane + 64 * n] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (lane == 0) rowstats[row].aux_sse = 0.f;
-        return;
-    }
+    } else {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
     const f32x4* hr = reinterpret_cast<const f32x4*>(x_hat + (size_t)row * D);
     const f32x4* br = reinterpret_cast<const f32x4*>(b_dec);
@@ -147,17 +281,42 @@ __global__ __launch_bounds__(256) void aux_resid_kernel(float* E, const float* x
                 const float diff = (e[c] + bv[c]) - (xv[c] - hv[c]);
                 sse += diff * diff;
                 g[c] = gscale * diff;
+                gmax = fmaxf(gmax, fabsf(g[c]));
             }
             er[q] = g;
         }
     }
     sse = wave_sum(sse);
     if (lane == 0) rowstats[row].aux_sse = sse;
+    }
+    }
+    if (part != nullptr) {
+        gmax = block_max4(gmax, sh);
+        if (threadIdx.x == 0) part[blockIdx.x] = gmax;
+    }
 }
 
 __global__ __launch_bounds__(256) void mask_apply_kernel(float* dA, const uint8_t* mask, long n) {
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long)gridDim.x * 256)
         if (!mask[q]) dA[q] = 0.f;
+}
+// ... four elements per thread, with the workgroup's max |dA| of the masked matrix (part[blockIdx.x])
+__global__ __launch_bounds__(256) void mask_apply_absmax_kernel(float* dA, const uint8_t* mask, long n4, float* part) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<f32x4*>(dA)[q];
+        const uint32_t mw = reinterpret_cast<const uint32_t*>(mask)[q];
+        if (mw != 0x01010101u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (((mw >> (8 * e)) & 0xFFu) == 0u) v[e] = 0.f;
+            reinterpret_cast<f32x4*>(dA)[q] = v;
+        }
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = block_max4(m, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = m;
 }
 
 // ---- a handful of dead latents (nd <= AUX_SMALL_MAX = 24, the measured break-even, and nd <= k_aux: every dead latent is "selected") ---------------
@@ -909,11 +1068,42 @@ hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, 
     return hipGetLastError();
 }
 hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const float* b_dec, int n_rows, int D,
-                            float gscale, RowStats* rowstats, hipStream_t s, const int32_t* nd_dev) {
-    return dispatch_nv(D, [&](auto nv) {
+                            float gscale, RowStats* rowstats, hipStream_t s, const int32_t* nd_dev, float* part, float* pair) {
+    hipError_t e = dispatch_nv(D, [&](auto nv) {
         hipLaunchKernelGGL(aux_resid_kernel<decltype(nv)::value>, dim3((n_rows + 3) / 4), dim3(256), 0, s, E, x, x_hat,
-                           b_dec, n_rows, D, gscale, rowstats, nd_dev);
+                           b_dec, n_rows, D, gscale, rowstats, nd_dev, part);
     });
+    if (e != hipSuccess || part == nullptr) return e;
+    hipLaunchKernelGGL(pow2_parts_kernel, dim3(1), dim3(256), 0, s, part, (n_rows + 3) / 4, pair);
+    return hipGetLastError();
+}
+int absmax_parts_max(int n_rows_cap) { return std::max(2048, (n_rows_cap + 3) / 4); }  // floats of `part` the launches here may write
+hipError_t launch_absmax_pow2(const float* x, long n, float* part, float* pair, hipStream_t s) {
+    const int grid = std::min(grid_for(n / 4), 2048);
+    hipLaunchKernelGGL(absmax_parts_kernel, dim3(grid), dim3(256), 0, s, x, n / 4, part);  // n % 4 == 0
+    hipLaunchKernelGGL(pow2_parts_kernel, dim3(1), dim3(256), 0, s, part, grid, pair);
+    return hipGetLastError();
+}
+hipError_t launch_mask_apply_absmax(float* dA, const uint8_t* mask, long n, float* part, float* pair, hipStream_t s) {
+    const int grid = std::min(grid_for(n / 4), 2048);
+    hipLaunchKernelGGL(mask_apply_absmax_kernel, dim3(grid), dim3(256), 0, s, dA, mask, n / 4, part);  // n % 4 == 0
+    hipLaunchKernelGGL(pow2_parts_kernel, dim3(1), dim3(256), 0, s, part, grid, pair);
+    return hipGetLastError();
+}
+bool aux_select_supported(int ndp) { return ndp > 0 && ndp % 4 == 0 && ndp <= 4096; }
+hipError_t launch_aux_select(const float* H, int n_rows, int ndp, int k, const int32_t* k_dev, float* A, uint8_t* mask, float* part,
+                             float* pair, hipStream_t s) {
+    const dim3 grid(std::max(1, std::min(1024, (n_rows + 3) / 4))), block(256);
+    const int nv = (ndp + 255) / 256;
+#define SAEV_AUX_SELECT(NV) hipLaunchKernelGGL(aux_select_kernel<NV>, grid, block, 0, s, H, n_rows, ndp, k, k_dev, A, mask, part)
+    if (nv <= 1) SAEV_AUX_SELECT(1);
+    else if (nv <= 2) SAEV_AUX_SELECT(2);
+    else if (nv <= 4) SAEV_AUX_SELECT(4);
+    else if (nv <= 8) SAEV_AUX_SELECT(8);
+    else SAEV_AUX_SELECT(16);
+    hipLaunchKernelGGL(pow2_parts_kernel, dim3(1), dim3(256), 0, s, part, (int)grid.x, pair);
+#undef SAEV_AUX_SELECT
+    return hipGetLastError();
 }
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s) {
     hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for(n)), dim3(256), 0, s, dA, mask, n);

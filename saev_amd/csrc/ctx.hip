@@ -162,6 +162,7 @@ struct saev_ctx {
     float* aux_parts = nullptr;
     int aux_kpad = 0;
     float *bias_dead = nullptr, *zero_bias = nullptr, *aux_scales = nullptr;  // aux_scales: {absmax, -, sA, 1, sg, 1}
+    float* aux_sync = nullptr;     // per-workgroup maxima of the AuxK kernels that leave an operand scale behind (auxk.hip: pow2_parts_kernel)
     int aux_Dp2 = 0;
     // F16R: per-row candidate margins and the max encoder column norm (W_enc^T in fp32 lives in dW_encT during forward)
     float *row_margin = nullptr, *wnorm_scratch = nullptr, *surv_val = nullptr;
@@ -413,7 +414,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
         c->Dp = (int)((D + 31) / 32 * 32);
         c->S_pad = (int)((S + 255) / 256 * 256);
         c->MB_pad = (int)((MB + 255) / 256 * 256);
-        A(zero_bias, std::max(S, D)); A(aux_scales, 16);
+        A(zero_bias, std::max(S, D)); A(aux_scales, 16); A(aux_sync, absmax_parts_max((int)MB));
     }
     if (c->cfg.encoder_mode != SAEV_ENCODER_F32) {
         A(xs, (size_t)c->MB_pad * 2 * c->Dp);
@@ -1397,28 +1398,33 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
                          own_images ? c->aux_scales + 6 : nullptr);
         if (rc != SAEV_OK) return rc;
     }
+    const bool fused_select = aux_select_supported(ndp) && c->dbg.aux_dense_route == 0;  // (1: the round-4 select / fill / scatter sequence)
     if (!c->aux_all) {
         SelectDenseArgs sd{};
         sd.h = c->H_dead; sd.n_rows = n; sd.S = ndp; sd.k = ku; sd.k_dev = ku_dev;
         sd.idx_out = c->aux_idx; sd.val_out = c->aux_val; sd.out_stride = c->cfg.k_aux;
-        HIPCHK(c, launch_select_dense(sd, s));
-        HIPCHK(c, hipMemsetAsync(c->A_dead, 0, (size_t)n * ndp * sizeof(float), s));
-        HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
-        HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s, ku_dev));
+        if (fused_select) {
+            // codes, mask, max |code| and the codes' operand scale in one launch (auxk.hip: aux_select_kernel)
+            HIPCHK(c, launch_aux_select(c->H_dead, n, ndp, ku, ku_dev, c->A_dead, c->A_mask, c->aux_sync, c->aux_scales + 2, s));
+        } else {
+            HIPCHK(c, launch_select_dense(sd, s));
+            HIPCHK(c, hipMemsetAsync(c->A_dead, 0, (size_t)n * ndp * sizeof(float), s));
+            HIPCHK(c, hipMemsetAsync(c->A_mask, 0, (size_t)n * ndp, s));
+            HIPCHK(c, launch_aux_scatter(c->aux_idx, c->aux_val, n, ku, c->cfg.k_aux, ndp, c->A_dead, c->A_mask, s, ku_dev));
+        }
     }
     {
         // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
         // (the codes are pre-activations of unknown magnitude: power-of-two scale from their device-side max)
-        HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
-        HIPCHK(c, launch_absmax(c->A_dead, (long)n * ndp, c->aux_scales, s));
-        HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 2, s));
+        if (c->aux_all || !fused_select) HIPCHK(c, launch_absmax_pow2(c->A_dead, (long)n * ndp, c->aux_sync, c->aux_scales + 2, s));
         HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, 0, s, 1.0f, c->aux_scales + 2));
         HIPCHK(c, launch_split_wT(c->Wdec_dead, ndp, D, (D + 255) / 256 * 256, Dp2, 256.0f, c->aux_ws2, 0, s));
         rc = dense_f16x3(c, c->aux_xsA, c->aux_ws2, c->zero_bias, n, Dp2, D, 256.0f, c->g_aux, s, c->aux_scales + 2);
     }
     if (rc != SAEV_OK) return rc;
+    // (g_aux leaves with its max and the operand scale the backward splits it with: aux_scales + 4)
     HIPCHK(c, launch_aux_resid(c->g_aux, c->x_last, c->x_hat, c->params + c->off_b_dec, n, D,
-                               c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s, nd_dev));
+                               c->cfg.alpha * 2.0f / ((float)n * (float)D), c->rowstats, s, nd_dev, c->aux_sync, c->aux_scales + 4));
     HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 1, c->upper_c, nullptr, c->stats, s, nullptr,
                                   c->stats_scratch));
     return SAEV_OK;
@@ -1461,23 +1467,21 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         // dA = g_aux W_dec[dl]^T.  g_aux carries the factor alpha * 2 / (n D) (~1e-10) times a residual of unknown
         // magnitude: bring it to [2^13, 2^14) with an exact power of two from its device-side max before the fp16 split;
         // W_dec[dl] rows are already "latent-major", so they split like x.
-        HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
-        HIPCHK(c, launch_absmax(c->g_aux, (long)n * D, c->aux_scales, s));
-        HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 4, s));
+        // (the scale from g_aux's device-side max: aux_resid_kernel left it at aux_scales + 4)
         HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 4));
         HIPCHK(c, launch_split_rows(c->Wdec_dead, ndp, D, c->Dp, c->aux_ws1, 0, s, 256.0f));
         rc = dense_f16x3(c, c->aux_xsg, c->aux_ws1, c->zero_bias, n, c->Dp, ndp, 256.0f, dA, s, c->aux_scales + 4);
     }
     if (rc != SAEV_OK) return rc;
-    if (!c->aux_all) HIPCHK(c, launch_mask_apply(dA, c->A_mask, (long)n * ndp, s));
+    // the selection's mask applied, max |dA| and dA's operand scale (aux_scales + 10) in one pass
+    if (!c->aux_all) HIPCHK(c, launch_mask_apply_absmax(dA, c->A_mask, (long)n * ndp, c->aux_sync, c->aux_scales + 10, s));
+    else HIPCHK(c, launch_absmax_pow2(dA, (long)n * ndp, c->aux_sync, c->aux_scales + 10, s));
     {
         // operand scales: A from the forward (aux_scales + 2), g_aux from above (+ 4), x from max|x| (+ 6), dA fresh
         rc = ksplit_f16x3(c, c->A_dead, c->aux_scales + 2, ndp, c->g_aux, c->aux_scales + 4, D, n, c->dWd, s);
         if (rc != SAEV_OK) return rc;
-        HIPCHK(c, hipMemsetAsync(c->aux_scales, 0, sizeof(float), s));
-        HIPCHK(c, launch_absmax(dA, (long)n * ndp, c->aux_scales, s));
-        HIPCHK(c, launch_pow2_scale(c->aux_scales, c->aux_scales + 10, s));
-        HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));
+        // (x's scale: the forward formed it when it made its own hi/lo images of x)
+        if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));
         rc = ksplit_f16x3(c, dA, c->aux_scales + 10, ndp, c->x_last, c->aux_scales + 6, D, n, c->dWe, s);
         if (rc != SAEV_OK) return rc;
     }

@@ -578,8 +578,15 @@ hipError_t launch_dead_bias_vec(const float* b_enc, const int32_t* dl, int nd, i
 hipError_t launch_aux_scatter(const int32_t* idx, const float* val, int n_rows, int k, int stride, int ndp, float* A,
                               uint8_t* mask, hipStream_t s, const int32_t* k_dev = nullptr);  // k_dev: min(k, *k_dev) codes per row
 hipError_t launch_aux_resid(float* E, const float* x, const float* x_hat, const float* b_dec, int n_rows, int D,
-                            float gscale, RowStats* rowstats, hipStream_t s,
-                            const int32_t* nd_dev = nullptr);  // *nd_dev <= 0: zero gradient, zero loss
+                            float gscale, RowStats* rowstats, hipStream_t s, const int32_t* nd_dev = nullptr, float* part = nullptr,
+                            float* pair = nullptr);
+// max |.| and the power-of-two operand scale {2^e, 1} as by-products (auxk.hip: pow2_parts_kernel; part: absmax_parts_max(rows) floats)
+int absmax_parts_max(int n_rows_cap);
+hipError_t launch_absmax_pow2(const float* x, long n, float* part, float* pair, hipStream_t s);
+hipError_t launch_mask_apply_absmax(float* dA, const uint8_t* mask, long n, float* part, float* pair, hipStream_t s);
+bool aux_select_supported(int ndp);
+hipError_t launch_aux_select(const float* H, int n_rows, int ndp, int k, const int32_t* k_dev, float* A, uint8_t* mask, float* part,
+                             float* pair, hipStream_t s);  // *nd_dev <= 0: zero gradient, zero loss
 hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t s);
 // a handful of dead latents (nd <= AUX_SMALL_MAX, all of them selected): row-wise forward, block-wise weight gradients
 constexpr int AUX_SMALL_MAX = 64;  // (one lane per dead latent in aux_small_fwd_kernel: at most the wave width)

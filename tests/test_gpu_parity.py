@@ -781,6 +781,51 @@ def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near, k_aux):
         assert min(deads[4:]) < n_dead + n_near - 10, deads   # the bound really was above the count
 
 
+@pytest.mark.parametrize("n_dead,k_aux,dup", [(100, 64, 1), (250, 128, 1), (300, 128, 4), (700, 256, 1), (1500, 512, 8), (3000, 1024, 1)])
+def test_dense_auxk_one_launch_selection_agrees_with_the_select_fill_scatter_sequence(n_dead, k_aux, dup):
+    """The dense AuxK algebra's selection in one launch (`aux_select_kernel`: the row's keys in registers, bit-wise search,
+    code matrix + mask + maximum + operand scale written together) against the round-4 sequence (radix select, two fills,
+    scatter, absmax, pow2 scale; `aux_dense_route=1`): the same k_aux columns per row -- ties on the k-th value broken
+    towards the lower column, which `dup` > 1 provokes by giving groups of `dup` dead latents the same encoder column and
+    bias -- hence the same operand scales and bit-identical losses and gradients.  Dead sets of 100 ... 3 000 columns cover
+    every register-count instantiation; the oracle is compared on the way (loose: it is the other tests' subject)."""
+    d, s, k, n, thr = 128, 4096, 8, 200, 1000
+    p = rand_params(d, s, seed=900 + n_dead)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(901 + n_dead))
+    toks = torch.zeros(s, dtype=torch.int64)
+    dead = torch.randperm(s, generator=torch.Generator().manual_seed(902))[:n_dead].sort().values
+    toks[dead] = thr
+    p["b_enc"][dead] = -100.0 + 0.05 * torch.randn(n_dead, generator=torch.Generator().manual_seed(903))
+    for j in range(0, n_dead - dup + 1, dup):  # groups of identical dead latents: exact ties among their pre-activations
+        p["W_enc"][:, dead[j:j + dup]] = p["W_enc"][:, dead[j:j + 1]]
+        p["b_enc"][dead[j:j + dup]] = p["b_enc"][dead[j]].item()
+    outs = []
+    for route in (0, 1):
+        eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n, aux_small_max=-1, aux_dead_cap=4096, aux_dense_route=route)
+        eng.load_params(p)
+        eng.set_tracker(toks)
+        eng.step_forward(x.cuda(), training=True)
+        eng.step_dead(n)
+        eng.step_backward()
+        st = eng.read_stats()
+        assert st.n_dead == n_dead and eng.aux_route() in (2, 3)
+        outs.append((st.aux, st.mse, {key: v.cpu().clone() for key, v in eng.grad_views().items()}))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1], (outs[0][:2], outs[1][:2])
+    for key in R.PARAM_ORDER:
+        assert torch.equal(outs[0][2][key], outs[1][2][key]), key
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
+    leaves = {k_: p[k_].clone().requires_grad_(True) for k_ in R.PARAM_ORDER}
+    leaves["W_dec"] = R.normalize_w_dec(p["W_dec"]).clone().requires_grad_(True)
+    out = R.objective_forward(leaves, x, cfg, toks_since_active=toks.clone(), training=True)
+    if dup == 1:  # (with exact ties the oracle's torch.topk may keep other members of a tied group, whose decoder rows differ)
+        assert math.isclose(outs[0][0], out.aux.item(), rel_tol=1e-4)
+        out.loss.backward()
+        for key in R.PARAM_ORDER:
+            # (a near-tie at a row's k_aux-th place resolved the other way moves a few elements of two rows: isolated elements allowed)
+            bad = ~torch.isclose(outs[0][2][key], leaves[key].grad, rtol=2e-3, atol=3e-7)
+            assert bad.float().mean() <= 1e-4, f"{key}: {bad.sum().item()} of {bad.numel()} elements off"
+
+
 def test_failed_bound_prediction_is_caught_and_repeated(encoder_mode):
     """Predicted TopK bounds (mean + z sigma of a sample of the row's pre-activations) are verified, not trusted: here
     the first 256 latents -- the sample of the first latent range -- have encoder columns a hundred times larger than the

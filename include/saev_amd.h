@@ -27,14 +27,15 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 8
+#define SAEV_AMD_ABI_VERSION 9
 
 typedef enum {
     SAEV_OK = 0,
     SAEV_INVALID_ARG = -1,
     SAEV_HIP_ERROR = -2,
     SAEV_UNSUPPORTED = -3,
-    SAEV_NOT_BOUND = -4
+    SAEV_NOT_BOUND = -4,
+    SAEV_RCCL_ERROR = -5
 } saev_status;
 
 /* Static configuration of one SAE (nn/modeling.py:259-284 SparseAutoencoderConfig, :119-130 TopK,
@@ -348,6 +349,28 @@ int saev_train_step(saev_ctx* ctx, const float* x, int32_t n_rows, float lr, flo
  * no pass of its own; it stays valid until the next call and is what saev_copy_last / the log block read as "x". */
 int saev_train_step_gather(saev_ctx* ctx, const float* pool, const int64_t* rows, float* x_out, int32_t n_rows, float lr,
                            float max_norm, int64_t adam_step, void* stream);
+/* DATA PARALLEL behind the ABI (SURVEY 8b "DDP": absent in the reference, whose train.py:760-769 has no distributed code at all).
+ * One process per GPU, one context per process.  saev_comm_unique_id fills 128 bytes on one rank (ncclGetUniqueId); the caller
+ * hands them to every rank by whatever means it has (torchrun's store, MPI, a file) and each rank calls saev_comm_init with its
+ * rank and the world size (ncclCommInitRank over xGMI).  RCCL is taken from the process at run time (the librccl the process
+ * has already loaded -- torch's, in the Python host -- else the system's): libsaev_amd.so does not link against it, and without
+ * it these entry points return SAEV_UNSUPPORTED.
+ * saev_train_step_dp is saev_train_step for a batch that is split evenly over the ranks: x_local holds this rank's n_local
+ * rows, the global batch is n_local * world rows.  Enqueued on `stream`, nothing read back:
+ *     forward on the local rows (the loss terms divide by the global row count)
+ *     all-reduce MAX of the "fired this step" flags      (d_sae int32: the dead-latent tracker counts the global batch)
+ *     dead-latent update and the auxiliary term, backward on the local rows
+ *     all-reduce SUM of the flat gradient buffer        (n_params fp32, one collective)
+ *     projection, clip on the global norm, Adam, with the gradient scaled by 1 / world (the mean over ranks of per-rank means)
+ * -- the sequence framework/ddp.py runs from Python with tail="replicated", exchange="dense" (the sharded tail and the sparse
+ * exchange exist there only).  Parameters must be identical on all ranks when the first step starts (broadcast them, or create
+ * every rank from the same seed); they stay identical because every rank applies the same update. */
+int saev_comm_unique_id(void* id128);
+int saev_comm_init(saev_ctx* ctx, const void* id128, int32_t rank, int32_t world);
+int saev_comm_world(const saev_ctx* ctx);   /* 0: no communicator */
+int saev_comm_destroy(saev_ctx* ctx);
+int saev_train_step_dp(saev_ctx* ctx, const float* x_local, int32_t n_local, float lr, float max_norm, int64_t adam_step,
+                       void* stream);
 /* PARAMETER OWNERSHIP.  With the f16r encoder the context keeps, from one call to the next, what its forward needs of W_enc
  * (fp16 operand images, a slice-major fp32 transpose, bias and norm shares: written by the Adam launch of saev_train_step, or by
  * the last forward that prepared them itself) and uses it for as long as only the library has written the parameter buffer.  A

@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class SaevCfg(C.Structure):
@@ -102,6 +102,11 @@ _SIGNATURES = {
     "saev_train_step": (C.c_int, [P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
     "saev_train_step_gather": (C.c_int, [P, P, P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
     "saev_params_touched": (C.c_int, [P]),
+    "saev_comm_unique_id": (C.c_int, [P]),
+    "saev_comm_init": (C.c_int, [P, P, C.c_int32, C.c_int32]),
+    "saev_comm_world": (C.c_int, [P]),
+    "saev_comm_destroy": (C.c_int, [P]),
+    "saev_train_step_dp": (C.c_int, [P, P, C.c_int32, C.c_float, C.c_float, C.c_int64, P]),
     "saev_last_idx": (P, [P]),
     "saev_last_val": (P, [P]),
     "saev_last_x_hat": (P, [P]),

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -201,6 +202,8 @@ struct saev_ctx {
     float *upper_c = nullptr, *mu_c = nullptr, *xnorm_c = nullptr, *xabs_c = nullptr;
     _Float16* xs_c = nullptr;
     saev_ctx* leader = nullptr;
+    void* comm = nullptr;        // ncclComm_t (saev_comm_init)
+    int comm_rank = 0, comm_world = 0;
     std::vector<saev_ctx*> followers;  // contexts whose `leader` is this one (saev_destroy / a new link clears them)
     const float* xprep_x = nullptr;  // what this context's own x-derived buffers currently describe
     int xprep_n = 0;
@@ -515,6 +518,7 @@ void saev_destroy(saev_ctx* c) {
     unlink_from_leader(c);
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    saev_comm_destroy(c);
     for (void* p : c->allocs) hipFree(p);
     for (void* p : c->aux_allocs) hipFree(p);
     if (c->G) hipFree(c->G);
@@ -2034,6 +2038,101 @@ int saev_train_step(saev_ctx* c, const float* x, int32_t n, float lr, float max_
     c->wenc_t_pending = false;
     c->train_fused = false;
     return rc;
+}
+
+// ---- data parallel behind the ABI: RCCL taken from the process at run time (include/saev_amd.h: DATA PARALLEL) ----------
+namespace {
+// (the few declarations of rccl.h this file needs -- the header is not included so that nothing here can end up as a link-time
+// dependency: ncclResult_t 0 = success; ncclDataType_t ncclInt32 = 2, ncclFloat32 = 7; ncclRedOp_t ncclSum = 0, ncclMax = 2)
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, const void*, int) = nullptr;  // (ncclUniqueId is passed by value: see comm_init_rank)
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool tried = false;
+};
+RcclApi g_rccl;
+struct UniqueId128 { char bytes[128]; };  // == ncclUniqueId (NCCL_UNIQUE_ID_BYTES 128)
+bool rccl_load() {
+    if (g_rccl.tried) return g_rccl.lib != nullptr;
+    g_rccl.tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {  // the copy the process already holds, if any ...
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+    }
+    if (!h)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {  // ... else the system's
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+    if (!h) return false;
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) return false;
+    g_rccl.lib = h;
+    return true;
+}
+int rccl_fail(saev_ctx* c, const char* what, int r) {
+    c->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error") + " (" + std::to_string(r) + ")";
+    return SAEV_RCCL_ERROR;
+}
+}  // namespace
+
+int saev_comm_unique_id(void* id128) {
+    if (!id128) return SAEV_INVALID_ARG;
+    if (!rccl_load()) return SAEV_UNSUPPORTED;
+    return g_rccl.GetUniqueId(id128) == 0 ? SAEV_OK : SAEV_RCCL_ERROR;
+}
+
+int saev_comm_init(saev_ctx* c, const void* id128, int32_t rank, int32_t world) {
+    if (!c || !id128) return SAEV_INVALID_ARG;
+    REQUIRE(c, world >= 1 && rank >= 0 && rank < world, SAEV_INVALID_ARG, "saev_comm_init: rank / world out of range");
+    REQUIRE(c, c->comm == nullptr, SAEV_INVALID_ARG, "saev_comm_init: this context already has a communicator (saev_comm_destroy first)");
+    REQUIRE(c, rccl_load(), SAEV_UNSUPPORTED, "saev_comm_init: no RCCL in this process and none found (librccl.so.1)");
+    HIPCHK(c, hipSetDevice(c->device));
+    // ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId /* by value: a 128-byte struct */, int rank)
+    UniqueId128 id;
+    std::memcpy(id.bytes, id128, sizeof(id.bytes));
+    auto init = reinterpret_cast<int (*)(void**, int, UniqueId128, int)>(reinterpret_cast<void*>(g_rccl.CommInitRank));
+    void* comm = nullptr;
+    const int r = init(&comm, world, id, rank);
+    if (r != 0) return rccl_fail(c, "ncclCommInitRank", r);
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return SAEV_OK;
+}
+
+int saev_comm_world(const saev_ctx* c) { return c && c->comm ? c->comm_world : 0; }
+
+int saev_comm_destroy(saev_ctx* c) {
+    if (!c) return SAEV_INVALID_ARG;
+    if (c->comm != nullptr && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr; c->comm_world = 0; c->comm_rank = 0;
+    return SAEV_OK;
+}
+
+int saev_train_step_dp(saev_ctx* c, const float* x_local, int32_t n_local, float lr, float max_norm, int64_t adam_step, void* stream) {
+    if (!c) return SAEV_INVALID_ARG;
+    REQUIRE(c, c->comm != nullptr, SAEV_INVALID_ARG, "saev_train_step_dp: no communicator (saev_comm_init)");
+    REQUIRE(c, c->grads != nullptr, SAEV_NOT_BOUND, "saev_train_step_dp: no gradient buffer bound");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_global = (int64_t)n_local * c->comm_world;
+    int rc = saev_step_forward(c, x_local, n_local, n_global, 1, stream);
+    if (rc != SAEV_OK) return rc;
+    int r = g_rccl.AllReduce(c->fired, c->fired, (size_t)c->cfg.d_sae, /*ncclInt32*/ 2, /*ncclMax*/ 2, c->comm, s);
+    if (r != 0) return rccl_fail(c, "ncclAllReduce(fired flags)", r);
+    rc = saev_step_dead(c, n_global, stream);
+    if (rc != SAEV_OK) return rc;
+    rc = saev_step_backward(c, stream);
+    if (rc != SAEV_OK) return rc;
+    r = g_rccl.AllReduce(c->grads, c->grads, (size_t)c->n_params, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, s);
+    if (r != 0) return rccl_fail(c, "ncclAllReduce(flat gradient)", r);
+    return saev_step_tail(c, lr, max_norm, 1.0f / (float)c->comm_world, adam_step, stream);
 }
 
 }  // extern "C"

@@ -441,6 +441,31 @@ class SaeEngine:
         self.adam_steps += 1
         self._chk(self.lib.saev_train_step(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps, _stream()), "saev_train_step")
 
+    # data parallel behind the C ABI (include/saev_amd.h: DATA PARALLEL): RCCL inside the library, two collectives per step
+    def comm_unique_id(self) -> bytes:
+        """128 bytes from ncclGetUniqueId: made on ONE rank, handed to all ranks (e.g. ``torch.distributed.broadcast_object_list``)."""
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.saev_comm_unique_id(buf), "saev_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != 128:
+            raise _lib.SaevError(f"a communicator id is 128 bytes, got {len(unique_id)}")
+        self._chk(self.lib.saev_comm_init(self.ctx, C.create_string_buffer(unique_id, 128), rank, world), "saev_comm_init")
+
+    def comm_world(self) -> int:
+        return int(self.lib.saev_comm_world(self.ctx))
+
+    def train_step_dp(self, x_local: torch.Tensor, lr: float, max_norm: float = 1.0):
+        """One optimizer step on the global batch of which ``x_local`` is this rank's share (equal shares on all ranks): forward,
+        all-reduce of the fired flags, AuxK + backward, all-reduce of the flat gradient, tail with the gradient averaged --
+        all enqueued by ONE call into the library (saev_train_step_dp), RCCL on torch's current stream."""
+        x = self._check_x(x_local)
+        self._x_keepalive = x
+        self._note_param_writes()
+        self.adam_steps += 1
+        self._chk(self.lib.saev_train_step_dp(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps, _stream()), "saev_train_step_dp")
+
     def train_step_gather(self, pool: torch.Tensor, rows: torch.Tensor, lr: float, max_norm: float = 1.0, out: torch.Tensor | None = None) -> torch.Tensor:
         """``train_step`` on the batch ``pool[rows]``, drawn inside the step (saev_train_step_gather): the step's first kernel reads
         the pool rows and leaves the batch as a contiguous matrix -- returned -- on its way."""

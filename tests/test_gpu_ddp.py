@@ -387,3 +387,39 @@ def test_two_rank_train_on_one_gpu_ends_with_identical_checkpoints(tmp_path, mod
     assert torch.equal(r0["toks"], r1["toks"])
     # (rank 0 logs, the global-batch block; the others keep no records)
     assert r1["mse"] == [] and len(r0["mse"]) >= 2 and r0["mse"][-1] < r0["mse"][0]
+
+
+def test_data_parallel_step_behind_the_c_abi_on_one_rank():
+    """`saev_comm_init` + `saev_train_step_dp` (include/saev_amd.h: DATA PARALLEL) with a one-rank RCCL communicator: both
+    all-reduces are the identity and 1 / world = 1, so four steps must leave exactly the parameters, Adam moments and tracker of
+    four steps made of the phases (forward, dead, backward, tail) -- this checks the library finds the process's RCCL, the
+    communicator, the stream the collectives are enqueued on and the order of the sequence.  More than one rank cannot be run
+    on this box (RCCL refuses two ranks on one device); the multi-rank arithmetic is the Python stepper's, tested over gloo."""
+    from saev_amd import _lib
+
+    outs = []
+    for dp in (False, True):
+        eng, x, s = _setup()
+        if dp:
+            try:
+                uid = eng.comm_unique_id()
+            except _lib.SaevError as e:
+                pytest.skip(f"no RCCL in this process: {e}")
+            assert eng.comm_world() == 0
+            eng.comm_init(uid, 0, 1)
+            assert eng.comm_world() == 1
+        for i in range(4):
+            if dp:
+                eng.train_step_dp(x, 1e-3, 1.0)
+            else:
+                eng.step_forward(x, training=True)
+                eng.step_dead(x.shape[0])
+                eng.step_backward()
+                eng.step_tail(1e-3, 1.0)
+        st = eng.read_stats()
+        assert st.n_dead > 0
+        outs.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.toks_since_active.clone(), st.mse, st.grad_norm))
+        eng.close()
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert outs[0][4] == outs[1][4] and outs[0][5] == outs[1][5]

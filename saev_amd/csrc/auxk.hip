@@ -948,9 +948,6 @@ __global__ __launch_bounds__(1024) void aux_fused_wsum_kernel(const float* part,
         reinterpret_cast<f32x4*>(dbe)[col] = tot;
     }
 }
-__global__ void scale_pair_kernel(const float* a, const float* b, float* out) {
-    if (threadIdx.x == 0) { out[0] = *a; out[1] = *b; }
-}
 
 // gW_dec[dl[j], :] += dWd[j, :]; gW_encT[dl[j], :] += dWe[j, :]; gb_enc[dl[j]] += dbe[j]   (one wave per dead latent)
 __global__ __launch_bounds__(256) void scatter_add_dead_kernel(const int32_t* dl, int nd, int D, const float* dWd,
@@ -1213,10 +1210,6 @@ hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* 
 }
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s) {
     hipLaunchKernelGGL(sum_parts_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, parts, n_parts, n / 4, out);  // n % 4 == 0
-    return hipGetLastError();
-}
-hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(scale_pair_kernel, dim3(1), dim3(64), 0, s, a, b, out);
     return hipGetLastError();
 }
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,

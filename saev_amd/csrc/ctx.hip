@@ -1316,9 +1316,8 @@ int ksplit_f16x3(saev_ctx* c, const float* P, const float* sP, int R, const floa
     const int Kp = (K + 16 * n_split - 1) / (16 * n_split) * (16 * n_split);  // <= aux_kpad
     HIPCHK(c, launch_split_wT(P, K, R, R256, Kp, 1.0f, c->aux_kA, 0, s, sP));
     HIPCHK(c, launch_split_wT(Q, K, C, C256, Kp, 1.0f, c->aux_kD, 0, s, sQ));
-    HIPCHK(c, launch_scale_pair(sP, sQ, c->aux_scales + 8, s));
     EncodeF16Args a{};
-    a.scale_dev = c->aux_scales + 8;
+    a.scale_dev = sP; a.scale_dev_b = sQ;  // (the two operands' scales where their producers left them)
     a.xs = c->aux_kA; a.ws = c->aux_kD; a.b_enc = c->zero_bias;
     a.n_rows = R; a.Dp = Kp / n_split; a.S = C; a.w_scale = 1.0f; a.arith = 0;
     a.s_splits = encoder_splits(R, C, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
         constexpr bool heur = HEUR;
         // lane owns batch rows bl(jb) = wb*64 + jb*32 + l31; latent of acc[sb][jb][r]:
         //   sl = ws*128 + sb*32 + 8*(r>>2) + 4*half + (r&3);   acc holds 2^8 * (x . w)
-        const float unscale = a.scale_dev != nullptr ? 1.0f / (a.w_scale * a.scale_dev[0] * a.scale_dev[1]) : 1.0f / a.w_scale;
+        const float unscale = a.scale_dev != nullptr ? 1.0f / (a.w_scale * a.scale_dev[0] * (a.scale_dev_b != nullptr ? a.scale_dev_b[0] : a.scale_dev[1])) : 1.0f / a.w_scale;
         if (EPI == EPI_DENSE) {
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
 
         // ---------------- epilogue (the 32-group TopK epilogue of encode_f16x3_kernel in this kernel's ownership) -------
         // lane owns batch rows bl(jb) = wb*64 + jb*16 + l15; latent of acc[sb][jb][e]: sl = ws*128 + sb*16 + 4*kg + e
-        const float unscale = a.scale_dev != nullptr ? 1.0f / (a.w_scale * a.scale_dev[0] * a.scale_dev[1]) : 1.0f / a.w_scale;
+        const float unscale = a.scale_dev != nullptr ? 1.0f / (a.w_scale * a.scale_dev[0] * (a.scale_dev_b != nullptr ? a.scale_dev_b[0] : a.scale_dev[1])) : 1.0f / a.w_scale;
         const int tile_no = st - st_begin;
         const bool refresh = tile_no < a.refresh_first || (tile_no & (a.refresh_every - 1)) == a.refresh_every - 1;
 #pragma unroll

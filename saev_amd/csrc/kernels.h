@@ -462,6 +462,7 @@ struct EncodeF16Args {
                               // one product
     const float* row_margin;  // (n_rows) or NULL: candidates are kept down to bound - row_margin[row] (EPI_TOPK)
     const float* scale_dev;   // NULL or two device floats: extra power-of-two scales of the x and W images
+    const float* scale_dev_b; // optional: the W images' scale lives elsewhere (*scale_dev_b instead of scale_dev[1])
     int s_splits;
     float* h_out;             // EPI_DENSE
     int ngroups;              // EPI_TOPK: 32 (bound = min over 32 group maxima; needs top_k <= 32) or 64 (bound = top_k-th
@@ -632,7 +633,6 @@ hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const floa
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
                                   const int32_t* nd_dev, float* part, hipStream_t s);  // part: ceil(n/64) x 2 x AUX_SMALL_MAX x D
 hipError_t launch_sum_parts(const float* parts, int n_parts, long n, float* out, hipStream_t s);  // out = sum_j parts[j], n % 4 == 0
-hipError_t launch_scale_pair(const float* a, const float* b, float* out, hipStream_t s);          // out = {*a, *b}
 // nd rows are scattered; with nd_dev the count is *nd_dev (<= nd, which then only sizes the grid)
 hipError_t launch_scatter_add_dead(const int32_t* dl, int nd, int D, const float* dWd, const float* dWe, const float* dbe,
                                    float* gW_dec, float* gW_encT, float* gb_enc, int lat_lo, int lat_hi, hipStream_t s,

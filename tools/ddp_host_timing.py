@@ -37,7 +37,7 @@ def main():
                    "same launches and collectives) shows what the host itself needs per step"}
     recs = []
     for D, S, K, row_list in ((64, 512, 8, (128,)), (1024, 32768, 32, (2048, 16384))):
-      for tail, exchange in (("none", "single-process"), ("replicated", "dense"), ("sharded", "dense"), ("replicated", "sparse")):
+      for tail, exchange in (("none", "single-process"), ("replicated", "dense"), ("sharded", "dense"), ("replicated", "sparse"), ("replicated", "c-abi")):
         for rows in row_list:
             single = exchange == "single-process"
             eng = SaeEngine(EngineConfig(d_model=D, d_sae=S, top_k=K, max_batch=rows, max_backward_rows=rows if exchange == "sparse" else 0,
@@ -48,8 +48,19 @@ def main():
             eng.view("W_dec").copy_(W)
             eng.view("W_enc").copy_(W.t())
             del W
-            st = DataParallelStepper(eng, None if single else dist, 1, force=not single, tail="replicated" if single else tail,
-                                     exchange="dense" if single else exchange)
+            if exchange == "c-abi":  # the same dense exchange issued by the library itself: ONE ctypes call per step (saev_train_step_dp)
+                class _CAbi:
+                    def train_step(self, x, lr, mn):
+                        eng.train_step_dp(x, lr, mn)
+
+                    def close(self):
+                        pass
+
+                eng.comm_init(eng.comm_unique_id(), 0, 1)
+                st = _CAbi()
+            else:
+                st = DataParallelStepper(eng, None if single else dist, 1, force=not single, tail="replicated" if single else tail,
+                                         exchange="dense" if single else exchange)
             x = torch.randn(rows, D, device=dev, generator=g) + torch.randn(D, device=dev, generator=g)
             for i in range(20):
                 st.train_step(x, 1e-4, 1.0)
@@ -62,7 +73,7 @@ def main():
             t2 = time.perf_counter()
             st.close()
             eng.close()
-            recs.append({"shape": f"{D} x {S}", "mode": f"{exchange}" if single else f"{exchange} exchange, {tail} tail", "rows_per_rank": rows,
+            recs.append({"shape": f"{D} x {S}", "mode": f"{exchange}" if single else ("dense exchange, replicated tail, collectives inside the library (saev_train_step_dp)" if exchange == "c-abi" else f"{exchange} exchange, {tail} tail"), "rows_per_rank": rows,
                          "enqueue_ms": (t1 - t0) / a.steps * 1e3, "device_ms": (t2 - t0) / a.steps * 1e3,
                          })
             del eng, x

@@ -683,6 +683,14 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_f16x3_kernel(EncodeF16Args
 //   one ds_read_b128; with the image swizzle (position c ^ ((4 - (r >> 2)) & 3)) each of the instruction's four service
 //   groups touches all 64 banks once.
 // Group of a latent (for the 32 shared group maxima): its position modulo 32.
+// cache policy of encode_m16_kernel's staging loads (" nt", " sc1", ...: experiments; the shipped kernel uses the default for both --
+// tools/experiments/r5_enc_policy.sh)
+#ifndef SAEV_ENC_W_POLICY
+#define SAEV_ENC_W_POLICY ""
+#endif
+#ifndef SAEV_ENC_X_POLICY
+#define SAEV_ENC_X_POLICY ""
+#endif
 template <int AR>
 __device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
     if constexpr (AR == 1)
@@ -745,9 +753,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
         const uint32_t lds_a = lds_w + (uint32_t)slot * (uint32_t)sizeof(KSlot);
         asm volatile(
             "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+            "global_load_lds_dwordx4 %2, %3" SAEV_ENC_W_POLICY "\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024" SAEV_ENC_W_POLICY "\n\t"
             "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
+            "global_load_lds_dwordx4 %2, %4" SAEV_ENC_X_POLICY "\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024" SAEV_ENC_X_POLICY
             ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(wsrc), "s"(xsrc)
             : "memory");
     };
@@ -786,9 +794,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
             const uint32_t lds_a = lds_w + (uint32_t)slot * (uint32_t)sizeof(KSlot);
             asm volatile(
                 "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-                "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                "global_load_lds_dwordx4 %2, %3" SAEV_ENC_W_POLICY "\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024" SAEV_ENC_W_POLICY "\n\t"
                 "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"
+                "global_load_lds_dwordx4 %2, %4" SAEV_ENC_X_POLICY "\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024" SAEV_ENC_X_POLICY
                 ::"s"(lds_a), "s"(lds_a + (uint32_t)sizeof(_Float16) * HTS * 32), "v"(lane_off), "s"(w_tile + koff), "s"(x_blk + koff)
                 : "memory");
             koff += (uint32_t)(img * sizeof(_Float16));

@@ -163,6 +163,8 @@ typedef struct {
     int32_t aux_dense_route; /* selection of the dense AuxK algebra: 0 = one launch leaves the code matrix, its mask, its maximum and its
                               operand scale (dead sets up to 4 096 columns), 1 = the round-4 sequence (radix select, two fills, scatter,
                               absmax, scale: six launches)                                                                    */
+    int32_t aux_small_route; /* 9 ... 32 dead latents (and 1 ... 8 where the one-pass kernel does not take the shape), d_model % 128 == 0:
+                              0 = the contractions as fp32 MFMA tiles (v_mfma_f32_32x32x2_f32), 1 = the vector-ALU kernels of rounds 3-4 */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

@@ -850,6 +850,196 @@ __global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, co
     }
 }
 
+// ---- 9 ... 32 dead latents on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------------------------------------------------
+// The five-pass kernels above do the few-dead-latents algebra on the vector ALUs: 0.21 + 0.11 ms at 30 dead latents for 5 GFLOP of
+// skinny contractions, bound by fmas, reduce-scatters and LDS traffic.  The same contractions as 32-wide fp32 MFMA tiles (true
+// fp32 multiply-adds: no operand splitting, 157 TFLOP/s dense) take what their passes over x / x_hat / g_aux cost:
+//   aux_mfma_dots_kernel    out[b][j] = <M[b, :], R[j, :]> (+ bias): the codes H (M = x, R = W_enc^T[dl]) and dA (M = g_aux, R = W_dec[dl])
+//   aux_mfma_expand_kernel  E = A W_dec[dl] + b_dec, residual, loss share, g_aux
+//   aux_mfma_wgrad_kernel   the block partials of dWd = A^T g_aux and dWe = dA^T x (aux_small_wgrad_kernel's layout and finish)
+// Instruction shape: D[32 x 32] += A[32 x 2] B[2 x 32]; lane l supplies A[l % 32][l / 32] and B[l / 32][l % 32] and holds, in
+// register r of the result, row 8 (r / 4) + 4 (l / 32) + r % 4 of column l % 32.  Which k a "slot" l / 32 stands for is free as
+// long as both operands agree, so every lane reads CONTIGUOUS pieces of its row (dots: eight floats per chunk of sixteen
+// columns; expand: sixteen codes; wgrad: 32 rows of one column) -- no transposes through LDS.  Latents past the count are zero
+// operands.  d_model % 128 == 0.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// one workgroup = 32 rows of M; its four waves take a quarter of the columns each and their partial tiles are added in wave order
+__global__ __launch_bounds__(256) void aux_mfma_dots_kernel(const float* __restrict__ M, const float* __restrict__ R, const float* __restrict__ bias,
+                                                            const int32_t* __restrict__ dl, int n_rows, int D, const int32_t* nd_dev,
+                                                            float* __restrict__ out) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > 32) return;
+    constexpr int ndp = AUX_SMALL_MAX;
+    __shared__ float sh[4][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    const int kq = D >> 2;  // columns per wave (a multiple of 32)
+    const float* mr = M + (size_t)min(row0 + i, n_rows - 1) * D + w * kq + 8 * h;
+    const float* rr = R + (size_t)i * D + w * kq + 8 * h;
+    const bool lat_ok = i < nd;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // (four chunks of sixteen columns per trip, their sixteen loads issued together: two waves per SIMD do not hide a memory round
+    // trip per chunk)
+#pragma unroll 1
+    for (int c = 0; c < kq; c += 64) {
+        f32x4 m[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = c + 16 * u < kq;  // (kq is a multiple of 32, not of 64)
+            m[2 * u] = in ? *reinterpret_cast<const f32x4*>(mr + c + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            m[2 * u + 1] = in ? *reinterpret_cast<const f32x4*>(mr + c + 16 * u + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            q[2 * u] = (in && lat_ok) ? *reinterpret_cast<const f32x4*>(rr + c + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            q[2 * u + 1] = (in && lat_ok) ? *reinterpret_cast<const f32x4*>(rr + c + 16 * u + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(m[u][e], q[u][e], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sh[w][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = threadIdx.x + 256 * u;
+        const int r = idx >> 6, l = idx & 63;
+        const int row = row0 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3), j = l & 31;
+        const float v = ((sh[0][r][l] + sh[1][r][l]) + sh[2][r][l]) + sh[3][r][l];
+        if (row < n_rows) {
+            out[(size_t)row * ndp + j] = j < nd ? v + (bias != nullptr ? bias[dl[j]] : 0.f) : 0.f;
+            out[(size_t)row * ndp + 32 + j] = 0.f;
+        }
+    }
+}
+
+// one workgroup = 32 rows; wave w takes the column blocks [w D / 128, (w + 1) D / 128) of 32 columns
+__global__ __launch_bounds__(256) void aux_mfma_expand_kernel(const float* __restrict__ A, const float* __restrict__ Wd, const float* __restrict__ b_dec,
+                                                              const float* __restrict__ x, const float* __restrict__ x_hat, int n_rows, int D,
+                                                              const int32_t* nd_dev, float gscale, float* __restrict__ g_aux, RowStats* rowstats) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > 32) return;
+    constexpr int ndp = AUX_SMALL_MAX;
+    __shared__ float shs[4][32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    // A operand: this lane's row, slot h <-> latents 16 h ... 16 h + 15 (columns past the count hold zeros)
+    f32x4 a4[4];
+    {
+        const f32x4* ar = reinterpret_cast<const f32x4*>(A + (size_t)min(row0 + j, n_rows - 1) * ndp + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = ar[q];
+    }
+    float sse[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sse[r] = 0.f;
+    const int nb = D >> 7;
+    for (int b = 0; b < nb; ++b) {
+        const int col = (w * nb + b) * 32 + j;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float wv[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) wv[p] = (16 * h + p < nd) ? Wd[(size_t)(16 * h + p) * D + col] : 0.f;
+        const float bd = b_dec[col];
+        float xv[16], hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t o = (size_t)min(row0 + 8 * (r >> 2) + 4 * h + (r & 3), n_rows - 1) * D + col;
+            xv[r] = x[o]; hv[r] = x_hat[o];
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) acc = mfma32(a4[p >> 2][p & 3], wv[p], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const float diff = (acc[r] + bd) - (xv[r] - hv[r]);
+            sse[r] = __builtin_fmaf(diff, diff, sse[r]);
+            if (row < n_rows) g_aux[(size_t)row * D + col] = gscale * diff;
+        }
+    }
+    // per-row sums of squares: over the 32 lanes of each half, then over the four waves in order
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = sse[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (j == 0) shs[w][8 * (r >> 2) + 4 * h + (r & 3)] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && row0 + threadIdx.x < n_rows)
+        rowstats[row0 + threadIdx.x].aux_sse = ((shs[0][threadIdx.x] + shs[1][threadIdx.x]) + shs[2][threadIdx.x]) + shs[3][threadIdx.x];
+}
+
+// one block of 64 rows per blockIdx.x (aux_small_wgrad_kernel's partial layout: part[blk][2][ndp][D]); the D / 32 column blocks go round
+// the 4 gridDim.y waves of the row block; slot h <-> rows 32 h ... 32 h + 31.  A column block's 2 x 32 operand loads are issued
+// together and the next block's before this one's products (a first version loaded eight rows at a time with one wave per SIMD:
+// 124 us at configs[1], every group waiting out a memory round trip)
+__global__ __launch_bounds__(256, 1) void aux_mfma_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ dA, const float* __restrict__ g,
+                                                                const float* __restrict__ x, int n_rows, int D, const int32_t* nd_dev,
+                                                                float* __restrict__ part) {
+    const int nd = *nd_dev;
+    if (nd <= 0 || nd > 32) return;
+    constexpr int ndp = AUX_SMALL_MAX;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * 64 + 32 * h;
+    const int wi = blockIdx.y * 4 + (threadIdx.x >> 6), nw = gridDim.y * 4, NB = D >> 5;
+    if (wi >= NB) return;
+    float av[32], dv[32];
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const bool ok = r0 + p < n_rows;  // (rows past the end: zero coefficients against the last row's values)
+        const size_t o = (size_t)min(r0 + p, n_rows - 1) * ndp + i;
+        av[p] = ok ? A[o] : 0.f;
+        dv[p] = ok ? dA[o] : 0.f;
+    }
+    float* const base = part + (size_t)blockIdx.x * 2 * ndp * D;
+    auto load = [&](int cb, float (&gv)[32], float (&xv)[32]) {
+        const int col = cb * 32 + i;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const size_t o = (size_t)min(r0 + p, n_rows - 1) * D + col;
+            gv[p] = g[o]; xv[p] = x[o];
+        }
+    };
+    auto products = [&](int cb, const float (&gv)[32], const float (&xv)[32]) {
+        const int col = cb * 32 + i;
+        f32x16 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+        for (int p = 0; p < 32; ++p) { c0 = mfma32(av[p], gv[p], c0); c1 = mfma32(dv[p], xv[p], c1); }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lat = 8 * (r >> 2) + 4 * h + (r & 3);
+            if (lat < nd) {
+                base[(size_t)lat * D + col] = c0[r];
+                base[(size_t)(ndp + lat) * D + col] = c1[r];
+            }
+        }
+    };
+    float ga[32], xa[32], gb[32], xb[32];
+    load(wi, ga, xa);
+#pragma unroll 1
+    for (int cb = wi; cb < NB; cb += 2 * nw) {
+        const bool more1 = cb + nw < NB, more2 = cb + 2 * nw < NB;
+        if (more1) load(cb + nw, gb, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        products(cb, ga, xa);
+        if (more2) load(cb + 2 * nw, ga, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) products(cb + nw, gb, xb);
+    }
+}
+
 // out[i] = sum_j parts[j][i] in the order j = 0, 1, ...: the contraction slices of a split product (fixed order, so the
 // result does not depend on scheduling)
 __global__ __launch_bounds__(256) void sum_parts_kernel(const float* parts, int n_parts, long n4, float* out) {
@@ -1200,6 +1390,23 @@ hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const floa
         default: AF(4); break;
     }
 #undef AF
+    return hipGetLastError();
+}
+bool aux_mfma_supported(int D) { return D % 128 == 0 && D >= 128; }
+hipError_t launch_aux_mfma_forward(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
+                                   const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale, float* A,
+                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s) {
+    if (!aux_mfma_supported(D)) return hipErrorInvalidValue;
+    const dim3 grid((n_rows + 31) / 32), block(256);
+    hipLaunchKernelGGL(aux_mfma_dots_kernel, grid, block, 0, s, x, WencT_dead, b_enc, dl, n_rows, D, nd_dev, A);
+    hipLaunchKernelGGL(aux_mfma_expand_kernel, grid, block, 0, s, A, Wdec_dead, b_dec, x, x_hat, n_rows, D, nd_dev, gscale, g_aux, rowstats);
+    hipLaunchKernelGGL(aux_mfma_dots_kernel, grid, block, 0, s, g_aux, Wdec_dead, nullptr, dl, n_rows, D, nd_dev, dA);
+    return hipGetLastError();
+}
+hipError_t launch_aux_mfma_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
+                                 const int32_t* nd_dev, float* part, hipStream_t s) {
+    if (!aux_mfma_supported(D)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(aux_mfma_wgrad_kernel, dim3((n_rows + 63) / 64, D >= 512 ? 2 : 1), dim3(256), 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part);
     return hipGetLastError();
 }
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,

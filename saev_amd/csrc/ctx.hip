@@ -155,6 +155,7 @@ struct saev_ctx {
           *dbe = nullptr, *aux_partials = nullptr, *WencT_dead = nullptr, *aux_small_part = nullptr, *aux_small_part2 = nullptr;
     bool aux_dev_count = false;  // dense branch sized by a host-side BOUND of the dead count; the count itself stays on the device
     bool aux_small = false;  // this step's AuxK ran on the few-dead-latents path
+    bool aux_mfma = false;   // ... in its fp32 matrix-core form (at most AUX_MFMA_MAX dead latents, d_model % 128 == 0: auxk.hip aux_mfma_*)
     bool aux_fused = false;  // ... in its one-pass form (at most AUX_FUSED_MAX dead latents: block partials instead of g_aux / A / dA)
     bool aux_all = false;    // dense branch with every dead latent selected (n_dead <= k_aux): no select, no mask
     uint8_t* A_mask = nullptr;
@@ -1338,6 +1339,7 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
     c->aux_small = true;
     c->aux_all = false;
     c->aux_fused = false;
+    c->aux_mfma = false;
     if (!c->dead_list_ready) HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s, nd_dev));
     HIPCHK(c, launch_gather_dead_small(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd_dev, D, S,
                                        c->WencT_dead, c->Wdec_dead, s));
@@ -1354,6 +1356,12 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
             HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, nullptr, c->stats, s, nd_dev, c->stats_scratch));
         return SAEV_OK;
     }
+    if (bound <= AUX_MFMA_MAX && aux_mfma_supported(D) && c->dbg.aux_small_route == 0) {
+        c->aux_mfma = true;
+        HIPCHK(c, launch_aux_mfma_forward(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
+                                          c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
+                                          c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
+    } else
     HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                    c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
                                    c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
@@ -1455,7 +1463,8 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
             c->aux_stats_pending = false;
             return SAEV_OK;
         }
-        HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
+        if (c->aux_mfma) HIPCHK(c, launch_aux_mfma_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
+        else HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
         HIPCHK(c, launch_aux_small_wsum(c->aux_small_part, nb, D, nd_dev, c->dWd, c->dWe, s));
         HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
         if (c->ov_x != nullptr) {  // gathered backward: the local share travels with the compact rows (saev_aux_compact_export)

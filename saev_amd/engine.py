@@ -65,6 +65,7 @@ class EngineConfig:
     #   SAEV_AMD_FIN              1: the backward's finalize re-reads the gradient rows for their statistics (round-4 kernels)
     #   SAEV_AMD_PREP             1: every f16r forward prepares its operands from x and W_enc itself (no streamed preparation)
     #   SAEV_AMD_AUX_DENSE        1: the dense AuxK algebra selects with the round-4 kernels (radix select, fills, scatter, absmax)
+    #   SAEV_AMD_AUX_SMALL        1: 9-32 dead latents on the vector-ALU kernels of rounds 3-4 instead of the fp32 MFMA ones
     dw_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_DW", "slices"))
     fwd_route: str = dataclasses.field(default_factory=lambda: os.environ.get("SAEV_AMD_FWD", "default"))
     enc_mfma: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_ENC_MFMA", "0")))
@@ -79,6 +80,7 @@ class EngineConfig:
     fin_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_FIN", "0")))
     prep_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_PREP", "0")))
     aux_dense_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_DENSE", "0")))
+    aux_small_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_SMALL", "0")))
 
 
 @dataclasses.dataclass
@@ -160,7 +162,7 @@ class SaeEngine:
                 struct_size=C.sizeof(_lib.SaevDebugCfg), dw_route={"slices": 0, "rows": 1, "slices_a": 2, "slices_s": 4}[cfg.dw_route], enc_mfma=cfg.enc_mfma,
                 fused_chain=int(cfg.fused_chain), ngroups=cfg.ngroups, enc_wgs=cfg.enc_wgs, refresh_first=cfg.refresh_first,
                 refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route={"default": 0, "rows": 1, "sum_pass": 2}[cfg.fwd_route],
-                dead_lag=cfg.dead_lag, csc_route=cfg.csc_route, fin_route=cfg.fin_route, prep_route=cfg.prep_route, aux_dense_route=cfg.aux_dense_route)
+                dead_lag=cfg.dead_lag, csc_route=cfg.csc_route, fin_route=cfg.fin_route, prep_route=cfg.prep_route, aux_dense_route=cfg.aux_dense_route, aux_small_route=cfg.aux_small_route)
             ctx = C.c_void_p()
             rc = self.lib.saev_create_ex(C.byref(ccfg), C.byref(dbg), self.device.index, C.byref(ctx))
             if rc != 0:

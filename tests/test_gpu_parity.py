@@ -1013,3 +1013,43 @@ def test_one_launch_exactness_chain_gives_the_same_codes(monkeypatch):
     assert torch.equal(idx0, idx1) and torch.equal(val0, val1)
     h = x.double() @ p["W_enc"].double() + p["b_enc"].double()
     torch.testing.assert_close(h.gather(1, idx1.cpu().long()).float(), val1.cpu(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n_dead,d,n", [(1, 128, 200), (9, 128, 200), (17, 256, 333), (24, 768, 96), (32, 1024, 64), (31, 1280, 130)])
+def test_few_dead_latents_on_the_matrix_cores_agree_with_the_vector_kernels_and_the_oracle(n_dead, d, n):
+    """9-32 dead latents (and fewer where the one-pass kernel does not take the shape): the AuxK contractions as fp32 MFMA tiles
+    (`aux_mfma_*`, default) against the vector-ALU kernels of rounds 3-4 (`aux_small_route=1`) and against the oracle -- loss,
+    tracker and all four gradients; ragged row counts (the last 32-row tile and the last 64-row block are partial), every
+    d_model % 128 class the step supports, the full 32 latents and a single one."""
+    s, k, k_aux, thr = 2048, 8, 64, 1000
+    p = rand_params(d, s, seed=700 + n_dead)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(701 + n_dead))
+    toks = torch.zeros(s, dtype=torch.int64)
+    dead = torch.randperm(s, generator=torch.Generator().manual_seed(702))[:n_dead]
+    toks[dead] = thr
+    p["b_enc"][dead] = -100.0
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
+    leaves = {k_: p[k_].clone().requires_grad_(True) for k_ in R.PARAM_ORDER}
+    leaves["W_dec"] = R.normalize_w_dec(p["W_dec"]).clone().requires_grad_(True)
+    out = R.objective_forward(leaves, x, cfg, toks_since_active=toks.clone(), training=True)
+    out.loss.backward()
+    got = []
+    for route in (0, 1):
+        # (aux_small_max = 64 keeps the one-pass kernel out of the way, as in the boundary test above)
+        eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n, aux_small_max=64, aux_small_route=route)
+        eng.load_params(p)
+        eng.set_tracker(toks)
+        eng.step_forward(x.cuda(), training=True)
+        eng.step_dead(n)
+        eng.step_backward()
+        st = eng.read_stats()
+        assert st.n_dead == out.n_dead == n_dead and eng.aux_route() in (1, 2)
+        assert math.isclose(st.aux, out.aux.item(), rel_tol=1e-4), (route, st.aux, out.aux.item())
+        gv = {key: v.cpu().clone() for key, v in eng.grad_views().items()}
+        for key in R.PARAM_ORDER:
+            torch.testing.assert_close(gv[key], leaves[key].grad, rtol=2e-3, atol=3e-7, msg=lambda m: f"route {route} {key}: {m}")
+        got.append((st.aux, gv))
+        eng.close()
+    assert math.isclose(got[0][0], got[1][0], rel_tol=2e-6)
+    for key in R.PARAM_ORDER:
+        torch.testing.assert_close(got[0][1][key], got[1][1][key], rtol=1e-4, atol=1e-8, msg=lambda m: f"{key}: {m}")

@@ -850,128 +850,173 @@ __global__ __launch_bounds__(256) void aux_small_wgrad_kernel(const float* A, co
     }
 }
 
-// ---- 9 ... 32 dead latents on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------------------------------------------------
+// ---- 9 ... 64 dead latents on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------------------------------------------------
 // The five-pass kernels above do the few-dead-latents algebra on the vector ALUs: 0.21 + 0.11 ms at 30 dead latents for 5 GFLOP of
 // skinny contractions, bound by fmas, reduce-scatters and LDS traffic.  The same contractions as 32-wide fp32 MFMA tiles (true
 // fp32 multiply-adds: no operand splitting, 157 TFLOP/s dense) take what their passes over x / x_hat / g_aux cost:
-//   aux_mfma_dots_kernel    out[b][j] = <M[b, :], R[j, :]> (+ bias): the codes H (M = x, R = W_enc^T[dl]) and dA (M = g_aux, R = W_dec[dl])
-//   aux_mfma_expand_kernel  E = A W_dec[dl] + b_dec, residual, loss share, g_aux
-//   aux_mfma_wgrad_kernel   the block partials of dWd = A^T g_aux and dWe = dA^T x (aux_small_wgrad_kernel's layout and finish)
+//   aux_mfma_forward_kernel  codes H = x W_enc[:, dl] + b_enc[dl], E = H W_dec[dl] + b_dec, residual, loss share, g_aux,
+//                            dA = g_aux W_dec[dl]^T -- one pass over x and x_hat per 32-row tile
+//   aux_mfma_wgrad_kernel    the block partials of dWd = A^T g_aux and dWe = dA^T x (aux_small_wgrad_kernel's layout and finish)
 // Instruction shape: D[32 x 32] += A[32 x 2] B[2 x 32]; lane l supplies A[l % 32][l / 32] and B[l / 32][l % 32] and holds, in
 // register r of the result, row 8 (r / 4) + 4 (l / 32) + r % 4 of column l % 32.  Which k a "slot" l / 32 stands for is free as
-// long as both operands agree, so every lane reads CONTIGUOUS pieces of its row (dots: eight floats per chunk of sixteen
-// columns; expand: sixteen codes; wgrad: 32 rows of one column) -- no transposes through LDS.  Latents past the count are zero
-// operands.  d_model % 128 == 0.
+// long as both operands agree, so every lane reads CONTIGUOUS pieces of its row (codes: eight floats per chunk of sixteen
+// columns; reconstruction: half of the row's codes; wgrad: 32 rows of one column).  NL = 1 / 2 blocks of 32 latents; latents past
+// the count are zero operands.  d_model % 128 == 0.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int mfma32_row(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
 
-// one workgroup = 32 rows of M; its four waves take a quarter of the columns each and their partial tiles are added in wave order
-__global__ __launch_bounds__(256) void aux_mfma_dots_kernel(const float* __restrict__ M, const float* __restrict__ R, const float* __restrict__ bias,
-                                                            const int32_t* __restrict__ dl, int n_rows, int D, const int32_t* nd_dev,
-                                                            float* __restrict__ out) {
+// One workgroup = 32 rows.  Phase 1: wave w forms the codes' share of columns [w D / 4, (w + 1) D / 4); the four shares are added in
+// wave order through LDS, the codes go out (A) and stay in LDS as the next phase's operand.  Phase 2: wave w walks its D / 128 column
+// blocks of 32: E block, residual, g_aux block (out, and transposed through a per-wave LDS tile: the result holds a COLUMN per lane,
+// the next product wants a ROW per lane), dA share of the block.  The dA shares of the four waves are added like the codes'.
+template <int NL>
+__global__ __launch_bounds__(256) void aux_mfma_forward_kernel(const float* __restrict__ x, const float* __restrict__ x_hat,
+                                                               const float* __restrict__ We, const float* __restrict__ Wd,
+                                                               const float* __restrict__ b_enc, const float* __restrict__ b_dec,
+                                                               const int32_t* __restrict__ dl, int n_rows, int D, const int32_t* nd_dev,
+                                                               float gscale, float* __restrict__ A, float* __restrict__ dA,
+                                                               float* __restrict__ g_aux, RowStats* rowstats) {
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > 32) return;
-    constexpr int ndp = AUX_SMALL_MAX;
-    __shared__ float sh[4][16][64];
+    if (nd <= 0 || nd > 32 * NL) return;
+    constexpr int ndp = AUX_SMALL_MAX, KH = 16 * NL;  // KH: latents per slot of the reconstruction's contraction
+    __shared__ float sh[4][NL][16][64];   // the four waves' shares of a 32 x (32 NL) tile
+    __shared__ float As[32][32 * NL + 1];  // the tile's codes, row-major
+    __shared__ float Gs[4][32][33];        // per wave: a 32 x 32 block of g_aux, row-major
+    __shared__ float shs[4][32];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * 32;
-    const int kq = D >> 2;  // columns per wave (a multiple of 32)
-    const float* mr = M + (size_t)min(row0 + i, n_rows - 1) * D + w * kq + 8 * h;
-    const float* rr = R + (size_t)i * D + w * kq + 8 * h;
-    const bool lat_ok = i < nd;
-    f32x16 acc;
+    const int rowc = min(row0 + i, n_rows - 1);
+    // every share of the tile, added in wave order; `fin(row, lat, sum)` receives the 32 x (32 NL) sums
+    auto tile_sum = [&](const f32x16 (&t)[NL], auto fin) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // (four chunks of sixteen columns per trip, their sixteen loads issued together: two waves per SIMD do not hide a memory round
-    // trip per chunk)
-#pragma unroll 1
-    for (int c = 0; c < kq; c += 64) {
-        f32x4 m[8], q[8];
+        for (int lb = 0; lb < NL; ++lb)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool in = c + 16 * u < kq;  // (kq is a multiple of 32, not of 64)
-            m[2 * u] = in ? *reinterpret_cast<const f32x4*>(mr + c + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
-            m[2 * u + 1] = in ? *reinterpret_cast<const f32x4*>(mr + c + 16 * u + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            q[2 * u] = (in && lat_ok) ? *reinterpret_cast<const f32x4*>(rr + c + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
-            q[2 * u + 1] = (in && lat_ok) ? *reinterpret_cast<const f32x4*>(rr + c + 16 * u + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 16; ++r) sh[w][lb][r][lane] = t[lb][r];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4 * NL; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            const int lb = idx >> 10, r = (idx >> 6) & 15, l = idx & 63;
+            fin(mfma32_row(r, l >> 5), 32 * lb + (l & 31), ((sh[0][lb][r][l] + sh[1][lb][r][l]) + sh[2][lb][r][l]) + sh[3][lb][r][l]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(m[u][e], q[u][e], acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sh[w][r][lane] = acc[r];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int idx = threadIdx.x + 256 * u;
-        const int r = idx >> 6, l = idx & 63;
-        const int row = row0 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3), j = l & 31;
-        const float v = ((sh[0][r][l] + sh[1][r][l]) + sh[2][r][l]) + sh[3][r][l];
-        if (row < n_rows) {
-            out[(size_t)row * ndp + j] = j < nd ? v + (bias != nullptr ? bias[dl[j]] : 0.f) : 0.f;
-            out[(size_t)row * ndp + 32 + j] = 0.f;
-        }
-    }
-}
-
-// one workgroup = 32 rows; wave w takes the column blocks [w D / 128, (w + 1) D / 128) of 32 columns
-__global__ __launch_bounds__(256) void aux_mfma_expand_kernel(const float* __restrict__ A, const float* __restrict__ Wd, const float* __restrict__ b_dec,
-                                                              const float* __restrict__ x, const float* __restrict__ x_hat, int n_rows, int D,
-                                                              const int32_t* nd_dev, float gscale, float* __restrict__ g_aux, RowStats* rowstats) {
-    const int nd = *nd_dev;
-    if (nd <= 0 || nd > 32) return;
-    constexpr int ndp = AUX_SMALL_MAX;
-    __shared__ float shs[4][32];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * 32;
-    // A operand: this lane's row, slot h <-> latents 16 h ... 16 h + 15 (columns past the count hold zeros)
-    f32x4 a4[4];
+        __syncthreads();
+    };
+    // ---- phase 1: codes ----
     {
-        const f32x4* ar = reinterpret_cast<const f32x4*>(A + (size_t)min(row0 + j, n_rows - 1) * ndp + 16 * h);
+        const int kq = D >> 2;  // columns per wave (a multiple of 32)
+        const float* mr = x + (size_t)rowc * D + w * kq + 8 * h;
+        f32x16 acc[NL];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a4[q] = ar[q];
+        for (int lb = 0; lb < NL; ++lb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[lb][r] = 0.f;
+        // (two chunks of sixteen columns per trip, their loads issued together)
+#pragma unroll 1
+        for (int c = 0; c < kq; c += 32) {
+            f32x4 m[4], q[NL][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                m[2 * u] = *reinterpret_cast<const f32x4*>(mr + c + 16 * u);
+                m[2 * u + 1] = *reinterpret_cast<const f32x4*>(mr + c + 16 * u + 4);
+#pragma unroll
+                for (int lb = 0; lb < NL; ++lb) {
+                    const bool ok = 32 * lb + i < nd;
+                    const float* rr = We + (size_t)(32 * lb + i) * D + w * kq + 8 * h + c + 16 * u;
+                    q[lb][2 * u] = ok ? *reinterpret_cast<const f32x4*>(rr) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    q[lb][2 * u + 1] = ok ? *reinterpret_cast<const f32x4*>(rr + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int lb = 0; lb < NL; ++lb) acc[lb] = mfma32(m[u][e], q[lb][u][e], acc[lb]);
+        }
+        tile_sum(acc, [&](int rl, int lat, float v) {
+            const float a = lat < nd ? v + b_enc[dl[lat]] : 0.f;
+            As[rl][lat] = a;
+            if (row0 + rl < n_rows) {
+                A[(size_t)(row0 + rl) * ndp + lat] = a;
+                if (NL == 1) A[(size_t)(row0 + rl) * ndp + 32 + lat] = 0.f;
+            }
+        });
     }
+    // ---- phase 2: reconstruction, residual, g_aux, dA ----
+    float av[KH];  // this lane's row: slot h <-> latents KH h ... KH h + KH - 1
+#pragma unroll
+    for (int p = 0; p < KH; ++p) av[p] = As[i][KH * h + p];
     float sse[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) sse[r] = 0.f;
+    f32x16 accD[NL];
+#pragma unroll
+    for (int lb = 0; lb < NL; ++lb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accD[lb][r] = 0.f;
     const int nb = D >> 7;
+#pragma unroll 1
     for (int b = 0; b < nb; ++b) {
-        const int col = (w * nb + b) * 32 + j;
-        f32x16 acc;
+        const int c0 = (w * nb + b) * 32, col = c0 + i;
+        float wv[KH];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float wv[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) wv[p] = (16 * h + p < nd) ? Wd[(size_t)(16 * h + p) * D + col] : 0.f;
+        for (int p = 0; p < KH; ++p) wv[p] = (KH * h + p < nd) ? Wd[(size_t)(KH * h + p) * D + col] : 0.f;
         const float bd = b_dec[col];
         float xv[16], hv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const size_t o = (size_t)min(row0 + 8 * (r >> 2) + 4 * h + (r & 3), n_rows - 1) * D + col;
+            const size_t o = (size_t)min(row0 + mfma32_row(r, h), n_rows - 1) * D + col;
             xv[r] = x[o]; hv[r] = x_hat[o];
         }
+        // (the dA product's second operand: W_dec[dl] rows of the latent blocks, this lane's 16 columns of the block)
+        f32x4 wd4[NL][4];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) acc = mfma32(a4[p >> 2][p & 3], wv[p], acc);
+        for (int lb = 0; lb < NL; ++lb) {
+            const bool ok = 32 * lb + i < nd;
+            const f32x4* wr = reinterpret_cast<const f32x4*>(Wd + (size_t)(32 * lb + i) * D + c0 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wd4[lb][q] = ok ? wr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < KH; ++p) acc = mfma32(av[p], wv[p], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = row0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const int rl = mfma32_row(r, h);
             const float diff = (acc[r] + bd) - (xv[r] - hv[r]);
             sse[r] = __builtin_fmaf(diff, diff, sse[r]);
-            if (row < n_rows) g_aux[(size_t)row * D + col] = gscale * diff;
+            const float gv = gscale * diff;
+            if (row0 + rl < n_rows) g_aux[(size_t)(row0 + rl) * D + col] = gv;
+            Gs[w][rl][i] = gv;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wave's own LDS writes, in order, before its reads of the tile)
+        float gr[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) gr[p] = Gs[w][i][16 * h + p];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int lb = 0; lb < NL; ++lb) accD[lb] = mfma32(gr[p], wd4[lb][p >> 2][p & 3], accD[lb]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (reads done before the next block's writes)
     }
+    tile_sum(accD, [&](int rl, int lat, float v) {
+        if (row0 + rl < n_rows) {
+            dA[(size_t)(row0 + rl) * ndp + lat] = lat < nd ? v : 0.f;
+            if (NL == 1) dA[(size_t)(row0 + rl) * ndp + 32 + lat] = 0.f;
+        }
+    });
     // per-row sums of squares: over the 32 lanes of each half, then over the four waves in order
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float v = sse[r];
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (j == 0) shs[w][8 * (r >> 2) + 4 * h + (r & 3)] = v;
+        if (i == 0) shs[w][mfma32_row(r, h)] = v;
     }
     __syncthreads();
     if (threadIdx.x < 32 && row0 + threadIdx.x < n_rows)
@@ -982,24 +1027,43 @@ __global__ __launch_bounds__(256) void aux_mfma_expand_kernel(const float* __res
 // the 4 gridDim.y waves of the row block; slot h <-> rows 32 h ... 32 h + 31.  A column block's 2 x 32 operand loads are issued
 // together and the next block's before this one's products (a first version loaded eight rows at a time with one wave per SIMD:
 // 124 us at configs[1], every group waiting out a memory round trip)
+template <int NL>
 __global__ __launch_bounds__(256, 1) void aux_mfma_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ dA, const float* __restrict__ g,
                                                                 const float* __restrict__ x, int n_rows, int D, const int32_t* nd_dev,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part, float* __restrict__ partb, float* __restrict__ partbe) {
+    // partb[blk][D] / partbe[blk][ndp]: the block's column sums of g_aux (db_dec's share) and of dA (db_enc[dl]) -- the operands are in
+    // registers anyway; rows 0 ... 31 in order, then rows 32 ... 63, then the two halves: one fixed order
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > 32) return;
+    if (nd <= 0 || nd > 32 * NL) return;
     constexpr int ndp = AUX_SMALL_MAX;
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * 64 + 32 * h;
     const int wi = blockIdx.y * 4 + (threadIdx.x >> 6), nw = gridDim.y * 4, NB = D >> 5;
     if (wi >= NB) return;
-    float av[32], dv[32];
+    float av[NL][32], dv[NL][32];
 #pragma unroll
     for (int p = 0; p < 32; ++p) {
         const bool ok = r0 + p < n_rows;  // (rows past the end: zero coefficients against the last row's values)
         const size_t o = (size_t)min(r0 + p, n_rows - 1) * ndp + i;
-        av[p] = ok ? A[o] : 0.f;
-        dv[p] = ok ? dA[o] : 0.f;
+#pragma unroll
+        for (int lb = 0; lb < NL; ++lb) {
+            av[lb][p] = ok ? A[o + 32 * lb] : 0.f;
+            dv[lb][p] = ok ? dA[o + 32 * lb] : 0.f;
+        }
+    }
+    if (wi == 0 && partbe != nullptr) {
+#pragma unroll
+        for (int lb = 0; lb < NL; ++lb) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) t += dv[lb][p];
+            const float o = __shfl_xor(t, 32, 64);
+            if (h == 0) {
+                partbe[(size_t)blockIdx.x * ndp + 32 * lb + i] = t + o;
+                if (NL == 1) partbe[(size_t)blockIdx.x * ndp + 32 + i] = 0.f;
+            }
+        }
     }
     float* const base = part + (size_t)blockIdx.x * 2 * ndp * D;
     auto load = [&](int cb, float (&gv)[32], float (&xv)[32]) {
@@ -1012,17 +1076,27 @@ __global__ __launch_bounds__(256, 1) void aux_mfma_wgrad_kernel(const float* __r
     };
     auto products = [&](int cb, const float (&gv)[32], const float (&xv)[32]) {
         const int col = cb * 32 + i;
-        f32x16 c0, c1;
+        if (partb != nullptr) {
+            float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+            for (int p = 0; p < 32; ++p) t += (r0 + p < n_rows) ? gv[p] : 0.f;
+            const float o = __shfl_xor(t, 32, 64);
+            if (h == 0) partb[(size_t)blockIdx.x * D + col] = t + o;
+        }
 #pragma unroll
-        for (int p = 0; p < 32; ++p) { c0 = mfma32(av[p], gv[p], c0); c1 = mfma32(dv[p], xv[p], c1); }
+        for (int lb = 0; lb < NL; ++lb) {
+            f32x16 c0, c1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lat = 8 * (r >> 2) + 4 * h + (r & 3);
-            if (lat < nd) {
-                base[(size_t)lat * D + col] = c0[r];
-                base[(size_t)(ndp + lat) * D + col] = c1[r];
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+            for (int p = 0; p < 32; ++p) { c0 = mfma32(av[lb][p], gv[p], c0); c1 = mfma32(dv[lb][p], xv[p], c1); }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lat = 32 * lb + mfma32_row(r, h);
+                if (lat < nd) {
+                    base[(size_t)lat * D + col] = c0[r];
+                    base[(size_t)(ndp + lat) * D + col] = c1[r];
+                }
             }
         }
     };
@@ -1080,9 +1154,10 @@ __global__ __launch_bounds__(256) void aux_small_wsum_kernel(const float* part, 
 __global__ __launch_bounds__(1024) void aux_fused_wsum_kernel(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd,
                                                               float* dWe, const float* partb, float* db_out, int db_accumulate,
                                                               const float* partbe, float* dbe, const RowStats* rs, int n_rows,
-                                                              float alpha, saev_step_stats* stats) {
+                                                              float alpha, saev_step_stats* stats, int ndo) {
+    // ndo: latent rows per half of a block partial (AUX_FUSED_MAX for aux_small_fused_kernel's, AUX_SMALL_MAX for aux_mfma_wgrad_kernel's)
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > AUX_FUSED_MAX) return;
+    if (nd <= 0 || nd > ndo) return;
     __shared__ f32x4 sh[16][64];
     const int D4 = D >> 2;
     if (blockIdx.y == 4) {  // the auxiliary loss of the step from the rows' shares (stats_reduce_kernel's with_aux = 2 launch)
@@ -1103,13 +1178,13 @@ __global__ __launch_bounds__(1024) void aux_fused_wsum_kernel(const float* part,
     // blockIdx.y: 0 decoder rows, 1 encoder rows (nd x D out of [blk][2][AUX_FUSED_MAX][D]); 2 db_dec's share (D out of [blk][D]);
     // 3 db_enc[dl] (AUX_FUSED_MAX out of [blk][AUX_FUSED_MAX]) -- the last two used to be two column-sum launches each
     const int kind = blockIdx.y;
-    const long n4 = kind < 2 ? (long)nd * D4 : (kind == 2 ? (long)D4 : (long)(AUX_FUSED_MAX / 4));
-    const long stride4 = kind < 2 ? (long)2 * AUX_FUSED_MAX * D4 : (kind == 2 ? (long)D4 : (long)(AUX_FUSED_MAX / 4));
+    const long n4 = kind < 2 ? (long)nd * D4 : (kind == 2 ? (long)D4 : (long)(ndo / 4));
+    const long stride4 = kind < 2 ? (long)2 * ndo * D4 : (kind == 2 ? (long)D4 : (long)(ndo / 4));
     if ((long)blockIdx.x * 64 >= n4) return;  // (uniform)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long col = (long)blockIdx.x * 64 + lane;
     const bool ok = col < n4;
-    const f32x4* base = kind < 2 ? reinterpret_cast<const f32x4*>(part) + (long)kind * AUX_FUSED_MAX * D4
+    const f32x4* base = kind < 2 ? reinterpret_cast<const f32x4*>(part) + (long)kind * ndo * D4
                                  : reinterpret_cast<const f32x4*>(kind == 2 ? partb : partbe);
     const f32x4* p = base + (ok ? col : 0);
     const int chunk = (n_blk + 15) / 16, b0 = w * chunk, b1 = min(n_blk, b0 + chunk);
@@ -1341,9 +1416,9 @@ hipError_t launch_aux_small_wsum(const float* part, int n_blk, int D, const int3
 }
 hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,
                                  const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe,
-                                 const RowStats* rs, int n_rows, float alpha, saev_step_stats* stats) {
-    hipLaunchKernelGGL(aux_fused_wsum_kernel, dim3((AUX_FUSED_MAX * (D >> 2) + 63) / 64, rs != nullptr ? 5 : 4), dim3(1024), 0, s, part, n_blk, D,
-                       nd_dev, dWd, dWe, partb, db_out, db_accumulate, partbe, dbe, rs, n_rows, alpha, stats);
+                                 const RowStats* rs, int n_rows, float alpha, saev_step_stats* stats, int ndo) {
+    hipLaunchKernelGGL(aux_fused_wsum_kernel, dim3((ndo * (D >> 2) + 63) / 64, rs != nullptr ? 5 : 4), dim3(1024), 0, s, part, n_blk, D,
+                       nd_dev, dWd, dWe, partb, db_out, db_accumulate, partbe, dbe, rs, n_rows, alpha, stats, ndo);
     return hipGetLastError();
 }
 bool aux_fused_supported(int D) { return D % 256 == 0 && D >= 256 && D <= 1024; }
@@ -1395,18 +1470,23 @@ hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const floa
 bool aux_mfma_supported(int D) { return D % 128 == 0 && D >= 128; }
 hipError_t launch_aux_mfma_forward(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                    const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale, float* A,
-                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s) {
-    if (!aux_mfma_supported(D)) return hipErrorInvalidValue;
+                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s, int bound) {
+    if (!aux_mfma_supported(D) || bound > AUX_MFMA_MAX) return hipErrorInvalidValue;
     const dim3 grid((n_rows + 31) / 32), block(256);
-    hipLaunchKernelGGL(aux_mfma_dots_kernel, grid, block, 0, s, x, WencT_dead, b_enc, dl, n_rows, D, nd_dev, A);
-    hipLaunchKernelGGL(aux_mfma_expand_kernel, grid, block, 0, s, A, Wdec_dead, b_dec, x, x_hat, n_rows, D, nd_dev, gscale, g_aux, rowstats);
-    hipLaunchKernelGGL(aux_mfma_dots_kernel, grid, block, 0, s, g_aux, Wdec_dead, nullptr, dl, n_rows, D, nd_dev, dA);
+    if (bound <= 32)
+        hipLaunchKernelGGL(aux_mfma_forward_kernel<1>, grid, block, 0, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev,
+                           gscale, A, dA, g_aux, rowstats);
+    else
+        hipLaunchKernelGGL(aux_mfma_forward_kernel<2>, grid, block, 0, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev,
+                           gscale, A, dA, g_aux, rowstats);
     return hipGetLastError();
 }
 hipError_t launch_aux_mfma_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
-                                 const int32_t* nd_dev, float* part, hipStream_t s) {
-    if (!aux_mfma_supported(D)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(aux_mfma_wgrad_kernel, dim3((n_rows + 63) / 64, D >= 512 ? 2 : 1), dim3(256), 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part);
+                                 const int32_t* nd_dev, float* part, float* partb, float* partbe, hipStream_t s, int bound) {
+    if (!aux_mfma_supported(D) || bound > AUX_MFMA_MAX) return hipErrorInvalidValue;
+    const dim3 grid((n_rows + 63) / 64, D >= 512 ? 2 : 1), block(256);
+    if (bound <= 32) hipLaunchKernelGGL(aux_mfma_wgrad_kernel<1>, grid, block, 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part, partb, partbe);
+    else hipLaunchKernelGGL(aux_mfma_wgrad_kernel<2>, grid, block, 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part, partb, partbe);
     return hipGetLastError();
 }
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,

@@ -152,9 +152,10 @@ struct saev_ctx {
     std::vector<void*> aux_allocs;
     int32_t* dead_list = nullptr;
     float *Wenc_dead = nullptr, *Wdec_dead = nullptr, *H_dead = nullptr, *A_dead = nullptr, *dWd = nullptr, *dWe = nullptr,
-          *dbe = nullptr, *aux_partials = nullptr, *WencT_dead = nullptr, *aux_small_part = nullptr, *aux_small_part2 = nullptr;
+          *dbe = nullptr, *aux_partials = nullptr, *WencT_dead = nullptr, *aux_small_part = nullptr, *aux_small_part2 = nullptr, *aux_small_partbe = nullptr;
     bool aux_dev_count = false;  // dense branch sized by a host-side BOUND of the dead count; the count itself stays on the device
     bool aux_small = false;  // this step's AuxK ran on the few-dead-latents path
+    int aux_mfma_bound = 0;
     bool aux_mfma = false;   // ... in its fp32 matrix-core form (at most AUX_MFMA_MAX dead latents, d_model % 128 == 0: auxk.hip aux_mfma_*)
     bool aux_fused = false;  // ... in its one-pass form (at most AUX_FUSED_MAX dead latents: block partials instead of g_aux / A / dA)
     bool aux_all = false;    // dense branch with every dead latent selected (n_dead <= k_aux): no select, no mask
@@ -1262,6 +1263,7 @@ int alloc_aux_buffers(saev_ctx* c, int cap) {
     c->WencT_dead = (float*)grab((size_t)AUX_SMALL_MAX * D * 4);
     c->aux_small_part = (float*)grab(((MB + 63) / 64) * (size_t)2 * AUX_SMALL_MAX * D * 4);
     c->aux_small_part2 = (float*)grab((size_t)(((MB + 63) / 64 + 63) / 64) * AUX_SMALL_MAX * D * 4);
+    c->aux_small_partbe = (float*)grab((size_t)((MB + 63) / 64) * AUX_SMALL_MAX * 4);  // (aux_mfma_wgrad_kernel: the blocks' column sums of dA)
     bool fast_ok = true;
     {  // operand images of the five contractions (every encoder mode runs them on the split-fp16 MFMA kernel)
         const size_t cap256 = ((size_t)cap + 255) / 256 * 256, D256 = (D + 255) / 256 * 256;
@@ -1360,7 +1362,11 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
         c->aux_mfma = true;
         HIPCHK(c, launch_aux_mfma_forward(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                           c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
-                                          c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s));
+                                          c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s, bound));
+        c->aux_mfma_bound = bound;
+        // (inside saev_train_step the backward's ordered-sum launch also forms the step's auxiliary loss, as for the one-pass kernel)
+        c->aux_stats_pending = c->train_fused;
+        if (c->aux_stats_pending) return SAEV_OK;
     } else
     HIPCHK(c, launch_aux_small_fwd(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                    c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
@@ -1463,8 +1469,19 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
             c->aux_stats_pending = false;
             return SAEV_OK;
         }
-        if (c->aux_mfma) HIPCHK(c, launch_aux_mfma_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
-        else HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
+        if (c->aux_mfma) {
+            // weight-gradient partials per block of 64 rows with the blocks' column sums of g_aux and dA riding along; ONE launch of
+            // ordered sums finishes all four gradients (and the auxiliary loss inside saev_train_step)
+            HIPCHK(c, launch_aux_mfma_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, c->aux_small_part2,
+                                            c->aux_small_partbe, s, c->aux_mfma_bound));
+            if (c->ov_x != nullptr) HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));  // (the count may be zero on the device)
+            HIPCHK(c, launch_aux_fused_wsum(c->aux_small_part, nb, D, nd_dev, c->dWd, c->dWe, s, c->aux_small_part2,
+                                            c->ov_x != nullptr ? c->db_aux : c->grads + c->off_b_dec, c->ov_x != nullptr ? 0 : 1, c->aux_small_partbe, c->dbe,
+                                            c->aux_stats_pending ? c->rowstats : nullptr, n, c->cfg.alpha, c->stats, AUX_SMALL_MAX));
+            c->aux_stats_pending = false;
+            return SAEV_OK;
+        }
+        HIPCHK(c, launch_aux_small_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, s));
         HIPCHK(c, launch_aux_small_wsum(c->aux_small_part, nb, D, nd_dev, c->dWd, c->dWe, s));
         HIPCHK(c, launch_colsum(dA, n, L, c->aux_partials, c->dbe, 0, nd_dev, s, 0, 1.0f, 1));
         if (c->ov_x != nullptr) {  // gathered backward: the local share travels with the compact rows (saev_aux_compact_export)
@@ -1550,7 +1567,10 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     // (saev_debug_cfg.aux_small_max: -1 sends every dead set down the dense route, for tests and A/B runs)
     // Default AUX_SMALL_DEFAULT: where the two routes cost the same at configs[1] (tools/experiments/r4_aux_sweep.sh: the
     // few-dead-latents kernels grow with the count, the dense algebra is flat up to 256 dead latents).
-    const int small_cap = c->dbg.aux_small_max < 0 ? 0 : (c->dbg.aux_small_max == 0 ? AUX_SMALL_DEFAULT : std::min(c->dbg.aux_small_max, (int)AUX_SMALL_MAX));
+    // (with the fp32-MFMA kernels -- d_model % 128 == 0 -- the few-dead-latents route costs +0.24 ms up to 32 and +0.32 ... +0.35 up to 64 dead
+    // latents against the dense route's +0.56: it takes everything it can hold, profiles/r05b_aux_mfma_sweep.txt)
+    const int small_default = (aux_mfma_supported(c->cfg.d_model) && c->dbg.aux_small_route == 0) ? (int)AUX_MFMA_MAX : (int)AUX_SMALL_DEFAULT;
+    const int small_cap = c->dbg.aux_small_max < 0 ? 0 : (c->dbg.aux_small_max == 0 ? small_default : std::min(c->dbg.aux_small_max, (int)AUX_SMALL_MAX));
     const int small_max = std::min(small_cap, c->cfg.k_aux);
     const int64_t s0 = step - lag;
     if (s0 >= c->rec_valid_from) {

@@ -619,21 +619,25 @@ constexpr int AUX_FUSED_ROWS = 32;  // activation rows per workgroup
 #define AUX_FUSED_PF4 1
 #endif
 bool aux_fused_supported(int D);
-// 9 ... 32 dead latents on the fp32 matrix cores (auxk.hip: aux_mfma_*): launch_aux_small_fwd's and launch_aux_small_wgrad's outputs
-// (A, dA: (n_rows, AUX_SMALL_MAX); g_aux; rowstats.aux_sse; the block partials) from three + one launches; d_model % 128 == 0
-constexpr int AUX_MFMA_MAX = 32;
+// 9 ... 64 dead latents on the fp32 matrix cores (auxk.hip: aux_mfma_*): launch_aux_small_fwd's and launch_aux_small_wgrad's outputs
+// (A, dA: (n_rows, AUX_SMALL_MAX); g_aux; rowstats.aux_sse; the block partials) from one + one launches; d_model % 128 == 0;
+// bound: the host's bound of the dead count (one or two blocks of 32 latents)
+constexpr int AUX_MFMA_MAX = 64;
 bool aux_mfma_supported(int D);
 hipError_t launch_aux_mfma_forward(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                    const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale, float* A,
-                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s);
+                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s, int bound);
+// (partb: blocks x D, partbe: blocks x AUX_SMALL_MAX -- the blocks' column sums of g_aux and dA; launch_aux_fused_wsum with
+// ndo = AUX_SMALL_MAX finishes all four gradients and the auxiliary loss in one launch)
 hipError_t launch_aux_mfma_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
-                                 const int32_t* nd_dev, float* part, hipStream_t s);
+                                 const int32_t* nd_dev, float* part, float* partb, float* partbe, hipStream_t s, int bound);
 // the ordered sums of all four partial sets in one launch: dWd / dWe rows, db_dec's share (db_out, added to what is there when
 // db_accumulate) and db_enc[dl] (dbe)
 hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,
                                  const float* partb, float* db_out, int db_accumulate, const float* partbe, float* dbe,
                                  // optional: the step's auxiliary loss from the rows' shares as well (stats->aux; a fused train step)
-                                 const RowStats* rs = nullptr, int n_rows = 0, float alpha = 0.f, saev_step_stats* stats = nullptr);
+                                 const RowStats* rs = nullptr, int n_rows = 0, float alpha = 0.f, saev_step_stats* stats = nullptr,
+                                 int ndo = AUX_FUSED_MAX);  // latent rows per half of a block partial
 int aux_fused_blocks(int n_rows);
 hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                   const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale,

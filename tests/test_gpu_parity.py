@@ -1015,12 +1015,13 @@ def test_one_launch_exactness_chain_gives_the_same_codes(monkeypatch):
     torch.testing.assert_close(h.gather(1, idx1.cpu().long()).float(), val1.cpu(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("n_dead,d,n", [(1, 128, 200), (9, 128, 200), (17, 256, 333), (24, 768, 96), (32, 1024, 64), (31, 1280, 130)])
+@pytest.mark.parametrize("n_dead,d,n", [(1, 128, 200), (9, 128, 200), (17, 256, 333), (24, 768, 96), (32, 1024, 64), (31, 1280, 130),
+                                         (33, 128, 200), (48, 512, 161), (64, 1024, 97)])
 def test_few_dead_latents_on_the_matrix_cores_agree_with_the_vector_kernels_and_the_oracle(n_dead, d, n):
-    """9-32 dead latents (and fewer where the one-pass kernel does not take the shape): the AuxK contractions as fp32 MFMA tiles
+    """9-64 dead latents (and fewer where the one-pass kernel does not take the shape): the AuxK contractions as fp32 MFMA tiles
     (`aux_mfma_*`, default) against the vector-ALU kernels of rounds 3-4 (`aux_small_route=1`) and against the oracle -- loss,
     tracker and all four gradients; ragged row counts (the last 32-row tile and the last 64-row block are partial), every
-    d_model % 128 class the step supports, the full 32 latents and a single one."""
+    d_model % 128 class the step supports, one and two blocks of 32 latents (full and partial) and a single latent."""
     s, k, k_aux, thr = 2048, 8, 64, 1000
     p = rand_params(d, s, seed=700 + n_dead)
     x = torch.randn(n, d, generator=torch.Generator().manual_seed(701 + n_dead))

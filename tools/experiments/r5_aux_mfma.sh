@@ -6,6 +6,10 @@ timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_known_answe
 tail -12 gpurun_out/${1}_aux_mfma_tests.txt
 {
 for nd in 0 9 16 24 32 33 40; do timeout 120 python tools/experiments/r4_aux_nd.py $nd 2>/dev/null; done
+echo "# SAEV_AMD_AUX_SMALL_MAX=64 (the few-dead-latents route up to its capacity)"
+for nd in 33 40 48 64; do SAEV_AMD_AUX_SMALL_MAX=64 timeout 120 python tools/experiments/r4_aux_nd.py $nd 2>/dev/null; done
+echo "# dense route (SAEV_AMD_AUX_SMALL_MAX=-1)"
+for nd in 40 64; do SAEV_AMD_AUX_SMALL_MAX=-1 timeout 120 python tools/experiments/r4_aux_nd.py $nd 2>/dev/null; done
 echo "# SAEV_AMD_AUX_SMALL=1 (vector-ALU kernels)"
 for nd in 9 16 24 32; do SAEV_AMD_AUX_SMALL=1 timeout 120 python tools/experiments/r4_aux_nd.py $nd 2>/dev/null; done
 } | tee gpurun_out/${1}_aux_mfma_sweep.txt

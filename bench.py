@@ -514,7 +514,7 @@ def main():
         auxk_active = []
         gsel = torch.Generator(device=dev).manual_seed(99)
         order = torch.randperm(D_SAE, device=dev, generator=gsel)
-        for nd in (8, 1000):
+        for nd in (8, 24, 48, 1000):  # one-pass kernel / fp32-MFMA kernels with one and two latent blocks / dense algebra
             sel = order[:nd]
             eng.view("b_enc")[sel] = -100.0  # never selected by the main path: they stay dead
             toks = torch.zeros(D_SAE, dtype=torch.int64, device=dev)

@@ -13,13 +13,14 @@ from test_gpu_parity import make_engine
 pytestmark = pytest.mark.gpu
 
 
-def _setup(tag="b", **kw):
+def _setup(tag="b", dead_every=9, **kw):
     g = load_golden(f"g9_train_{tag}")
     d, s, k, bsz = int(g["d"]), int(g["s"]), int(g["k"]), int(g["bsz"])
     eng = make_engine(d, s, k, k_aux=int(g["k_aux"]), thr=int(g["thr"]), max_batch=bsz, **kw)
     eng.load_params({key: g["init_" + key] for key in R.PARAM_ORDER})
     toks = torch.zeros(s, dtype=torch.int64)
-    toks[::9] = int(g["thr"])  # dead latents: the AuxK branch contributes gradient rows too
+    toks[::dead_every] = int(g["thr"])  # dead latents: the AuxK branch contributes gradient rows too (9: the dense route; 40: 26 of
+    # 1 024, the few-dead-latents kernels)
     eng.set_tracker(toks)
     return eng, g["acts"][:bsz].cuda(), s
 
@@ -154,7 +155,7 @@ def test_chunked_tail_covers_the_padded_layout_exactly(world, encoder_mode):
         assert (flat[pad] == 0).all()
 
 
-def _two_rank_worker(rank, world, port, out, tail, exchange="dense", prefixes=None):
+def _two_rank_worker(rank, world, port, out, tail, exchange="dense", prefixes=None, dead_every=9):
     import os
 
     import torch.distributed as dist
@@ -164,7 +165,7 @@ def _two_rank_worker(rank, world, port, out, tail, exchange="dense", prefixes=No
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng, x, s = _setup(shard_world=world if tail == "sharded" else 1)
+        eng, x, s = _setup(shard_world=world if tail == "sharded" else 1, dead_every=dead_every)
         g = load_golden("g9_train_b")
         bsz = int(g["bsz"])
         stepper = DataParallelStepper(eng, dist, world, tail=tail, exchange=exchange)
@@ -181,9 +182,10 @@ def _two_rank_worker(rank, world, port, out, tail, exchange="dense", prefixes=No
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tail,exchange,prefixes", [("replicated", "dense", None), ("sharded", "dense", None),
-                                                    ("replicated", "sparse", None), ("replicated", "sparse", (100, 300, 1024))])
-def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, tail, exchange, prefixes, encoder_mode):
+@pytest.mark.parametrize("tail,exchange,prefixes,dead_every", [("replicated", "dense", None, 9), ("sharded", "dense", None, 9),
+                                                               ("replicated", "sparse", None, 9), ("replicated", "sparse", (100, 300, 1024), 9),
+                                                               ("replicated", "sparse", None, 40), ("sharded", "dense", None, 40)])
+def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, tail, exchange, prefixes, dead_every, encoder_mode):
     """The REAL engines under a real two-rank exchange: two processes share the one GPU of the test box and talk over
     gloo (RCCL refuses two ranks on one device; gloo stages device tensors through the host, which is all this needs).
     Rank r trains on rows r::2 of every batch; both tails -- and the sparse-state exchange, where no gradient crosses
@@ -196,7 +198,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
 
     out = str(tmp_path / "rank{rank}.pt")
     try:
-        mp.spawn(_two_rank_worker, args=(2, _free_port(), out, tail, exchange, prefixes), nprocs=2, join=True)
+        mp.spawn(_two_rank_worker, args=(2, _free_port(), out, tail, exchange, prefixes, dead_every), nprocs=2, join=True)
     except Exception as exc:  # a gloo build without device-tensor support for these collectives
         if "gloo" in str(exc).lower() and ("not support" in str(exc).lower() or "unsupported" in str(exc).lower()):
             pytest.skip(f"gloo cannot run this collective on device tensors here: {exc}")
@@ -205,7 +207,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_step(tmp_path, ta
     for k in R.PARAM_ORDER:
         assert torch.equal(r0["params"][k], r1["params"][k]), k
     assert torch.equal(r0["toks"], r1["toks"]) and r0["n_dead"] == r1["n_dead"]
-    eng, x, s = _setup()
+    eng, x, s = _setup(dead_every=dead_every)
     if prefixes is not None:  # (Matryoshka: the gathered gradient block is (rows, P, D) suffix sums)
         eng.set_prefixes(list(prefixes))
     g = load_golden("g9_train_b")
@@ -287,10 +289,11 @@ def test_two_saes_sharing_x_under_the_sparse_exchange(tmp_path, encoder_mode):
 
 
 @pytest.mark.parametrize("prefixes", [None, (300, 900, 2048)])
-@pytest.mark.parametrize("n_dead", [0, 5, 80])
+@pytest.mark.parametrize("n_dead", [0, 5, 20, 50, 80])
 def test_two_pass_backward_is_bit_identical_to_the_single_pass(n_dead, prefixes):
     """saev_backward_rows_part: decoder pass (dval kept per pair), then encoder pass = the one-pass backward, bit for bit --
-    with no dead latents, a few (the count-predicated AuxK kernels) and many (dense AuxK route)."""
+    with no dead latents, a few (the count-predicated AuxK kernels: one-pass, matrix cores with one and two latent blocks) and
+    many (dense AuxK route)."""
     import sae_ref as R
     from saev_amd.engine import EngineConfig, SaeEngine
 

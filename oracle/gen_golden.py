@@ -25,6 +25,8 @@ Fixture index:
   G13 matryoshka       objective fwd/bwd with 4 fixed prefixes (with and without dead latents)
   G9c train_c          the train_b run with grad_clip = 0.02: the clip coefficient is < 1 on every step
   G15 sample_prefixes  the reference's Matryoshka prefix draws under fixed seeds
+  G16 legacy_ckpt      headers in every older checkpoint layout the reference's nn.load still reads (pre-schema, schema 1 in
+                       both of its forms, schemas 2-4) and the config the reference's loader makes of each
   G14 inference        the reference's framework/inference.worker_fn over a small protocol-2.1 cache (with and
                        without labels.bin / ignore_labels): CSR token_acts, mean_values, sparsity, distributions,
                        metrics.json; plus Metadata.hash and IndexMap known answers for the same cache
@@ -415,6 +417,43 @@ def g12_checkpoint(ref):
     buf.unlink()
 
 
+def g16_legacy_checkpoints(ref):
+    """Legacy header layouts (described in the reference loader's branches, modeling.py:586-645), each written in front of a
+    state dict and read back by the REFERENCE's nn.load; the fixture holds the header and the loaded config as the
+    reference's own dump would write it."""
+    M = ref.modeling
+    tree = lambda act: M._serialize_dataclass(act)
+    old_tree = {"cls": "TopK", "params": {"kind": "top-k", "top_k": 6, "sparsity": {}, "aux": {"cls": "AuxK", "params": {"kind": "auxk", "k_aux": 9, "alpha": 0.25}}}}
+    old_relu = {"cls": "Relu", "params": {"key": "relu", "sparsity": {"coeff": 0.002}, "aux": {"cls": "NoAux", "params": {"key": "no-aux"}}}}
+    headers = {
+        "pre_schema": {"d_vit": 16, "exp_factor": 3, "sparsity_coeff": 4e-4, "ghost_grads": False, "seed": 3, "n_reinit_samples": 1024,
+                       "remove_parallel_grads": True, "normalize_w_dec": True},
+        "s1a_topk": {"schema": 1, "cls": "TopK", "cfg": {"d_model": 16, "exp_factor": 3, "seed": 1}},  # (a "top_k" entry here makes the reference's loader raise)
+        "s1a_relu": {"schema": 1, "cls": "Relu", "cfg": {"d_model": 16, "d_sae": 48, "n_reinit_samples": 8}},
+        "s1b_tree": {"schema": 1, "cls": "SparseAutoencoderConfig", "cfg": {"d_model": 16, "d_sae": 48, "activation": old_tree}},
+        "s1b_nocls": {"schema": 1, "cfg": {"d_model": 16, "exp_factor": 3, "activation": tree(M.TopK(top_k=7))}},
+        "s2_kind": {"schema": 2, "cfg": {"d_model": 16, "d_sae": 48, "activation": old_tree, "reinit_blend": 0.5}},
+        "s3_l1": {"schema": 3, "cfg": {"d_model": 16, "d_sae": 48, "activation": old_relu, "seed": 7}},
+        "s4_current_tree": {"schema": 4, "cfg": {"d_model": 16, "d_sae": 48, "normalize_w_dec": False,
+                                                  "activation": tree(M.TopK(top_k=4, aux=M.AuxK(k_aux=11, alpha=0.5)))}},
+    }
+    sae = make_sae(ref, 16, 48, 4, seed=71)
+    blob = io.BytesIO()
+    torch.save(sae.state_dict(), blob)
+    out = {"names": np.array(list(headers)), **{"sd_" + k: v for k, v in sae.state_dict().items()}}
+    tmp = pathlib.Path("/tmp/_gold_legacy.pt")
+    for name, hdr in headers.items():
+        tmp.write_bytes(json.dumps(hdr).encode() + b"\n" + blob.getvalue())
+        got = M.load(tmp)
+        cfg = dataclasses.asdict(got.cfg)
+        cfg["activation"] = M._serialize_dataclass(got.cfg.activation)
+        assert all(torch.equal(v, sae.state_dict()[k]) for k, v in got.state_dict().items())
+        out["hdr_" + name] = np.frombuffer(json.dumps(hdr).encode(), dtype=np.uint8)
+        out["cfg_" + name] = np.frombuffer(json.dumps(cfg, sort_keys=True).encode(), dtype=np.uint8)
+    tmp.unlink()
+    npz("g16_legacy_checkpoints", **out)
+
+
 def g14_inference(ref, tag, with_labels):
     """Runs the reference's inference pass (its own OrderedDataLoader, manager process included) on a cache written
     by this repo's protocol-2.1 writer and a checkpoint written by the reference's nn.dump."""
@@ -495,6 +534,9 @@ def main():
     if "--only-g4" in sys.argv:
         g4_auxk(ref)
         return
+    if "--only-g16" in sys.argv:
+        g16_legacy_checkpoints(ref)
+        return
     if "--only-g14" in sys.argv:
         g14_inference(ref, "plain", False)
         g14_inference(ref, "labels", True)
@@ -517,6 +559,7 @@ def main():
     g15_sample_prefixes(ref)
     g11_schedule(ref)
     g12_checkpoint(ref)
+    g16_legacy_checkpoints(ref)
     g13_matryoshka(ref)
     g14_inference(ref, "plain", False)
     g14_inference(ref, "labels", True)

@@ -388,19 +388,89 @@ def dump(fpath: pathlib.Path | str, sae: SparseAutoencoder):
         torch.save(state, fd)
 
 
+# Header layouts older than schema 5 (what ``load`` accepts besides the current one; the reference reads the same set,
+# modeling.py:586-645).  Each layout is reduced to the field dict of ``SparseAutoencoderConfig`` by ``_config_fields``:
+#
+#   no "schema" key   the header IS the field dict of the first ReLU trainer: ``d_vit`` for d_model, ``exp_factor`` for
+#                     the width, loss / seed knobs that no longer exist; the activation is always ReLU
+#   schema 1, form A  ``"cls"`` names the activation (Relu / TopK / BatchTopK) and ``cfg`` is flat (``top_k`` beside the widths)
+#   schema 1, form B  ``cfg["activation"]`` is a ``{"cls", "params"}`` tree -- as schemas 2-4
+#   schemas 2-4       the tree of schema 5 with two older spellings inside it: a field called ``kind`` where the dataclasses
+#                     now say ``key``, and ``sparsity`` as a bare dict (``{}`` = none, ``{"coeff": c}`` = L1)
+_RETIRED_FIELDS = ("sparsity_coeff", "ghost_grads", "l1_coeff", "use_ghost_grads", "seed", "n_reinit_samples")
+_FLAT_ACTIVATIONS = {"Relu": Relu, "TopK": TopK, "BatchTopK": BatchTopK}
+
+
+def _widths(fields: dict[str, tp.Any]) -> dict[str, tp.Any]:
+    """Drop retired knobs; turn ``exp_factor`` into ``d_sae`` (older trainers stored the expansion, not the width)."""
+    out = {k: v for k, v in fields.items() if k not in _RETIRED_FIELDS}
+    if "exp_factor" in out:
+        factor = out.pop("exp_factor")
+        if "d_sae" not in out:
+            if out.get("d_model") is None:
+                raise ValueError("legacy checkpoint stores exp_factor but no d_model: the latent width cannot be derived")
+            out["d_sae"] = out["d_model"] * factor
+    return out
+
+
+def _deser_legacy(value: tp.Any, field: str = "") -> tp.Any:
+    """``_deser`` for schemas 1-4: ``kind`` reads as ``key``; a bare ``sparsity`` dict becomes its dataclass."""
+    if isinstance(value, list):
+        return [_deser_legacy(v, field) for v in value]
+    if not isinstance(value, dict):
+        return value
+    if "cls" in value and "params" in value:
+        if value["cls"] not in _CONFIG_CLASSES:
+            raise ValueError(f"checkpoint names a config class this package does not have: {value['cls']!r}")
+        kwargs: dict[str, tp.Any] = {}
+        for name, v in value["params"].items():
+            name = "key" if name == "kind" else name
+            if name in kwargs:
+                raise ValueError(f"{value['cls']}: both 'kind' and 'key' present in a legacy checkpoint header")
+            kwargs[name] = _deser_legacy(v, name)
+        return _CONFIG_CLASSES[value["cls"]](**kwargs)
+    if field == "sparsity":
+        if not value:
+            return NoSparsity()
+        if set(value) <= {"coeff"}:
+            return L1Sparsity(**value)
+    return {k: _deser_legacy(v, field) for k, v in value.items()}
+
+
+def _config_fields(header: dict[str, tp.Any], where: str) -> dict[str, tp.Any]:
+    """Field dict of ``SparseAutoencoderConfig`` from a checkpoint header of any schema the reference reads."""
+    if "schema" not in header:
+        fields = dict(header)
+        fields["d_model"] = fields.pop("d_vit")
+        fields = _widths(fields)
+        fields["activation"] = Relu()
+        return fields
+    schema = header["schema"]
+    if schema == SCHEMA_VERSION:
+        fields = _widths(dict(header["cfg"]))
+        fields["activation"] = _deser(fields["activation"])
+        return fields
+    if schema in (1, 2, 3, 4):
+        fields = _widths(dict(header["cfg"]))
+        flat = _FLAT_ACTIVATIONS.get(header.get("cls", "")) if schema == 1 else None
+        if flat is not None:  # schema 1, form A
+            top_k = fields.pop("top_k", 32)
+            fields["activation"] = flat() if flat is Relu else flat(top_k=top_k)
+        elif "activation" in fields or schema != 1:
+            fields["activation"] = _deser_legacy(fields["activation"])
+        return fields
+    raise ValueError(f"{where}: checkpoint schema {schema!r} is not supported (this loader reads schemas 1-{SCHEMA_VERSION} "
+                     "and the pre-schema layout)")
+
+
 def load(fpath: pathlib.Path | str, *, device="cpu") -> SparseAutoencoder:
-    """Read an ``sae.pt`` of the current on-disk format -- schema 5, what ``dump`` here and the reference's ``nn.dump``
-    (modeling.py:548-574) write.  Older schemas belong to checkpoints that predate the TopK / AuxK config tree this package
-    trains; they are refused by number rather than guessed at (convert them with the reference's loader)."""
+    """Read an ``sae.pt``: schema 5 (what ``dump`` here and the reference's ``nn.dump`` write, modeling.py:548-574) and every
+    older layout the reference's loader still reads (modeling.py:586-645; table above ``_config_fields``).  Only TopK
+    checkpoints run on the HIP path; ReLU / BatchTopK ones load (parameters and config) and raise when run."""
     with open(fpath, "rb") as fd:
         first_line = fd.readline()
         payload = io.BytesIO(fd.read())
-    header = json.loads(first_line)
-    schema = header.get("schema")
-    if schema != SCHEMA_VERSION:
-        raise ValueError(f"{fpath}: checkpoint schema {schema!r} is not supported (this loader reads schema {SCHEMA_VERSION})")
-    fields = dict(header["cfg"])
-    fields["activation"] = _deser(fields["activation"])
+    fields = _config_fields(json.loads(first_line), str(fpath))
     model = SparseAutoencoder(SparseAutoencoderConfig(**fields))
     model.load_state_dict(torch.load(payload, weights_only=True, map_location="cpu"))
     return model.to(device)

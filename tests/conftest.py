@@ -12,8 +12,26 @@ sys.path.insert(0, str(ROOT / "oracle"))
 GOLDEN = ROOT / "tests" / "golden"
 
 
+ENCODER_MODES = ("f32", "f16x3", "f16r")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "encoder_modes(*modes): the encoder arithmetics a GPU test is collected for (default: all three)")
+
+
+def pytest_generate_tests(metafunc):
+    """GPU tests are collected once per encoder arithmetic (f32 / f16x3 / f16r: all fp32-accurate) unless they name the
+    modes that make sense for them with ``@pytest.mark.encoder_modes``; CPU tests are collected once.  Nothing is skipped
+    at run time for the mode's sake, so a skip in the GPU log always means the environment."""
+    if "encoder_mode" not in metafunc.fixturenames:
+        return
+    if metafunc.definition.get_closest_marker("gpu") is None:
+        return
+    mark = metafunc.definition.get_closest_marker("encoder_modes")
+    modes = mark.args if mark is not None else ENCODER_MODES
+    assert modes and all(m in ENCODER_MODES for m in modes), modes
+    metafunc.parametrize("encoder_mode", list(modes), indirect=True)
 
 
 def pytest_collection_modifyitems(config, items):
@@ -42,16 +60,16 @@ def golden():
     return load_golden
 
 
-@pytest.fixture(params=["f32", "f16x3", "f16r"], autouse=True)
+@pytest.fixture(autouse=True)
 def encoder_mode(request, monkeypatch):
-    """GPU tests run once per encoder arithmetic (both are fp32-accurate); CPU tests ignore it."""
-    if "gpu" not in request.keywords:
-        if request.param != "f32":
-            pytest.skip("encoder mode only matters on the GPU")
-        yield request.param
+    """The encoder arithmetic of the engines a GPU test creates (pytest_generate_tests above); CPU tests see "f32" and
+    no environment change."""
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield "f32"
         return
-    monkeypatch.setenv("SAEV_AMD_ENCODER", request.param)
-    yield request.param
+    monkeypatch.setenv("SAEV_AMD_ENCODER", mode)
+    yield mode
 
 
 @pytest.fixture

@@ -13,13 +13,7 @@ import sae_ref as R
 from conftest import load_golden
 from test_gpu_parity import codes_to_dense, make_engine, rand_params
 
-pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(autouse=True)
-def _once(encoder_mode):
-    if encoder_mode != "f32":
-        pytest.skip("bf16 tests pick their own encoder mode; run once")
+pytestmark = [pytest.mark.gpu, pytest.mark.encoder_modes("f32")]  # bf16 tests pick their own encoder mode: collected once
 
 
 @pytest.mark.parametrize("n,d,s", [(96, 48, 320), (300, 128, 1024), (5, 16, 24), (257, 256, 768), (64, 100, 260)])

@@ -15,13 +15,7 @@ import torch
 
 import sae_ref as R
 
-pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(autouse=True)
-def _once(encoder_mode):
-    if encoder_mode != "f16r":
-        pytest.skip("full-shape config tests pick their own encoder mode; run once")
+pytestmark = [pytest.mark.gpu, pytest.mark.encoder_modes("f16r")]  # full-shape config tests pick their own encoder mode: collected once
 
 
 def build(d, s, k, b, seed=0, **kw):

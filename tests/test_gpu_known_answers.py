@@ -339,9 +339,8 @@ def test_mse_nonzero_matches_plain_square():  # test_nn_objectives.py:29-34
     assert math.isclose(mse, 4.0, rel_tol=1e-6)
 
 
+@pytest.mark.encoder_modes("f32", "f16r")  # the opt-in f16x3 encoder splits x into fp16 halves without a scale: |x| is limited to the fp16 range there
 def test_safe_mse_large_x(encoder_mode):  # test_nn_objectives.py:37-45 (the reference uses 3e28 with norm=True; this path is norm=False, where 3e18 keeps mse * upper^2 finite)
-    if encoder_mode == "f16x3":
-        pytest.skip("the opt-in f16x3 encoder splits x into fp16 halves without a scale: |x| is limited to the fp16 range there")
     x, x_hat = torch.full((3, 2), 3e18), torch.ones(3, 2)
     mse, _, upper = mse_through_decode(x_hat, x)
     assert math.isfinite(mse) and upper == torch.tensor(3e18).item()
@@ -366,14 +365,12 @@ def test_g3_golden_mse_through_decode_kernel(encoder_mode):
 # ---- G6 / G7 / G8 fed straight to the tail's kernels ---------------------------------------------------------------------------
 
 
-def _once(encoder_mode):
-    if encoder_mode != "f16r":
-        pytest.skip("independent of the encoder: run once")
+_once = pytest.mark.encoder_modes("f16r")  # independent of the encoder: collected once
 
 
+@_once
 @pytest.mark.parametrize("entry", ["saev_remove_parallel_grads", "saev_tail_prepare"])
 def test_g6_remove_parallel_grads_kernel(entry, encoder_mode):
-    _once(encoder_mode)
     from saev_amd.engine import EngineConfig, SaeEngine
 
     g = load_golden("g6_rpg")
@@ -392,11 +389,11 @@ def test_g6_remove_parallel_grads_kernel(entry, encoder_mode):
     assert torch.equal(out[5], g["g_in"][5]), "zero-norm row untouched"
 
 
+@_once
 @pytest.mark.parametrize("tag", ["clipped", "unclipped"])
 def test_g7_clip_inside_the_tail(tag, encoder_mode):
     """The clip coefficient is applied inside Adam (the clipped gradient is never written back): Adam's first moment after
     one step from zero is 0.1 x the clipped gradient, which is how the fixture's outputs are observed."""
-    _once(encoder_mode)
     from saev_amd.engine import EngineConfig, SaeEngine
 
     g = load_golden(f"g7_clip_{tag}")
@@ -413,8 +410,8 @@ def test_g7_clip_inside_the_tail(tag, encoder_mode):
         assert torch.equal(eng.view(name, eng.grads).cpu(), g[f"in{i}"])
 
 
+@_once
 def test_g8_adam_five_steps_first_lr_zero_on_the_hip_kernel(encoder_mode):
-    _once(encoder_mode)
     from saev_amd.engine import EngineConfig, SaeEngine
 
     g = load_golden("g8_adam")

@@ -380,13 +380,12 @@ def test_wide_d_model_step_matches_oracle(d):
         torch.testing.assert_close(eng.view(key).cpu(), state.params[key], rtol=1e-2, atol=2e-5, msg=lambda m: f"{key}: {m}")
 
 
+@pytest.mark.encoder_modes("f32")  # picks its own encoder modes; run once
 def test_f16r_refinement_resolves_near_ties_exactly(encoder_mode):
     """The fp16 first pass of the f16r encoder has a relative error of ~5e-4 per pre-activation.  Build rows whose
     largest pre-activations come in pairs that differ by 1e-4 relative (well inside that error, well outside fp32
     rounding): without the exact refinement the cut at k would pick the wrong member of a pair in many rows.  The
     codes must agree with the exact-fp32 encoder's."""
-    if encoder_mode != "f32":
-        pytest.skip("picks its own encoder modes; run once")
     d, half_s, n, k = 256, 2048, 512, 33  # odd k: the cut splits a pair in every row
     g = torch.Generator().manual_seed(11)
     base = torch.randn(d, half_s, generator=g) / d**0.5
@@ -422,6 +421,7 @@ def test_f16r_refinement_resolves_near_ties_exactly(encoder_mode):
     assert (approx_sets != exact_sets).any(dim=1).float().mean() > 0.05
 
 
+@pytest.mark.encoder_modes("f32")  # picks its own encoder modes; run once
 @pytest.mark.parametrize("tiny", [1.0e-5, 1.0e-9, 1.0e-12])
 def test_f16r_rows_far_smaller_than_their_batch(encoder_mode, tiny):
     """The power-of-two scale of the x images follows the BATCH's largest centred element, so a row that is many orders of
@@ -430,8 +430,6 @@ def test_f16r_rows_far_smaller_than_their_batch(encoder_mode, tiny):
     small after centring.  Their codes must be the exact-fp32 encoder's, up to what fp32 itself cannot separate -- whichever way
     the step gets there: at 1e-5 the lists stay short; from ~1e-7 down the absolute term makes such a row's list overflow and the
     step takes the exact dense route (tools/experiments/r4_tiny_rows_probe.py)."""
-    if encoder_mode != "f32":
-        pytest.skip("picks its own encoder modes; run once")
     d, s, n, k = 256, 4096, 512, 32
     g = torch.Generator().manual_seed(31)
     p = rand_params(d, s, seed=32)
@@ -463,13 +461,12 @@ def test_f16r_rows_far_smaller_than_their_batch(encoder_mode, tiny):
     assert n_diff <= 6, n_diff
 
 
+@pytest.mark.encoder_modes("f32")  # picks its own encoder modes; run once
 @pytest.mark.parametrize("bad", [float("inf"), float("nan")])
 def test_f16r_nonfinite_element_sends_the_batch_down_the_exact_route(encoder_mode, bad):
     """One inf / NaN element poisons the column mean the f16r first pass is centred on, and with it every row's image.  The rows'
     margins then read "keep everything", the lists overflow, and the step runs on the exact dense route (uncentred fp32): the
     other rows get the codes the exact encoder gives them, as they do in the reference."""
-    if encoder_mode != "f32":
-        pytest.skip("picks its own encoder modes; run once")
     d, s, n, k = 128, 2048, 300, 16
     p = rand_params(d, s, seed=41)
     x = torch.randn(n, d, generator=torch.Generator().manual_seed(42))
@@ -487,12 +484,11 @@ def test_f16r_nonfinite_element_sends_the_batch_down_the_exact_route(encoder_mod
     torch.testing.assert_close(out["f32"][1][rows], out["f16r"][1][rows], rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.encoder_modes("f32")  # picks its own encoder mode; run once
 @pytest.mark.parametrize("scale", [3.0e5, 1.0e-6])
 def test_f16r_handles_any_activation_scale(encoder_mode, scale):
     """fp16 tops out at 65504 and flushes below 6e-8; the f16r images are pre-scaled by a power of two taken from
     max|x| on the device, so the codes of scaled activations are the codes of the unscaled ones (AuxK included)."""
-    if encoder_mode != "f32":
-        pytest.skip("picks its own encoder mode; run once")
     d, s, k, n = 64, 1024, 16, 200
     p = rand_params(d, s, seed=21)
     p["b_enc"] = torch.zeros(s)  # no biases: a pure scaling of x then scales pre-activations, reconstruction and losses
@@ -519,11 +515,10 @@ def test_f16r_handles_any_activation_scale(encoder_mode, scale):
     assert out[0][4] == out[1][4] > 0
 
 
+@pytest.mark.encoder_modes("f32")  # picks its own encoder mode; run once
 def test_f16r_refinement_overflow_takes_the_exact_dense_route(encoder_mode):
     """More than 512 latents within the error margin of the cut (here: 700 identical encoder columns that lead every row)
     cannot be refined in place; the device flag must send the launch down the exact dense route."""
-    if encoder_mode != "f32":
-        pytest.skip("picks its own encoder mode; run once")
     d, s, k, n = 64, 2048, 16, 96
     p = rand_params(d, s, seed=31)
     g = torch.Generator().manual_seed(32)
@@ -541,13 +536,12 @@ def test_f16r_refinement_overflow_takes_the_exact_dense_route(encoder_mode):
     torch.testing.assert_close(h.gather(1, idx.cpu().long()), val.cpu(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.encoder_modes("f32")  # picks its own encoder modes; run once
 @pytest.mark.parametrize("offset", [30.0, 300.0])
 def test_f16r_first_pass_is_centred_on_the_batch_mean(encoder_mode, offset):
     """ViT residual streams carry a large common offset and a few "massive" channels.  The f16r first pass runs on
     x - mean(x) with the bias shifted by mean(x) W_enc, so its error margin follows the spread of the batch, not the
     offset: the fused route must hold (no dense fallback) and the codes must be the exact-fp32 encoder's."""
-    if encoder_mode != "f32":
-        pytest.skip("picks its own encoder modes; run once")
     d, s, k, n = 256, 8192, 32, 1024
     g = torch.Generator().manual_seed(41)
     p = rand_params(d, s, seed=42)
@@ -580,12 +574,11 @@ def test_f16r_first_pass_is_centred_on_the_batch_mean(encoder_mode, offset):
     assert math.isclose(out["f32"][2].mse, out["f16r"][2].mse, rel_tol=2e-4)  # the swapped near-ties move it a little
 
 
+@pytest.mark.encoder_modes("f32")  # picks its own encoder mode; run once
 def test_f16r_survives_replaced_parameters(encoder_mode):
     """The f16r W images are scaled with the previous call's largest encoder-column norm (one pass over W_enc per step).
     Parameters belong to the caller: when they are replaced by something of a very different magnitude the device-side
     check must send that call down the exact dense route, and the next call is back on the fused route."""
-    if encoder_mode != "f32":
-        pytest.skip("picks its own encoder mode; run once")
     d, s, k, n = 128, 4096, 16, 512
     p = rand_params(d, s, seed=51)
     x = torch.randn(n, d, generator=torch.Generator().manual_seed(52))
@@ -826,13 +819,12 @@ def test_dense_auxk_one_launch_selection_agrees_with_the_select_fill_scatter_seq
             assert bad.float().mean() <= 1e-4, f"{key}: {bad.sum().item()} of {bad.numel()} elements off"
 
 
+@pytest.mark.encoder_modes("f16x3", "f16r")  # the exact-fp32 MFMA encoder has guaranteed bounds only
 def test_failed_bound_prediction_is_caught_and_repeated(encoder_mode):
     """Predicted TopK bounds (mean + z sigma of a sample of the row's pre-activations) are verified, not trusted: here
     the first 256 latents -- the sample of the first latent range -- have encoder columns a hundred times larger than the
     rest, so the predicted bound of every row is far above its true k-th largest value; the select stage must notice, the
     launch must be repeated with guaranteed bounds on the device, and the codes must be the exact top-k as always."""
-    if encoder_mode == "f32":
-        pytest.skip("the exact-fp32 MFMA encoder has guaranteed bounds only")
     d, s, k, n = 128, 4096, 16, 300
     p = rand_params(d, s, seed=70)
     # the sample of the first latent range: biases of +-50, i.e. a spread of 50 where the rest of the row has about 1 ->
@@ -857,11 +849,10 @@ def test_failed_bound_prediction_is_caught_and_repeated(encoder_mode):
     assert again["launches"] == after["launches"] + 1 and again["repeats"] == after["repeats"]
 
 
+@pytest.mark.encoder_modes("f16x3", "f16r")  # the exact-fp32 MFMA encoder has guaranteed bounds only
 def test_guaranteed_and_predicted_bounds_give_the_same_codes(encoder_mode):
     from saev_amd.engine import EngineConfig, SaeEngine
 
-    if encoder_mode == "f32":
-        pytest.skip("the exact-fp32 MFMA encoder has guaranteed bounds only")
     d, s, k, n = 256, 8192, 32, 700
     p = rand_params(d, s, seed=73)
     x = (torch.randn(n, d, generator=torch.Generator().manual_seed(74)) + 0.5).cuda()

@@ -91,13 +91,12 @@ def test_gradients_agree_with_dval_formed_in_the_backward_wide(d, k, encoder_mod
     test_gradients_agree_with_dval_formed_in_the_backward(d, 1, encoder_mode, k=k)
 
 
+@pytest.mark.encoder_modes("f16r")  # the decode does not depend on the encoder arithmetic: run once
 @pytest.mark.parametrize("d", [256, 512, 768, 1024])
 @pytest.mark.parametrize("n_pre", [1, 5])
 def test_gradients_agree_with_dval_formed_in_the_backward(d, n_pre, encoder_mode, k=32):
     """The same forward + backward with dval = <dL/dx_hat row (or the prefix block's suffix sum), decoder row> taken from the decode
     and formed by the first pass of the column slices: the four gradients agree to rounding, codes and loss bit for bit."""
-    if encoder_mode != "f16r":
-        pytest.skip("the decode does not depend on the encoder arithmetic: run once")
     s, n = 8 * d, 1000
     p = rand_params(d, s, seed=400 + d)
     x = (torch.randn(n, d, generator=torch.Generator().manual_seed(401 + d)) + 0.2).cuda()
@@ -123,13 +122,12 @@ def test_gradients_agree_with_dval_formed_in_the_backward(d, n_pre, encoder_mode
     assert out["slices"][0]["W_enc"].abs().sum() > 0
 
 
+@pytest.mark.encoder_modes("f32", "f16r")  # run in the exact-fp32 and the default mode
 @pytest.mark.parametrize("d", [256, 512, 768, 1024])
 @pytest.mark.parametrize("n_dead", [1, 5, 8])
 def test_one_pass_auxk_matches_the_oracle_and_the_five_pass_kernels(d, n_dead, encoder_mode):
     """At most eight dead latents: aux_small_fused_kernel.  Teacher-forced steps against the oracle (aux loss, dead count, gradient
     norm, parameters incl. the dead latents' rows), and the same steps on the five-pass kernels (aux_small_max = 64 keeps them)."""
-    if encoder_mode == "f16x3":
-        pytest.skip("run in the exact-fp32 and the default mode")
     s, k, n, k_aux, thr = 4 * d, 8, 210, 64, 100_000
     p = rand_params(d, s, seed=500 + d + n_dead)
     dead = torch.randperm(s, generator=torch.Generator().manual_seed(502 + d))[:n_dead]
@@ -177,13 +175,12 @@ def test_one_pass_auxk_matches_the_oracle_and_the_five_pass_kernels(d, n_dead, e
     assert engs["one_pass"].aux_route() in (1, 2) and engs["five_pass"].aux_route() in (1, 2)
 
 
+@pytest.mark.encoder_modes("f16r")  # the decode does not depend on the encoder arithmetic: run once
 @pytest.mark.parametrize("d,n", [(1024, 1000), (768, 300), (256, 515)])
 def test_slice_decode_agrees_with_the_row_decode(d, n, encoder_mode):
     """SAEV_AMD_DW=slices_s: the decode out of 32-column slices of W_dec (sparse.hip: decode_s_kernel; opt-in) against the default
     register decode: the same codes, x_hat and loss bit for bit (both sum x_hat in code order), gradients to rounding (the dval
     shares are added in another order)."""
-    if encoder_mode != "f16r":
-        pytest.skip("the decode does not depend on the encoder arithmetic: run once")
     s, k = 8 * d, 32
     p = rand_params(d, s, seed=600 + d)
     x = (torch.randn(n, d, generator=torch.Generator().manual_seed(601 + d)) + 0.2).cuda()

@@ -9,13 +9,7 @@ import math
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(autouse=True)
-def _once(encoder_mode):
-    if encoder_mode != "f16r":
-        pytest.skip("the streamed preparation belongs to the f16r encoder")
+pytestmark = [pytest.mark.gpu, pytest.mark.encoder_modes("f16r")]  # the streamed preparation belongs to the f16r encoder
 
 
 def _engine(d, s, k, b, prep_route, seed=0, **kw):

@@ -162,8 +162,33 @@ def test_dump_matches_reference_header_and_roundtrips(tmp_path):
     assert back.W_enc.data_ptr() != back.W_dec.data_ptr()
 
 
-def test_load_refuses_other_schemas_by_number(tmp_path):
-    """SURVEY 8 f2 asks for schema 5 both ways; checkpoints of older layouts are refused, not guessed at."""
+def test_load_reads_legacy_schemas(tmp_path):
+    """Every older header layout the reference's nn.load reads (modeling.py:586-645) gives the config the REFERENCE's
+    loader makes of it (fixture G16: the reference read these very headers) and the stored parameters."""
+    import dataclasses
+    import io
+
+    from saev_amd.nn import modeling as M
+
+    g = load_golden("g16_legacy_checkpoints")
+    sd = {k: g["sd_" + k] for k in R.PARAM_ORDER}
+    blob = io.BytesIO()
+    torch.save({k: sd[k] for k in ("W_dec", "b_dec", "W_enc", "b_enc")}, blob)
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 8
+    for name in names:
+        hdr = bytes(g["hdr_" + name].numpy().tolist())
+        want = json.loads(bytes(g["cfg_" + name].numpy().tolist()).decode())
+        (tmp_path / "old.pt").write_bytes(hdr + b"\n" + blob.getvalue())
+        sae = M.load(tmp_path / "old.pt")
+        got = dataclasses.asdict(sae.cfg)
+        got["activation"] = M._ser(sae.cfg.activation)
+        assert got == want, name
+        for k in R.PARAM_ORDER:
+            assert torch.equal(getattr(sae, k), sd[k]), (name, k)
+
+
+def test_load_legacy_edge_cases(tmp_path):
     import io
 
     from saev_amd.nn import modeling as M
@@ -171,10 +196,25 @@ def test_load_refuses_other_schemas_by_number(tmp_path):
     sae = M.SparseAutoencoder(M.SparseAutoencoderConfig(d_model=8, d_sae=16, activation=M.TopK(top_k=2)))
     buf = io.BytesIO()
     torch.save(sae.state_dict(), buf)
-    for hdr in ({"schema": 2, "cfg": {"d_model": 8, "d_sae": 16}}, {"schema": 99, "cfg": {}}, {"d_vit": 8}):
+
+    def load(hdr):
         (tmp_path / "old.pt").write_bytes(json.dumps(hdr).encode() + b"\n" + buf.getvalue())
-        with pytest.raises(ValueError, match="schema .* is not supported"):
-            M.load(tmp_path / "old.pt")
+        return M.load(tmp_path / "old.pt")
+
+    # schema 1 with the activation named beside a flat config that carries its own top_k (the reference's loader trips over
+    # the extra key; the value is what the trainer of that time used, so it is honoured here)
+    assert load({"schema": 1, "cls": "TopK", "cfg": {"d_model": 8, "d_sae": 16, "top_k": 2}}).cfg.activation == M.TopK(top_k=2)
+    with pytest.raises(ValueError, match="schema 99 is not supported"):
+        load({"schema": 99, "cfg": {}})
+    with pytest.raises(ValueError, match="exp_factor but no d_model"):
+        load({"schema": 2, "cfg": {"exp_factor": 2, "activation": {"cls": "TopK", "params": {"top_k": 2}}}})
+    with pytest.raises(ValueError, match="both 'kind' and 'key'"):
+        load({"schema": 3, "cfg": {"d_model": 8, "d_sae": 16, "activation": {"cls": "TopK", "params": {"kind": "top-k", "key": "top-k"}}}})
+    with pytest.raises(ValueError, match="does not have"):
+        load({"schema": 4, "cfg": {"d_model": 8, "d_sae": 16, "activation": {"cls": "Gelu", "params": {}}}})
+    # schema 5 is strict: the older spellings are not accepted there
+    with pytest.raises(TypeError):
+        load({"schema": 5, "cfg": {"d_model": 8, "d_sae": 16, "activation": {"cls": "TopK", "params": {"kind": "top-k"}}}})
 
 
 def test_reference_loader_reads_our_checkpoint(tmp_path):

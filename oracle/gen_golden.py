@@ -27,6 +27,7 @@ Fixture index:
   G15 sample_prefixes  the reference's Matryoshka prefix draws under fixed seeds
   G16 legacy_ckpt      headers in every older checkpoint layout the reference's nn.load still reads (pre-schema, schema 1 in
                        both of its forms, schemas 2-4) and the config the reference's loader makes of each
+  G17 batch_entropy    the reference's loader-coverage metrics of the log block (utils/statistics.py) on seeded index batches
   G14 inference        the reference's framework/inference.worker_fn over a small protocol-2.1 cache (with and
                        without labels.bin / ignore_labels): CSR token_acts, mean_values, sparsity, distributions,
                        metrics.json; plus Metadata.hash and IndexMap known answers for the same cache
@@ -369,6 +370,24 @@ def g15_sample_prefixes(ref):
     npz("g15_sample_prefixes", cases=np.array(cases), seeds=np.array([0, 1, 42, 1234]), **out)
 
 
+def g17_batch_entropy(ref):
+    """The reference's calc_batch_entropy on seeded index batches (uniform, skewed, single-token support)."""
+    import importlib
+
+    st = importlib.import_module("saev.utils.statistics")
+    g = torch.Generator().manual_seed(170)
+    out = {}
+    for tag, (n_ex, n_tok, b) in {"a": (1000, 256, 4096), "b": (37, 16, 64), "c": (5, 1, 200), "d": (1, 3, 7)}.items():
+        e = torch.randint(0, n_ex, (b,), generator=g, dtype=torch.int32)
+        t = (torch.rand(b, generator=g) ** 2 * n_tok).to(torch.int32).clamp_(max=n_tok - 1)  # skewed towards the first positions
+        m = st.calc_batch_entropy(e, t, n_ex, n_tok)
+        out[f"{tag}_example_idx"], out[f"{tag}_token_idx"] = e, t
+        out[f"{tag}_support"] = np.array([n_ex, n_tok])
+        out[f"{tag}_keys"] = np.array(sorted(m))
+        out[f"{tag}_vals"] = np.array([m[k] for k in sorted(m)], dtype=np.float64)
+    npz("g17_batch_entropy", **out)
+
+
 def g10_make_saes(ref):
     d, s, bsz = 24, 96, 64
     acts = lowrank_data(320, d, seed=100)
@@ -536,6 +555,7 @@ def main():
         return
     if "--only-g16" in sys.argv:
         g16_legacy_checkpoints(ref)
+        g17_batch_entropy(ref)
         return
     if "--only-g14" in sys.argv:
         g14_inference(ref, "plain", False)
@@ -560,6 +580,7 @@ def main():
     g11_schedule(ref)
     g12_checkpoint(ref)
     g16_legacy_checkpoints(ref)
+    g17_batch_entropy(ref)
     g13_matryoshka(ref)
     g14_inference(ref, "plain", False)
     g14_inference(ref, "labels", True)

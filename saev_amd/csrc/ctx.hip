@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1041,6 +1042,10 @@ int saev_encode_topk(saev_ctx* c, const float* x, int32_t n, int32_t* idx_out, f
     HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int32_t), s));
     bind_x_sources(c, x, n, false);
     c->xprep_x = nullptr;
+    // An API encode always takes the full preparation: `stream_step` is what the LAST step's forward decided, and the images it
+    // streamed from may be stale by now (a parameter write announced through saev_params_touched, an unfused tail); the streamed
+    // launches would also clear the step's statistics and max |x|, which are not this call's to touch.
+    c->stream_step = false;
     return encode_topk_impl(c, x, n, idx_out, val_out, c->flags, s);
 }
 
@@ -2077,15 +2082,14 @@ struct RcclApi {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, const void*, int) = nullptr;  // (ncclUniqueId is passed by value: see comm_init_rank)
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    bool tried = false;
 };
 RcclApi g_rccl;
+std::once_flag g_rccl_once;
 struct UniqueId128 { char bytes[128]; };  // == ncclUniqueId (NCCL_UNIQUE_ID_BYTES 128)
-bool rccl_load() {
-    if (g_rccl.tried) return g_rccl.lib != nullptr;
-    g_rccl.tried = true;
+bool rccl_load_once() {
     void* h = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so"}) {  // the copy the process already holds, if any ...
         h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
@@ -2101,10 +2105,27 @@ bool rccl_load() {
     g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(h, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
     g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.CommAbort = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommAbort"));
     g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) return false;
     g_rccl.lib = h;
     return true;
+}
+// (contexts of several host threads may initialise their communicators at the same time: the lookup runs once)
+bool rccl_load() {
+    std::call_once(g_rccl_once, [] { rccl_load_once(); });
+    return g_rccl.lib != nullptr;
+}
+// A rank that fails between the step's two collectives leaves its peers inside a collective it will never join: the
+// communicator is aborted (ncclCommAbort: the peers' pending calls return with an error instead of blocking) and dropped; the
+// error names what failed.  The Python stepper has a watchdog for the same situation (framework/ddp.py: CollectiveWatchdog).
+int dp_fail(saev_ctx* c, int rc) {
+    if (c->comm != nullptr) {
+        if (g_rccl.CommAbort) g_rccl.CommAbort(c->comm);
+        c->comm = nullptr; c->comm_world = 0; c->comm_rank = 0;
+        c->err += " [data-parallel step abandoned: communicator aborted, saev_comm_init again to continue]";
+    }
+    return rc;
 }
 int rccl_fail(saev_ctx* c, const char* what, int r) {
     c->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error") + " (" + std::to_string(r) + ")";
@@ -2150,17 +2171,19 @@ int saev_train_step_dp(saev_ctx* c, const float* x_local, int32_t n_local, float
     REQUIRE(c, c->grads != nullptr, SAEV_NOT_BOUND, "saev_train_step_dp: no gradient buffer bound");
     hipStream_t s = (hipStream_t)stream;
     const int64_t n_global = (int64_t)n_local * c->comm_world;
+    const float inv_world = 1.0f / (float)c->comm_world;
     int rc = saev_step_forward(c, x_local, n_local, n_global, 1, stream);
-    if (rc != SAEV_OK) return rc;
+    if (rc != SAEV_OK) return dp_fail(c, rc);
     int r = g_rccl.AllReduce(c->fired, c->fired, (size_t)c->cfg.d_sae, /*ncclInt32*/ 2, /*ncclMax*/ 2, c->comm, s);
-    if (r != 0) return rccl_fail(c, "ncclAllReduce(fired flags)", r);
+    if (r != 0) return dp_fail(c, rccl_fail(c, "ncclAllReduce(fired flags)", r));
     rc = saev_step_dead(c, n_global, stream);
-    if (rc != SAEV_OK) return rc;
+    if (rc != SAEV_OK) return dp_fail(c, rc);
     rc = saev_step_backward(c, stream);
-    if (rc != SAEV_OK) return rc;
+    if (rc != SAEV_OK) return dp_fail(c, rc);
     r = g_rccl.AllReduce(c->grads, c->grads, (size_t)c->n_params, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, s);
-    if (r != 0) return rccl_fail(c, "ncclAllReduce(flat gradient)", r);
-    return saev_step_tail(c, lr, max_norm, 1.0f / (float)c->comm_world, adam_step, stream);
+    if (r != 0) return dp_fail(c, rccl_fail(c, "ncclAllReduce(flat gradient)", r));
+    rc = saev_step_tail(c, lr, max_norm, inv_world, adam_step, stream);
+    return rc == SAEV_OK ? rc : dp_fail(c, rc);
 }
 
 }  // extern "C"

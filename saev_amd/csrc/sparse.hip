@@ -1653,8 +1653,10 @@ __device__ __forceinline__ void colsum_final_plain(const ColsumPlain& c, int bid
     if (slice == 0 && d < c.D) c.out[d] = ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col])) * 1.0f;
 }
 // The two scan launches in one (decoupled look-back): a workgroup scans its 1 024 latents, publishes its three totals and then the
-// build's epoch as the "ready" word, and adds up the totals of the workgroups before it as they appear -- at most 80 workgroups of
-// 1 024 threads (d_sae <= 81 920), all resident at once, so the wait cannot deadlock.  Same sums in the same order as
+// build's epoch as the "ready" word, and adds up the totals of the workgroups before it as they appear.  The launch admits at most
+// 128 scan workgroups of 1 024 threads (d_sae <= 131 072; configs[3] has 80) plus the column-sum workgroups behind them: one per
+// CU fits 256 CUs, so all of them are resident at once -- and even where they were not, a workgroup only ever waits for workgroups
+// with LOWER indices, which the dispatcher starts first (in-order dispatch), so the wait cannot deadlock.  Same sums in the same order as
 // csc_scan_block_kernel + csc_scan_offset_kernel.  Workgroups past the scan finish the build's column sums (colsum_final_plain).
 __global__ __launch_bounds__(1024) void csc_scan_fused_kernel(CscArgs a, int n_scan, ColsumPlain c, int have_colsum) {
     __shared__ int wave_tot[16][3];

@@ -34,6 +34,7 @@ from .. import data as saev_data
 from .. import nn
 from ..nn import modeling, objectives
 from ..utils import scheduling
+from ..utils.statistics import batch_entropy
 from .ddp import DataParallelStepper
 
 logger = logging.getLogger("train")
@@ -256,6 +257,7 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
                 drawn_by_step = True
         n_patches_seen += (len(batch["rows"]) if x is None else len(x)) * world
         metrics = []
+        spread = _loader_spread(batch, dataloader, dist, world) if log_now else {}
         for i, (sae, st, c) in enumerate(zip(saes, steppers, cfgs)):
             # Matryoshka cut points: sampled per SAE per step from torch's global CPU RNG, like the reference
             # (objectives.py:125); every rank draws the same sequence (same seed, same call order)
@@ -269,6 +271,7 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
                 pre = {}
                 st.train_step(x, lrs[i], c.grad_clip, pre_tail=lambda sae=sae, pre=pre, c=c: pre.update(_decoder_metrics(sae, c)))
                 m = _log_metrics(sae, st.engine, x, lrs[i], n_patches_seen, c, pre, dataloader, dist, world)
+                m.update(spread)
                 metrics.append(m)
             else:
                 st.train_step(x, lrs[i], c.grad_clip)
@@ -282,6 +285,21 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
         st.sync_params()  # (sharded tail: the last step's parameter gathers run on a side stream)
     logger.info("trained %d steps in %.1fs", global_step, time.time() - t_start)
     return saes, objs, run, global_step
+
+
+def _loader_spread(batch, dataloader, dist=None, world: int = 1) -> dict[str, float]:
+    """``loader/{example,token}_{entropy,entropy_normalized,coverage}`` of the log block (train.py:369-377) for the GLOBAL
+    batch: under data parallelism the ranks' index vectors are all-gathered first (2 x 4 B per row, log steps only).  Feeds
+    that carry no cache indices (e.g. an extraction feed) log nothing here."""
+    ex, tk, md = batch.get("example_idx"), batch.get("token_idx"), getattr(dataloader, "metadata", None)
+    if ex is None or tk is None or md is None:
+        return {}
+    if dist is not None and world > 1:
+        both = torch.stack([ex.to(torch.int32), tk.to(torch.int32)])
+        parts = [torch.empty_like(both) for _ in range(world)]
+        dist.all_gather(parts, both)
+        ex, tk = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    return batch_entropy(ex, tk, md.n_examples, md.content_tokens_per_example)
 
 
 @torch.no_grad()

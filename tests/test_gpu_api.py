@@ -496,6 +496,11 @@ def test_streaming_feed_reports_its_fill(tmp_path, monkeypatch):
     saes, objs, run, steps = T.train([cfg])
     fills = [m["loader/buffer_fill"] for _, m in run.records[0]]
     assert fills and all(0.0 <= f <= 1.0 for f in fills) and any(f < 1.0 for f in fills)
+    # the loader-coverage figures of the reference's log block (train.py:369-377) ride along: rows of a shuffled batch are
+    # spread over many examples and over all 8 token positions
+    for _, m in run.records[0]:
+        assert 0.0 < m["loader/example_entropy_normalized"] <= 1.0 and 0.0 < m["loader/example_coverage"] <= 1.0
+        assert m["loader/token_coverage"] == 1.0 and m["loader/token_entropy"] > 0.9 * math.log(8)
 
 
 def test_group_of_saes_shares_the_batch_work_and_matches_single_runs(tmp_path):

@@ -153,25 +153,37 @@ def test_chunked_tail_covers_the_padded_layout_exactly(world, encoder_mode):
         assert (flat[pad] == 0).all()
 
 
-def _two_rank_worker(rank, world, port, out, tail, exchange="dense", prefixes=None, dead_every=9):
+def _two_rank_worker(rank, world, port, out, tail, exchange="dense", prefixes=None, dead_every=9, backend="gloo"):
+    """One rank of a data-parallel run on fixture G9b's batches.  backend "gloo": all ranks on cuda:0 (the one-GPU test box);
+    "nccl": rank r on cuda:r over RCCL -- and tail "c_abi" takes the step from the library itself (saev_train_step_dp) with a
+    communicator of its own instead of the Python stepper."""
     import os
 
     import torch.distributed as dist
 
     from saev_amd.framework.ddp import DataParallelStepper
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         eng, x, s = _setup(shard_world=world if tail == "sharded" else 1, dead_every=dead_every)
         g = load_golden("g9_train_b")
         bsz = int(g["bsz"])
-        stepper = DataParallelStepper(eng, dist, world, tail=tail, exchange=exchange)
+        if tail == "c_abi":
+            box = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            eng.comm_init(box[0], rank, world)
+            assert eng.comm_world() == world
+            step = eng.train_step_dp
+        else:
+            step = DataParallelStepper(eng, dist, world, tail=tail, exchange=exchange).train_step
         if prefixes is not None:
             eng.set_prefixes(list(prefixes))
         n_dead = []
         for i, xb in enumerate(g["acts"].split(bsz)[:5]):
-            stepper.train_step(xb[rank::world].contiguous().cuda(), 1e-3 * i, 0.05)
+            step(xb[rank::world].contiguous().cuda(), 1e-3 * i, 0.05)
             n_dead.append(eng.read_stats().n_dead)
         torch.cuda.synchronize()
         torch.save({"params": {k: v.cpu().clone() for k, v in eng.param_views().items()}, "toks": eng.toks_since_active.cpu(),
@@ -262,6 +274,41 @@ def _two_sae_engine(g, j, **kw):
     toks[::9] = int(g["thr"])  # dead latents from the start: the auxiliary term's compact rows cross ranks too
     eng.set_tracker(toks)
     return eng, params
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X in the box (RCCL refuses two ranks on one device)")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("tail,exchange,dead_every", [("replicated", "dense", 9), ("sharded", "dense", 9), ("replicated", "sparse", 9),
+                                                      ("sharded", "dense", 40), ("c_abi", "dense", 9), ("c_abi", "dense", 40)])
+@pytest.mark.encoder_modes("f16r")  # one encoder mode is enough here
+def test_ranks_on_their_own_gpus_over_rccl_reproduce_the_single_process_step(tmp_path, tail, exchange, dead_every, encoder_mode):
+    """The hardware half of SURVEY 8e, run by itself the first time the box has more than one GPU: one process per GPU, backend
+    nccl (= RCCL over xGMI), the three exchanges of DataParallelStepper and the library's own saev_train_step_dp.  Both ranks
+    must hold identical parameters and trackers, and they must match one process on the full batches: bit for bit where the
+    summation order is the single process's (sparse exchange), to rounding where gradients are summed across ranks."""
+    import torch.multiprocessing as mp
+
+    world = min(torch.cuda.device_count(), 2)
+    out = str(tmp_path / "rank{rank}.pt")
+    mp.spawn(_two_rank_worker, args=(world, _free_port(), out, tail, exchange, None, dead_every, "nccl"), nprocs=world, join=True)
+    r0, r1 = (torch.load(out.format(rank=r)) for r in range(2))
+    for k in R.PARAM_ORDER:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    assert torch.equal(r0["toks"], r1["toks"]) and r0["n_dead"] == r1["n_dead"]
+    eng, x, s = _setup(dead_every=dead_every)
+    g = load_golden("g9_train_b")
+    bsz = int(g["bsz"])
+    n_dead = []
+    for i, xb in enumerate(g["acts"].split(bsz)[:5]):
+        eng.train_step(xb.cuda(), 1e-3 * i, 0.05)
+        n_dead.append(eng.read_stats().n_dead)
+    assert n_dead == r0["n_dead"] and max(n_dead) > 0
+    assert torch.equal(eng.toks_since_active.cpu(), r0["toks"])
+    for k in R.PARAM_ORDER:
+        bad = ~torch.isclose(eng.view(k).cpu(), r0["params"][k], rtol=2e-4, atol=2e-6)
+        assert bad.float().mean() <= 1e-4, f"{k}: {bad.sum().item()} of {bad.numel()} elements off"
 
 
 @pytest.mark.encoder_modes("f16r")  # the slice-major x only exists in the f16r mode

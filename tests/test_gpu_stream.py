@@ -94,6 +94,30 @@ def test_streamed_step_survives_what_happens_between_steps():
     _same(*engs)
 
 
+def test_api_encode_after_a_streamed_step_sees_an_announced_parameter_write():
+    """Round-5 advisor finding: saev_encode_topk keyed on the `stream_step` the last training forward had left, skipped the
+    preparation and encoded with the images of the parameters as they WERE.  Streamed training steps, a write to a few elements
+    of b_enc / W_enc (announced), then the API encode: the codes must be those of a fresh engine holding the same parameters --
+    and the call must leave the step statistics alone."""
+    d, s, k, b = 256, 2048, 16, 512
+    eng = _engine(d, s, k, b, 0, seed=14)
+    xs = _batches(d, b, 5, seed=15)
+    for x in xs[:4]:
+        eng.train_step(x, 1e-3, 1.0)
+    before = eng.read_stats()
+    eng.view("b_enc").data[7] += 50.0            # one latent now leads every row
+    eng.view("W_enc").data[:, 11] *= -3.0        # and one column changes sign and size
+    eng.params_touched()
+    idx, val = eng.encode_topk(xs[4])
+    fresh = _engine(d, s, k, b, 1, seed=99)
+    fresh.load_params({n: eng.view(n).clone() for n in ("W_dec", "b_dec", "W_enc", "b_enc")})
+    idx_f, val_f = fresh.encode_topk(xs[4])
+    assert (idx == 7).any(dim=1).all(), "the raised bias is in every row's codes"
+    assert torch.equal(idx, idx_f) and torch.equal(val, val_f)
+    after = eng.read_stats()
+    assert after.mse == before.mse and after.l0 == before.l0, "an API encode does not clear the last step's statistics"
+
+
 def test_a_jump_in_the_data_takes_the_exact_route_and_recovers():
     """The x images of a streamed step are scaled with the previous batch's maximum and centred on its mean.  A batch a thousand
     times larger leaves fp16's range: the step must notice and take the exact dense route; so does the first small batch after

@@ -585,3 +585,39 @@ def test_shard_validation_reports_every_bad_file_up_front(tmp_path):
     with pytest.raises(FileNotFoundError) as exc:
         info.validate(d)
     assert "Truncated" not in str(exc.value)
+
+
+def test_batch_entropy_matches_the_reference_on_fixture_g17():
+    """The loader-coverage figures of the log block (reference utils/statistics.py:57-122, train.py:369-377)."""
+    from saev_amd.utils.statistics import batch_entropy
+
+    g = load_golden("g17_batch_entropy")
+    for tag in "abcd":
+        n_ex, n_tok = g[f"{tag}_support"].tolist()
+        got = batch_entropy(g[f"{tag}_example_idx"], g[f"{tag}_token_idx"], n_ex, n_tok)
+        keys = [str(k) for k in g[f"{tag}_keys"]]
+        assert sorted(got) == keys
+        for k, want in zip(keys, g[f"{tag}_vals"].tolist()):
+            assert math.isclose(got[k], want, rel_tol=1e-12, abs_tol=1e-15), (tag, k, got[k], want)
+    with pytest.raises(ValueError):
+        batch_entropy(torch.zeros(3, dtype=torch.int32), torch.zeros(4, dtype=torch.int32), 5, 5)
+    with pytest.raises(ValueError):
+        batch_entropy(torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), 5, 5)
+    with pytest.raises(ValueError):
+        batch_entropy(torch.zeros(3, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), 0, 5)
+
+
+def test_loader_spread_covers_the_global_batch_and_skips_index_free_feeds():
+    from saev_amd.framework import train as T
+
+    class MD:
+        n_examples, content_tokens_per_example = 10, 4
+
+    class DL:
+        metadata = MD()
+
+    b = {"act": None, "example_idx": torch.tensor([0, 1, 1, 9], dtype=torch.int32), "token_idx": torch.tensor([0, 0, 3, 3], dtype=torch.int32)}
+    m = T._loader_spread(b, DL())
+    assert math.isclose(m["loader/example_coverage"], 0.3) and math.isclose(m["loader/token_coverage"], 0.5)
+    assert math.isclose(m["loader/token_entropy"], math.log(2))
+    assert T._loader_spread({"act": None}, DL()) == {} and T._loader_spread(b, object()) == {}

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAEV_AMD_ABI_VERSION 9
+#define SAEV_AMD_ABI_VERSION 10
 
 typedef enum {
     SAEV_OK = 0,
@@ -35,7 +35,9 @@ typedef enum {
     SAEV_HIP_ERROR = -2,
     SAEV_UNSUPPORTED = -3,
     SAEV_NOT_BOUND = -4,
-    SAEV_RCCL_ERROR = -5
+    SAEV_RCCL_ERROR = -5,
+    SAEV_STALE_PARAMS = -6 /* W_enc was written outside the library without saev_params_touched and a step has already run on
+                              stale operand images (PARAMETER OWNERSHIP below); the context itself recovers */
 } saev_status;
 
 /* Static configuration of one SAE (nn/modeling.py:259-284 SparseAutoencoderConfig, :119-130 TopK,
@@ -378,9 +380,15 @@ int saev_train_step_dp(saev_ctx* ctx, const float* x_local, int32_t n_local, flo
  * the last forward that prepared them itself) and uses it for as long as only the library has written the parameter buffer.  A
  * caller that writes W_enc / b_enc / W_dec itself -- loads a checkpoint, broadcasts, pokes a value -- must say so before the
  * next call; saev_bind does it implicitly.  (The Python host calls it whenever torch's version counter of the buffer moved.)
- * Safety net, not a substitute: every streamed step compares a few thousand pseudo-random elements of W_enc / b_enc with the
- * copies its images came with; a difference sends that step down the exact dense route (correct codes, a slow step) and makes
- * the next forward prepare from scratch.  A bulk write is caught with certainty, a poke at a few elements is not. */
+ * Behind the contract, two checks so that a forgotten announcement is never a silent wrong answer:
+ *   (1) before the images are used: every streamed step compares ALL of b_enc and a few thousand pseudo-random elements of W_enc
+ *       with the copies its images came with; a difference sends that step down the exact dense route (correct codes, a slow
+ *       step) and makes the next forward prepare from scratch.  Any write to b_enc and any bulk write to W_enc end here.
+ *   (2) after they were used: the fused Adam of saev_train_step leaves two checksum words per 32 x 256 tile of W_enc as it writes
+ *       it and compares them with the tile as it reads it one step later -- every element, at no extra traffic.  A write to even
+ *       one element that (1) missed is found at the end of the first step that ran on the stale images; that step cannot be
+ *       redone, so the next saev_step_forward / saev_train_step returns SAEV_STALE_PARAMS (once; saev_last_error says how many
+ *       tiles) and the context prepares from scratch from there on. */
 int saev_params_touched(saev_ctx* ctx);
 
 /* Codes / reconstruction of the last saev_step_forward (device pointers into context scratch):

@@ -13,7 +13,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("SAEV_AMD_LIB", _HERE / "libsaev_amd.so"))
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class SaevCfg(C.Structure):

@@ -185,7 +185,12 @@ struct saev_ctx {
     float *WeS = nullptr;         // slice-major fp32 W_enc^T of its own (the gradient scratch dW_encT no longer doubles as it)
     float *xn_part = nullptr, *amax_part = nullptr, *cmax_part = nullptr;
     float* b_seen = nullptr;      // b_enc as bias_finish read it (the staleness samples of xprep_kernel compare against it)
-    int32_t *stale_host = nullptr, *stale_dev = nullptr;  // pinned word: a streamed step found the parameters changed behind its back
+    int32_t *stale_host = nullptr, *stale_dev = nullptr;  // pinned words: [0] a streamed step found the parameters changed behind its
+                                                          // back before using its images (and took the exact route); [1] the fused
+                                                          // Adam found W_enc tiles changed AFTER the step had used them (AdamImageArgs::chk)
+    uint32_t* wchk = nullptr;     // two checksum words per 32 x 256 tile of W_enc, left by the fused Adam that wrote it
+    bool wchk_valid = false;      // wchk describes W_enc as the library last wrote it, and only the library may have written it since
+    bool fwd_reused_wimg = false; // the forward in flight ran on operand images a previous step's Adam left (their checksums are due)
     uint32_t stale_salt = 0;
     int scale_par = 0;            // which half of f16r_scales (2 x 8 floats) belongs to the step in flight
     bool prep_valid = false;      // mu and scales[par][0, 4] describe a previous batch of this context
@@ -435,6 +440,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
         A(WeS, S * D); A(xn_part, (size_t)(D / 32) * c->MB_pad * 2);
         A(amax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(cmax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(b_seen, S);
     }
+    if (c->stream_ok || c->cfg.encoder_mode == SAEV_ENCODER_BF16) A(wchk, (size_t)2 * ((S + 255) / 256) * ((D + 31) / 32));
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
     A(tau_max, MB); A(heur_state, 8); A(stats_scratch, STATS_SCRATCH_DOUBLES); A(tickets, 8); A(db_aux, D);
 #undef A
@@ -448,12 +454,12 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     hipMemset(c->fired, 0, S * sizeof(int32_t));
     hipMemset(c->dead, 0, S * sizeof(int32_t));
     hipMemset(c->flags, 0, 16 * sizeof(int32_t));
-    if (c->stream_ok) {
+    if (c->stream_ok || c->cfg.encoder_mode == SAEV_ENCODER_BF16) {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer(reinterpret_cast<void**>(&c->stale_dev), hp, 0) == hipSuccess) {
             c->stale_host = static_cast<int32_t*>(hp);
-            *c->stale_host = 0;
+            c->stale_host[0] = 0; c->stale_host[1] = 0;
         } else {
             if (hp) hipHostFree(hp);
             c->stale_host = nullptr; c->stale_dev = nullptr;  // (the device-side part of the check still works)
@@ -546,6 +552,7 @@ int saev_bind(saev_ctx* c, float* params, float* grads, float* adam_m, float* ad
     c->wn2_fresh = false;
     c->wimg_fresh = false;
     c->wimg_bf16_fresh = false;
+    c->wchk_valid = false;
     c->grads = grads;
     c->adam_m = adam_m;
     c->adam_v = adam_v;
@@ -799,6 +806,7 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
     { int rcw = wait_wenc(c, s); if (rcw != SAEV_OK) return rcw; }
     // (bf16: the fused Adam of the previous step has left the images of the W_enc it wrote -- AdamImageArgs::mode 1 -- and nothing
     // has written the parameters since: include/saev_amd.h, PARAMETER OWNERSHIP)
+    c->fwd_reused_wimg = bf && c->wimg_bf16_fresh;
     if (!(bf && c->wimg_bf16_fresh))
         HIPCHK(c, launch_split_wT(c->params + c->off_W_enc, D, S, c->S_pad, c->Dp, bf ? 1.0f : 256.0f, c->ws, bf ? 1 : 0, s));
     if (bf && c->dbg.prep_route == 0 && c->Dp == D && D % 32 == 0) c->wimg_bf16_fresh = true;  // (the images describe W_enc as it is)
@@ -1136,6 +1144,18 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     const bool borrowed = bind_x_sources(c, x, n, true);
     // The streamed preparation: this context neither lends nor borrows, a previous batch has left a centre, a scale
     // and a normaliser, and the operand images of W_enc describe the parameters as they are, centred on that very centre.
+    if (c->stale_host != nullptr && reinterpret_cast<volatile int32_t*>(c->stale_host)[1] != 0) {
+        // the fused Adam of an earlier step read W_enc tiles that were not the ones it had written: that step's forward ran on
+        // operand images of other values.  Nothing can be redone: say so, loudly; the next forward prepares from scratch.
+        const int n_tiles = reinterpret_cast<volatile int32_t*>(c->stale_host)[1];
+        reinterpret_cast<volatile int32_t*>(c->stale_host)[1] = 0;
+        c->wimg_fresh = false; c->wimg_bf16_fresh = false; c->wn2_fresh = false;
+        c->err = "W_enc was written outside the library without saev_params_touched (" + std::to_string(n_tiles) +
+                 " 32 x 256 tiles changed between two optimizer steps): a recent step encoded with operand images of the OLD values. "
+                 "Announce such writes (saev_params_touched / SaeEngine.params_touched) or make them through torch in-place "
+                 "operations on the parameter tensors; the context prepares from scratch from here on";
+        return SAEV_STALE_PARAMS;
+    }
     if (c->stale_host != nullptr && *reinterpret_cast<volatile int32_t*>(c->stale_host) != 0) {
         // a streamed step found W_enc / b_enc changed behind its back (it took the exact route itself): prepare from scratch
         *reinterpret_cast<volatile int32_t*>(c->stale_host) = 0;
@@ -1144,6 +1164,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     }
     c->stream_step = c->stream_ok && c->prep_valid && c->wimg_fresh && c->wimg_mu_serial == c->mu_serial && c->leader == nullptr &&
                      c->followers.empty() && c->wenc_ready == nullptr && c->fwd_step;
+    c->fwd_reused_wimg = c->stream_step;  // (the bf16 encoder decides in prepare_encoder)
     if (c->gather_pool != nullptr && !c->stream_step)  // (the batch as a contiguous matrix first: every other route reads x itself)
         HIPCHK(c, launch_gather_rows(c->gather_pool, c->gather_rows, n, D, const_cast<float*>(x), s));
     if (c->stream_step) {
@@ -1964,6 +1985,8 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     const bool emit = c->train_fused && c->stream_ok && c->prep_valid && c->leader == nullptr && c->followers.empty() && shard_rank < 0 &&
                       c->tail_proj_in_adam && c->wenc_t_pending;
     c->wimg_fresh = false;  // (W_enc moves: only the fused Adam below leaves images of what it writes)
+    const bool chk_was_valid = c->wchk_valid;
+    c->wchk_valid = false;
     const bool emit_bf16 = c->train_fused && c->cfg.encoder_mode == SAEV_ENCODER_BF16 && c->wimg_bf16_fresh && shard_rank < 0 &&
                            c->tail_proj_in_adam && c->wenc_t_pending;
     c->wimg_bf16_fresh = false;
@@ -1987,10 +2010,18 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
             im.mu = c->mu; im.wmax_prev = c->wmax_prev; im.scales_next = scl_next(c); im.nks = c->Dp / 32; im.S_pad = c->S_pad;
         }
         if (emit_bf16) { im.ws = c->ws; im.nks = c->Dp / 32; im.S_pad = c->S_pad; im.mode = 1; }
+        if ((emit || emit_bf16) && c->wchk != nullptr) {
+            // the tiles' checksums: left for the next step, and -- when this step's forward ran on images an earlier Adam left --
+            // compared with what that Adam left (an evaluation forward in between changes nothing: W_enc did not move)
+            im.chk = c->wchk; im.late = c->stale_dev != nullptr ? c->stale_dev + 1 : nullptr;
+            im.verify = (chk_was_valid && c->fwd_reused_wimg && im.late != nullptr) ? 1 : 0;
+            im.early = emit ? c->flags + 13 : nullptr;
+        }
         HIPCHK(c, launch_adam_fused(a, c->row_proj, c->dW_encT, (int)S, (int)D, S * D, c->off_W_enc - S * D, c->off_W_enc,
                                     c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr,
                                     (emit || emit_bf16) ? &im : nullptr));
         c->unused_valid = false;
+        c->wchk_valid = (emit || emit_bf16) && c->wchk != nullptr;
         c->wimg_bf16_fresh = emit_bf16;
         if (emit) {
             // the bias of the next centred first pass and the column-norm maxima its margins need: W-only, so they are finished here
@@ -2042,6 +2073,7 @@ int saev_train_step_gather(saev_ctx* c, const float* pool, const int64_t* rows, 
 
 int saev_params_touched(saev_ctx* c) {
     if (!c) return SAEV_INVALID_ARG;
+    c->wchk_valid = false;
     c->wimg_fresh = false;
     c->wimg_bf16_fresh = false;
     c->wn2_fresh = false;

@@ -401,6 +401,13 @@ struct AdamImageArgs {
     const float* mu; const float* wmax_prev; float* scales_next;
     int nks, S_pad;
     int mode;  // 0: the f16r set described above; 1: the bf16 encoder -- only ws, W_enc^T rounded to bf16 (nothing else is read)
+    // Ownership check (include/saev_amd.h: PARAMETER OWNERSHIP): the launch leaves two 32-bit checksums of every W_enc tile AS IT
+    // WRITES IT (chk: [tiles][2], a plain sum and a sum of position-rotated words of the bit patterns) and, with `verify`, compares
+    // the checksums of the tile AS IT READS IT with what the previous launch left: they differ exactly when somebody else wrote the
+    // tile in between -- i.e. when the step that ends here ran on operand images of other values.  Every element is covered at no
+    // extra traffic (Adam reads and writes all of W_enc anyway); a mismatch counts into *late (pinned host memory).
+    uint32_t* chk; int32_t* late; int verify;
+    const int32_t* early;  // != 0: the step's first kernels found the write themselves and the step took the exact route (XprepArgs::stale)
 };
 hipError_t launch_adam_fused(const AdamArgs& a, const float2* row_proj, const float* gT, int S, int D, long off_b_dec, long n_b_dec,
                              long off_W_enc, long off_b_enc, long n_b_enc, hipStream_t stream, const int32_t* lat_unused = nullptr,
@@ -526,10 +533,11 @@ struct XprepArgs {
     float* amax_part;      // [row blocks * nks]
     float* cmax_part;      // [row blocks * nks]
     // Safety net behind the parameter-ownership contract (include/saev_amd.h): every workgroup compares two pseudo-random elements
-    // of W_enc with the slice-major copy the images came with, and one of b_enc with the copy bias_finish kept -- equal bit for bit
-    // unless somebody wrote the parameters without saying so.  A difference raises *stale: pre_encode2_kernel then sends the step
-    // down the exact dense route and tells the host (a bulk write -- a copy, an optimizer step, a broadcast -- is caught with
-    // certainty; a poke at a handful of elements is not: that is what saev_params_touched is for).
+    // of W_enc with the slice-major copy the images came with, and the launch compares ALL of b_enc with the copy bias_finish kept
+    // -- equal bit for bit unless somebody wrote the parameters without saying so.  A difference raises *stale: pre_encode2_kernel
+    // then sends the step down the exact dense route and tells the host (any write to b_enc and a bulk write to W_enc -- a copy, an
+    // optimizer step, a broadcast -- are caught here, before the images are used; a poke at a handful of elements of W_enc is caught
+    // with certainty at the END of the step, by the tile checksums of the fused Adam: AdamImageArgs::chk).
     const float* W_enc; const float* WeS; const float* b_enc; const float* b_seen;
     int S; uint32_t salt; int32_t* stale;
 };

@@ -1050,10 +1050,14 @@ __global__ __launch_bounds__(256) void pre_encode2_kernel(PreEncode2Args a) {
         int pre = 0;
         if (!f16r_scale_ok(wmax, a.scales[1])) pre = 1;
         if (!(cmax * x_scale < 60000.0f)) pre = 1;  // an element of this step's x image left fp16's range (or is not finite)
-        if (a.stale != nullptr && *a.stale != 0) {  // the parameters are not the ones the images were made of (XprepArgs::stale)
-            pre = 1;
-            *a.stale = 0;
-            if (a.stale_host != nullptr) *a.stale_host = 1;
+        if (a.stale != nullptr) {
+            const bool caught = *a.stale != 0;  // the parameters are not the ones the images were made of (XprepArgs::stale)
+            if (caught) {
+                pre = 1;
+                *a.stale = 0;
+                if (a.stale_host != nullptr) *a.stale_host = 1;
+            }
+            a.stale[1] = caught ? 1 : 0;  // (this step takes the exact route: the tile checksums of its Adam have nothing to report)
         }
         *a.pre_flag = pre;
         *a.wmax_prev = wmax;

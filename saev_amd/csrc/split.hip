@@ -272,18 +272,17 @@ __global__ __launch_bounds__(1024) void xprep_kernel(XprepArgs a) {
         a.amax_part[bid] = m0;
         a.cmax_part[bid] = m1;
     }
-    if (a.stale != nullptr && i >= 64 && i < 67) {  // the samples of XprepArgs::stale (a wave that has nothing else left to do)
+    if (a.stale != nullptr && i >= 64 && i < 66) {  // the W_enc samples of XprepArgs::stale (a wave that has nothing else left to do)
         uint32_t h = ((uint32_t)bid * 3u + (uint32_t)(i - 64)) * 2654435761u + a.salt * 40503u;
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        bool differs;
-        if (i < 66) {
-            const uint32_t d = h % (uint32_t)a.D, sidx = (h >> 8) % (uint32_t)a.S;
-            const float w = a.W_enc[(size_t)d * a.S + sidx], c = a.WeS[((size_t)(d >> 5) * a.S + sidx) * 32 + (d & 31)];
-            differs = __float_as_uint(w) != __float_as_uint(c);
-        } else {
-            const uint32_t sidx = h % (uint32_t)a.S;
-            differs = __float_as_uint(a.b_enc[sidx]) != __float_as_uint(a.b_seen[sidx]);
-        }
+        const uint32_t d = h % (uint32_t)a.D, sidx = (h >> 8) % (uint32_t)a.S;
+        const float w = a.W_enc[(size_t)d * a.S + sidx], c = a.WeS[((size_t)(d >> 5) * a.S + sidx) * 32 + (d & 31)];
+        if (__float_as_uint(w) != __float_as_uint(c)) atomicOr(a.stale, 1);
+    }
+    if (a.stale != nullptr && i >= 128 && i < 192) {  // ... and ALL of b_enc, 64 elements per workgroup (another idle wave)
+        bool differs = false;
+        for (int sidx = bid * 64 + (i - 128); sidx < a.S; sidx += (int)gridDim.x * 64)
+            differs |= __float_as_uint(a.b_enc[sidx]) != __float_as_uint(a.b_seen[sidx]);
         if (differs) atomicOr(a.stale, 1);
     }
 }

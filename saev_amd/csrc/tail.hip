@@ -294,6 +294,10 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
         const bool emit = f.img.ws != nullptr;
         if (sidx >= S && !emit) return;
         f32x4 pn[8];
+        // (AdamImageArgs::chk: the tile's checksums as read / as written -- a plain sum of the bit patterns, which no change of a
+        // single element leaves alone, and a sum of words rotated by their position in the thread's share, against permutations)
+        uint32_t ck_r0 = 0u, ck_r1 = 0u, ck_w0 = 0u, ck_w1 = 0u;
+        const bool chk_on = emit && f.img.chk != nullptr;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int dl = dr + 4 * i, d = d0 + dl;
@@ -304,10 +308,24 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
             f32x4 m = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(M + o));
             f32x4 v = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(V + o));
             const f32x4 g = *reinterpret_cast<const f32x4*>(&tile[dl][sl]);
+            if (chk_on) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t u = __float_as_uint(p[e]);
+                    ck_r0 += u; ck_r1 += __builtin_amdgcn_alignbit(u, u, (4 * i + e + 1) & 31);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const AdamElem q = adam_elem(p[e], scaled_grad(g[e], gs), m[e], v[e], a, step_size);
                 p[e] = q.p; m[e] = q.m; v[e] = q.v;
+            }
+            if (chk_on) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t u = __float_as_uint(p[e]);
+                    ck_w0 += u; ck_w1 += __builtin_amdgcn_alignbit(u, u, (4 * i + e + 1) & 31);
+                }
             }
             __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(P + o));
             __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(M + o));
@@ -319,7 +337,24 @@ __device__ __forceinline__ void adam_wenc_tile(const AdamFusedArgs& f, const Ada
         // the updated values go back through the LDS tile, then thread rl owns latent s0 + rl: its 32 k as four fp16 chunks in the
         // encoder's image order, the slice-major fp32 row for the exact refinement, and the image's shares of <mu, w>, ||w||^2
         // and ||w - fp16(w)||^2 (bias_finish_kernel adds the shares of the D / 32 images)
+        __shared__ uint32_t ck_sh[4][4];
+        if (chk_on) {  // (integer sums: any order gives the same words)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ck_r0 += __shfl_xor(ck_r0, o, 64); ck_r1 += __shfl_xor(ck_r1, o, 64);
+                ck_w0 += __shfl_xor(ck_w0, o, 64); ck_w1 += __shfl_xor(ck_w1, o, 64);
+            }
+            if ((threadIdx.x & 63) == 0) { uint32_t* q = ck_sh[threadIdx.x >> 6]; q[0] = ck_r0; q[1] = ck_r1; q[2] = ck_w0; q[3] = ck_w1; }
+        }
         __syncthreads();  // (every thread has taken its gradient out of the tile)
+        if (chk_on && threadIdx.x == 0) {
+            uint32_t c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = (ck_sh[0][j] + ck_sh[1][j]) + (ck_sh[2][j] + ck_sh[3][j]);
+            uint32_t* const slot = f.img.chk + 2 * (size_t)t;
+            if (f.img.verify && (slot[0] != c[0] || slot[1] != c[1]) && (f.img.early == nullptr || *f.img.early == 0)) atomicAdd(f.img.late, 1);
+            slot[0] = c[2]; slot[1] = c[3];
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&tile[dr + 4 * i][sl]) = pn[i];
         const int rl = threadIdx.x, ks = d0 / TD;

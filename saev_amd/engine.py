@@ -250,10 +250,32 @@ class SaeEngine:
         except RuntimeError:  # a buffer created under torch.inference_mode() has no version counter: nothing to go by
             return None
 
+    def watch(self, tensors) -> None:
+        """Tensors that alias the parameter buffer but carry version counters of their own -- the four Parameters of a
+        ``SparseAutoencoder`` bound to this engine (``p.data = view`` keeps the Parameter's counter).  Every entry point that
+        reads the parameters compares their counters too, so an in-place write through the module (``sae.W_enc.mul_()``,
+        ``load_state_dict``, an initialiser) is noticed even when the caller drives the engine directly, as ``train()`` does."""
+        import weakref
+
+        self._watched = [weakref.ref(t) for t in tensors]
+        self._watched_versions = self._wversions()
+
+    def _wversions(self):
+        out = []
+        for r in getattr(self, "_watched", ()):
+            t = r()
+            try:
+                out.append(None if t is None else t._version)
+            except RuntimeError:  # inference tensors carry no version counter
+                out.append(-1)
+        return out
+
     def _note_param_writes(self) -> None:
         v = self._pversion()
-        if v is None or v != self._params_version:
+        w = self._wversions()
+        if v is None or v != self._params_version or w != getattr(self, "_watched_versions", []) or -1 in w:
             self.params_touched()
+            self._watched_versions = w
 
     def _check_x(self, x: torch.Tensor) -> torch.Tensor:
         if x.device != self.device or x.dtype != torch.float32:
@@ -440,8 +462,8 @@ class SaeEngine:
         x = self._check_x(x)
         self._x_keepalive = x
         self._note_param_writes()
-        self.adam_steps += 1
-        self._chk(self.lib.saev_train_step(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps, _stream()), "saev_train_step")
+        self._chk(self.lib.saev_train_step(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps + 1, _stream()), "saev_train_step")
+        self.adam_steps += 1  # (counted once the step is enqueued: a refused call -- SAEV_STALE_PARAMS -- is not an optimizer step)
 
     # data parallel behind the C ABI (include/saev_amd.h: DATA PARALLEL): RCCL inside the library, two collectives per step
     def comm_unique_id(self) -> bytes:
@@ -465,8 +487,8 @@ class SaeEngine:
         x = self._check_x(x_local)
         self._x_keepalive = x
         self._note_param_writes()
-        self.adam_steps += 1
-        self._chk(self.lib.saev_train_step_dp(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps, _stream()), "saev_train_step_dp")
+        self._chk(self.lib.saev_train_step_dp(self.ctx, _ptr(x), x.shape[0], lr, max_norm, self.adam_steps + 1, _stream()), "saev_train_step_dp")
+        self.adam_steps += 1  # (counted once the step is enqueued: a refused call -- SAEV_STALE_PARAMS -- is not an optimizer step)
 
     def train_step_gather(self, pool: torch.Tensor, rows: torch.Tensor, lr: float, max_norm: float = 1.0, out: torch.Tensor | None = None) -> torch.Tensor:
         """``train_step`` on the batch ``pool[rows]``, drawn inside the step (saev_train_step_gather): the step's first kernel reads
@@ -480,9 +502,9 @@ class SaeEngine:
             out = torch.empty(n, self.cfg.d_model, device=self.device, dtype=torch.float32)
         self._x_keepalive = (pool, rows, out)
         self._note_param_writes()
-        self.adam_steps += 1
-        self._chk(self.lib.saev_train_step_gather(self.ctx, _ptr(pool), _ptr(rows), _ptr(out), n, lr, max_norm, self.adam_steps, _stream()),
+        self._chk(self.lib.saev_train_step_gather(self.ctx, _ptr(pool), _ptr(rows), _ptr(out), n, lr, max_norm, self.adam_steps + 1, _stream()),
                   "saev_train_step_gather")
+        self.adam_steps += 1
         return out
 
     def read_stats(self) -> StepStats:

@@ -270,6 +270,7 @@ class SparseAutoencoder(torch.nn.Module):
                 old.close()
             for n in eng.offsets:
                 getattr(self, n).data = eng.view(n)
+            eng.watch([getattr(self, n) for n in eng.offsets])  # (their version counters are their own: see SaeEngine.watch)
             self.__dict__["_engine"] = eng
             self.__dict__["_engine_max_batch"] = eng.cfg.max_batch
         # The engine keeps what its forward needs of W_enc / W_dec between calls (include/saev_amd.h, PARAMETER OWNERSHIP).  The four

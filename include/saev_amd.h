@@ -167,6 +167,13 @@ typedef struct {
                               absmax, scale: six launches)                                                                    */
     int32_t aux_small_route; /* 9 ... 64 dead latents (and 1 ... 8 where the one-pass kernel does not take the shape), d_model % 128 == 0:
                               0 = the contractions as fp32 MFMA tiles (v_mfma_f32_32x32x2_f32), 1 = the vector-ALU kernels of rounds 3-4 */
+    int32_t own_check;     /* PARAMETER OWNERSHIP, check (2): 0 = the fused Adam leaves / compares tile checksums of W_enc, 1 = off
+                              (A/B measurements of the Adam launch only)                                                     */
+    int32_t enc_rot;       /* fused encoder: 0 = the workgroups of an XCD that share a W_enc tile walk its k-steps rotated by one
+                              step each, 1 = in lock step (same order: the tile's images are read by all of them at once)     */
+    int32_t dec_route;     /* register decode with 32 < top_k <= 64: 0 = all 64 decoder rows of a row's codes in registers, two columns
+                              per lane, every row gathered once; 1 = the round-5 kernel (two halves of 32 rows, the first half gathered
+                              twice)                                                                                         */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

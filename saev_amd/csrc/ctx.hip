@@ -829,6 +829,7 @@ static int run_encoder(saev_ctx* c, const float* x, int n, int epi, float* h_out
         const int enc_wgs = c->dbg.enc_wgs > 0 ? c->dbg.enc_wgs : 256;
         a.mfma32 = c->dbg.enc_mfma == 32 ? 1 : 0;
         a.s_splits = encoder_splits(n, a.S, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), enc_wgs);
+        a.no_rot = c->dbg.enc_rot == 1 ? 1 : 0;
         a.h_out = h_out;
         a.ngroups = f16_ngroups(c); a.top_k = c->cfg.top_k;
         a.gmax = c->gmax; a.gmax_stride = c->gmax_stride; a.cand_cnt = c->cand_cnt; a.cand_val = c->cand_val; a.cand_idx = c->cand_idx;
@@ -1215,6 +1216,7 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.upper = c->upper_c;
     a.gscale = 2.0f / ((float)n * (float)D * (float)c->P);
     a.training = training ? 1 : 0;
+    a.k64_route = c->dbg.dec_route == 1 ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
     c->dws_rows = 0;
     c->dval_fwd = false;
@@ -2010,7 +2012,7 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
             im.mu = c->mu; im.wmax_prev = c->wmax_prev; im.scales_next = scl_next(c); im.nks = c->Dp / 32; im.S_pad = c->S_pad;
         }
         if (emit_bf16) { im.ws = c->ws; im.nks = c->Dp / 32; im.S_pad = c->S_pad; im.mode = 1; }
-        if ((emit || emit_bf16) && c->wchk != nullptr) {
+        if ((emit || emit_bf16) && c->wchk != nullptr && c->dbg.own_check == 0) {
             // the tiles' checksums: left for the next step, and -- when this step's forward ran on images an earlier Adam left --
             // compared with what that Adam left (an evaluation forward in between changes nothing: W_enc did not move)
             im.chk = c->wchk; im.late = c->stale_dev != nullptr ? c->stale_dev + 1 : nullptr;
@@ -2021,7 +2023,7 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
                                     c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr,
                                     (emit || emit_bf16) ? &im : nullptr));
         c->unused_valid = false;
-        c->wchk_valid = (emit || emit_bf16) && c->wchk != nullptr;
+        c->wchk_valid = (emit || emit_bf16) && c->wchk != nullptr && c->dbg.own_check == 0;
         c->wimg_bf16_fresh = emit_bf16;
         if (emit) {
             // the bias of the next centred first pass and the column-norm maxima its margins need: W-only, so they are finished here

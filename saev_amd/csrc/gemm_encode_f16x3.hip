@@ -735,7 +735,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void encode_m16_kernel(EncodeF16Args a
     const int b0 = bb * HTB;
 
     const int nks = Dp / 32;  // k-steps per tile
-    const int rot = (bb & 7) % nks;  // see encode_f16x3_kernel
+    const int rot = a.no_rot ? 0 : (bb & 7) % nks;  // see encode_f16x3_kernel (saev_debug_cfg.enc_rot = 1: lock step)
     auto kmap = [&](int t) { const int k = t + rot; return k >= nks ? k - nks : k; };
 
     const size_t img = (size_t)256 * 32;  // halfs per image

@@ -172,6 +172,7 @@ struct DecodeArgs {
     // sets bit (latent, row) for it, so that the backward's build starts at its count pass (launch_csc_build: prefilled)
     uint32_t* csc_bitmap;
     int csc_words;
+    int k64_route;         // 32 < k <= 64: 0 = decode_q2_kernel (64 rows in registers, one gather each), 1 = the two-half decode_q_kernel<NW, 2>
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 // whether launch_decode forms dval_out for this shape (otherwise the pointer is ignored and pass A forms the products)
@@ -471,6 +472,7 @@ struct EncodeF16Args {
     const float* scale_dev;   // NULL or two device floats: extra power-of-two scales of the x and W images
     const float* scale_dev_b; // optional: the W images' scale lives elsewhere (*scale_dev_b instead of scale_dev[1])
     int s_splits;
+    int no_rot;            // 1: every workgroup walks the k-steps of a tile in the same order (saev_debug_cfg.enc_rot)
     float* h_out;             // EPI_DENSE
     int ngroups;              // EPI_TOPK: 32 (bound = min over 32 group maxima; needs top_k <= 32) or 64 (bound = top_k-th
                               // largest of 64 group maxima; top_k <= 64)

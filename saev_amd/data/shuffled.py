@@ -55,6 +55,31 @@ class Config:
     use_tmpdir: bool = False
 
 
+class _DeferredBatch(dict):
+    """A batch whose rows the consumer draws itself (``defer_gather``): ``{"act": None, "rows", "pool"}`` plus the cache indices
+    ``example_idx`` / ``token_idx`` of the rows, which are gathered only when somebody asks for them -- the train loop does on
+    its log steps (two indexing kernels and their dispatch per step otherwise, for values nobody reads)."""
+
+    _LAZY = ("example_idx", "token_idx")
+
+    def __init__(self, loader, rows):
+        super().__init__(act=None, rows=rows, pool=loader.pool)
+        self._loader = loader
+
+    def __missing__(self, key):
+        if key in self._LAZY:
+            value = getattr(self._loader, key)[self["rows"]]
+            self[key] = value
+            return value
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key in self._LAZY or super().__contains__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class DataLoader:
     """Iterable over shuffled batches of one epoch; re-iterable (a new permutation each epoch)."""
 
@@ -313,7 +338,7 @@ class DataLoader:
                 return
             if self.defer_gather and self.engine is not None:
                 # the consumer draws the rows itself, inside its train step (SaeEngine.train_step_gather): "act" is what it gets back
-                yield {"act": None, "rows": rows, "pool": self.pool, "example_idx": self.example_idx[rows], "token_idx": self.token_idx[rows]}
+                yield _DeferredBatch(self, rows)
                 continue
             if self.engine is not None:
                 act = self.engine.gather_rows(self.pool, rows)

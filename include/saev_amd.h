@@ -171,9 +171,6 @@ typedef struct {
                               (A/B measurements of the Adam launch only)                                                     */
     int32_t enc_rot;       /* fused encoder: 0 = the workgroups of an XCD that share a W_enc tile walk its k-steps rotated by one
                               step each, 1 = in lock step (same order: the tile's images are read by all of them at once)     */
-    int32_t dec_route;     /* register decode with 32 < top_k <= 64: 0 = all 64 decoder rows of a row's codes in registers, two columns
-                              per lane, every row gathered once; 1 = the round-5 kernel (two halves of 32 rows, the first half gathered
-                              twice)                                                                                         */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

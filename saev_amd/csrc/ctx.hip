@@ -1216,7 +1216,6 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
     a.upper = c->upper_c;
     a.gscale = 2.0f / ((float)n * (float)D * (float)c->P);
     a.training = training ? 1 : 0;
-    a.k64_route = c->dbg.dec_route == 1 ? 1 : 0;
     a.g = c->g; a.x_hat = c->x_hat; a.fired = c->fired; a.rowstats = c->rowstats;
     c->dws_rows = 0;
     c->dval_fwd = false;

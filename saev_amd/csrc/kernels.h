@@ -172,7 +172,6 @@ struct DecodeArgs {
     // sets bit (latent, row) for it, so that the backward's build starts at its count pass (launch_csc_build: prefilled)
     uint32_t* csc_bitmap;
     int csc_words;
-    int k64_route;         // 32 < k <= 64: 0 = decode_q2_kernel (64 rows in registers, one gather each), 1 = the two-half decode_q_kernel<NW, 2>
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
 // whether launch_decode forms dval_out for this shape (otherwise the pointer is ignored and pass A forms the products)

@@ -301,114 +301,6 @@ __global__ __launch_bounds__(64 * NW) void decode_q_kernel(DecodeArgs a) {
     }
 }
 
-// decode_q_kernel for 32 < k <= 64 with ALL 64 decoder rows of the codes in registers: the row is spread over NW2 = D / 128 waves, a
-// lane owns TWO columns (64 float2 = 128 registers), so every decoder row is gathered ONCE -- decode_q_kernel<NW, 2> holds 32 float4
-// rows and gathers the first half a second time for its dval (96 row gathers per activation row; configs[3]: 846 us).  x_hat is
-// summed in code order exactly as there (bit-identical); a dval is the sum of the lanes' two-column products, reduce-scattered
-// over the wave in two halves of 32 and added over the waves in wave order.
-template <int NW2>
-__global__ __launch_bounds__(64 * NW2) void decode_q2_kernel(DecodeArgs a) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef int i32x2_ __attribute__((ext_vector_type(2)));
-    __shared__ float sh_dv[NW2][64];
-    __shared__ float sh_f[NW2];
-    __shared__ double sh_d[NW2][2];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row = blockIdx.x;
-    constexpr int D2 = 64 * NW2;  // column pairs per row
-    const int q = w * 64 + lane;
-    const int32_t* idx_row = a.idx + (size_t)row * a.code_stride;
-    const float* val_row = a.val + (size_t)row * a.code_stride;
-    int32_t raw_i = -1;
-    float raw_v = 0.f;
-    if (lane < a.k) { raw_i = idx_row[lane]; raw_v = val_row[lane]; }
-    const int32_t my_i = (raw_i < 0 || raw_i >= a.idx_limit) ? -1 : raw_i;
-    f32x2 acc = reinterpret_cast<const f32x2*>(a.b_dec)[q];
-    const f32x2 xv = reinterpret_cast<const f32x2*>(a.x + (size_t)row * a.D)[q];
-    __builtin_amdgcn_sched_barrier(0);
-    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W_dec), 0, (uint32_t)a.S * (uint32_t)(D2 * 8), 0x00020000);
-    const uint32_t voff = (uint32_t)q * 8u;
-    f32x2 wv[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {  // all 64 gathers in flight together (an absent code reads row 0 and is not used)
-        const int i = __builtin_amdgcn_readlane(my_i, j);
-        const i32x2_ t = __builtin_amdgcn_raw_buffer_load_b64(wres, voff, (uint32_t)max(i, 0) * (uint32_t)(D2 * 8), 0);
-        wv[j] = f32x2{__int_as_float(t[0]), __int_as_float(t[1])};
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const int i = __builtin_amdgcn_readlane(my_i, j);
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw_v), j));
-        if (i >= 0) acc += v * wv[j];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (a.x_hat) reinterpret_cast<f32x2*>(a.x_hat + (size_t)row * a.D)[q] = acc;
-    const float u = a.upper ? fmaxf(*a.upper, 1e-12f) : 1.0f;
-    float sse_scaled = 0.f;
-    double sse64 = 0.0, sumsq64 = 0.0;
-    f32x2 g;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float t = acc[e] / u - xv[e] / u;
-        sse_scaled += t * t * u * u;
-        g[e] = a.gscale * t * u;
-        const float r = xv[e] - acc[e];
-        sse64 += (double)r * (double)r;
-        sumsq64 += (double)xv[e] * (double)xv[e];
-    }
-    if (a.training) {
-        reinterpret_cast<f32x2*>(a.g + (size_t)row * a.D)[q] = g;
-        if (a.gS != nullptr) {  // slice-major [D / 32][rows][32]: float4 (q >> 1) of the row, its half (q & 1)
-            const size_t o = (((size_t)(q >> 4) * a.n_rows + row) * 8 + ((q >> 1) & 7)) * 2 + (q & 1);
-            reinterpret_cast<f32x2*>(a.gS)[o] = g;
-            if (a.xS != nullptr) reinterpret_cast<f32x2*>(a.xS)[o] = xv;
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float pd[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) pd[j] = g[0] * wv[32 * h + j][0] + g[1] * wv[32 * h + j][1];
-        const float r = wave_reduce_scatter32(pd, lane);  // lane l: the wave's sum of pd[(l >> 1) & 31]
-        if ((lane & 1) == 0) sh_dv[w][32 * h + (lane >> 1)] = r;
-    }
-    sse_scaled = wave_sum(sse_scaled);
-    sse64 = wave_sum_d(sse64);
-    sumsq64 = wave_sum_d(sumsq64);
-    if (lane == 0) { sh_f[w] = sse_scaled; sh_d[w][0] = sse64; sh_d[w][1] = sumsq64; }
-    __syncthreads();
-    if (w != 0) return;
-    {
-        float s_ = sh_dv[0][lane];
-#pragma unroll
-        for (int v = 1; v < NW2; ++v) s_ += sh_dv[v][lane];
-        if (lane < a.k) a.dval_out[(size_t)row * a.code_stride + lane] = s_;
-    }
-    float l0 = 0.f, l1 = 0.f;
-    if (raw_i >= 0 && raw_v != 0.f) {
-        l0 = 1.f;
-        l1 = fabsf(raw_v);
-        if (a.training && a.fired) a.fired[raw_i] = 1;
-    }
-    csc_mark(a, raw_i, row);
-    if (a.rowstats) {
-        l0 = wave_sum(l0);
-        l1 = wave_sum(l1);
-        if (lane == 0) {
-            RowStats rs;
-            float f = sh_f[0];
-            double d0 = sh_d[0][0], d1 = sh_d[0][1];
-#pragma unroll
-            for (int v = 1; v < NW2; ++v) { f += sh_f[v]; d0 += sh_d[v][0]; d1 += sh_d[v][1]; }
-            rs.sse_scaled = f; rs.l0 = l0; rs.l1 = l1; rs.aux_sse = 0.f;
-            rs.sse64 = d0; rs.sumsq64 = d1;
-            a.rowstats[row] = rs;
-        }
-    }
-}
-
 // Matryoshka variant of decode_kernel: P nested reconstructions per row.  Codes are in ascending latent order, so
 // one sweep emits prefix p whenever the next code's latent reaches cuts[p].  Writes g_p = dL/dx_hat_p for every
 // prefix, turns them into suffix sums C_p (what a code in prefix block p receives from all reconstructions that
@@ -2057,12 +1949,13 @@ bool decode_matry_forms_dval(int D, int k) { return k <= 32 && D % 256 == 0 && D
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return hipSuccess;
     if (a.dval_out != nullptr && a.x != nullptr && decode_forms_dval(a.D, a.k)) {
-        // (32 < k <= 64: every decoder row gathered once, two columns per lane -- decode_q2_kernel; DecodeArgs::k64_route = 1 keeps the
-        // two-half kernel of round 5 for A/B runs)
+        // (32 < k <= 64 in two halves of 32 rows.  Round 6 built the one-pass form -- all 64 rows in registers, two columns per lane, 10
+        // waves per row at d_model 1280, every row gathered once: 64 x 8-byte loads per lane instead of 96 x 16-byte ones -- and measured
+        // it at configs[3]: 6.09-6.11 ms per step against 6.04-6.12, no gain (the gathers are bound by vector-memory INSTRUCTIONS, 640
+        // per row against 480, not by bytes); tools/experiments/wip_decode_q2.patch)
 #define DQ(NW)                                                                                                             \
     if (a.k <= 32) hipLaunchKernelGGL((decode_q_kernel<NW, 1>), dim3(a.n_rows), dim3(64 * NW), 0, stream, a);              \
-    else if (a.k64_route == 1) hipLaunchKernelGGL((decode_q_kernel<NW, 2>), dim3(a.n_rows), dim3(64 * NW), 0, stream, a);  \
-    else hipLaunchKernelGGL((decode_q2_kernel<2 * NW>), dim3(a.n_rows), dim3(128 * NW), 0, stream, a)
+    else hipLaunchKernelGGL((decode_q_kernel<NW, 2>), dim3(a.n_rows), dim3(64 * NW), 0, stream, a)
         switch (a.D / 256) {
             case 1: DQ(1); break;
             case 2: DQ(2); break;

@@ -167,6 +167,66 @@ def other_config_record(dev, *, name, d, s, k, b, encoder, n_prefixes=1, steps=1
     return rec
 
 
+def sweep_group_record(dev, n_saes=4, steps=20, warmup=8):
+    """The reference's main training mode (framework/train.py:334-348; grouping :669-695): `n_saes` SAEs of configs[1]'s shape on
+    the SAME batches, one after the other per batch, the first building what a step derives from x alone for all of them
+    (saev_share_x).  Reports the cost of a batch through the whole group, per SAE, beside one SAE alone on the same loop
+    (from random init, so both sides are in the same regime: compare with `single_ms_per_step`, not with the headline)."""
+    import dataclasses
+
+    from saev_amd.engine import EngineConfig, SaeEngine
+
+    ecfg = EngineConfig(d_model=D_MODEL, d_sae=D_SAE, top_k=TOP_K, max_batch=BATCH)
+    pool = synthetic_pool(dev, "mean", 8 * BATCH, D_MODEL)
+    x = torch.empty(BATCH, D_MODEL, device=dev)
+
+    def run(n):
+        engs = []
+        for j in range(n):
+            e = SaeEngine(ecfg, dev)
+            g = torch.Generator(device=dev).manual_seed(42 + j)
+            W = (torch.rand(D_SAE, D_MODEL, device=dev, generator=g) * 2 - 1) * math.sqrt(6.0 / D_MODEL)
+            W /= W.norm(dim=1, keepdim=True)
+            e.view("W_dec").copy_(W)
+            e.view("W_enc").copy_(W.t())
+            del W
+            if j:
+                e.share_x(engs[0])
+            engs.append(e)
+        rows = torch.arange(BATCH, device=dev)
+
+        def one(i):
+            lr = 4e-4 * min(1.0, i / 500)
+            r = rows + (i % 8) * BATCH
+            if n == 1:
+                engs[0].train_step_gather(pool, r, lr, 1.0, out=x)
+                return
+            engs[0].gather_rows(pool, r, out=x)
+            for e in engs:
+                e.train_step(x, lr, 1.0)
+
+        for i in range(warmup):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            one(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps * 1e3
+        for e in reversed(engs):
+            e.close()
+        del engs
+        torch.cuda.empty_cache()
+        return dt
+
+    single = run(1)
+    group = run(n_saes)
+    return {"n_saes": n_saes, "steps": steps, "group_ms_per_batch": group, "ms_per_sae": group / n_saes, "single_ms_per_step": single,
+            "per_sae_over_single": group / n_saes / single,
+            "note": "n_saes SAEs of configs[1]'s shape trained on the same batches (saev_share_x), first steps from random init; "
+                    "`single_ms_per_step` is one SAE alone on the same loop"}
+
+
 def vendor_gemm_record(dev, b=BATCH, d=D_MODEL, s=D_SAE, launches=200):
     """Anchor for the encoder's first pass (measurement only -- nothing in the product path calls a library GEMM): what the vendor
     fp16 GEMM (torch.matmul -> hipBLASLt) reaches on THIS box for the encoder's own contraction, `launches` back-to-back launches
@@ -564,11 +624,12 @@ def main():
                                        sparse_bytes_per_rank=sparse_rows * (8 * D_MODEL + 8 * TOP_K))
         collectives["note"] = ("RCCL on the live communicator, mean of 5 after 2 warm-up calls, max over ranks; busbw = algbw x 2(n-1)/n (all-reduce) "
                                "or x (n-1)/n (reduce-scatter / all-gather); the sparse step state is sized for 2 048 rows per rank")
-    vendor_gemm = data_regimes = train_e2e = None
+    vendor_gemm = data_regimes = train_e2e = sweep_group = None
     if world == 1 and not args.no_extras and B == BATCH:
         vendor_gemm = vendor_gemm_record(dev)
         data_regimes = [data_regime_record(dev, kind) for kind in ("isotropic", "lowrank")]
         train_e2e = train_e2e_record(dev)
+        sweep_group = sweep_group_record(dev)
     extract_e2e = None
     if world == 1 and args.extract_e2e:
         from tools.bench_extract_e2e import run as extract_run
@@ -672,6 +733,8 @@ def main():
             out["data_regimes"] = data_regimes
         if train_e2e is not None:
             out["train_e2e"] = train_e2e
+        if sweep_group is not None:
+            out["sweep_group"] = sweep_group
         if extract_e2e is not None:
             out["extract_e2e"] = extract_e2e
         if collectives is not None:

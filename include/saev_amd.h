@@ -171,6 +171,9 @@ typedef struct {
                               (A/B measurements of the Adam launch only)                                                     */
     int32_t enc_rot;       /* fused encoder: 0 = the workgroups of an XCD that share a W_enc tile walk its k-steps rotated by one
                               step each, 1 = in lock step (same order: the tile's images are read by all of them at once)     */
+    int32_t group_route;   /* several SAEs on the same batches (saev_share_x): 0 = the lender streams its preparation like a context on
+                              its own and every member's fused Adam leaves its own W_enc images (from the third step of a group nobody
+                              prepares anything from scratch), 1 = round 5: every member prepares from scratch on every step        */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

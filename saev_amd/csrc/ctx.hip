@@ -189,6 +189,15 @@ struct saev_ctx {
                                                           // back before using its images (and took the exact route); [1] the fused
                                                           // Adam found W_enc tiles changed AFTER the step had used them (AdamImageArgs::chk)
     uint32_t* wchk = nullptr;     // two checksum words per 32 x 256 tile of W_enc, left by the fused Adam that wrote it
+    // Several SAEs on the same batches (saev_share_x) with the streamed preparation: the lender streams as a context on its own does and
+    // keeps what its followers need of the step's x side (XprepArgs::mu_keep / xside_keep); a follower's fused Adam leaves ITS W images
+    // centred on the lender's next mu, so that from the third step of a group nobody prepares anything from scratch.
+    float *mu_keep = nullptr, *xside_keep = nullptr;
+    bool fwd_streamed = false;     // (lender) the forward that built the current x-derived buffers took the streamed preparation ...
+    bool fwd_moves_mu = false;     // ... inside saev_train_step: its second launch has moved mu on to this batch's mean
+    int64_t fwd_mu_serial = -1;    // ... with the centre of this serial
+    bool borrow_streamed = false;  // (follower) the forward in flight borrowed the x side of a streamed step of its lender
+    bool follow_stream = false;    // ... and runs on W images its own Adam left: no preparation at all
     bool wchk_valid = false;      // wchk describes W_enc as the library last wrote it, and only the library may have written it since
     bool fwd_reused_wimg = false; // the forward in flight ran on operand images a previous step's Adam left (their checksums are due)
     uint32_t stale_salt = 0;
@@ -439,6 +448,7 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     if (c->stream_ok) {
         A(WeS, S * D); A(xn_part, (size_t)(D / 32) * c->MB_pad * 2);
         A(amax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(cmax_part, (size_t)(c->MB_pad / 256) * (D / 32)); A(b_seen, S);
+        A(mu_keep, D); A(xside_keep, 4);
     }
     if (c->stream_ok || c->cfg.encoder_mode == SAEV_ENCODER_BF16) A(wchk, (size_t)2 * ((S + 255) / 256) * ((D + 31) / 32));
     A(toks, S); A(fired, S); A(dead, S); A(flags, 16); A(upper, 1); A(stats, 1);
@@ -728,6 +738,9 @@ static bool bind_x_sources(saev_ctx* c, const float* x, int n, bool allow_borrow
     const bool borrow = allow_borrow && l != nullptr && l->xprep_x == x && l->xprep_n == n && l->xprep_serial != c->leader_serial_seen;
     saev_ctx* src = borrow ? l : c;
     c->upper_c = src->upper; c->mu_c = src->mu; c->xnorm_c = src->xnorm; c->xabs_c = src->xabs_part; c->xs_c = src->xs;
+    // (a streamed step of the lender has moved its mu on already: the centre of the images it lends is the copy it kept)
+    c->borrow_streamed = borrow && l->fwd_streamed && l->mu_keep != nullptr;
+    if (c->borrow_streamed) c->mu_c = l->mu_keep;
     // (the slice route of the refinement needs the source's slice-major x as well: a leader without it sends this step down
     // the row route)
     c->fwd_step = c->fwd_slices && (src == c || src->fwd_slices);
@@ -775,6 +788,9 @@ static int prepare_encoder(saev_ctx* c, const float* x, int n, int32_t* pre_flag
         // (the x scale depends on x alone: a borrowing context recomputes the same value from the leader's maxima, next
         // to its own W scale.  Folding this reduction into center_stats_kernel's last workgroup was tried: a release fence
         // per workgroup of four rows took that kernel from 12 to 115 us)
+        if (c->borrow_streamed)  // (the lender's images carry the scale of ITS previous batch, not this batch's maxima)
+            HIPCHK(c, launch_follower_scales(c->leader->xside_keep, c->wmax_prev, scl(c), pre_flag != nullptr ? pre_flag : c->flags, 0, s));
+        else
         HIPCHK(c, launch_f16r_scales(c->xabs_c, (n + 3) / 4, c->wmax_prev, scl(c), s));
         // (the slice-major W_enc^T: in the gradient scratch, free until the backward -- or, where the streamed step may follow, in a
         // buffer of its own, so that it survives the backward)
@@ -905,7 +921,10 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
     const bool predict_mode = fused_supported(c->cfg) && c->cfg.bound_mode != 0 && c->cfg.encoder_mode != SAEV_ENCODER_F32 &&
                               f16_ngroups(c) == 32;
     const bool one_launch_pre = fused_supported(c->cfg) && !predict_mode;  // margins + encoder state + list flags in one launch
-    if (!c->stream_step) {
+    if (c->follow_stream) {
+        // nothing to prepare: the x side is the lender's, the W side this context's own Adam has left (its W scale with it)
+        HIPCHK(c, launch_follower_scales(c->leader->xside_keep, c->wmax_prev, scl(c), const_cast<int32_t*>(pre_flag), 1, s));
+    } else if (!c->stream_step) {
         int rc0 = prepare_encoder(c, x, n, const_cast<int32_t*>(pre_flag), s, xmax_dev, x_borrowed, one_launch_pre);
         if (rc0 != SAEV_OK) return rc0;
         rc0 = wait_wenc(c, s);  // (the f32 encoder has no preparation: it reads W_enc from here on)
@@ -1002,6 +1021,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 xp.xn_part = c->xn_part; xp.col_part = c->colsum_partials; xp.amax_part = c->amax_part; xp.cmax_part = c->cmax_part;
                 xp.W_enc = c->params + c->off_W_enc; xp.WeS = c->WeS; xp.b_enc = c->params + c->off_b_enc; xp.b_seen = c->b_seen;
                 xp.S = S_; xp.salt = ++c->stale_salt; xp.stale = c->flags + 12;
+                if (!c->followers.empty()) { xp.mu_keep = c->mu_keep; xp.xside_keep = c->xside_keep; }
                 HIPCHK(c, launch_xprep(xp, s));
                 PreEncode2Args pe{};
                 pe.cand_cnt = c->cand_cnt; pe.n_rows = n; pe.gmax = c->gmax; pe.n_gmax = ng * c->gmax_stride;
@@ -1012,6 +1032,7 @@ static int encode_topk_impl(saev_ctx* c, const float* x, int n, int32_t* idx_out
                 pe.inv_n = 1.0f / (float)n; pe.update_mu = c->train_fused ? 1 : 0;
                 pe.amax_part = c->amax_part; pe.cmax_part = c->cmax_part; pe.n_img = ((n + 255) / 256) * (D_ / 32);
                 pe.upper = c->upper; pe.stats = c->stats; pe.stale = c->flags + 12; pe.stale_host = c->stale_dev;
+                pe.xside_keep = c->followers.empty() ? nullptr : c->xside_keep;
                 HIPCHK(c, launch_pre_encode2(pe, s));
                 if (c->train_fused) c->mu_serial++;
             } else
@@ -1055,6 +1076,7 @@ int saev_encode_topk(saev_ctx* c, const float* x, int32_t n, int32_t* idx_out, f
     // streamed from may be stale by now (a parameter write announced through saev_params_touched, an unfused tail); the streamed
     // launches would also clear the step's statistics and max |x|, which are not this call's to touch.
     c->stream_step = false;
+    c->follow_stream = false;
     return encode_topk_impl(c, x, n, idx_out, val_out, c->flags, s);
 }
 
@@ -1163,9 +1185,18 @@ int saev_step_forward(saev_ctx* c, const float* x, int32_t n, int64_t n_rows_glo
         c->wimg_fresh = false;
         c->wn2_fresh = false;
     }
+    // (a lender streams like a context on its own; what its followers need beyond its second launch it keeps: XprepArgs::mu_keep)
     c->stream_step = c->stream_ok && c->prep_valid && c->wimg_fresh && c->wimg_mu_serial == c->mu_serial && c->leader == nullptr &&
-                     c->followers.empty() && c->wenc_ready == nullptr && c->fwd_step;
-    c->fwd_reused_wimg = c->stream_step;  // (the bf16 encoder decides in prepare_encoder)
+                     c->wenc_ready == nullptr && c->fwd_step && (c->followers.empty() || c->dbg.group_route == 0);
+    if (!borrowed) {
+        c->fwd_streamed = c->stream_step;
+        c->fwd_moves_mu = c->stream_step && c->train_fused;
+        c->fwd_mu_serial = c->mu_serial;
+    }
+    // A follower of a streamed step whose own Adam has left W images centred on that very mu prepares nothing at all.
+    c->follow_stream = borrowed && c->borrow_streamed && c->stream_ok && c->wimg_fresh && c->wimg_mu_serial == c->leader->fwd_mu_serial &&
+                       c->wenc_ready == nullptr && c->fwd_step && c->cfg.encoder_mode == SAEV_ENCODER_F16R;
+    c->fwd_reused_wimg = c->stream_step || c->follow_stream;  // (the bf16 encoder decides in prepare_encoder)
     if (c->gather_pool != nullptr && !c->stream_step)  // (the batch as a contiguous matrix first: every other route reads x itself)
         HIPCHK(c, launch_gather_rows(c->gather_pool, c->gather_rows, n, D, const_cast<float*>(x), s));
     if (c->stream_step) {
@@ -1983,8 +2014,12 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
     if (rc != SAEV_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     c->wn2_fresh = false;  // (W_dec moves)
-    const bool emit = c->train_fused && c->stream_ok && c->prep_valid && c->leader == nullptr && c->followers.empty() && shard_rank < 0 &&
-                      c->tail_proj_in_adam && c->wenc_t_pending;
+    // (a follower's images are centred on its lender's NEXT mu -- there once the lender's step, which ran first, was a streamed
+    // saev_train_step: fwd_moves_mu -- and carry the lender's serial of it)
+    const bool emit_follow = c->leader != nullptr && c->borrow_streamed && c->leader->fwd_moves_mu && c->dbg.group_route == 0 &&
+                             c->cfg.encoder_mode == SAEV_ENCODER_F16R && c->fwd_step;
+    const bool emit = c->train_fused && c->stream_ok && (c->leader == nullptr ? c->prep_valid && (c->followers.empty() || c->dbg.group_route == 0) : emit_follow) &&
+                      shard_rank < 0 && c->tail_proj_in_adam && c->wenc_t_pending;
     c->wimg_fresh = false;  // (W_enc moves: only the fused Adam below leaves images of what it writes)
     const bool chk_was_valid = c->wchk_valid;
     c->wchk_valid = false;
@@ -2008,7 +2043,7 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
             // normaliser on to the next one (a streamed step's second launch has written them already)
             if (!c->stream_step) HIPCHK(c, hipMemcpyAsync(scl_next(c), scl(c), 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
             im.ws = c->ws; im.WeS = c->WeS; im.dot_part = reinterpret_cast<double*>(c->dot_part); im.sq_part = c->sq_part;
-            im.mu = c->mu; im.wmax_prev = c->wmax_prev; im.scales_next = scl_next(c); im.nks = c->Dp / 32; im.S_pad = c->S_pad;
+            im.mu = c->leader != nullptr ? c->leader->mu : c->mu; im.wmax_prev = c->wmax_prev; im.scales_next = scl_next(c); im.nks = c->Dp / 32; im.S_pad = c->S_pad;
         }
         if (emit_bf16) { im.ws = c->ws; im.nks = c->Dp / 32; im.S_pad = c->S_pad; im.mode = 1; }
         if ((emit || emit_bf16) && c->wchk != nullptr && c->dbg.own_check == 0) {
@@ -2016,7 +2051,7 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
             // compared with what that Adam left (an evaluation forward in between changes nothing: W_enc did not move)
             im.chk = c->wchk; im.late = c->stale_dev != nullptr ? c->stale_dev + 1 : nullptr;
             im.verify = (chk_was_valid && c->fwd_reused_wimg && im.late != nullptr) ? 1 : 0;
-            im.early = emit ? c->flags + 13 : nullptr;
+            im.early = (emit && c->leader == nullptr) ? c->flags + 13 : nullptr;  // (a follower's first kernels do not look at W_enc)
         }
         HIPCHK(c, launch_adam_fused(a, c->row_proj, c->dW_encT, (int)S, (int)D, S * D, c->off_W_enc - S * D, c->off_W_enc,
                                     c->off_b_enc, c->n_params - c->off_b_enc, s, c->unused_valid ? c->lat_unused : nullptr,
@@ -2030,7 +2065,7 @@ int saev_tail_apply(saev_ctx* c, float lr, float max_norm, float grad_scale, int
                                          c->params + c->off_b_enc, c->b_shift, c->wnorm_scratch, s, c->b_seen));
             c->scale_par ^= 1;
             c->wimg_fresh = true;
-            c->wimg_mu_serial = c->mu_serial;
+            c->wimg_mu_serial = c->leader != nullptr ? c->leader->mu_serial : c->mu_serial;
         }
         return SAEV_OK;
     }

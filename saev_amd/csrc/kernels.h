@@ -541,6 +541,10 @@ struct XprepArgs {
     // with certainty at the END of the step, by the tile checksums of the fused Adam: AdamImageArgs::chk).
     const float* W_enc; const float* WeS; const float* b_enc; const float* b_seen;
     int S; uint32_t salt; int32_t* stale;
+    // A context that LENDS its x-derived buffers (saev_share_x) keeps what its followers need of this step's x side beyond the
+    // step's second launch, which moves mu on: mu_keep (D) = the centre these images were formed with, xside_keep[0] = their scale
+    // (workgroup 0 copies both; pre_encode2_kernel adds xside_keep[1] != 0 when the images left fp16's range).  NULL otherwise.
+    float* mu_keep; float* xside_keep;
 };
 hipError_t launch_xprep(const XprepArgs& a, hipStream_t stream);
 // ... and its second launch (select.hip: pre_encode2_kernel): row norms / margins, encoder state, batch maxima, flags, next mu.
@@ -561,10 +565,15 @@ struct PreEncode2Args {
     const float* amax_part; const float* cmax_part; int n_img;
     float* upper;                            // max |x| of this batch
     int32_t* stale; int32_t* stale_host;     // XprepArgs::stale (consumed and cleared here); optional pinned word the host polls
+    float* xside_keep;                       // optional: [1] = 1 when this step's x images are unusable (XprepArgs::xside_keep)
     saev_step_stats* stats;                  // zeroed
     int nb_rows;                             // (set by the launcher)
 };
 hipError_t launch_pre_encode2(PreEncode2Args a, hipStream_t stream);
+// A context that borrows the x side of a STREAMED step (saev_share_x): scales[0] = scales[2] = the x scale of the lender's images,
+// scales[3] = 1, scales[1] = the power-of-two W scale from *wmax unless keep_w (its own Adam has left it); the lender's verdict on the
+// images (xside[1] != 0: out of fp16's range) raises *pre_flag.
+hipError_t launch_follower_scales(const float* xside, const float* wmax, float* scales, int32_t* pre_flag, int keep_w, hipStream_t stream);
 hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, const float* scales, const float* mu, const float* W,
                              int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream,
                              float* xS = nullptr, int wt_slices = 0);

@@ -1050,6 +1050,7 @@ __global__ __launch_bounds__(256) void pre_encode2_kernel(PreEncode2Args a) {
         int pre = 0;
         if (!f16r_scale_ok(wmax, a.scales[1])) pre = 1;
         if (!(cmax * x_scale < 60000.0f)) pre = 1;  // an element of this step's x image left fp16's range (or is not finite)
+        if (a.xside_keep != nullptr && !(cmax * x_scale < 60000.0f)) a.xside_keep[1] = 1.0f;  // (the followers' images are the same ones)
         if (a.stale != nullptr) {
             const bool caught = *a.stale != 0;  // the parameters are not the ones the images were made of (XprepArgs::stale)
             if (caught) {
@@ -1088,6 +1089,17 @@ __global__ __launch_bounds__(256) void pre_encode2_kernel(PreEncode2Args a) {
     const float xn = back * sqrtf(s2) * 1.000001f, xd = back * sqrtf(d2) * 1.000002f;  // (rounded up: they bound errors)
     if (a.xnorm != nullptr) { a.xnorm[2 * i] = xn; a.xnorm[2 * i + 1] = xd; }
     a.margin[i] = f16r_margin(xn, xd, wmax, dwmax, bmax, a.D, x_scale);
+}
+__global__ void follower_scales_kernel(const float* xside, const float* wmax, float* scales, int32_t* pre_flag, int keep_w) {
+    if (threadIdx.x != 0) return;
+    scales[0] = xside[0];
+    scales[2] = xside[0];
+    scales[3] = 1.0f;
+    if (!keep_w) {
+        const float wm = *wmax;
+        scales[1] = (wm > 0.f && wm < 3.0e38f) ? exp2f(13.0f - floorf(log2f(wm))) : 1.0f;
+    }
+    if (xside[1] != 0.f) *pre_flag = 1;
 }
 // {2^e, 1} with 2^e * absmax in [2^13, 2^14): operand scale for an fp16 split of a matrix whose magnitude is only known
 // on the device (AuxK codes and gradients)
@@ -1222,6 +1234,10 @@ hipError_t launch_pre_encode(int32_t* cand_cnt, int n_rows, int32_t* gmax, int n
     const int n = std::max(1, n_rows > n_gmax ? n_rows : n_gmax);
     hipLaunchKernelGGL(pre_encode_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cand_cnt, n_rows, gmax, n_gmax, xnorm, D,
                        wg_part, n_part, scales, pre_flag, wmax_prev, margin, flags1);
+    return hipGetLastError();
+}
+hipError_t launch_follower_scales(const float* xside, const float* wmax, float* scales, int32_t* pre_flag, int keep_w, hipStream_t stream) {
+    hipLaunchKernelGGL(follower_scales_kernel, dim3(1), dim3(64), 0, stream, xside, wmax, scales, pre_flag, keep_w);
     return hipGetLastError();
 }
 hipError_t launch_pre_encode2(PreEncode2Args a, hipStream_t stream) {

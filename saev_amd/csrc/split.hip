@@ -272,6 +272,10 @@ __global__ __launch_bounds__(1024) void xprep_kernel(XprepArgs a) {
         a.amax_part[bid] = m0;
         a.cmax_part[bid] = m1;
     }
+    if (a.mu_keep != nullptr && bid == 0 && i >= 192) {  // (the lender's snapshot: waves 3.. of workgroup 0)
+        for (int d = i - 192; d < a.D; d += 1024 - 192) a.mu_keep[d] = a.mu[d];
+        if (i == 192) { a.xside_keep[0] = scale; a.xside_keep[1] = 0.f; }
+    }
     if (a.stale != nullptr && i >= 64 && i < 66) {  // the W_enc samples of XprepArgs::stale (a wave that has nothing else left to do)
         uint32_t h = ((uint32_t)bid * 3u + (uint32_t)(i - 64)) * 2654435761u + a.salt * 40503u;
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;

@@ -323,38 +323,36 @@ class DataLoader:
         finally:
             res.stop()
 
-    def _draw_perm(self, epoch: int) -> torch.Tensor:
-        g = torch.Generator().manual_seed(self.cfg.seed + 1000 * epoch + self.rank)
-        perm = torch.randperm(self.n_local, generator=g)[: self.n_epoch]
-        return perm.pin_memory() if self.device.type == "cuda" else perm
-
     def _take_perm(self, epoch: int) -> torch.Tensor:
-        """This epoch's permutation -- from the helper thread if it has drawn it -- and the request for the next one."""
-        import concurrent.futures
-
-        ahead = self.__dict__.get("_perm_ahead")
-        perm = ahead[1].result() if ahead is not None and ahead[0] == epoch else self._draw_perm(epoch)
-        if self.device.type == "cuda":
-            pool = self.__dict__.get("_perm_pool")
-            if pool is None:
-                pool = self._perm_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="saev-perm")
-            self._perm_ahead = (epoch + 1, pool.submit(self._draw_perm, epoch + 1))
+        """This epoch's row order on the device.  Drawn on the host (the order is then independent of the device type: tests replay
+        it on CPU) into one of two page-locked staging buffers and uploaded WITHOUT blocking: a pageable ``.to(device)`` is a
+        synchronous copy behind everything the stream still holds -- the host then sits out the whole queue at every epoch
+        boundary and the device runs dry while it catches up (profiles/r06_train_host_profile.txt: ~10 ms per epoch, the gap
+        between train() and the bare engine loop on a slow host)."""
+        g = torch.Generator().manual_seed(self.cfg.seed + 1000 * epoch + self.rank)
+        if self.device.type != "cuda":
+            return torch.randperm(self.n_local, generator=g)[: self.n_epoch].to(self.device)
+        stage = self.__dict__.get("_perm_stage")
+        if stage is None or stage[0][0].numel() != self.n_local:
+            stage = self._perm_stage = [[torch.empty(self.n_local, dtype=torch.int64).pin_memory(), None] for _ in range(2)]
+        buf, done = stage[epoch % 2]
+        if done is not None:
+            done.synchronize()  # (the upload of two epochs ago has long run; an epoch of one or two steps is the exception)
+        torch.randperm(self.n_local, generator=g, out=buf)
+        perm = buf[: self.n_epoch].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        stage[epoch % 2][1] = ev
         return perm
 
     def __iter__(self):
         if self.reservoir is not None:
             yield from self._iter_streaming()
             return
-        # host-side permutation: the row order is then independent of the device type (tests replay it on CPU).  The NEXT epoch's
-        # is drawn by a helper thread while this one trains: randperm over a million rows plus its upload is ~10 ms of host time,
-        # and a host that stops for that long at every epoch boundary lets the device run dry (the train loop keeps only a few
-        # steps queued) -- profiles/r06_train_host_profile.txt: 0.3 ms per step at a 32-batch pool, the whole gap between
-        # train() and the bare engine loop.
+        # (host-side permutation, uploaded without blocking: _take_perm)
         epoch = self._epoch
         self._epoch += 1
-        perm_host = self._take_perm(epoch)
-        self._perm_keep = perm_host  # (a non-blocking upload reads it until the copy has run)
-        perm = perm_host.to(self.device, non_blocking=True)
+        perm = self._take_perm(epoch)
         B = self.local_batch
         for lo in range(0, self.n_epoch, B):
             rows = perm[lo : lo + B]

@@ -655,14 +655,10 @@ def main():
                 "kernel_ms": enc_ms, "traffic": None}
         # HBM/fabric bytes per launch of that kernel come from rocprofv3 PMC passes (they cannot be collected inside the
         # timed run); the committed summaries are the source, and they only apply to the shape/encoder they were taken on
-        tfile = {"f16x3": ROOT / "profiles" / "r01_d_encoder_traffic.json",
-                 "f16r": ROOT / "profiles" / "r05_encoder_traffic.json"}.get(eng.cfg.encoder)
-        if tfile is not None and not tfile.exists() and eng.cfg.encoder == "f16r":
-            tfile = ROOT / "profiles" / "r04_encoder_traffic.json"
-        if tfile is not None and not tfile.exists() and eng.cfg.encoder == "f16r":
-            tfile = ROOT / "profiles" / "r03_encoder_traffic.json"
-        if tfile is not None and not tfile.exists() and eng.cfg.encoder == "f16r":
-            tfile = ROOT / "profiles" / "r02_encoder_traffic.json"
+        tfile = {"f16x3": ROOT / "profiles" / "r01_d_encoder_traffic.json"}.get(eng.cfg.encoder)
+        if eng.cfg.encoder == "f16r":  # (the newest committed PMC summary of this kernel)
+            tfile = next((ROOT / "profiles" / f"r0{r}_encoder_traffic.json" for r in (6, 5, 4, 3, 2)
+                          if (ROOT / "profiles" / f"r0{r}_encoder_traffic.json").exists()), None)
         # what a register-resident loop of the same MFMA sustains on random fp16 operands (tools/ubench/mfma_issue.hip,
         # profiles/r02_mfma_issue.txt): the matrix pipes are clock-limited by power on real data
         roof["power_limited_mfma_ceiling_tflops"] = 1930.0 if eng.cfg.encoder in ("f16r", "bf16") else 1690.0  # 16x16x32 / 32x32x16

@@ -245,6 +245,7 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
         dataloader.defer_gather = True
 
     global_step, n_patches_seen = 0, 0
+    drawn_buf = None
     t_start = time.time()
     for batch in limiter:
         x = batch["act"]
@@ -264,7 +265,10 @@ def train(cfgs: list[Config], *, train_pool: Tensor | None = None, train_feed=No
             if c.objective.n_prefixes > 1:
                 st.engine.set_prefixes(objectives.sample_prefixes(c.sae.d_sae, c.objective.n_prefixes))
             if drawn_by_step and i == 0:
-                x = st.engine.train_step_gather(batch["pool"], batch["rows"], lrs[i], c.grad_clip)
+                # (the drawn batch lands in one buffer that every step reuses: it is read by this step's group only)
+                if drawn_buf is None or drawn_buf.shape[0] != len(batch["rows"]):
+                    drawn_buf = torch.empty(len(batch["rows"]), batch["pool"].shape[1], device=batch["pool"].device, dtype=torch.float32)
+                x = st.engine.train_step_gather(batch["pool"], batch["rows"], lrs[i], c.grad_clip, out=drawn_buf)
                 lrs[i] = scheds[i].step()
                 continue
             if log_now:

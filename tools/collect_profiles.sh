@@ -18,5 +18,5 @@ for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BU
 done
 python tools/pmc_summary.py $W "$OUT/${TAG}_pmc.txt" "$OUT/${TAG}_encoder_traffic.json" "$TAG"
 # the bench line last, so that its roofline block can cite the traffic file just written (bench.py reads profiles/)
-mkdir -p profiles && cp "$OUT/${TAG}_encoder_traffic.json" profiles/r05_encoder_traffic.json 2>/dev/null
+mkdir -p profiles && cp "$OUT/${TAG}_encoder_traffic.json" profiles/r06_encoder_traffic.json 2>/dev/null
 python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line.json"

@@ -521,18 +521,25 @@ int saev_create_ex(const saev_cfg* cfg, const saev_debug_cfg* dbg, int device, s
     return SAEV_OK;
 }
 
+// (W images a context keeps are centred on a mu identified by a SERIAL of whoever owned that mu: its lender's while it follows,
+// its own otherwise.  Serials of different contexts are unrelated numbers, so the images are dropped whenever the owner changes --
+// an equal number must never pass for an equal centre.)
 static void unlink_from_leader(saev_ctx* c) {
     if (c->leader != nullptr) {
         auto& f = c->leader->followers;
         f.erase(std::remove(f.begin(), f.end(), c), f.end());
         c->leader = nullptr;
+        c->wimg_fresh = false;
+        c->wchk_valid = false;
+        c->borrow_streamed = false;
+        c->follow_stream = false;
     }
 }
 
 void saev_destroy(saev_ctx* c) {
     if (!c) return;
     // no dangling links either way: followers fall back to their own x-derived buffers, the leader forgets this context
-    for (saev_ctx* f : c->followers) f->leader = nullptr;
+    for (saev_ctx* f : c->followers) { f->leader = nullptr; f->wimg_fresh = false; f->wchk_valid = false; f->borrow_streamed = false; f->follow_stream = false; }
     c->followers.clear();
     unlink_from_leader(c);
     hipSetDevice(c->device);
@@ -637,6 +644,8 @@ int saev_share_x(saev_ctx* c, saev_ctx* leader) {
     REQUIRE(c, c->followers.empty(), SAEV_INVALID_ARG, "saev_share_x: a context that lends its buffers cannot borrow");
     unlink_from_leader(c);
     c->leader = leader;
+    c->wimg_fresh = false;  // (see unlink_from_leader: the images' centre changes owner)
+    c->wchk_valid = false;
     leader->followers.push_back(c);
     c->leader_serial_seen = leader->xprep_serial;  // nothing built before this call is borrowed
     return SAEV_OK;

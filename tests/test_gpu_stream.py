@@ -356,3 +356,50 @@ def test_module_parameter_writes_are_seen_by_an_engine_driven_directly():
     assert (idx == 9).any(dim=1).all() and eng.read_stats().dense_route == 0
     eng.train_step(xs[4], 1e-4, 1.0)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("group_route", [0, 1])
+def test_a_group_streams_through_writes_evaluations_and_relinking(group_route):
+    """saev_share_x with the streamed preparation: the lender streams, the followers run on W images their own Adam
+    left -- through an announced write to a FOLLOWER's parameters (its images are dropped: it prepares its W side with the centre the
+    lender kept), one to the LENDER's (it prepares from scratch: the followers' images no longer match its centre), an evaluation
+    forward of the whole group in between, a smaller batch, and a member that leaves the group.  Every member must end with bit for
+    bit the parameters it gets when trained alone on the same batches with the same interventions; group_route = 1 is round 5's
+    behaviour (every member prepares from scratch on every step), the same contract."""
+    d, s, k, b = 256, 2048, 16, 512
+    xs = _batches(d, b, 12, seed=91)
+    ev = _batches(d, 300, 1, seed=92)[0]
+
+    def run(members, grouped):
+        engs = [_engine(d, s, k, b, 0, seed=93 + j, group_route=group_route, k_aux=32, dead_threshold_tokens=3 * b) for j in members]
+        if grouped:
+            for e in engs[1:]:
+                e.share_x(engs[0])
+        for i, x in enumerate(xs):
+            if i == 4:
+                for j, e in zip(members, engs):
+                    if j == 1:
+                        e.view("W_enc").data[:, 5] *= 1.5
+                        e.params_touched()
+            if i == 6:
+                for e in engs:
+                    e.step_forward(ev, training=False)
+            if i == 8:
+                for j, e in zip(members, engs):
+                    if j == 0:
+                        e.view("b_enc").data.add_(0.01)
+                        e.params_touched()
+            if i == 10 and grouped and len(engs) > 2:
+                engs[2].share_x(None)  # leaves the group: on its own from here on
+            x_used = x[:400].contiguous() if i == 9 else x
+            for e in engs:
+                e.train_step(x_used, 1e-3, 1.0)
+                assert e.read_stats().dense_route == 0, i
+        torch.cuda.synchronize()
+        return engs
+
+    group = run([0, 1, 2], True)
+    for j in range(3):
+        alone = run([j], False)[0]
+        assert torch.equal(alone.params, group[j].params), f"member {j}: the group run differs from the single run"
+        assert torch.equal(alone.adam_v, group[j].adam_v) and torch.equal(alone.toks_since_active, group[j].toks_since_active)

@@ -174,6 +174,9 @@ typedef struct {
     int32_t group_route;   /* several SAEs on the same batches (saev_share_x): 0 = the lender streams its preparation like a context on
                               its own and every member's fused Adam leaves its own W_enc images (from the third step of a group nobody
                               prepares anything from scratch), 1 = round 5: every member prepares from scratch on every step        */
+    int32_t aux_split_route; /* dense AuxK route, operand images of the split-fp16 contractions: 0 = the codes, g_aux, x and the dead latents'
+                              decoder rows written in BOTH operand forms by one pass each (six image launches), 1 = round 5: one launch
+                              per form (ten)                                                                                  */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

@@ -162,7 +162,8 @@ struct saev_ctx {
     bool aux_all = false;    // dense branch with every dead latent selected (n_dead <= k_aux): no select, no mask
     uint8_t* A_mask = nullptr;
     // AuxK contractions on the f16x3 encoder kernel (F16X3 mode): operand images and compact vectors
-    _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr, *aux_kA = nullptr, *aux_kD = nullptr;
+    _Float16 *aux_ws1 = nullptr, *aux_ws2 = nullptr, *aux_xsA = nullptr, *aux_xsg = nullptr, *aux_kA = nullptr, *aux_kD = nullptr, *aux_kX = nullptr;
+    bool aux_both = false;  // the dense route's forward has left the k-major images of A (aux_kA) and x (aux_kX) beside the row-form ones
     float* aux_parts = nullptr;
     int aux_kpad = 0;
     float *bias_dead = nullptr, *zero_bias = nullptr, *aux_scales = nullptr;  // aux_scales: {absmax, -, sA, 1, sg, 1}
@@ -1344,8 +1345,9 @@ int alloc_aux_buffers(saev_ctx* c, int cap) {
         c->aux_kpad = (int)((MB + 16 * AUX_KSPLIT_MAX - 1) / (16 * AUX_KSPLIT_MAX) * (16 * AUX_KSPLIT_MAX));
         c->aux_kA = (_Float16*)grab(cap256 * 2 * (size_t)c->aux_kpad * sizeof(_Float16));   // A^T, later dA^T
         c->aux_kD = (_Float16*)grab(D256 * 2 * (size_t)c->aux_kpad * sizeof(_Float16));     // g_aux^T, later x^T
+        c->aux_kX = (_Float16*)grab(D256 * 2 * (size_t)c->aux_kpad * sizeof(_Float16));     // x^T when the forward writes both forms of x at once (split_both_kernel)
         c->aux_parts = (float*)grab((size_t)AUX_KSPLIT_MAX * cap * D * sizeof(float));
-        fast_ok = c->aux_ws1 && c->aux_ws2 && c->aux_xsA && c->aux_xsg && c->bias_dead && c->aux_kA && c->aux_kD && c->aux_parts;
+        fast_ok = c->aux_ws1 && c->aux_ws2 && c->aux_xsA && c->aux_xsg && c->bias_dead && c->aux_kA && c->aux_kD && c->aux_kX && c->aux_parts;
     }
     if (!fast_ok || !c->Wenc_dead || !c->Wdec_dead || !c->H_dead || !c->A_dead || !c->A_mask || !c->dWd || !c->dWe || !c->dbe ||
         !c->aux_partials || !c->WencT_dead || !c->aux_small_part || !c->aux_small_part2) {
@@ -1377,18 +1379,26 @@ int dense_f16x3(saev_ctx* c, const _Float16* xs, const _Float16* ws, const float
 // P (K x R), Q (K x C): the AuxK weight gradients.  Both are split into hi/lo fp16 images of their transposes
 // (split_wT), the contraction is cut into n_split slices that run as one batched launch of the encoder kernel (a single
 // slice would leave most CUs idle: R x C is only a few tiles), and the slices are added in a fixed order.
-int ksplit_f16x3(saev_ctx* c, const float* P, const float* sP, int R, const float* Q, const float* sQ, int C, int K,
-                 float* out, hipStream_t s) {
+// (slices and padded length of the batch-long contraction of an R x C weight gradient: the images of its operands are laid out for them)
+void ksplit_shape(int R, int C, int K, int* n_split_out, int* Kp_out) {
     const int R256 = (R + 255) / 256 * 256, C256 = (C + 255) / 256 * 256;
     const int tiles = (R256 / 256) * (C256 / 256);
     int n_split = 1;
     while (n_split < AUX_KSPLIT_MAX && tiles * n_split < 256) n_split *= 2;
-    const int Kp = (K + 16 * n_split - 1) / (16 * n_split) * (16 * n_split);  // <= aux_kpad
-    HIPCHK(c, launch_split_wT(P, K, R, R256, Kp, 1.0f, c->aux_kA, 0, s, sP));
-    HIPCHK(c, launch_split_wT(Q, K, C, C256, Kp, 1.0f, c->aux_kD, 0, s, sQ));
+    *n_split_out = n_split;
+    *Kp_out = (K + 16 * n_split - 1) / (16 * n_split) * (16 * n_split);  // <= aux_kpad
+}
+// imgP / imgQ: the operand's k-major images if somebody has written them already (split_both_kernel, with THIS Kp), else NULL
+int ksplit_f16x3(saev_ctx* c, const float* P, const float* sP, int R, const float* Q, const float* sQ, int C, int K,
+                 float* out, hipStream_t s, const _Float16* imgP = nullptr, const _Float16* imgQ = nullptr) {
+    const int R256 = (R + 255) / 256 * 256, C256 = (C + 255) / 256 * 256;
+    int n_split, Kp;
+    ksplit_shape(R, C, K, &n_split, &Kp);
+    if (imgP == nullptr) { HIPCHK(c, launch_split_wT(P, K, R, R256, Kp, 1.0f, c->aux_kA, 0, s, sP)); imgP = c->aux_kA; }
+    if (imgQ == nullptr) { HIPCHK(c, launch_split_wT(Q, K, C, C256, Kp, 1.0f, c->aux_kD, 0, s, sQ)); imgQ = c->aux_kD; }
     EncodeF16Args a{};
     a.scale_dev = sP; a.scale_dev_b = sQ;  // (the two operands' scales where their producers left them)
-    a.xs = c->aux_kA; a.ws = c->aux_kD; a.b_enc = c->zero_bias;
+    a.xs = imgP; a.ws = imgQ; a.b_enc = c->zero_bias;
     a.n_rows = R; a.Dp = Kp / n_split; a.S = C; a.w_scale = 1.0f; a.arith = 0;
     a.s_splits = encoder_splits(R, C, encode_f16x3_tile_rows(), encode_f16x3_tile_latents(), 256);
     a.ngroups = 32;
@@ -1454,6 +1464,9 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
     // the exact pre-activations (the bf16 mode's oracle does the same).  Only the f16x3 mode already has hi/lo x images.
     const bool own_images = c->cfg.encoder_mode != SAEV_ENCODER_F16X3;
     const int ndp256 = (ndp + 255) / 256 * 256, Dp2 = (ndp + 31) / 32 * 32;
+    // Operand images in both forms from one pass over their source (split.hip: split_both_kernel): six image launches instead of
+    // ten, bit-identical images (saev_debug_cfg.aux_split_route = 1 keeps the ten)
+    c->aux_both = own_images && c->dbg.aux_split_route == 0 && D % 4 == 0;
     // aux_dev_count: nd / ku are upper bounds (the tracker record of a few steps ago, saev_step_dead); the true count and
     // min(k_aux, count) are flags[4] / flags[5].  Columns of the dead set past the true count are padding -- zero weights,
     // bias -inf (never selected) or 0 (all-selected mode) -- exactly like the columns that pad nd to a multiple of four,
@@ -1475,6 +1488,11 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         if (own_images) {  // the step's x images are single fp16 / bf16 or absent: make the hi/lo ones (the buffer is free until the backward)
             // (with the step's power-of-two x scale, so that no activation magnitude can overflow fp16)
             HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));  // from max|x| of the step (uncentred here)
+            if (c->aux_both) {  // ... and its k-major images for the backward's dWe, from the same pass over x
+                int ns, Kp;
+                ksplit_shape(ndp, D, n, &ns, &Kp);
+                HIPCHK(c, launch_split_both(c->x_last, n, D, 1.0f, c->aux_scales + 6, c->aux_xsg, c->Dp, c->aux_kX, Kp, s));
+            } else
             HIPCHK(c, launch_split_rows(c->x_last, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 6));
             xs_hl = c->aux_xsg;
         }
@@ -1501,8 +1519,17 @@ int auxk_forward(saev_ctx* c, hipStream_t s) {
         // E = A W_dec[dl]: rows = batch, contraction over the dead set, "latents" = the d_model outputs
         // (the codes are pre-activations of unknown magnitude: power-of-two scale from their device-side max)
         if (c->aux_all || !fused_select) HIPCHK(c, launch_absmax_pow2(c->A_dead, (long)n * ndp, c->aux_sync, c->aux_scales + 2, s));
+        if (c->aux_both) {
+            int ns, Kp;
+            ksplit_shape(ndp, D, n, &ns, &Kp);
+            // the codes as a row operand (E) and k-major (dWd); the dead latents' decoder rows k-major (E) and as a row operand (dA:
+            // aux_ws1 is free again, H is done)
+            HIPCHK(c, launch_split_both(c->A_dead, n, ndp, 1.0f, c->aux_scales + 2, c->aux_xsA, Dp2, c->aux_kA, Kp, s));
+            HIPCHK(c, launch_split_both(c->Wdec_dead, ndp, D, 256.0f, nullptr, c->aux_ws1, c->Dp, c->aux_ws2, Dp2, s));
+        } else {
         HIPCHK(c, launch_split_rows(c->A_dead, n, ndp, Dp2, c->aux_xsA, 0, s, 1.0f, c->aux_scales + 2));
         HIPCHK(c, launch_split_wT(c->Wdec_dead, ndp, D, (D + 255) / 256 * 256, Dp2, 256.0f, c->aux_ws2, 0, s));
+        }
         rc = dense_f16x3(c, c->aux_xsA, c->aux_ws2, c->zero_bias, n, Dp2, D, 256.0f, c->g_aux, s, c->aux_scales + 2);
     }
     if (rc != SAEV_OK) return rc;
@@ -1564,8 +1591,14 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
         // magnitude: bring it to [2^13, 2^14) with an exact power of two from its device-side max before the fp16 split;
         // W_dec[dl] rows are already "latent-major", so they split like x.
         // (the scale from g_aux's device-side max: aux_resid_kernel left it at aux_scales + 4)
+        if (c->aux_both) {  // g_aux in both forms (dA here, dWd below); the decoder rows' row-form images are the forward's
+            int ns, Kp;
+            ksplit_shape(ndp, D, n, &ns, &Kp);
+            HIPCHK(c, launch_split_both(c->g_aux, n, D, 1.0f, c->aux_scales + 4, c->aux_xsg, c->Dp, c->aux_kD, Kp, s));
+        } else {
         HIPCHK(c, launch_split_rows(c->g_aux, n, D, c->Dp, c->aux_xsg, 0, s, 1.0f, c->aux_scales + 4));
         HIPCHK(c, launch_split_rows(c->Wdec_dead, ndp, D, c->Dp, c->aux_ws1, 0, s, 256.0f));
+        }
         rc = dense_f16x3(c, c->aux_xsg, c->aux_ws1, c->zero_bias, n, c->Dp, ndp, 256.0f, dA, s, c->aux_scales + 4);
     }
     if (rc != SAEV_OK) return rc;
@@ -1574,11 +1607,13 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
     else HIPCHK(c, launch_absmax_pow2(dA, (long)n * ndp, c->aux_sync, c->aux_scales + 10, s));
     {
         // operand scales: A from the forward (aux_scales + 2), g_aux from above (+ 4), x from max|x| (+ 6), dA fresh
-        rc = ksplit_f16x3(c, c->A_dead, c->aux_scales + 2, ndp, c->g_aux, c->aux_scales + 4, D, n, c->dWd, s);
+        rc = ksplit_f16x3(c, c->A_dead, c->aux_scales + 2, ndp, c->g_aux, c->aux_scales + 4, D, n, c->dWd, s,
+                          c->aux_both ? c->aux_kA : nullptr, c->aux_both ? c->aux_kD : nullptr);
         if (rc != SAEV_OK) return rc;
         // (x's scale: the forward formed it when it made its own hi/lo images of x)
         if (c->cfg.encoder_mode == SAEV_ENCODER_F16X3) HIPCHK(c, launch_pow2_scale(c->upper_c, c->aux_scales + 6, s));
-        rc = ksplit_f16x3(c, dA, c->aux_scales + 10, ndp, c->x_last, c->aux_scales + 6, D, n, c->dWe, s);
+        rc = ksplit_f16x3(c, dA, c->aux_scales + 10, ndp, c->x_last, c->aux_scales + 6, D, n, c->dWe, s, nullptr,
+                          c->aux_both ? c->aux_kX : nullptr);
         if (rc != SAEV_OK) return rc;
     }
     HIPCHK(c, launch_colsum(dA, n, ndp, c->aux_partials, c->dbe, 0, nullptr, s));

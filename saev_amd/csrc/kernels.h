@@ -574,6 +574,11 @@ hipError_t launch_pre_encode2(PreEncode2Args a, hipStream_t stream);
 // scales[3] = 1, scales[1] = the power-of-two W scale from *wmax unless keep_w (its own Adam has left it); the lender's verdict on the
 // images (xside[1] != 0: out of fp16's range) raises *pre_flag.
 hipError_t launch_follower_scales(const float* xside, const float* wmax, float* scales, int32_t* pre_flag, int keep_w, hipStream_t stream);
+// Row-operand images (rf: rows of M, k = its columns padded to kp_r) and k-major-operand images (tf: rows = columns of M, k = its rows
+// padded to kp_t) of an fp32 matrix M (R x C) in one pass (split.hip: split_both_kernel; either may be NULL).  Images of the split-fp16
+// mode (16-wide k-steps, hi | lo); kp_r / kp_t multiples of 16; k-steps past kp are not written, rows / columns past R / C are zeros.
+hipError_t launch_split_both(const float* M, int R, int C, float scale, const float* scale_dev, void* rf, int kp_r, void* tf, int kp_t,
+                             hipStream_t stream);
 hipError_t launch_split_f16r(const float* x, int n, int D, int Dp, void* xs, const float* scales, const float* mu, const float* W,
                              int S, int S_pad, void* ws, double* dot_part, float* sq_part, float* W_T, hipStream_t stream,
                              float* xS = nullptr, int wt_slices = 0);

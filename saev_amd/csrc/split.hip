@@ -171,6 +171,66 @@ __global__ __launch_bounds__(1024) void split_wT_kernel(const float* __restrict_
     __shared__ float mu_s[KS];
     split_wT_body<MODE>(blockIdx.x, gridDim.x, tile, mu_s, W, D, S, nks, scale, scale_dev, ws, mu, dot_part, sq_part, W_T, wt_slices);
 }
+// Both operand forms of one fp32 matrix M (R x C, row-major) for the split-fp16 contractions of the dense AuxK route, in ONE pass
+// over M (MODE 0 images: hi | lo halves of 16-wide k-steps):
+//   rf: M as a row operand     -- image rows = rows of M (blocks of 256), k = columns of M      (what split_rows_kernel<0> writes)
+//   tf: M as a k-major operand -- image rows = COLUMNS of M (blocks of 256), k = rows of M      (what split_wT_kernel<0> writes)
+// The codes, dL/dx_hat of the auxiliary term, x and the dead latents' decoder rows are each needed in both forms (the forward
+// contracts over their columns, the weight gradients over their rows): ten image launches were six reads too many.  A workgroup
+// holds a 256 x 64 tile of M * scale in LDS and writes the tile's four row-form images whole and its 64-row share of sixteen
+// k-major images; same values, same rounding as the two kernels it replaces (bit-identical images).
+__global__ __launch_bounds__(1024) void split_both_kernel(const float* __restrict__ M, int R, int C, float scale,
+                                                          const float* __restrict__ scale_dev, _Float16* __restrict__ rf, int nks_r,
+                                                          _Float16* __restrict__ tf, int nks_t) {
+    __shared__ float tile[256][64];  // element (r, c) at column c ^ (r & 31): both read patterns below spread over the banks
+    if (scale_dev != nullptr) scale *= *scale_dev;
+    const int ctiles = (C + 63) / 64;
+    const int rb = blockIdx.x / ctiles, ct = blockIdx.x % ctiles;
+    const int r0 = rb * 256, c0 = ct * 64;
+    for (int q = threadIdx.x; q < 256 * 16; q += 1024) {  // 16 bytes per lane (C % 4 == 0)
+        const int rl = q >> 4, cl = (q & 15) * 4;
+        const int r = r0 + rl, c = c0 + cl;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < R && c < C) v = *reinterpret_cast<const f32x4*>(M + (size_t)r * C + c) * scale;
+        const int sw = rl & 31;
+        tile[rl][cl ^ sw] = v[0]; tile[rl][(cl + 1) ^ sw] = v[1]; tile[rl][(cl + 2) ^ sw] = v[2]; tile[rl][(cl + 3) ^ sw] = v[3];
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (rf != nullptr) {
+        const int rl = i >> 2, p = i & 3;
+        const int c = p ^ ((4 - ((rl >> 2) & 3)) & 3);
+        const int part = c >> 1, h = c & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ks = c0 / 16 + j;
+            if (ks >= nks_r) break;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[rl][(16 * j + 8 * h + e) ^ (rl & 31)];
+            reinterpret_cast<half8*>(rf + ((size_t)rb * nks_r + ks) * 256 * 32)[i] = split8(v, part);
+        }
+    }
+    if (tf != nullptr) {
+        const int cb = c0 / 256, crow0 = c0 % 256;  // the k-major operand's row block and this tile's 64 rows inside it
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int idx = i + 1024 * qq;
+            const int j = idx >> 8, within = idx & 255;
+            const int cl = within >> 2, p = within & 3;
+            const int rl_t = crow0 + cl;
+            const int c = p ^ ((4 - ((rl_t >> 2) & 3)) & 3);
+            const int part = c >> 1, h = c & 1;
+            const int ks = r0 / 16 + j;
+            if (ks >= nks_t) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[16 * j + 8 * h + e][cl ^ ((16 * j + 8 * h + e) & 31)];
+            reinterpret_cast<half8*>(tf + ((size_t)cb * nks_t + ks) * 256 * 32)[rl_t * 4 + p] = split8(v, part);
+        }
+    }
+}
+
 // The f16r step's two image passes in one launch (they depend on the same scales and on nothing of each other): workgroups
 // [0, n_x) write the centred x images, the rest the W_enc^T images with everything else that pass produces.
 struct SplitF16rArgs {
@@ -350,6 +410,15 @@ hipError_t launch_split_wT(const float* W, int D, int S, int S_pad, int Dp, floa
     if (mode == 1) hipLaunchKernelGGL(split_wT_kernel<1>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr, 0);
     else if (mode == 2) hipLaunchKernelGGL(split_wT_kernel<2>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, mu, dot_part, sq_part, W_T, wt_slices);
     else hipLaunchKernelGGL(split_wT_kernel<0>, grid, dim3(1024), 0, stream, W, D, S, nks, scale, scale_dev, o, nullptr, nullptr, nullptr, nullptr, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_both(const float* M, int R, int C, float scale, const float* scale_dev, void* rf, int kp_r, void* tf, int kp_t,
+                             hipStream_t stream) {
+    if (R <= 0 || C <= 0) return hipSuccess;
+    const int grid = ((R + 255) / 256) * ((C + 63) / 64);
+    hipLaunchKernelGGL(split_both_kernel, dim3(grid), dim3(1024), 0, stream, M, R, C, scale, scale_dev, reinterpret_cast<_Float16*>(rf), kp_r / 16,
+                       reinterpret_cast<_Float16*>(tf), kp_t / 16);
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -27,6 +28,22 @@ struct __attribute__((aligned(16))) KSlot {
 
 enum { MODE_LOOP = 0, MODE_SEQ = 1, MODE_STAG = 2 };
 constexpr int NKS = 32, EPI = 3, PER = NKS + EPI, OFFSET = 17;
+
+// one third of the epilogue's vector work (C = 0, 1, 2: latent blocks 0-2, 3-5, 6-7): per accumulator value scale-and-bias, compare,
+// mask -- the instruction mix of the real epilogue's first passes
+template <int C>
+__device__ __forceinline__ void epi_chunk(f32x4 (&acc)[8][4], uint32_t& mask) {
+    constexpr int sb0 = C == 0 ? 0 : (C == 1 ? 3 : 6), sb1 = C == 0 ? 3 : (C == 1 ? 6 : 8);
+    const float u = 1.0009765625f, b = 0.125f, tau = 3.0e30f;
+#pragma unroll
+    for (int sb = sb0; sb < sb1; ++sb)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                asm volatile("v_fma_f32 %0, %0, %2, %3\n\tv_cmp_ge_f32 vcc, %0, %4\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                             : "+v"(acc[sb][jb][e]), "+v"(mask) : "v"(u), "v"(b), "v"(tau) : "vcc");
+}
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void stag_kernel(const _Float16* __restrict__ wimg, const _Float16* __restrict__ ximg, int ntiles, float* out,
@@ -86,48 +103,44 @@ __global__ __launch_bounds__(512, 2) void stag_kernel(const _Float16* __restrict
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // one third of the epilogue's vector work: for every accumulator value of latent blocks [sb0, sb1) scale-and-bias, compare, mask
-    auto epi_chunk = [&](int c) {
-        const float u = 1.0009765625f, b = 0.125f, tau = 3.0e30f;
-#pragma unroll
-        for (int sb = 0; sb < 8; ++sb) {
-            if ((c == 0 && sb >= 3) || (c == 1 && (sb < 3 || sb >= 6)) || (c == 2 && sb < 6)) continue;
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    asm volatile("v_fma_f32 %0, %0, %2, %3\n\tv_cmp_ge_f32 vcc, %0, %4\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                                 : "+v"(acc[sb][jb][e]), "+v"(mask) : "v"(u), "v"(b), "v"(tau) : "vcc");
-        }
+    int p = 0;  // the period: which ring slot is current, which operands are staged
+    auto period_end = [&]() {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ++p;
     };
-    const int offset = (MODE == MODE_STAG) ? grp * OFFSET : 0;
-    const int per = (MODE == MODE_LOOP) ? NKS : PER;
-    const int P = ntiles * per + ((MODE == MODE_STAG) ? OFFSET : 0);
+    const int lead = (MODE == MODE_STAG) ? grp * OFFSET : 0, trail = (MODE == MODE_STAG) ? OFFSET - lead : 0;
     const unsigned long long c0 = __builtin_readcyclecounter();
     stage(0, 0); stage(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     stage(2, 2);
-    for (int p = 0; p < P; ++p) {
-        stage((p + 3) & 3, p + 3);
-        const int q = p - offset;
-        if (q >= 0 && q < ntiles * per) {
-            const int phase = q % per;
-            if (phase < NKS) kstep_compute(slot[p & 3]);
-            else {
-                epi_chunk(phase - NKS);
-                if (phase == per - 1) {  // the tile is done: its accumulators are cleared for the next one
-                    total += (float)mask;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { total += acc[i][j][0]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                }
-            }
+    for (int i = 0; i < lead; ++i) { stage((p + 3) & 3, p + 3); period_end(); }  // (the late half waits out its offset: staging and barriers only)
+    for (int tile = 0; tile < ntiles; ++tile) {
+#pragma unroll 1
+        for (int t = 0; t < NKS; ++t) {
+            stage((p + 3) & 3, p + 3);
+            kstep_compute(slot[p & 3]);
+            period_end();
         }
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (MODE != MODE_LOOP) {
+            stage((p + 3) & 3, p + 3); epi_chunk<0>(acc, mask); period_end();
+            stage((p + 3) & 3, p + 3); epi_chunk<1>(acc, mask); period_end();
+            stage((p + 3) & 3, p + 3); epi_chunk<2>(acc, mask);
+            total += (float)mask;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { total += acc[i][j][0]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            period_end();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { total += acc[i][j][0]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
     }
+    for (int i = 0; i < trail; ++i) { stage((p + 3) & 3, p + 3); period_end(); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 8; ++i)

@@ -774,6 +774,38 @@ def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near, k_aux):
         assert min(deads[4:]) < n_dead + n_near - 10, deads   # the bound really was above the count
 
 
+@pytest.mark.parametrize("d,n,n_dead,k_aux", [(128, 200, 100, 64), (256, 700, 300, 512), (192, 333, 1030, 256), (1024, 1000, 70, 512)])
+def test_dense_auxk_images_in_both_forms_from_one_pass_are_the_ten_launches_images(d, n, n_dead, k_aux):
+    """The operand images of the dense AuxK route's five contractions: the codes, g_aux, x and the dead latents' decoder rows are each
+    needed as a row operand and as a k-major operand; `split_both_kernel` writes both forms from one pass over the source (default),
+    `aux_split_route=1` keeps one launch per form.  Same values, same rounding, same image layout: losses and all four gradients
+    agree bit for bit -- at widths that are not multiples of the 64-column tile, dead sets that straddle 256-column blocks,
+    n_dead < k_aux (every dead latent selected: no mask) and > k_aux, ragged row counts."""
+    s, k, thr = 4096, 8, 1000
+    p = rand_params(d, s, seed=700 + n_dead)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(701 + n_dead))
+    toks = torch.zeros(s, dtype=torch.int64)
+    dead = torch.randperm(s, generator=torch.Generator().manual_seed(702))[:n_dead].sort().values
+    toks[dead] = thr
+    p["b_enc"][dead] = -100.0 + 0.05 * torch.randn(n_dead, generator=torch.Generator().manual_seed(703))
+    outs = []
+    for route in (0, 1):
+        eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n, aux_small_max=-1, aux_dead_cap=4096, aux_split_route=route)
+        eng.load_params(p)
+        eng.set_tracker(toks)
+        for _ in range(2):  # (the second step reuses the image buffers of the first)
+            eng.step_forward(x.cuda(), training=True)
+            eng.step_dead(n)
+            eng.step_backward()
+        st = eng.read_stats()
+        assert st.n_dead == n_dead and eng.aux_route() == 3
+        outs.append((st.aux, st.mse, {key: v.cpu().clone() for key, v in eng.grad_views().items()}))
+        eng.close()
+    assert outs[0][0] == outs[1][0] > 0 and outs[0][1] == outs[1][1], (outs[0][:2], outs[1][:2])
+    for key in R.PARAM_ORDER:
+        assert torch.equal(outs[0][2][key], outs[1][2][key]), key
+
+
 @pytest.mark.parametrize("n_dead,k_aux,dup", [(100, 64, 1), (250, 128, 1), (300, 128, 4), (700, 256, 1), (1500, 512, 8), (3000, 1024, 1)])
 def test_dense_auxk_one_launch_selection_agrees_with_the_select_fill_scatter_sequence(n_dead, k_aux, dup):
     """The dense AuxK algebra's selection in one launch (`aux_select_kernel`: the row's keys in registers, bit-wise search,

@@ -781,7 +781,7 @@ def test_dense_auxk_images_in_both_forms_from_one_pass_are_the_ten_launches_imag
     `aux_split_route=1` keeps one launch per form.  Same values, same rounding, same image layout: losses and all four gradients
     agree bit for bit -- at widths that are not multiples of the 64-column tile, dead sets that straddle 256-column blocks,
     n_dead < k_aux (every dead latent selected: no mask) and > k_aux, ragged row counts."""
-    s, k, thr = 4096, 8, 1000
+    s, k, thr = 4096, 8, 1_000_000  # (far above the rows of the two steps: the dead set stays the one dictated here)
     p = rand_params(d, s, seed=700 + n_dead)
     x = torch.randn(n, d, generator=torch.Generator().manual_seed(701 + n_dead))
     toks = torch.zeros(s, dtype=torch.int64)

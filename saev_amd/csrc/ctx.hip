@@ -303,8 +303,12 @@ int f16_ngroups(const saev_ctx* c) {
 int encoder_splits(int n_rows, int S, int tile_rows, int tile_latents, int target_wgs) {
     const int nb = (n_rows + tile_rows - 1) / tile_rows;
     const int nst = (S + tile_latents - 1) / tile_latents;
-    int sp = (target_wgs + nb - 1) / nb;
-    return std::max(1, std::min(sp, nst));
+    int sp = std::max(1, std::min((target_wgs + nb - 1) / nb, nst));
+    // the fewest splits that keep the longest walk as short: 24 tiles over 16 splits are walks of 1 and 2 tiles -- as long as 12
+    // splits of 2 each, with a third more workgroups paying a first tile's bound refresh and sharing the board's power
+    // (configs[0]: encoder 92 -> 84 us, step 0.435 -> 0.415 ms; profiles/r06_c0_encoder_grid.txt)
+    const int longest = (nst + sp - 1) / sp;
+    return (nst + longest - 1) / longest;
 }
 
 bool fused_supported(const saev_cfg& c) { return c.top_k <= 64; }

@@ -130,6 +130,12 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} not found: build the HIP extension first (`make` in the repo root or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
             )
+        # torch first: PyTorch-ROCm carries its own libamdhip64, and a process must hold ONE HIP runtime.  Loaded after torch, this
+        # library's libamdhip64.so dependency resolves to the copy torch has mapped; loaded before it, the system's copy comes in
+        # and torch's follows -- two runtimes, and every call here (hipSetDevice first of all) fails on pointers / devices of the
+        # other one (`python __graft_entry__.py smoke`: build() loaded the library before smoke() imported torch).
+        import torch  # noqa: F401
+
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

@@ -177,6 +177,8 @@ typedef struct {
     int32_t aux_split_route; /* dense AuxK route, operand images of the split-fp16 contractions: 0 = the codes, g_aux, x and the dead latents'
                               decoder rows written in BOTH operand forms by one pass each (six image launches), 1 = round 5: one launch
                               per form (ten)                                                                                  */
+    int32_t aux_wide_route; /* few-dead-latents AuxK on the fp32 matrix cores: 0 = dead sets bounded by up to 128 (one launch per count window
+                              [1, 32], [33, 64], [65, 128], the device-side count picks), 1 = round 5: up to 64, the dense algebra beyond */
 } saev_debug_cfg;
 
 int saev_abi_version(void);

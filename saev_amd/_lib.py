@@ -30,7 +30,7 @@ class SaevDebugCfg(C.Structure):
     """Route switches (include/saev_amd.h: saev_debug_cfg); all zero = shipped defaults."""
 
     _fields_ = [(n, C.c_int32) for n in ("struct_size", "dw_route", "enc_mfma", "fused_chain", "ngroups", "enc_wgs", "refresh_first",
-                                         "refresh_every", "aux_small_max", "fwd_route", "dead_lag", "csc_route", "fin_route", "prep_route", "aux_dense_route", "aux_small_route", "own_check", "enc_rot", "group_route", "aux_split_route")]
+                                         "refresh_every", "aux_small_max", "fwd_route", "dead_lag", "csc_route", "fin_route", "prep_route", "aux_dense_route", "aux_small_route", "own_check", "enc_rot", "group_route", "aux_split_route", "aux_wide_route")]
 
 
 class SaevLayout(C.Structure):

@@ -345,9 +345,9 @@ __device__ __forceinline__ float aux_reduce_scatter8(float (&p)[8], int lane) {
 // WencT_dead (AUX_SMALL_MAX, D) = W_enc[:, dl]^T and Wdec_dead (AUX_SMALL_MAX, D) = W_dec[dl] (zero rows beyond nd)
 __global__ __launch_bounds__(256) void gather_dead_small_kernel(const float* W_enc, const float* W_dec, const int32_t* dl,
                                                                 const int32_t* nd_dev, int D, int S, float* WencT_dead,
-                                                                float* Wdec_dead) {
+                                                                float* Wdec_dead, int cap) {
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > AUX_SMALL_MAX) return;
+    if (nd <= 0 || nd > cap) return;
     const long total = (long)nd * D;  // rows past nd are never read (every consumer loops to the device-side count)
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
         const int j = (int)(q / D), d = (int)(q % D);
@@ -876,11 +876,13 @@ __global__ __launch_bounds__(256) void aux_mfma_forward_kernel(const float* __re
                                                                const float* __restrict__ b_enc, const float* __restrict__ b_dec,
                                                                const int32_t* __restrict__ dl, int n_rows, int D, const int32_t* nd_dev,
                                                                float gscale, float* __restrict__ A, float* __restrict__ dA,
-                                                               float* __restrict__ g_aux, RowStats* rowstats) {
+                                                               float* __restrict__ g_aux, RowStats* rowstats, int ndp, int nd_min) {
+    // ndp: row pitch of A / dA (AUX_SMALL_MAX, or AUX_MFMA_MAX for the wide dead sets); nd_min: the launch sequence enqueues one
+    // instantiation per count window [nd_min, 32 NL] and the device-side count picks the one that runs
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > 32 * NL) return;
-    constexpr int ndp = AUX_SMALL_MAX, KH = 16 * NL;  // KH: latents per slot of the reconstruction's contraction
-    __shared__ float sh[4][NL][16][64];   // the four waves' shares of a 32 x (32 NL) tile
+    if (nd < nd_min || nd <= 0 || nd > 32 * NL) return;
+    constexpr int KH = 16 * NL;  // KH: latents per slot of the reconstruction's contraction
+    __shared__ float sh[4][16][64];        // the four waves' shares of one 32 x 32 block of a tile (blocks go through it in turn)
     __shared__ float As[32][32 * NL + 1];  // the tile's codes, row-major
     __shared__ float Gs[4][32][33];        // per wave: a 32 x 32 block of g_aux, row-major
     __shared__ float shs[4][32];
@@ -891,17 +893,18 @@ __global__ __launch_bounds__(256) void aux_mfma_forward_kernel(const float* __re
     // every share of the tile, added in wave order; `fin(row, lat, sum)` receives the 32 x (32 NL) sums
     auto tile_sum = [&](const f32x16 (&t)[NL], auto fin) {
 #pragma unroll
-        for (int lb = 0; lb < NL; ++lb)
+        for (int lb = 0; lb < NL; ++lb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sh[w][lb][r][lane] = t[lb][r];
-        __syncthreads();
+            for (int r = 0; r < 16; ++r) sh[w][r][lane] = t[lb][r];
+            __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4 * NL; ++u) {
-            const int idx = threadIdx.x + 256 * u;
-            const int lb = idx >> 10, r = (idx >> 6) & 15, l = idx & 63;
-            fin(mfma32_row(r, l >> 5), 32 * lb + (l & 31), ((sh[0][lb][r][l] + sh[1][lb][r][l]) + sh[2][lb][r][l]) + sh[3][lb][r][l]);
+            for (int u = 0; u < 4; ++u) {
+                const int idx = threadIdx.x + 256 * u;
+                const int r = (idx >> 6) & 15, l = idx & 63;
+                fin(mfma32_row(r, l >> 5), 32 * lb + (l & 31), ((sh[0][r][l] + sh[1][r][l]) + sh[2][r][l]) + sh[3][r][l]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     };
     // ---- phase 1: codes ----
     {
@@ -1030,12 +1033,14 @@ __global__ __launch_bounds__(256) void aux_mfma_forward_kernel(const float* __re
 template <int NL>
 __global__ __launch_bounds__(256, 1) void aux_mfma_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ dA, const float* __restrict__ g,
                                                                 const float* __restrict__ x, int n_rows, int D, const int32_t* nd_dev,
-                                                                float* __restrict__ part, float* __restrict__ partb, float* __restrict__ partbe) {
+                                                                float* __restrict__ part, float* __restrict__ partb, float* __restrict__ partbe,
+                                                                int ndp, int nd_min, int nd_max, int lat0) {
     // partb[blk][D] / partbe[blk][ndp]: the block's column sums of g_aux (db_dec's share) and of dA (db_enc[dl]) -- the operands are in
     // registers anyway; rows 0 ... 31 in order, then rows 32 ... 63, then the two halves: one fixed order
+    // this launch: latents [lat0, lat0 + 32 NL) of a dead set whose device-side count lies in [nd_min, nd_max] (the launch sequence
+    // enqueues one launch per window and latent range; the count picks what runs); ndp: row pitch of A / dA and of the partials
     const int nd = *nd_dev;
-    if (nd <= 0 || nd > 32 * NL) return;
-    constexpr int ndp = AUX_SMALL_MAX;
+    if (nd < nd_min || nd <= 0 || nd > nd_max) return;
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * 64 + 32 * h;
@@ -1045,7 +1050,7 @@ __global__ __launch_bounds__(256, 1) void aux_mfma_wgrad_kernel(const float* __r
 #pragma unroll
     for (int p = 0; p < 32; ++p) {
         const bool ok = r0 + p < n_rows;  // (rows past the end: zero coefficients against the last row's values)
-        const size_t o = (size_t)min(r0 + p, n_rows - 1) * ndp + i;
+        const size_t o = (size_t)min(r0 + p, n_rows - 1) * ndp + lat0 + i;
 #pragma unroll
         for (int lb = 0; lb < NL; ++lb) {
             av[lb][p] = ok ? A[o + 32 * lb] : 0.f;
@@ -1060,7 +1065,7 @@ __global__ __launch_bounds__(256, 1) void aux_mfma_wgrad_kernel(const float* __r
             for (int p = 0; p < 32; ++p) t += dv[lb][p];
             const float o = __shfl_xor(t, 32, 64);
             if (h == 0) {
-                partbe[(size_t)blockIdx.x * ndp + 32 * lb + i] = t + o;
+                partbe[(size_t)blockIdx.x * ndp + lat0 + 32 * lb + i] = t + o;
                 if (NL == 1) partbe[(size_t)blockIdx.x * ndp + 32 + i] = 0.f;
             }
         }
@@ -1092,7 +1097,7 @@ __global__ __launch_bounds__(256, 1) void aux_mfma_wgrad_kernel(const float* __r
             for (int p = 0; p < 32; ++p) { c0 = mfma32(av[lb][p], gv[p], c0); c1 = mfma32(dv[lb][p], xv[p], c1); }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int lat = 32 * lb + mfma32_row(r, h);
+                const int lat = lat0 + 32 * lb + mfma32_row(r, h);
                 if (lat < nd) {
                     base[(size_t)lat * D + col] = c0[r];
                     base[(size_t)(ndp + lat) * D + col] = c1[r];
@@ -1372,9 +1377,9 @@ hipError_t launch_mask_apply(float* dA, const uint8_t* mask, long n, hipStream_t
     return hipGetLastError();
 }
 hipError_t launch_gather_dead_small(const float* W_enc, const float* W_dec, const int32_t* dl, const int32_t* nd_dev, int D,
-                                    int S, float* WencT_dead, float* Wdec_dead, hipStream_t s) {
-    hipLaunchKernelGGL(gather_dead_small_kernel, dim3(grid_for((long)AUX_SMALL_MAX * D)), dim3(256), 0, s, W_enc, W_dec, dl,
-                       nd_dev, D, S, WencT_dead, Wdec_dead);
+                                    int S, float* WencT_dead, float* Wdec_dead, hipStream_t s, int cap) {
+    hipLaunchKernelGGL(gather_dead_small_kernel, dim3(grid_for((long)cap * D)), dim3(256), 0, s, W_enc, W_dec, dl,
+                       nd_dev, D, S, WencT_dead, Wdec_dead, cap);
     return hipGetLastError();
 }
 hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead,
@@ -1468,25 +1473,35 @@ hipError_t launch_aux_small_fused(const float* x, const float* x_hat, const floa
     return hipGetLastError();
 }
 bool aux_mfma_supported(int D) { return D % 128 == 0 && D >= 128; }
+// One instantiation per count window, each predicated on the device-side count (a launch whose window the count misses leaves in its
+// first instruction, ~4 us): the host only knows a BOUND of the count -- the tracker record of a few steps ago -- and a bound of 100
+// usually stands for 20 dead latents (the sustained segment took the dense route, +0.57 ms, on every sixth step for
+// that reason).  bound <= 32: one launch; <= 64: two; <= AUX_MFMA_MAX (128): three, and row pitch ndp = AUX_MFMA_MAX.
 hipError_t launch_aux_mfma_forward(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                    const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale, float* A,
-                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s, int bound) {
-    if (!aux_mfma_supported(D) || bound > AUX_MFMA_MAX) return hipErrorInvalidValue;
+                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s, int bound, int ndp) {
+    if (!aux_mfma_supported(D) || bound > AUX_MFMA_MAX || bound > ndp) return hipErrorInvalidValue;
     const dim3 grid((n_rows + 31) / 32), block(256);
-    if (bound <= 32)
-        hipLaunchKernelGGL(aux_mfma_forward_kernel<1>, grid, block, 0, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev,
-                           gscale, A, dA, g_aux, rowstats);
-    else
+    hipLaunchKernelGGL(aux_mfma_forward_kernel<1>, grid, block, 0, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev,
+                       gscale, A, dA, g_aux, rowstats, ndp, 1);
+    if (bound > 32)
         hipLaunchKernelGGL(aux_mfma_forward_kernel<2>, grid, block, 0, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev,
-                           gscale, A, dA, g_aux, rowstats);
+                           gscale, A, dA, g_aux, rowstats, ndp, 33);
+    if (bound > 64)
+        hipLaunchKernelGGL(aux_mfma_forward_kernel<4>, grid, block, 0, s, x, x_hat, WencT_dead, Wdec_dead, b_enc, b_dec, dl, n_rows, D, nd_dev,
+                           gscale, A, dA, g_aux, rowstats, ndp, 65);
     return hipGetLastError();
 }
+// (the weight gradients are independent per latent block: beyond 64 dead latents the two-block kernel runs once per 64 latents)
 hipError_t launch_aux_mfma_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
-                                 const int32_t* nd_dev, float* part, float* partb, float* partbe, hipStream_t s, int bound) {
-    if (!aux_mfma_supported(D) || bound > AUX_MFMA_MAX) return hipErrorInvalidValue;
+                                 const int32_t* nd_dev, float* part, float* partb, float* partbe, hipStream_t s, int bound, int ndp) {
+    if (!aux_mfma_supported(D) || bound > AUX_MFMA_MAX || bound > ndp) return hipErrorInvalidValue;
     const dim3 grid((n_rows + 63) / 64, D >= 512 ? 2 : 1), block(256);
-    if (bound <= 32) hipLaunchKernelGGL(aux_mfma_wgrad_kernel<1>, grid, block, 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part, partb, partbe);
-    else hipLaunchKernelGGL(aux_mfma_wgrad_kernel<2>, grid, block, 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part, partb, partbe);
+    hipLaunchKernelGGL(aux_mfma_wgrad_kernel<1>, grid, block, 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part, partb, partbe, ndp, 1, 32, 0);
+    if (bound > 32)
+        hipLaunchKernelGGL(aux_mfma_wgrad_kernel<2>, grid, block, 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part, partb, partbe, ndp, 33, AUX_MFMA_MAX, 0);
+    if (bound > 64)
+        hipLaunchKernelGGL(aux_mfma_wgrad_kernel<2>, grid, block, 0, s, A, dA, g_aux, x, n_rows, D, nd_dev, part, nullptr, partbe, ndp, 65, AUX_MFMA_MAX, 64);
     return hipGetLastError();
 }
 hipError_t launch_aux_small_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,

@@ -157,6 +157,8 @@ struct saev_ctx {
     bool aux_dev_count = false;  // dense branch sized by a host-side BOUND of the dead count; the count itself stays on the device
     bool aux_small = false;  // this step's AuxK ran on the few-dead-latents path
     int aux_mfma_bound = 0;
+    int aux_ndp = AUX_SMALL_MAX;  // row pitch of A / dA / the block partials of the few-dead-latents step in flight (AUX_MFMA_MAX beyond 64)
+    int aux_mfma_cap = AUX_SMALL_MAX;  // largest bound the matrix-core kernels take in this context (its buffers decide)
     bool aux_mfma = false;   // ... in its fp32 matrix-core form (at most AUX_MFMA_MAX dead latents, d_model % 128 == 0: auxk.hip aux_mfma_*)
     bool aux_fused = false;  // ... in its one-pass form (at most AUX_FUSED_MAX dead latents: block partials instead of g_aux / A / dA)
     bool aux_all = false;    // dense branch with every dead latent selected (n_dead <= k_aux): no select, no mask
@@ -1332,10 +1334,15 @@ int alloc_aux_buffers(saev_ctx* c, int cap) {
     c->dWe = (float*)grab(capA * D * 4);
     c->dbe = (float*)grab(capA * 4);
     c->aux_partials = (float*)grab(((MB + 63) / 64) * capA * 4);
-    c->WencT_dead = (float*)grab((size_t)AUX_SMALL_MAX * D * 4);
-    c->aux_small_part = (float*)grab(((MB + 63) / 64) * (size_t)2 * AUX_SMALL_MAX * D * 4);
-    c->aux_small_part2 = (float*)grab((size_t)(((MB + 63) / 64 + 63) / 64) * AUX_SMALL_MAX * D * 4);
-    c->aux_small_partbe = (float*)grab((size_t)((MB + 63) / 64) * AUX_SMALL_MAX * 4);  // (aux_mfma_wgrad_kernel: the blocks' column sums of dA)
+    // (the matrix-core kernels take dead sets up to AUX_MFMA_MAX where the compact buffers hold that many rows and the step's
+    // backward runs over this context's own rows: gathered backwards -- max_backward_rows -- keep the round-5 limit)
+    const size_t mcap = (aux_mfma_supported((int)D) && capA >= (size_t)AUX_MFMA_MAX && c->cfg.max_backward_rows == 0 && c->dbg.aux_wide_route == 0)
+                            ? (size_t)AUX_MFMA_MAX : (size_t)AUX_SMALL_MAX;
+    c->aux_mfma_cap = (int)mcap;
+    c->WencT_dead = (float*)grab(mcap * D * 4);
+    c->aux_small_part = (float*)grab(((MB + 63) / 64) * (size_t)2 * mcap * D * 4);
+    c->aux_small_part2 = (float*)grab((size_t)(((MB + 63) / 64 + 63) / 64) * mcap * D * 4);
+    c->aux_small_partbe = (float*)grab((size_t)((MB + 63) / 64) * mcap * 4);  // (aux_mfma_wgrad_kernel: the blocks' column sums of dA)
     bool fast_ok = true;
     {  // operand images of the five contractions (every encoder mode runs them on the split-fp16 MFMA kernel)
         const size_t cap256 = ((size_t)cap + 255) / 256 * 256, D256 = (D + 255) / 256 * 256;
@@ -1424,8 +1431,9 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
     c->aux_fused = false;
     c->aux_mfma = false;
     if (!c->dead_list_ready) HIPCHK(c, launch_dead_compact(c->dead, S, c->dead_list, s, nd_dev));
+    c->aux_ndp = bound > AUX_SMALL_MAX ? AUX_MFMA_MAX : AUX_SMALL_MAX;
     HIPCHK(c, launch_gather_dead_small(c->params + c->off_W_enc, c->params + c->off_W_dec, c->dead_list, nd_dev, D, S,
-                                       c->WencT_dead, c->Wdec_dead, s));
+                                       c->WencT_dead, c->Wdec_dead, s, c->aux_ndp));
     if (bound <= AUX_FUSED_MAX && aux_fused_supported(D) && c->dbg.aux_small_max != AUX_SMALL_MAX) {
         // a handful of dead latents: one pass over x and x_hat leaves the block partials of every gradient of the auxiliary term
         // (partials in the buffers the two-kernel form uses for its own: aux_small_part; g_aux and A_dead are free in this form)
@@ -1439,11 +1447,11 @@ int auxk_small_forward(saev_ctx* c, hipStream_t s, int bound) {
             HIPCHK(c, launch_stats_reduce(c->rowstats, n, D, c->P_last, c->cfg.alpha, 2, c->upper_c, nullptr, c->stats, s, nd_dev, c->stats_scratch));
         return SAEV_OK;
     }
-    if (bound <= AUX_MFMA_MAX && aux_mfma_supported(D) && c->dbg.aux_small_route == 0) {
+    if (bound <= c->aux_mfma_cap && aux_mfma_supported(D) && c->dbg.aux_small_route == 0) {
         c->aux_mfma = true;
         HIPCHK(c, launch_aux_mfma_forward(c->x_last, c->x_hat, c->WencT_dead, c->Wdec_dead, c->params + c->off_b_enc,
                                           c->params + c->off_b_dec, c->dead_list, n, D, nd_dev,
-                                          c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s, bound));
+                                          c->cfg.alpha * 2.0f / ((float)n * (float)D), c->A_dead, c->H_dead, c->g_aux, c->rowstats, s, bound, c->aux_ndp));
         c->aux_mfma_bound = bound;
         // (inside saev_train_step the backward's ordered-sum launch also forms the step's auxiliary loss, as for the one-pass kernel)
         c->aux_stats_pending = c->train_fused;
@@ -1571,11 +1579,11 @@ int auxk_backward(saev_ctx* c, hipStream_t s) {
             // weight-gradient partials per block of 64 rows with the blocks' column sums of g_aux and dA riding along; ONE launch of
             // ordered sums finishes all four gradients (and the auxiliary loss inside saev_train_step)
             HIPCHK(c, launch_aux_mfma_wgrad(c->A_dead, dA, c->g_aux, c->x_last, n, D, nd_dev, c->aux_small_part, c->aux_small_part2,
-                                            c->aux_small_partbe, s, c->aux_mfma_bound));
+                                            c->aux_small_partbe, s, c->aux_mfma_bound, c->aux_ndp));
             if (c->ov_x != nullptr) HIPCHK(c, hipMemsetAsync(c->db_aux, 0, (size_t)D * sizeof(float), s));  // (the count may be zero on the device)
             HIPCHK(c, launch_aux_fused_wsum(c->aux_small_part, nb, D, nd_dev, c->dWd, c->dWe, s, c->aux_small_part2,
                                             c->ov_x != nullptr ? c->db_aux : c->grads + c->off_b_dec, c->ov_x != nullptr ? 0 : 1, c->aux_small_partbe, c->dbe,
-                                            c->aux_stats_pending ? c->rowstats : nullptr, n, c->cfg.alpha, c->stats, AUX_SMALL_MAX));
+                                            c->aux_stats_pending ? c->rowstats : nullptr, n, c->cfg.alpha, c->stats, c->aux_ndp));
             c->aux_stats_pending = false;
             return SAEV_OK;
         }
@@ -1675,7 +1683,10 @@ int saev_step_dead(saev_ctx* c, int64_t n_rows_global, void* stream) {
     // few-dead-latents kernels grow with the count, the dense algebra is flat up to 256 dead latents).
     // (with the fp32-MFMA kernels -- d_model % 128 == 0 -- the few-dead-latents route costs +0.24 ms up to 32 and +0.32 ... +0.35 up to 64 dead
     // latents against the dense route's +0.56: it takes everything it can hold, profiles/r05b_aux_mfma_sweep.txt)
-    const int small_default = (aux_mfma_supported(c->cfg.d_model) && c->dbg.aux_small_route == 0) ? (int)AUX_MFMA_MAX : (int)AUX_SMALL_DEFAULT;
+    // (round 6: up to AUX_MFMA_MAX = 128 where the context's buffers allow -- aux_mfma_cap -- with one launch per count window
+    // [1, 32], [33, 64], [65, 128] up to the bound: the device-side count picks the one that runs)
+    const bool mfma_route = aux_mfma_supported(c->cfg.d_model) && c->dbg.aux_small_route == 0;
+    const int small_default = mfma_route ? std::max((int)AUX_SMALL_MAX, c->aux_mfma_cap) : (int)AUX_SMALL_DEFAULT;
     const int small_cap = c->dbg.aux_small_max < 0 ? 0 : (c->dbg.aux_small_max == 0 ? small_default : std::min(c->dbg.aux_small_max, (int)AUX_SMALL_MAX));
     const int small_max = std::min(small_cap, c->cfg.k_aux);
     const int64_t s0 = step - lag;
@@ -1867,7 +1878,7 @@ int saev_backward_rows_part(saev_ctx* c, int32_t lat_lo, int32_t lat_hi, int32_t
                                           c->aux_dev_count ? c->flags + 4 : nullptr, part, a.row_proj, a.W_dec, a.project, a.enc_sq,
                                           c->unused_valid ? c->lat_unused : nullptr, c->sq_wave_n > 0 ? c->starts : nullptr));
     else if (c->aux_route != AUX_NONE)  // few dead latents: the device knows how many
-        HIPCHK(c, launch_scatter_add_dead(c->dead_list, AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
+        HIPCHK(c, launch_scatter_add_dead(c->dead_list, c->aux_mfma ? c->aux_ndp : AUX_SMALL_MAX, D, c->dWd, c->dWe, c->dbe, c->grads + c->off_W_dec,
                                           c->dW_encT, c->grads + c->off_b_enc, lat_lo, lat_hi, s, c->flags + 4, part,
                                           a.row_proj, a.W_dec, a.project, a.enc_sq, c->unused_valid ? c->lat_unused : nullptr,
                                           c->sq_wave_n > 0 ? c->starts : nullptr));
@@ -1915,7 +1926,7 @@ int saev_backward_override(saev_ctx* c, const float* x_all, const float* g_all, 
 
 int32_t saev_aux_compact_rows(const saev_ctx* c) {
     if (!c || c->aux_route == AUX_NONE) return 0;
-    return c->aux_route == AUX_DENSE ? (c->n_dead_host + 3) / 4 * 4 : AUX_SMALL_MAX;
+    return c->aux_route == AUX_DENSE ? (c->n_dead_host + 3) / 4 * 4 : (c->aux_mfma ? c->aux_ndp : AUX_SMALL_MAX);
 }
 
 // [dWd rows x D | dWe rows x D | dbe rows | db_aux D]

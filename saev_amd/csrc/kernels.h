@@ -619,7 +619,7 @@ constexpr int AUX_SMALL_DEFAULT = 40;  // largest dead set that takes them unles
 // the host can enqueue them without knowing it.  Leading dimension of A / dA and row count of the compact weight buffers:
 // AUX_SMALL_MAX.
 hipError_t launch_gather_dead_small(const float* W_enc, const float* W_dec, const int32_t* dl, const int32_t* nd_dev, int D,
-                                    int S, float* WencT_dead, float* Wdec_dead, hipStream_t s);
+                                    int S, float* WencT_dead, float* Wdec_dead, hipStream_t s, int cap = AUX_SMALL_MAX);
 hipError_t launch_aux_small_fwd(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead,
                                 const float* b_enc, const float* b_dec, const int32_t* dl, int n_rows, int D,
                                 const int32_t* nd_dev, float gscale, float* A, float* dA, float* g_aux, RowStats* rowstats,
@@ -645,15 +645,17 @@ bool aux_fused_supported(int D);
 // 9 ... 64 dead latents on the fp32 matrix cores (auxk.hip: aux_mfma_*): launch_aux_small_fwd's and launch_aux_small_wgrad's outputs
 // (A, dA: (n_rows, AUX_SMALL_MAX); g_aux; rowstats.aux_sse; the block partials) from one + one launches; d_model % 128 == 0;
 // bound: the host's bound of the dead count (one or two blocks of 32 latents)
-constexpr int AUX_MFMA_MAX = 64;
+constexpr int AUX_MFMA_MAX = 128;  // (beyond AUX_SMALL_MAX = 64 with row pitch AUX_MFMA_MAX: launch_aux_mfma_forward)
 bool aux_mfma_supported(int D);
 hipError_t launch_aux_mfma_forward(const float* x, const float* x_hat, const float* WencT_dead, const float* Wdec_dead, const float* b_enc,
                                    const float* b_dec, const int32_t* dl, int n_rows, int D, const int32_t* nd_dev, float gscale, float* A,
-                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s, int bound);
-// (partb: blocks x D, partbe: blocks x AUX_SMALL_MAX -- the blocks' column sums of g_aux and dA; launch_aux_fused_wsum with
+                                   float* dA, float* g_aux, RowStats* rowstats, hipStream_t s, int bound, int ndp = AUX_SMALL_MAX);
+// (ndp: row pitch of A / dA and of the partials -- AUX_SMALL_MAX, or AUX_MFMA_MAX when the bound exceeds it.  One launch per count
+// window [1, 32], [33, 64], [65, 128] up to the bound, each predicated on the device-side count)
+// (partb: blocks x D, partbe: blocks x ndp -- the blocks' column sums of g_aux and dA; launch_aux_fused_wsum with
 // ndo = AUX_SMALL_MAX finishes all four gradients and the auxiliary loss in one launch)
 hipError_t launch_aux_mfma_wgrad(const float* A, const float* dA, const float* g_aux, const float* x, int n_rows, int D,
-                                 const int32_t* nd_dev, float* part, float* partb, float* partbe, hipStream_t s, int bound);
+                                 const int32_t* nd_dev, float* part, float* partb, float* partbe, hipStream_t s, int bound, int ndp = AUX_SMALL_MAX);
 // the ordered sums of all four partial sets in one launch: dWd / dWe rows, db_dec's share (db_out, added to what is there when
 // db_accumulate) and db_enc[dl] (dbe)
 hipError_t launch_aux_fused_wsum(const float* part, int n_blk, int D, const int32_t* nd_dev, float* dWd, float* dWe, hipStream_t s,

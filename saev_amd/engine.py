@@ -85,6 +85,7 @@ class EngineConfig:
     enc_rot: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_ENC_ROT", "0")))
     group_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_GROUP", "0")))
     aux_split_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_SPLIT", "0")))
+    aux_wide_route: int = dataclasses.field(default_factory=lambda: int(os.environ.get("SAEV_AMD_AUX_WIDE", "0")))
 
 
 @dataclasses.dataclass
@@ -167,7 +168,7 @@ class SaeEngine:
                 fused_chain=int(cfg.fused_chain), ngroups=cfg.ngroups, enc_wgs=cfg.enc_wgs, refresh_first=cfg.refresh_first,
                 refresh_every=cfg.refresh_every, aux_small_max=cfg.aux_small_max, fwd_route={"default": 0, "rows": 1, "sum_pass": 2}[cfg.fwd_route],
                 dead_lag=cfg.dead_lag, csc_route=cfg.csc_route, fin_route=cfg.fin_route, prep_route=cfg.prep_route, aux_dense_route=cfg.aux_dense_route, aux_small_route=cfg.aux_small_route,
-                own_check=cfg.own_check, enc_rot=cfg.enc_rot, group_route=cfg.group_route, aux_split_route=cfg.aux_split_route)
+                own_check=cfg.own_check, enc_rot=cfg.enc_rot, group_route=cfg.group_route, aux_split_route=cfg.aux_split_route, aux_wide_route=cfg.aux_wide_route)
             ctx = C.c_void_p()
             rc = self.lib.saev_create_ex(C.byref(ccfg), C.byref(dbg), self.device.index, C.byref(ctx))
             if rc != 0:

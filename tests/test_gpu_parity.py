@@ -1077,3 +1077,87 @@ def test_few_dead_latents_on_the_matrix_cores_agree_with_the_vector_kernels_and_
     assert math.isclose(got[0][0], got[1][0], rel_tol=2e-6)
     for key in R.PARAM_ORDER:
         torch.testing.assert_close(got[0][1][key], got[1][1][key], rtol=1e-4, atol=1e-8, msg=lambda m: f"{key}: {m}")
+
+
+@pytest.mark.parametrize("n_dead,d,n", [(65, 128, 200), (100, 256, 333), (128, 1024, 97), (96, 512, 161), (127, 1280, 130)])
+def test_wide_dead_sets_on_the_matrix_cores_agree_with_the_dense_route_and_the_oracle(n_dead, d, n):
+    """65-128 dead latents on the fp32 matrix cores (round 6: `aux_mfma_forward_kernel<4>`, the two-block weight-gradient kernel once
+    per 64 latents, row pitch 128) against the oracle -- loss, tracker, all four gradients -- and against the dense algebra the same
+    dead set took before (`aux_wide_route=1`): three and four blocks of 32 latents, full and partial, ragged row counts, every
+    d_model % 128 class."""
+    s, k, k_aux, thr = 2048, 8, 128, 1000
+    p = rand_params(d, s, seed=800 + n_dead)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(801 + n_dead))
+    toks = torch.zeros(s, dtype=torch.int64)
+    dead = torch.randperm(s, generator=torch.Generator().manual_seed(802))[:n_dead]
+    toks[dead] = thr
+    p["b_enc"][dead] = -100.0
+    cfg = R.RefConfig(d_model=d, d_sae=s, top_k=k, k_aux=k_aux, dead_threshold_tokens=thr)
+    leaves = {k_: p[k_].clone().requires_grad_(True) for k_ in R.PARAM_ORDER}
+    leaves["W_dec"] = R.normalize_w_dec(p["W_dec"]).clone().requires_grad_(True)
+    out = R.objective_forward(leaves, x, cfg, toks_since_active=toks.clone(), training=True)
+    out.loss.backward()
+    got = []
+    for wide_off in (0, 1):
+        eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n, aux_wide_route=wide_off)
+        eng.load_params(p)
+        eng.set_tracker(toks)
+        eng.step_forward(x.cuda(), training=True)
+        eng.step_dead(n)
+        eng.step_backward()
+        st = eng.read_stats()
+        assert st.n_dead == out.n_dead == n_dead
+        assert eng.aux_route() == (3 if wide_off else 2), eng.aux_route()
+        assert math.isclose(st.aux, out.aux.item(), rel_tol=1e-4), (wide_off, st.aux, out.aux.item())
+        gv = {key: v.cpu().clone() for key, v in eng.grad_views().items()}
+        for key in R.PARAM_ORDER:
+            torch.testing.assert_close(gv[key], leaves[key].grad, rtol=2e-3, atol=3e-7, msg=lambda m: f"wide_off {wide_off} {key}: {m}")
+        got.append((st.aux, gv))
+        eng.close()
+    assert math.isclose(got[0][0], got[1][0], rel_tol=1e-5)
+    for key in R.PARAM_ORDER:
+        torch.testing.assert_close(got[0][1][key], got[1][1][key], rtol=1e-3, atol=1e-7, msg=lambda m: f"{key}: {m}")
+
+
+@pytest.mark.encoder_modes("f16r")  # one encoder mode is enough here
+def test_a_loose_bound_of_the_dead_count_runs_the_kernels_of_the_true_count(encoder_mode):
+    """What the wide route is for: the host sizes a step's auxiliary work by a BOUND of the dead count (the tracker record of four
+    steps ago: dead, or within four steps of the threshold), and latents that come close to the threshold and then fire again make
+    that bound several times the count.  Here 20 latents stay dead while 90 more go quiet for six steps at a time and fire on the
+    seventh: the bound is ~110 while 20 are dead.  The matrix-core route enqueues one launch per count window and the device-side
+    count picks (round 5 sent such steps down the dense algebra, +0.57 ms at configs[1]); every step must agree with a run that is
+    told to do exactly that (`aux_wide_route=1`), and no step may read the count back."""
+    d, s, k, k_aux, n = 256, 2048, 8, 128, 256
+    thr = 6 * n + n // 2  # dead after seven quiet steps
+    p = rand_params(d, s, seed=850)
+    g = torch.Generator().manual_seed(851)
+    perm = torch.randperm(s, generator=g)
+    dead, sleepy = perm[:20], perm[20:110]
+    p["b_enc"][dead] = -100.0
+    p["b_enc"][sleepy] = -100.0
+    p["W_enc"][0, sleepy] = 300.0      # ... unless the batch carries a large first coordinate
+    xs = []
+    for i in range(16):
+        x = torch.randn(n, d, generator=g)
+        x[:, 0] = 1.0 if i % 7 == 6 else 0.0
+        xs.append(x.cuda())
+    runs = []
+    for wide_off in (0, 1):
+        eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n, aux_wide_route=wide_off)
+        eng.load_params(p)
+        rec = []
+        for x in xs:
+            eng.train_step(x, 0.0, 1.0)  # (lr 0: both runs see the same parameters on every step, whatever the rounding of their AuxK)
+            st = eng.read_stats()
+            rec.append((st.n_dead, eng.aux_route(), st.aux, st.grad_norm))
+        runs.append((rec, eng.dead_readbacks()))
+        eng.close()
+    (wide, rb_w), (dense, rb_d) = runs
+    assert [r[0] for r in wide] == [r[0] for r in dense]
+    late = [i for i, r in enumerate(wide) if i >= 8 and r[0] > 0]
+    assert late and all(wide[i][0] <= 25 for i in late), [r[0] for r in wide]
+    assert any(dense[i][1] == 3 for i in late), "the scenario is meant to push the round-5 rule onto the dense route"
+    assert all(wide[i][1] == 1 for i in late), [wide[i][1] for i in late]
+    for i in late:
+        assert math.isclose(wide[i][2], dense[i][2], rel_tol=1e-4) and math.isclose(wide[i][3], dense[i][3], rel_tol=1e-4), (i, wide[i], dense[i])
+

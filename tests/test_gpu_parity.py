@@ -740,7 +740,8 @@ def test_dense_auxk_sized_by_a_bound_needs_no_readback(n_dead, n_near, k_aux):
     toks[dead] = thr
     toks[near] = thr - 2 * n
     p["b_enc"][dead] = -100.0  # never selected: they stay dead
-    eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n)
+    # (aux_wide_route=1: the matrix-core kernels stop at 64 dead latents, as in round 5 -- this test is about the dense algebra behind them)
+    eng = make_engine(d, s, k, k_aux=k_aux, thr=thr, max_batch=n, aux_wide_route=1)
     eng.load_params(p)
     eng.set_tracker(toks)
     routes, deads = [], []
@@ -1123,23 +1124,23 @@ def test_wide_dead_sets_on_the_matrix_cores_agree_with_the_dense_route_and_the_o
 def test_a_loose_bound_of_the_dead_count_runs_the_kernels_of_the_true_count(encoder_mode):
     """What the wide route is for: the host sizes a step's auxiliary work by a BOUND of the dead count (the tracker record of four
     steps ago: dead, or within four steps of the threshold), and latents that come close to the threshold and then fire again make
-    that bound several times the count.  Here 20 latents stay dead while 90 more go quiet for six steps at a time and fire on the
-    seventh: the bound is ~110 while 20 are dead.  The matrix-core route enqueues one launch per count window and the device-side
+    that bound several times the count.  Here 20 latents stay dead while 80 more go quiet for 29 steps at a time and fire on the
+    30th: on steps 60-62 the bound is 100 while 20 are dead (the oracle's tracker says so).  The matrix-core route enqueues one launch per count window and the device-side
     count picks (round 5 sent such steps down the dense algebra, +0.57 ms at configs[1]); every step must agree with a run that is
     told to do exactly that (`aux_wide_route=1`), and no step may read the count back."""
     d, s, k, k_aux, n = 256, 2048, 8, 128, 256
-    thr = 6 * n + n // 2  # dead after seven quiet steps
+    thr = 30 * n + n // 2  # dead after 31 quiet steps
     p = rand_params(d, s, seed=850)
     g = torch.Generator().manual_seed(851)
     perm = torch.randperm(s, generator=g)
-    dead, sleepy = perm[:20], perm[20:110]
+    dead, sleepy = perm[:20], perm[20:100]
     p["b_enc"][dead] = -100.0
     p["b_enc"][sleepy] = -100.0
-    p["W_enc"][0, sleepy] = 300.0      # ... unless the batch carries a large first coordinate
+    p["W_enc"][0, sleepy] = 300.0      # ... unless the batch carries a large first coordinate: every 30th does
     xs = []
-    for i in range(16):
+    for i in range(68):
         x = torch.randn(n, d, generator=g)
-        x[:, 0] = 1.0 if i % 7 == 6 else 0.0
+        x[:, 0] = 1.0 if i % 30 == 29 else 0.0
         xs.append(x.cuda())
     runs = []
     for wide_off in (0, 1):
@@ -1154,10 +1155,11 @@ def test_a_loose_bound_of_the_dead_count_runs_the_kernels_of_the_true_count(enco
         eng.close()
     (wide, rb_w), (dense, rb_d) = runs
     assert [r[0] for r in wide] == [r[0] for r in dense]
-    late = [i for i, r in enumerate(wide) if i >= 8 and r[0] > 0]
-    assert late and all(wide[i][0] <= 25 for i in late), [r[0] for r in wide]
-    assert any(dense[i][1] == 3 for i in late), "the scenario is meant to push the round-5 rule onto the dense route"
+    late = [i for i, r in enumerate(wide) if i >= 35 and r[0] > 0]
+    assert late and all(wide[i][0] == 20 for i in late), [r[0] for r in wide]
+    assert [dense[i][1] for i in (60, 61, 62)] == [3, 3, 3], "the scenario is meant to push the round-5 rule onto the dense route"
     assert all(wide[i][1] == 1 for i in late), [wide[i][1] for i in late]
+    assert rb_w == rb_d, (rb_w, rb_d)  # (the first steps after creation read the count back on either rule; none later)
     for i in late:
         assert math.isclose(wide[i][2], dense[i][2], rel_tol=1e-4) and math.isclose(wide[i][3], dense[i][3], rel_tol=1e-4), (i, wide[i], dense[i])
 

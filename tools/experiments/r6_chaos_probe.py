@@ -18,21 +18,27 @@ def make(wide_off):
     W /= W.norm(dim=1, keepdim=True)
     e.view("W_dec").copy_(W); e.view("W_enc").copy_(W.t())
     return e
-engs = {"B0 (up to 64)": make(1), "B1 (up to 64, one ulp at step 700)": make(1), "A (up to 128)": make(0)}
+if len(sys.argv) > 2 and sys.argv[2] == "six":  # three trajectories per rule: every engine but the first of its rule gets its own ulp
+    engs = {"B0 (up to 64)": make(1), "B1 (up to 64, ulp)": make(1), "B2 (up to 64, ulp)": make(1),
+            "A0 (up to 128)": make(0), "A1 (up to 128, ulp)": make(0), "A2 (up to 128, ulp)": make(0)}
+else:
+    engs = {"B0 (up to 64)": make(1), "B1 (up to 64, one ulp at step 700)": make(1), "A (up to 128)": make(0)}
 names = list(engs)
 x = torch.empty(B, D, device=dev)
 lr = lambda i: 4e-4 * min(1.0, i / 500)
 tot = {n: 0.0 for n in names}
 dead = {n: [] for n in names}
 routes = {n: {} for n in names}
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
 for i in range(PRE + N):
     rows = perm[(i % 64) * B:(i % 64 + 1) * B]
     engs[names[0]].gather_rows(pool, rows, out=x)
     if i == 700:
-        w = engs[names[1]].view("W_enc")
-        w[3, 5] = torch.nextafter(w[3, 5], w[3, 5] + 1)
-    order = names[i % 3:] + names[:i % 3]
+        for j, nme in enumerate(names):
+            if "ulp" in nme:
+                w = engs[nme].view("W_enc")
+                w[3 + j, 5] = torch.nextafter(w[3 + j, 5], w[3 + j, 5] + 1)
+    order = names[i % len(names):] + names[:i % len(names)]
     ev[0].record()
     for j, n in enumerate(order):
         engs[n].train_step(x, lr(i), 1.0)
@@ -45,4 +51,4 @@ for i in range(PRE + N):
         if i % 100 == 0:
             for n in names: dead[n].append(engs[n].read_stats().n_dead)
 for n in names:
-    print(f"{n:40s} {tot[n] / N:.4f} ms per step over {N} steps; routes {dict(sorted(routes[n].items()))}; n_dead every 100 steps {dead[n]}")
+    print(f"{n:40s} {tot[n] / N:.4f} ms per step over {N} steps; routes {dict(sorted(routes[n].items()))}; mean n_dead (every 100 steps) {sum(dead[n]) / max(1, len(dead[n])):.1f}; n_dead every 100 steps {dead[n]}")

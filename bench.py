@@ -513,13 +513,18 @@ def main():
         for st2 in extra:
             st2.train_step(x, lr_sched(i), 1.0)
 
-    def timed(first, n):
+    route_hist = {}
+
+    def timed(first, n, routes=False):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for i in range(first, first + n):
             one_step(i)
+            if routes:  # (a host-side field of the context: no synchronisation)
+                r = eng.aux_route()
+                route_hist[r] = route_hist.get(r, 0) + 1
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -570,7 +575,7 @@ def main():
             one_step(i)
         step_i += args.sustained_after
         rb0 = eng.dead_readbacks()
-        t_sus = timed(step_i, args.sustained_steps)
+        t_sus = timed(step_i, args.sustained_steps, routes=True)
         step_i += args.sustained_steps
         st_s = eng.read_stats()
         sustained = {
@@ -579,8 +584,12 @@ def main():
             "dead_threshold_tokens": dead_thr, "tokens_seen_at_start": (step_i - args.sustained_steps) * B * world,
             "n_dead_last": st_s.n_dead, "aux_last": st_s.aux, "mse_last": st_s.mse, "aux_route_last": eng.aux_route(),
             "n_dead_readbacks_in_segment": eng.dead_readbacks() - rb0,
-            "note": "the headline's loop, continued for a long window (the step time keeps fluctuating by a few per cent with the "
-                    "number of latents that happen to be dead: tools/experiments/long_run_probe.py)",
+            "aux_route_steps": {{0: "no auxiliary work", 1: "few-dead-latents kernels", 2: "few-dead-latents kernels after a read-back",
+                                 3: "dense algebra"}.get(r_, str(r_)): n_ for r_, n_ in sorted(route_hist.items())},
+            "note": "the headline's loop, continued for a long window.  A TRAJECTORY figure: the dead count drifts between 0 and ~35 with "
+                    "bursts of 100-240 latents every ~600 steps (dense-algebra steps, +0.3 ... +0.6 ms each), and one ulp on one parameter at "
+                    "step 700 moves this mean by +-0.03 ms on one box (tools/experiments/r6_chaos_probe.py, "
+                    "profiles/r06_sustained_chaos_probe_six.txt)",
         }
 
     # ---- AuxK active on a forced dead set (configs[2]'s single-GPU half) --------------------------------------------

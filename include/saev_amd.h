@@ -145,7 +145,7 @@ typedef struct {
     int32_t enc_wgs;       /* workgroups the fused encoder's grid aims at (0 = 256, one per CU)                           */
     int32_t refresh_first; /* bound refresh on a workgroup's first N tiles (0 = 8) ...                                    */
     int32_t refresh_every; /* ... then on every M-th, M a power of two (0 = 2; the 64-group bound defaults to 1)          */
-    int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 64 where d_model % 128 == 0 (fp32-MFMA kernels), else 40; -1 = never (dense algebra
+    int32_t aux_small_max; /* largest dead set the few-dead-latents AuxK kernels take: 0 = 128 where d_model % 128 == 0 (fp32-MFMA kernels; 64 with aux_wide_route = 1), else 40; -1 = never (dense algebra
                               whatever the count); values above 64 are clamped                                           */
     int32_t fwd_route;     /* exact refinement of the f16r encoder: 0 = from 32-column slices of W_enc^T that the XCD L2s hold
                               where the geometry allows (their D / 32 shares per survivor added by the final select), 1 = whole-row
@@ -265,7 +265,8 @@ int saev_step_forward(saev_ctx* ctx, const float* x, int32_t n_rows, int64_t n_r
  * forward (modeling.py:75-103).  Training mode only.  The reference reads n_dead back on every step
  * (`.item()`, modeling.py:92).  Here the update kernel leaves a record in pinned host memory each step; the
  * call looks at the record of four steps earlier, which bounds the current count from above, and while that
- * bound is <= min(64, k_aux) (40 unless d_model % 128 == 0; saev_debug_cfg.aux_small_max) -- zero dead latents included -- it enqueues kernels that take the count from
+ * bound is <= min(128, k_aux) (fp32 matrix-core kernels, d_model % 128 == 0: one launch per count window, saev_debug_cfg.aux_wide_route; 40 for other widths;
+ * saev_debug_cfg.aux_small_max) -- zero dead latents included -- it enqueues kernels that take the count from
  * the device: no read-back, no stream synchronisation.  Only when the bound is larger (or no valid record
  * exists yet: the first four steps after creation / saev_bind_tracker / saev_tracker_touched) does it read
  * n_dead back and size the dense AuxK algebra on the host.  saev_last_aux_route tells which happened:
